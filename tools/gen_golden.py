@@ -1,0 +1,479 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container (needs /root/reference). The reference's pure-torch modules are
+imported read-only (PYTHONDONTWRITEBYTECODE, nothing is written under /root/reference); `deepinv`
+is not installed, so an in-memory shell of the three names the physics package imports
+(`LinearPhysics`, `GaussianNoise`, `adjoint_function`) is registered first. None of the stub's
+arithmetic is exercised by the goldens below except `adjoint_function`, which is a plain
+`torch.autograd.functional.vjp` (flagged "vjp" in the fixture names).
+
+What is written is DATA ONLY: seeded inputs and the outputs the reference produced for them
+(SURVEY.md section 8c, G1..G11). The reference cannot travel to the GPU box; these files can.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz + manifest json
+"""
+import importlib
+import importlib.util
+import json
+import os
+import sys
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+REF_SRC = os.path.join(REF, "src")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+# --------------------------------------------------------------------------------------------
+# deepinv shell (names only; see module docstring)
+# --------------------------------------------------------------------------------------------
+def _install_deepinv_shell():
+    dinv = types.ModuleType("deepinv")
+    phys = types.ModuleType("deepinv.physics")
+    fwd = types.ModuleType("deepinv.physics.forward")
+
+    class LinearPhysics(torch.nn.Module):
+        def __init__(self, **kwargs):
+            super().__init__()
+            self.noise_model = lambda x: x
+
+        def forward(self, x):
+            return self.noise_model(self.A(x))
+
+    class GaussianNoise(torch.nn.Module):
+        def __init__(self, sigma=0.1):
+            super().__init__()
+            self.sigma = sigma
+
+        def forward(self, x):
+            return x + torch.randn_like(x) * self.sigma
+
+    def adjoint_function(A, input_size, device="cpu", dtype=torch.float):
+        x = torch.ones(input_size, device=device, dtype=dtype)
+        (_, vjpfunc) = torch.func.vjp(A, x)
+
+        def adj(y):
+            return vjpfunc(y)[0]
+
+        return adj
+
+    phys.LinearPhysics = LinearPhysics
+    phys.GaussianNoise = GaussianNoise
+    phys.adjoint_function = adjoint_function
+    fwd.LinearPhysics = LinearPhysics
+    dinv.physics = phys
+    phys.forward = fwd
+    sys.modules["deepinv"] = dinv
+    sys.modules["deepinv.physics"] = phys
+    sys.modules["deepinv.physics.forward"] = fwd
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  ({len(arrays)} arrays)")
+
+
+def _rand(shape, seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g, dtype=torch.float32).to(dtype)
+
+
+def _randn(shape, seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float32).to(dtype)
+
+
+def _fwd_vjp(fn, x, seed):
+    """forward + vjp against a seeded cotangent, at x's dtype."""
+    x = x.clone().requires_grad_(True)
+    y = fn(x)
+    ct = _randn(tuple(y.shape), seed, y.dtype)
+    (gx,) = torch.autograd.grad(y, x, ct)
+    return y.detach(), ct, gx.detach()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    _install_deepinv_shell()
+    sys.path.insert(0, REF_SRC)
+    physics = importlib.import_module("physics")
+    transforms = importlib.import_module("transforms")
+    scheduler = importlib.import_module("scheduler")
+    kernels = importlib.import_module("physics.kernels")
+    sure = _load_by_path("ref_sure", os.path.join(REF_SRC, "losses", "sure.py"))
+    conv = _load_by_path("ref_convolutional", os.path.join(REF_SRC, "models", "convolutional.py"))
+    torch.set_num_threads(8)
+
+    # ---------------- G1: kernel table --------------------------------------------------------
+    print("G1 kernels")
+    _save("g1_kernels", **{n: _np(kernels.get_kernel(n)) for n in kernels._table})
+
+    # ---------------- G2: BlurV2 (FFT circular blur) fwd + vjp; legacy Blur --------------------
+    print("G2 blur")
+    arrs = {}
+    for kname in ["Gaussian_R2", "Box_R3", "Gaussian_R1"]:
+        k = physics.BlurKernel(kname).to_tensor("cpu")
+        op = physics.BlurV2(kernel=k)
+        for tag, shape, seed in [("sq", (2, 3, 48, 48), 11), ("rect", (1, 3, 40, 56), 12),
+                                 ("tiny", (1, 1, 16, 20), 13)]:
+            for dt, dn in [(torch.float32, "f32"), (torch.float64, "f64")]:
+                x = _rand(shape, seed, dt)
+                y, ct, gx = _fwd_vjp(op.A, x, seed + 100)
+                p = f"{kname}.{tag}.{dn}."
+                if dn == "f32":
+                    arrs[p + "x"] = _np(x)
+                    arrs[p + "ct"] = _np(ct)
+                arrs[p + "y"] = _np(y)
+                arrs[p + "gx"] = _np(gx)
+        # legacy operator (--no-physics_v2): same math by a different route
+        x = _rand((2, 3, 24, 24), 14)
+        leg = physics.Blur(filter=k.float(), padding="circular", device="cpu")
+        arrs[f"{kname}.legacy.x"] = _np(x)
+        arrs[f"{kname}.legacy.y"] = _np(leg.A(x))
+        arrs[f"{kname}.legacy.adj"] = _np(leg.A_adjoint(x))
+    _save("g2_blur", **arrs)
+
+    # ---------------- G3: Downsampling (AA bicubic) fwd + vjp + deprecated adjoint ------------
+    print("G3 downsampling")
+    arrs = {}
+    for rate in [2, 3, 4]:
+        op = physics.Downsampling(rate=rate, antialias=True)
+        for tag, shape, seed in [("sq", (2, 3, 96, 96), 21), ("rect", (1, 3, 48, 72), 22)]:
+            for dt, dn in [(torch.float32, "f32"), (torch.float64, "f64")]:
+                x = _rand(shape, seed, dt)
+                y, ct, gx = _fwd_vjp(op.A, x, seed + 100)
+                p = f"r{rate}.{tag}.{dn}."
+                if dn == "f32":
+                    arrs[p + "x"] = _np(x)
+                    arrs[p + "ct"] = _np(ct)
+                arrs[p + "y"] = _np(y)
+                arrs[p + "gx"] = _np(gx)
+        # A_adjoint default (plain bicubic upsample, a=-0.75) and true adjoint
+        yy = _rand((1, 3, 12, 16), 23)
+        arrs[f"r{rate}.adj.y"] = _np(yy)
+        arrs[f"r{rate}.adj.plain"] = _np(op.A_adjoint(yy))
+        op_t = physics.Downsampling(rate=rate, antialias=True, true_adjoint=True)
+        arrs[f"r{rate}.adj.true"] = _np(op_t.A_adjoint(yy))
+    _save("g3_downsampling", **arrs)
+
+    # ---------------- G4/G5: scale transform ---------------------------------------------------
+    print("G4/G5 scale transform")
+    arrs = {}
+    # RNG draw table (a12): manual_seed(k) -> rates, centers, for B=4, CPU f32
+    for k in range(4):
+        torch.manual_seed(k)
+        r, c = transforms.sample_downsampling_parameters(4, "cpu", torch.float32, [0.75, 0.5])
+        arrs[f"draw.seed{k}.rate"] = _np(r)
+        arrs[f"draw.seed{k}.center"] = _np(c)
+    cases = [
+        ("b4s48", (4, 3, 48, 48), 31, [0.75, 0.5, 0.75, 0.5],
+         [[-0.3852, 0.2682], [-0.0198, 0.7929], [0.95, -0.97], [-1.0, 1.0]]),
+        ("b2s96", (2, 3, 96, 96), 32, [0.5, 0.75], [[0.25, -0.6], [0.0, 0.0]]),
+        ("b1s20", (1, 2, 20, 20), 33, [0.5], [[0.999, 0.999]]),
+    ]
+    for tag, shape, seed, rates, centers in cases:
+        for dt, dn in [(torch.float32, "f32"), (torch.float64, "f64")]:
+            x = _rand(shape, seed, dt)
+            # f32-rounded parameters in both precisions, so the f64 run sees the same inputs
+            r = torch.tensor(rates, dtype=torch.float32).to(dt)
+            c = torch.tensor(centers, dtype=torch.float32).to(dt).view(len(rates), 1, 1, 2)
+            fn = lambda t: transforms.padded_downsampling_transform(
+                t, downsampling_rate=r, center=c, mode="bicubic", padding_mode="reflection",
+                antialiased=False)
+            y, ct, gx = _fwd_vjp(fn, x, seed + 100)
+            p = f"{tag}.{dn}."
+            if dn == "f32":
+                arrs[p + "x"] = _np(x)
+                arrs[p + "rate"] = _np(r)
+                arrs[p + "center"] = _np(c.view(-1, 2))
+                arrs[p + "ct"] = _np(ct)
+            arrs[p + "y"] = _np(y)
+            arrs[p + "gx"] = _np(gx)
+    # antialiased variant (a15): all rates equal so torch.stack succeeds
+    x = _rand((2, 3, 48, 48), 34)
+    r = torch.tensor([0.5, 0.5])
+    c = torch.tensor([[0.1, -0.2], [0.4, 0.3]]).view(2, 1, 1, 2)
+    arrs["aa.x"] = _np(x)
+    arrs["aa.rate"] = _np(r)
+    arrs["aa.center"] = _np(c.view(-1, 2))
+    arrs["aa.y"] = _np(transforms.padded_downsampling_transform(
+        x, downsampling_rate=r, center=c, mode="bicubic", padding_mode="reflection", antialiased=True))
+    # G5: the grid itself
+    g = transforms.get_downsampling_grid((2, 3, 6, 6), torch.tensor([0.75, 0.5]).double(),
+                                         torch.tensor([[0.2, -0.4], [0.0, 0.5]]).double().view(2, 1, 1, 2),
+                                         torch.float64, "cpu")
+    arrs["grid.b2s6"] = _np(g)
+    # normal kind (a16): deterministic given the rate
+    x = _rand((2, 3, 24, 24), 35)
+    arrs["normal.x"] = _np(x)
+    for rr in [0.75, 0.5]:
+        for aa in [False, True]:
+            arrs[f"normal.r{rr}.aa{int(aa)}"] = _np(
+                transforms.normal_downsampling_transform(x, rr, "bicubic", aa))
+    _save("g4_scale_transform", **arrs)
+
+    # ---------------- G6: SURE with a linear stand-in model and injected randn ----------------
+    print("G6 sure")
+    arrs = {}
+    k = physics.BlurKernel("Gaussian_R2").to_tensor("cpu")
+    blur = physics.BlurV2(kernel=k)
+    y = _rand((2, 3, 48, 48), 41)
+    w = torch.tensor(0.9, requires_grad=True)
+    model = lambda t: w * t + 0.05 * t * t
+    for margin in [0, 6]:
+        bfull = _randn((2, 3, 48 - 2 * margin, 48 - 2 * margin), 42 + margin)
+        saved = (torch.randn, torch.randn_like)
+        torch.randn = lambda *a, **kw: bfull.clone()
+        torch.randn_like = lambda t, **kw: bfull.clone()
+        try:
+            for cst in [False, True]:
+                lf = sure.SureGaussianLoss(sigma=5 / 255, margin=margin, cropped_div=True,
+                                           averaged_cst=cst)
+                x_net = model(y)
+                val = lf(y=y, x_net=x_net, physics=blur, model=model)
+                (gw,) = torch.autograd.grad(val, w)
+                arrs[f"m{margin}.cst{int(cst)}.loss"] = _np(val)
+                arrs[f"m{margin}.cst{int(cst)}.gw"] = _np(gw)
+        finally:
+            torch.randn, torch.randn_like = saved
+        arrs[f"m{margin}.b"] = _np(bfull)
+    arrs["y"] = _np(y)
+    _save("g6_sure", **arrs)
+
+    # ---------------- G7: the U-Net ------------------------------------------------------------
+    print("G7 unet")
+
+    def sd_np(m):
+        return {k: _np(v) for k, v in m.state_dict().items()}
+
+    def grads_np(m):
+        return {k: _np(p.grad) for k, p in m.named_parameters()}
+
+    # per-layer goldens
+    arrs = {}
+    torch.manual_seed(7)
+    for H in [48, 24, 12, 6, 20]:
+        x = _rand((2, 3, H, H), 50 + H)
+        arrs[f"ideal_down2.{H}.x"] = _np(x)
+        arrs[f"ideal_down2.{H}.y"] = _np(conv.IdealDownsample(2)(x))
+        arrs[f"ideal_down2.{H}.y64"] = _np(conv.IdealDownsample(2)(x.double()))
+    x = _rand((1, 2, 16, 32), 59)
+    arrs["ideal_down2.rect.x"] = _np(x)
+    arrs["ideal_down2.rect.y"] = _np(conv.IdealDownsample(2)(x))
+    for H in [3, 6, 12, 24, 10]:
+        x = _rand((2, 3, H, H), 60 + H)
+        arrs[f"ideal_up2.{H}.x"] = _np(x)
+        arrs[f"ideal_up2.{H}.y"] = _np(conv.IdealUpsample(2)(x))
+        arrs[f"ideal_up2.{H}.y64"] = _np(conv.IdealUpsample(2)(x.double()))
+    for rate, H in [(4, 12), (4, 48), (3, 18)]:
+        x = _rand((1, 3, H, H), 70 + H)
+        arrs[f"ideal_up{rate}.{H}.x"] = _np(x)
+        arrs[f"ideal_up{rate}.{H}.y"] = _np(conv.IdealUpsample(rate)(x))
+    # reference quirk: an odd rate with a width = 0 (mod 4) cannot embed its spectrum and raises
+    try:
+        conv.IdealUpsample(3)(_rand((1, 3, 16, 16), 1))
+        arrs["ideal_up3.16.raises"] = np.array(0)
+    except RuntimeError:
+        arrs["ideal_up3.16.raises"] = np.array(1)
+    x = _rand((1, 2, 16, 32), 79)
+    arrs["ideal_up2.rect.x"] = _np(x)
+    arrs["ideal_up2.rect.y"] = _np(conv.IdealUpsample(2)(x))
+    _save("g7_ideal_resamplers", **arrs)
+
+    arrs = {}
+    torch.manual_seed(8)
+    for name, mod, shape in [
+        ("convblock16", conv.ConvBlock(16), (2, 16, 12, 12)),
+        ("convblock8", conv.ConvBlock(8), (1, 8, 5, 7)),
+        ("layernorm12", conv.LayerNorm(12, eps=1e-6), (2, 12, 6, 6)),
+        ("downsample8", conv.Downsample(in_channels=8), (2, 8, 12, 12)),
+        ("upsample32", conv.Upsample(in_channels=32, rate=2), (2, 32, 6, 6)),
+        ("upsample3x4", conv.Upsample(in_channels=3, out_channels=3, rate=4), (1, 3, 12, 12)),
+    ]:
+        # perturb the norm affine params so that they are not the identity
+        with torch.no_grad():
+            for n, p in mod.named_parameters():
+                if ".ln." in n or n.startswith("ln."):
+                    p.add_(0.1 * torch.randn_like(p))
+        x = _randn(shape, 80 + shape[1]).requires_grad_(True)
+        y = mod(x)
+        ct = _randn(tuple(y.shape), 90 + shape[1])
+        mod.zero_grad()
+        (gx,) = torch.autograd.grad(y, x, ct, retain_graph=True)
+        y.backward(ct)
+        arrs[f"{name}.x"] = _np(x)
+        arrs[f"{name}.y"] = _np(y)
+        arrs[f"{name}.ct"] = _np(ct)
+        arrs[f"{name}.gx"] = _np(gx)
+        for k2, v in sd_np(mod).items():
+            arrs[f"{name}.sd.{k2}"] = v
+        for k2, v in grads_np(mod).items():
+            arrs[f"{name}.grad.{k2}"] = v
+    _save("g7_layers", **arrs)
+
+    # whole-model goldens, small configs
+    for tag, kw, xshape in [
+        ("h8s3_deblur", dict(in_channels=3, upsampling_rate=1, residual=True, inner_residual=True,
+                             num_conv_blocks=1, hidden_channels=8, inout_convs=True, scales=3),
+         (2, 3, 48, 48)),
+        ("h8s3_sr2", dict(in_channels=3, upsampling_rate=2, residual=True, inner_residual=True,
+                          num_conv_blocks=1, hidden_channels=8, inout_convs=True, scales=3),
+         (2, 3, 24, 24)),
+        ("h2s4_pad", dict(in_channels=3, upsampling_rate=1, residual=True, inner_residual=True,
+                          num_conv_blocks=1, hidden_channels=2, inout_convs=True, scales=4),
+         (1, 3, 45, 50)),
+        ("h8s2_nb2", dict(in_channels=3, upsampling_rate=1, residual=False, inner_residual=False,
+                          num_conv_blocks=2, hidden_channels=8, inout_convs=True, scales=2),
+         (1, 3, 16, 16)),
+        ("h2s4_sr4", dict(in_channels=3, upsampling_rate=4, residual=True, inner_residual=True,
+                          num_conv_blocks=1, hidden_channels=2, inout_convs=True, scales=4),
+         (1, 3, 12, 12)),
+    ]:
+        torch.manual_seed(0)
+        m = conv.ConvolutionalModel(**kw)
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if ".ln." in n:
+                    p.add_(0.05 * torch.randn_like(p))
+        x = _rand(xshape, 100).requires_grad_(True)
+        y = m(x)
+        ct = _randn(tuple(y.shape), 101)
+        m.zero_grad()
+        (gx,) = torch.autograd.grad(y, x, ct, retain_graph=True)
+        y.backward(ct)
+        arrs = {"x": _np(x), "y": _np(y), "ct": _np(ct), "gx": _np(gx),
+                "cfg": np.frombuffer(json.dumps(kw).encode(), dtype=np.uint8)}
+        for k2, v in sd_np(m).items():
+            arrs[f"sd.{k2}"] = v
+        # float64 run of the same reference module on the same (f32-valued) inputs: the tight pin.
+        # Parameter gradients are stored rounded to f32 (6e-8 relative) to keep the fixture small.
+        import copy
+        m64 = copy.deepcopy(m).double()
+        x64 = x.detach().double().requires_grad_(True)
+        y64 = m64(x64)
+        m64.zero_grad()
+        (gx64,) = torch.autograd.grad(y64, x64, ct.double(), retain_graph=True)
+        y64.backward(ct.double())
+        arrs["y64"] = _np(y64)
+        arrs["gx64"] = _np(gx64)
+        for k2, v in grads_np(m64).items():
+            arrs[f"grad.{k2}"] = v.astype(np.float32)
+        _save(f"g7_unet_{tag}", **arrs)
+
+    # ---------------- G8: default-config manifest ----------------------------------------------
+    print("G8 manifest")
+    manifest = {}
+    for tag, up in [("deblur", 1), ("sr2", 2), ("sr4", 4)]:
+        with torch.device("meta"):
+            m = conv.ConvolutionalModel(in_channels=3, upsampling_rate=up, residual=True,
+                                        inner_residual=True, num_conv_blocks=1, hidden_channels=32,
+                                        inout_convs=True, scales=5)
+        sd = m.state_dict()
+        manifest[tag] = {
+            "num_parameters": int(sum(p.numel() for p in m.parameters())),
+            "keys": [[k2, list(v.shape)] for k2, v in sd.items()],
+        }
+        print(f"  {tag}: {manifest[tag]['num_parameters']} parameters, {len(sd)} tensors")
+    with open(os.path.join(OUT, "g8_state_dict_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0)
+
+    # ---------------- G9: LR schedule ----------------------------------------------------------
+    print("G9 scheduler")
+    out = {}
+    for kind in ["delayed_linear_decay", "multi_step_decay"]:
+        for epochs in [10, 20]:
+            p = torch.nn.Parameter(torch.zeros(1))
+            opt = torch.optim.Adam([p], lr=1e-4)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                sch = scheduler.get_lr_scheduler(opt, epochs, kind)
+                lrs = []
+                for _ in range(epochs):
+                    lrs.append(opt.param_groups[0]["lr"])
+                    opt.step()
+                    sch.step()
+            out[f"{kind}.{epochs}"] = lrs
+    with open(os.path.join(OUT, "g9_lr_schedule.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+    # ---------------- G11: composite proposed loss ---------------------------------------------
+    # Reference pieces (U-Net, BlurV2 / Downsampling, SureGaussianLoss, padded_downsampling_transform)
+    # composed by the EI glue restated from deepinv v0.2.0's documented EILoss behaviour
+    # ([recollection]): x2 = T(x_net) under no_grad; y2 = A(x2) + sigma*n; x3 = model(y2);
+    # loss_ei = alpha * mean((x3 - x2)^2).  All randomness injected and saved.
+    print("G11 composite loss")
+    for tag, task, rate in [("deblur", "deblurring", 1), ("sr2", "sr", 2)]:
+        torch.manual_seed(0)
+        m = conv.ConvolutionalModel(in_channels=3, upsampling_rate=rate, residual=True,
+                                    inner_residual=True, num_conv_blocks=1, hidden_channels=8,
+                                    inout_convs=True, scales=3)
+        sd32 = sd_np(m)
+        m = m.double()          # float64 throughout: this golden pins formulas, not rounding
+        if task == "deblurring":
+            phys_op = blur
+            margin = 6
+        else:
+            phys_op = physics.Downsampling(rate=rate, antialias=True)
+            margin = 0
+        B, S = 2, 24 if task == "deblurring" else 16
+        y = _rand((B, 3, S, S), 110).double()
+        b = _randn((B, 3, S - 2 * margin, S - 2 * margin), 111).double()
+        n = _randn((B, 3, S, S), 112).double()
+        r = torch.tensor([0.75, 0.5]).double()
+        c = torch.tensor([[0.3, -0.2], [-0.5, 0.6]]).double().view(B, 1, 1, 2)
+        sigma = 5 / 255
+        saved = (torch.randn, torch.randn_like)
+        torch.randn = lambda *a, **kw: b.clone()
+        torch.randn_like = lambda t, **kw: b.clone()
+        try:
+            x_net = m(y)
+            lf = sure.SureGaussianLoss(sigma=sigma, margin=margin, cropped_div=True, averaged_cst=None)
+            l_sure = lf(y=y, x_net=x_net, physics=phys_op, model=m)
+        finally:
+            torch.randn, torch.randn_like = saved
+        with torch.no_grad():
+            x2 = transforms.padded_downsampling_transform(
+                x_net, downsampling_rate=r, center=c, mode="bicubic", padding_mode="reflection",
+                antialiased=False)
+        y2 = phys_op.A(x2) + sigma * n
+        x3 = m(y2)
+        l_ei = torch.nn.functional.mse_loss(x3, x2)
+        total = l_sure + 1.0 * l_ei
+        m.zero_grad()
+        total.backward()
+        arrs = {"y": _np(y), "b": _np(b), "n": _np(n), "rate": _np(r), "center": _np(c.view(-1, 2)),
+                "x_net": _np(x_net), "x2": _np(x2), "x3": _np(x3),
+                "loss_sure": _np(l_sure), "loss_ei": _np(l_ei), "loss": _np(total)}
+        arrs = {k2: (v.astype(np.float32) if k2 in ("y", "b", "n", "rate", "center") else v)
+                for k2, v in arrs.items()}
+        for k2, v in sd32.items():
+            arrs[f"sd.{k2}"] = v
+        for k2, v in grads_np(m).items():
+            arrs[f"grad.{k2}"] = v.astype(np.float32)
+        _save(f"g11_proposed_{tag}", **arrs)
+
+    print("done ->", OUT)
+
+
+if __name__ == "__main__":
+    main()
