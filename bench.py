@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Benchmark of the proposed-loss training step (BASELINE.json metric: training images/sec).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: Loss.forward (random 48-crop of the 256x256 pairs)
+-> SURE + scale-equivariant loss (three U-Net evaluations, two physics operators, the EI resample)
+-> backward -> gradient all-reduce (N>1) -> Adam. One "image" = one 256x256 pair entering Loss.forward.
+Workload: config[1] of BASELINE.json -- deblurring, Gaussian_R2, noise 5, proposed loss, the reference's
+default ConvolutionalModel (hidden 32, 5 scales, 645,063,043 parameters), per-GPU batch 32 (config[3]'s
+256 / 8), synthetic inputs resident in HBM, random-init weights (torch.manual_seed(0)).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
+  roofline     -- the dominant kernel (sei_gemm_f32: all 1x1 convolutions and their gradients), timed
+                  live with HIP events on the launch stream during the timed steps.
+  cpu_baseline -- the oracle's torch-CPU restatement of the same step on the host cores (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "scale-equivariant-imaging_amd"))
+sys.path.insert(1, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+CROP, NOISE, KERNEL = 48, 5, "Gaussian_R2"
+
+
+def reference_args(device, hidden=32, scales=5):
+    return argparse.Namespace(
+        device=device, task="deblurring", kernel=KERNEL, sr_factor=None, noise_level=NOISE, physics_v2=True,
+        physics_true_adjoint=False, model_kind="Proposed", ProposedModel__architecture="Convolutional",
+        ConvolutionalModel__residual=True, ConvolutionalModel__inner_residual=True,
+        ConvolutionalModel__num_conv_blocks=1, ConvolutionalModel__inout_convs=True,
+        ConvolutionalModel__hidden_channels=hidden, ConvolutionalModel__scales=scales,
+        data_parallel_devices=None, method="proposed", partial_sure=True, sure_margin=None,
+        partial_sure_sr=False, sure_cropped_div=True, sure_averaged_cst=None, Loss__crop_training_pairs=True,
+        Loss__crop_size=CROP, ProposedLoss__stop_gradient=True, ProposedLoss__sure_alternative=None,
+        ProposedLoss__alpha_tradeoff=1.0, ProposedLoss__transforms="Scaling_Transforms",
+        ScalingTransform__kind="padded", ScalingTransform__antialias=False)
+
+
+def cpu_baseline(batch, hidden, scales):
+    """The oracle's restatement of the same training step on the host CPU (kind "port")."""
+    from oracle import torch_path as tp
+    torch.manual_seed(0)
+    threads = torch.get_num_threads()
+    sd = {k: v.requires_grad_(True) for k, v in tp.unet_init_state_dict(hidden, scales).items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-4)
+    k = tp.blur_kernel(KERNEL)
+    A = lambda v: tp.blur_fft(v, k)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand((batch, 3, 256, 256), generator=g)
+    y = tp.add_noise(A(x), NOISE / 255)
+    model = lambda v: tp.unet_forward(sd, v, scales=scales)
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    _, yc = tp.crop_pair(x, y, CROP, 1)
+    rate, center = tp.sample_scale_params(batch)
+    loss, _ = tp.proposed_loss(yc.contiguous(), A, model, NOISE / 255, margin=6, rate=rate, center=center)
+    loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 un-warmed proposed-loss step (crop {CROP}, 3 fwd + 3 bwd + Adam) of the same U-Net at "
+                      f"batch {batch}, float32, torch CPU ops in the reference's order (oracle/torch_path.py), "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--hidden", type=int, default=32)
+    ap.add_argument("--scales", type=int, default=5)
+    ap.add_argument("--cpu-baseline", action=argparse.BooleanOptionalAction, default=True)
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--profile-gemms", action=argparse.BooleanOptionalAction, default=True)
+    opt = ap.parse_args()
+
+    import parallel
+    rank, local_rank, world = parallel.init_from_env()
+    if world != opt.gpus:
+        raise SystemExit(f"--gpus {opt.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)
+
+    import torch.distributed as dist
+    from losses import get_loss
+    from models import _ops, get_model
+    from optim import FlatAdam
+    from physics import get_physics
+
+    args = reference_args(device, opt.hidden, opt.scales)
+    torch.manual_seed(0)
+    physics = get_physics(args, device)
+    model = get_model(args, physics, device)
+    model.to(device)
+    model.train()
+    backbone = model.get_backbone()
+    nparams = backbone.flat_params.numel()
+    if world > 1:
+        parallel.broadcast_parameters(backbone.flat_params)
+    loss_fn = get_loss(args, physics)
+    reducer = parallel.FlatGradientReducer(backbone.flat_grads) if world > 1 else None
+    optimizer = FlatAdam(model, lr=1e-4, betas=(0.9, 0.999), reducer=reducer)
+
+    # synthetic 256x256 pairs, resident in HBM before the timed region
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand((opt.batch, 3, 256, 256), generator=g).to(device)
+    torch.manual_seed(4321 + rank)
+    torch.cuda.manual_seed(4321 + rank)
+    y = physics(x)
+
+    def step():
+        optimizer.zero_grad()
+        loss = loss_fn(x=x, y=y, model=model)
+        loss.backward()
+        if reducer is not None:
+            reducer.reduce_async()
+        optimizer.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(opt.warmup):
+        step()
+    fence()
+    if opt.profile_gemms:
+        _ops.profile_gemms(True)
+    t0 = time.perf_counter()
+    for _ in range(opt.steps):
+        last = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    records = _ops.profile_gemms(False) if opt.profile_gemms else None
+    loss_value = float(last)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    roofline = None
+    if records:
+        flops = sum(r[0] for r in records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in records)
+        achieved = flops / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "sei_gemm_f32 (gemm_f32_kernel<*>)", "achieved": round(achieved, 2),
+                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches_per_step": len(records) // opt.steps,
+                    "avg_launch_us": round(1e3 * ms / len(records), 2),
+                    "gemm_share_of_step": round(ms / (elapsed * 1e3), 3),
+                    "algorithmic_gflop_per_step": round(flops / opt.steps / 1e9, 1)}
+
+    if rank == 0:
+        images = opt.batch * world * opt.steps
+        out = {
+            "metric": "training images/sec (256x256 crops), proposed-loss deblur",
+            "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": opt.steps,
+            "warmup": opt.warmup, "ms_per_step": round(1e3 * elapsed / opt.steps, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: deblurring Gaussian_R2 noise=5, proposed loss (SURE + "
+                                   "scale-EI), 256x256 pairs cropped to 48 in Loss.forward, ConvolutionalModel "
+                                   f"hidden={opt.hidden} scales={opt.scales}",
+                       "parameters": nparams, "batch_per_gpu": opt.batch, "global_batch": opt.batch * world,
+                       "parallelism": f"dp{world}", "optimizer": "Adam (fused, flat bucket)",
+                       "final_loss": loss_value},
+            "roofline": roofline,
+        }
+        if opt.cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(opt.cpu_batch, opt.hidden, opt.scales)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

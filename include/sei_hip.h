@@ -1,0 +1,183 @@
+/*
+ * sei_hip.h -- C ABI of libsei_hip.so: the MI355X (gfx950) kernels behind the proposed-loss
+ * training hot path of Scale-Equivariant-Imaging.
+ *
+ * Conventions (every entry point):
+ *   - extern "C", returns int: 0 = ok, otherwise a hipError_t value (launch errors) or
+ *     SEI_ERR_* (argument errors detected on the host BEFORE anything is launched). Never throws.
+ *   - all tensor pointers are DEVICE pointers owned by the caller; nothing is allocated inside.
+ *   - `stream` is a hipStream_t (passed as void* so that C callers need no HIP headers); all work
+ *     is enqueued on it and the call returns without synchronising. No hidden globals: re-entrant.
+ *   - float32 storage unless the name says bf16 (bf16 = upper 16 bits of an IEEE float32, passed as
+ *     uint16_t*), float32 accumulation everywhere.
+ *   - image tensors at the physics/loss boundary are NCHW planar ("planes" = B*C images of H x W);
+ *     U-Net activations are NHWC ("rows" = B*H*W pixels of C contiguous channels).
+ *
+ * Each group cites the reference code (paths under the reference repo) whose arithmetic it replaces.
+ * The reference is pure Python; it has no FFI of its own -- INTEGRATION.md shows the ctypes
+ * binding a maintainer would add at each call site.
+ */
+#ifndef SEI_HIP_H
+#define SEI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEI_OK 0
+#define SEI_ERR_BAD_ARG 10001      /* NULL pointer, non-positive size, unsupported size */
+#define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
+
+/* ABI version of this header; sei_abi_version() returns the value the library was built with. */
+#define SEI_ABI_VERSION 1
+int sei_abi_version(void);
+/* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
+int sei_build_target(char *name, int n);
+
+/* ---------------------------------------------------------------------------------------------
+ * Physics: circular blur.
+ * Replaces BlurV2.A, src/physics/blur/__init__.py:205-223 (rfft2 * OTF -> irfft2 == circular
+ * convolution) and, with transpose=1, its autograd backward / A_adjoint (:225-227) == circular
+ * correlation. Also serves the legacy Blur/conv/conv_transpose, :9-194 (same arithmetic).
+ *   y[p,i,j] = sum_{a,b} tv[a]*th[b] * x[p, (i-a+kv/2) mod H, (j-b+kh/2) mod W]     (transpose=0)
+ *   y[p,i,j] = sum_{a,b} tv[a]*th[b] * x[p, (i+a-kv/2) mod H, (j+b-kh/2) mod W]     (transpose=1)
+ * tv (kv taps) and th (kh taps) are the rank-1 factors of the kernel (device pointers).
+ * kv, kh <= 63.
+ * ------------------------------------------------------------------------------------------- */
+int sei_blur_sep_circ(const float *x, float *y, const float *tv, const float *th, int kv, int kh,
+                      int planes, int H, int W, int transpose, void *stream);
+/* Non-separable kernels (loaded from a file, src/physics/__init__.py:20-22): k is (kv,kh) row-major. */
+int sei_blur_dense_circ(const float *x, float *y, const float *k, int kv, int kh, int planes,
+                        int H, int W, int transpose, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Physics: separable banded resampling  y[p] = Wv * x[p] * Wh^T.
+ * Replaces Downsampling.A, src/physics/downsampling/__init__.py:16-19
+ * (F.interpolate bicubic antialias=True), its autograd backward / true adjoint (:21-31, the
+ * transposed band matrices), the deprecated adjoint (:33-34, plain bicubic upsample), and the
+ * antialias pre-filter of the EI transform, src/transforms.py:46-57.
+ * Band form per axis: row o of W has nb consecutive weights w[o*nb .. o*nb+nb) starting at input
+ * index lo[o] (entries beyond the band are zero-padded; lo is non-decreasing; lo[o]+nb may exceed
+ * the input size only on zero weights). stepv/steph = max_o (lo[o+1]-lo[o]) of each axis (the
+ * caller built the bands on the host and knows it); it bounds the LDS footprint of a tile.
+ * ------------------------------------------------------------------------------------------- */
+int sei_resample_sepband(const float *x, float *y, int planes, int Hi, int Wi, int Ho, int Wo,
+                         const float *wv, const int *lov, int nbv, int stepv,
+                         const float *wh, const int *loh, int nbh, int steph, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * EI transform: per-image zoom-out by bicubic grid sampling with reflection.
+ * Replaces padded_downsampling_transform + get_downsampling_grid, src/transforms.py:27-43,60-83
+ * (F.grid_sample bicubic / reflection / align_corners=True on the grid (g - c)/rate + c); the grid
+ * is generated in-kernel, never materialised. rate: (B,), center: (B,2) = (cx, cy) per image.
+ * x is (B,C,Hi,Wi), y is (B,C,H,W); (Hi,Wi) = (H,W) except for --ScalingTransform__antialias, where the
+ * reference samples the pre-shrunk image on the grid of the original shape (transforms.py:63-76).
+ * _bwd accumulates d x (must be zero-filled by the caller) -- only needed with
+ * --no-ProposedLoss__stop_gradient.
+ * ------------------------------------------------------------------------------------------- */
+int sei_scale_resample_fwd(const float *x, float *y, const float *rate, const float *center,
+                           int B, int C, int Hi, int Wi, int H, int W, void *stream);
+int sei_scale_resample_bwd(const float *gy, float *gx, const float *rate, const float *center,
+                           int B, int C, int Hi, int Wi, int H, int W, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss-side streaming kernels.
+ * sei_axpy: out = a + alpha*b  (GaussianNoise y + sigma*n, deepinv; SURE probe y + tau*b,
+ *           src/losses/sure.py:24).
+ * sei_sure_terms: src/losses/sure.py:24-31,57-62. Over the interior [m:H-m, m:W-m] of every plane:
+ *   out[0] = sum b*(y2-y1)/tau ,  out[1] = sum (y1-y)^2      (sums; the caller divides)
+ *   and, fused, the gradients of  L = c_mse*out[1] + c_div*out[0]  w.r.t. y1 and y2:
+ *   g1 = 2*c_mse*(y1-y) - c_div*b/tau ,  g2 = c_div*b/tau   (zero outside the interior).
+ *   margin_div / margin_mse select the two interiors separately (cropped_div flag, sure.py:51-54).
+ *   `work` must hold 2*SEI_REDUCE_BLOCKS floats.
+ * sei_mse_terms: deepinv mse metric used by EILoss (src/losses/__init__.py:117-122):
+ *   out[0] = sum (a-b)^2 ; ga = scale*(a-b) (caller passes scale = 2*alpha/N). `work` as above.
+ * ------------------------------------------------------------------------------------------- */
+#define SEI_REDUCE_BLOCKS 256
+int sei_axpy(const float *a, const float *b, float alpha, float *out, size_t n, void *stream);
+int sei_sure_terms(const float *y, const float *y1, const float *y2, const float *b, int planes,
+                   int H, int W, int margin_div, int margin_mse, float tau, float c_mse,
+                   float c_div, float *out2, float *g1, float *g2, float *work, void *stream);
+int sei_mse_terms(const float *a, const float *b, size_t n, float scale, float *out1, float *ga,
+                  float *work, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * U-Net (src/models/convolutional.py), NHWC activations ("rows" = B*H*W pixels of C channels).
+ * Parameter-gradient outputs (gw, gb, ggamma, gbeta, colsum `out`) are ACCUMULATED into with float
+ * atomics: zero them (or keep the running gradient in them) before the call.
+ *
+ * sei_conv3x3_fwd: UNet.in_conv / out_conv, :174-176 (3x3, zero 'same' padding, small channel counts).
+ *   x is NCHW (nchw_in=1) or NHWC; y likewise (nchw_out); optional residual `res` in y's layout (the
+ *   global residual x + x0, :246-247). transposed=1 evaluates the DATA gradient instead: pass the
+ *   forward weight (Cout_f,Cin_f,3,3) with Cin=Cout_f, Cout=Cin_f, x = upstream gradient.
+ * sei_conv3x3_bwd_weight: gw (Cout,Cin,3,3) += sum_p gy[p,co] x[p+tap,ci]; gb (Cout) += sum_p gy.
+ * sei_dwconv7_fwd: ConvBlock.conv1, :36-38 -- depthwise 7x7, zero pad 3, w is (C,1,7,7) as torch stores
+ *   it, bias may be NULL; y = conv + bias + res_scale*res when res != NULL (NHWC, same shape).
+ *   flip=1 correlates with the flipped taps = the data gradient.
+ * sei_dwconv7_bwd_weight: gw (C,49) += sum_p gy[p,c] x[p+tap,c]; gbias (C) += sum_p gy (may be NULL).
+ * sei_ln_fwd / sei_ln_bwd: channel LayerNorm, :21-30 (eps inside the sqrt, biased variance). fwd
+ *   saves per-row mean and rstd; bwd needs the fwd INPUT x. C <= 8192.
+ * sei_gemm_f32: every 1x1 Conv2d (:40,42,106,143) and its gradients as a row-major GEMM on the
+ *   exact-f32 matrix cores: D[M,N] = op(A)[M,K] * op(B)[K,N] with a fused epilogue.
+ *   A is (M,K) row-major when transA=0, (K,M) row-major when transA=1;
+ *   B is (K,N) row-major when transB=0, (N,K) row-major when transB=1. D is (M,N) row-major.
+ *   SEI_EPI_ACCUM may split K across workgroups and combine with float atomics.
+ *   sei_gemm_f32_ex adds a batch of `batch` independent problems (element strides) and a switch to
+ *   forbid split-K (bitwise reproducible accumulation).
+ * sei_sepmap2: IdealDownsample / IdealUpsample (:54-92,113-133) as the real separable rank-2 map
+ *   y[b,:,:,c] = L1 X R1^T + L2 X R2^T (L: (Ho,Hi), R: (Wo,Wi), row-major), the DFT-matrix form of the
+ *   reference's rfft2/fftshift/mask-or-embed/irfft2 sequence including its discarded ifftshift.
+ *   Backward = the same call with the transposed matrices. `work` >= 2*B*Hi*Wo*C floats.
+ * sei_colsum_f32: out[n] += sum_m X[m,n]  (bias gradients of the 1x1 convolutions).
+ * sei_adam_fused: torch.optim.Adam step (demo/train.py:157-186; amsgrad=False) over one flat bucket;
+ *   grad is multiplied by grad_scale first (1/world_size after a summing all-reduce). step >= 1.
+ * ------------------------------------------------------------------------------------------- */
+int sei_conv3x3_fwd(const float *x, const float *w, const float *bias, const float *res, float *y,
+                    int B, int H, int W, int Cin, int Cout, int nchw_in, int nchw_out, int transposed,
+                    void *stream);
+int sei_conv3x3_bwd_weight(const float *x, const float *gy, float *gw, float *gb, int B, int H, int W,
+                           int Cin, int Cout, int nchw_x, int nchw_gy, void *stream);
+
+int sei_dwconv7_fwd(const float *x, const float *w, const float *bias, const float *res,
+                    float res_scale, float *y, int B, int H, int W, int C, int flip, void *stream);
+int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
+                           int W, int C, void *stream);
+
+int sei_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+               float *rstd, size_t rows, int C, float eps, void *stream);
+int sei_ln_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
+               const float *gy, float *gx, float *ggamma, float *gbeta, size_t rows, int C,
+               void *stream);
+
+#define SEI_EPI_NONE 0
+#define SEI_EPI_BIAS 1            /* D = acc + bias[n]                                        */
+#define SEI_EPI_BIAS_GELU 2       /* D = acc + bias[n]; D2 = gelu(D)   (two outputs)          */
+#define SEI_EPI_BIAS_RES 3        /* D = acc + bias[n] + R1 (+ R2 if non-NULL)                */
+#define SEI_EPI_MUL_DGELU 4       /* D = acc * gelu'(R1)                                      */
+#define SEI_EPI_ACCUM 5           /* D += acc   (gradient accumulation)                       */
+#define SEI_EPI_BIAS_ROWSCALE 6   /* D = acc + bias[n]*R1[m]                                  */
+int sei_gemm_f32(const float *A, const float *B, float *D, int M, int N, int K, int transA,
+                 int transB, int epilogue, const float *bias, const float *R1, const float *R2,
+                 float *D2, void *stream);
+int sei_gemm_f32_ex(const float *A, const float *B, float *D, int M, int N, int K, int transA,
+                    int transB, int epilogue, const float *bias, const float *R1, const float *R2,
+                    float *D2, int batch, long long strideA, long long strideB, long long strideD,
+                    int allow_splitk, void *stream);
+
+int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                const float *L1, const float *R1, const float *L2, const float *R2, float *work,
+                size_t work_floats, void *stream);
+
+int sei_colsum_f32(const float *X, float *out, size_t M, int N, void *stream);
+
+int sei_adam_fused(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   float grad_scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEI_HIP_H */

@@ -1,0 +1,107 @@
+"""ctypes binding of libsei_hip.so (C ABI declared in include/sei_hip.h).
+
+This is the only place the Python host layer touches native code. There is NO fallback: if the
+library is missing, or a tensor is not a contiguous float32 tensor on an AMD GPU, the call raises.
+PyTorch is used for device memory and streams only: every call passes raw device pointers and the
+current HIP stream, so the launches are captured by `torch.cuda.graph` like any other kernel.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsei_hip.so")
+
+SEI_REDUCE_BLOCKS = 256
+
+_c = ctypes
+_P, _I, _F, _Z, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_longlong
+
+# name -> argument ctypes (all return int). Kept in the order of include/sei_hip.h;
+# tests/test_abi.py checks this table against the header and against the built library.
+SIGNATURES = {
+    "sei_abi_version": [],
+    "sei_build_target": [_c.c_char_p, _I],
+    "sei_blur_sep_circ": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sei_blur_dense_circ": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sei_resample_sepband": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+    "sei_scale_resample_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sei_scale_resample_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sei_axpy": [_P, _P, _F, _P, _Z, _P],
+    "sei_sure_terms": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
+    "sei_mse_terms": [_P, _P, _Z, _F, _P, _P, _P, _P],
+    "sei_conv3x3_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "sei_conv3x3_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "sei_dwconv7_fwd": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
+    "sei_dwconv7_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sei_ln_fwd": [_P, _P, _P, _P, _P, _P, _Z, _I, _F, _P],
+    "sei_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P],
+    "sei_gemm_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "sei_gemm_f32_ex": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _L, _L, _L, _I, _P],
+    "sei_sepmap2": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P],
+    "sei_colsum_f32": [_P, _P, _Z, _I, _P],
+    "sei_adam_fused": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P],
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises NativeLibraryError (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name, None)
+            if fn is None:
+                continue            # reported by tests/test_abi.py; a call would raise AttributeError
+            fn.argtypes = argtypes
+            fn.restype = _I
+        if handle.sei_abi_version() != 1:
+            raise NativeLibraryError("libsei_hip.so was built from a different include/sei_hip.h")
+        _lib = handle
+    return _lib
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check_tensor(t, name="tensor", dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise NativeLibraryError(
+            f"{name} is on {t.device}: this build runs on MI355X only (HIP kernels, no CPU path); "
+            "use the CPU oracle under oracle/ for host-side checks")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def call(name, *args):
+    """Invoke an entry point with the current stream appended; raise on a non-zero status."""
+    rc = getattr(lib(), name)(*args, stream())
+    if rc != 0:
+        if rc == 10001:
+            what = "SEI_ERR_BAD_ARG"
+        elif rc == 10002:
+            what = "SEI_ERR_TOO_LARGE"
+        else:
+            what = f"hipError_t {rc}"
+        raise NativeLibraryError(f"{name} failed: {what}")

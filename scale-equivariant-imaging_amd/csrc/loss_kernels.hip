@@ -1,0 +1,137 @@
+// Loss-side streaming kernels for gfx950: axpy (noise / SURE probe), fused SURE terms + gradients,
+// fused MSE + gradient. HBM-bound; reductions are two-stage (per-block partials in a caller-provided
+// workspace, then one finishing block) so results are bitwise reproducible run to run (no float atomics).
+//
+//   sei_axpy       : y + sigma*n (deepinv GaussianNoise), y + tau*b (losses/sure.py:24)
+//   sei_sure_terms : losses/sure.py:24-31 (mc_div) and :57-62 (cropped mse) + d/dy1, d/dy2
+//   sei_mse_terms  : deepinv `mse` metric inside EILoss (losses/__init__.py:117-122) + d/dx3
+#include "sei_common.h"
+
+namespace {
+
+constexpr int RED_THREADS = 256;
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                   float alpha, float *__restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n / 4;
+    const float4 *a4 = reinterpret_cast<const float4 *>(a);
+    const float4 *b4 = reinterpret_cast<const float4 *>(b);
+    float4 *o4 = reinterpret_cast<float4 *>(out);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 va = a4[i], vb = b4[i];
+        o4[i] = make_float4(fmaf(alpha, vb.x, va.x), fmaf(alpha, vb.y, va.y), fmaf(alpha, vb.z, va.z),
+                            fmaf(alpha, vb.w, va.w));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = fmaf(alpha, b[i], a[i]);
+}
+
+// stage 1: per-block partial sums of the two SURE terms + elementwise gradients
+__global__ __launch_bounds__(RED_THREADS) void sure_terms_kernel(
+    const float *__restrict__ y, const float *__restrict__ y1, const float *__restrict__ y2,
+    const float *__restrict__ b, size_t total, int H, int W, int md, int mm, float inv_tau, float c_mse,
+    float c_div, float *__restrict__ g1, float *__restrict__ g2, float *__restrict__ work) {
+    __shared__ float scratch[RED_THREADS / 64];
+    float s_div = 0.f, s_mse = 0.f;
+    const size_t stride = (size_t)gridDim.x * RED_THREADS;
+    for (size_t i = (size_t)blockIdx.x * RED_THREADS + threadIdx.x; i < total; i += stride) {
+        const int p = (int)(i % ((size_t)H * W));
+        const int r = p / W, c = p - r * W;
+        const bool in_d = r >= md && r < H - md && c >= md && c < W - md;
+        const bool in_m = r >= mm && r < H - mm && c >= mm && c < W - mm;
+        const float v1 = y1[i];
+        float ga = 0.f, gb = 0.f;
+        if (in_d) {
+            const float bb = b[i];
+            s_div += bb * (y2[i] - v1) * inv_tau;
+            gb = c_div * bb * inv_tau;
+            ga = -gb;
+        }
+        if (in_m) {
+            const float d = v1 - y[i];
+            s_mse = fmaf(d, d, s_mse);
+            ga = fmaf(2.f * c_mse, d, ga);
+        }
+        g1[i] = ga;
+        g2[i] = gb;
+    }
+    const float bd = sei_block_sum<RED_THREADS>(s_div, scratch);
+    const float bm = sei_block_sum<RED_THREADS>(s_mse, scratch);
+    if (threadIdx.x == 0) {
+        work[blockIdx.x] = bd;
+        work[SEI_REDUCE_BLOCKS + blockIdx.x] = bm;
+    }
+}
+
+__global__ __launch_bounds__(RED_THREADS) void mse_terms_kernel(const float *__restrict__ a,
+                                                                const float *__restrict__ b, size_t n,
+                                                                float scale, float *__restrict__ ga,
+                                                                float *__restrict__ work) {
+    __shared__ float scratch[RED_THREADS / 64];
+    float s = 0.f;
+    const size_t stride = (size_t)gridDim.x * RED_THREADS;
+    for (size_t i = (size_t)blockIdx.x * RED_THREADS + threadIdx.x; i < n; i += stride) {
+        const float d = a[i] - b[i];
+        s = fmaf(d, d, s);
+        ga[i] = scale * d;
+    }
+    const float bs = sei_block_sum<RED_THREADS>(s, scratch);
+    if (threadIdx.x == 0) work[blockIdx.x] = bs;
+}
+
+// stage 2: one block sums `nparts` partials of each of `nout` quantities (stored SEI_REDUCE_BLOCKS apart)
+__global__ __launch_bounds__(RED_THREADS) void finish_sums_kernel(const float *__restrict__ work, int nparts,
+                                                                  int nout, float *__restrict__ out) {
+    __shared__ float scratch[RED_THREADS / 64];
+    for (int q = 0; q < nout; ++q) {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += RED_THREADS) v += work[q * SEI_REDUCE_BLOCKS + i];
+        const float s = sei_block_sum<RED_THREADS>(v, scratch);
+        if (threadIdx.x == 0) out[q] = s;
+    }
+}
+
+inline int reduce_blocks(size_t n) {
+    size_t g = sei_ceil_div(n, (size_t)RED_THREADS * 4);
+    if (g < 1) g = 1;
+    if (g > SEI_REDUCE_BLOCKS) g = SEI_REDUCE_BLOCKS;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int sei_axpy(const float *a, const float *b, float alpha, float *out, size_t n, void *stream) {
+    SEI_REQUIRE(a && b && out && n > 0);
+    SEI_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0);
+    size_t grid = sei_ceil_div(n / 4 + 1, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, b, alpha, out, n);
+    return sei_launch_status();
+}
+
+extern "C" int sei_sure_terms(const float *y, const float *y1, const float *y2, const float *b, int planes,
+                              int H, int W, int margin_div, int margin_mse, float tau, float c_mse,
+                              float c_div, float *out2, float *g1, float *g2, float *work, void *stream) {
+    SEI_REQUIRE(y && y1 && y2 && b && out2 && g1 && g2 && work);
+    SEI_REQUIRE(planes > 0 && H > 0 && W > 0 && margin_div >= 0 && margin_mse >= 0 && tau != 0.f);
+    SEI_REQUIRE(2 * margin_div < H && 2 * margin_div < W && 2 * margin_mse < H && 2 * margin_mse < W);
+    const size_t total = (size_t)planes * H * W;
+    const int grid = reduce_blocks(total);
+    hipLaunchKernelGGL(sure_terms_kernel, dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, y, y1, y2, b,
+                       total, H, W, margin_div, margin_mse, 1.0f / tau, c_mse, c_div, g1, g2, work);
+    hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(RED_THREADS), 0, (hipStream_t)stream,
+                       (const float *)work, grid, 2, out2);
+    return sei_launch_status();
+}
+
+extern "C" int sei_mse_terms(const float *a, const float *b, size_t n, float scale, float *out1, float *ga,
+                             float *work, void *stream) {
+    SEI_REQUIRE(a && b && out1 && ga && work && n > 0);
+    const int grid = reduce_blocks(n);
+    hipLaunchKernelGGL(mse_terms_kernel, dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, n, scale,
+                       ga, work);
+    hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(RED_THREADS), 0, (hipStream_t)stream,
+                       (const float *)work, grid, 1, out1);
+    return sei_launch_status();
+}

@@ -1,0 +1,55 @@
+// Shared device/host helpers for libsei_hip.so (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sei_hip.h"
+
+#define SEI_WAVE 64
+
+#define SEI_REQUIRE(cond) \
+    do {                  \
+        if (!(cond)) return SEI_ERR_BAD_ARG; \
+    } while (0)
+
+static inline int sei_launch_status() { return (int)hipGetLastError(); }
+
+static inline size_t sei_ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ int sei_mod(int v, int n) {
+    int r = v % n;
+    return r < 0 ? r + n : r;
+}
+
+__device__ __forceinline__ float sei_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over the whole block (THREADS a multiple of 64, <= 1024); result valid in thread 0.
+// `scratch` must hold THREADS/64 floats of LDS.
+template <int THREADS>
+__device__ __forceinline__ float sei_block_sum(float v, float *scratch) {
+    v = sei_wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (wave == 0) {
+        r = (lane < THREADS / 64) ? scratch[lane] : 0.f;
+        r = sei_wave_sum(r);
+    }
+    __syncthreads();
+    return r;
+}
+
+// exact (erf) GELU and its derivative, as torch.nn.GELU() (approximate='none')
+__device__ __forceinline__ float sei_gelu(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float sei_dgelu(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

@@ -1,0 +1,718 @@
+// U-Net streaming kernels for gfx950 (reference: src/models/convolutional.py), NHWC float32.
+//
+//   sei_dwconv7_fwd / _bwd_weight : ConvBlock.conv1, depthwise 7x7, zero pad 3            (:36-38,46)
+//   sei_ln_fwd / sei_ln_bwd       : LayerNorm over channels, eps 1e-6, biased variance     (:21-30)
+//   sei_conv3x3_fwd / _bwd_weight : UNet.in_conv / out_conv, 3x3 'same'                    (:174-176)
+//   sei_sepmap2                   : IdealDownsample / IdealUpsample as L1 X R1^T + L2 X R2^T (:54-133)
+//   sei_colsum_f32                : bias gradients of the 1x1 convolutions
+//   sei_adam_fused                : torch.optim.Adam step on a flat bucket (demo/train.py:157-186)
+//
+// All are HBM-bound streaming kernels: channels are the contiguous axis, so lanes map to channels and
+// every global access is a coalesced 256-B wave row. Small parameter gradients are accumulated with
+// float atomics after an in-block LDS reduction (gradients are accumulators by contract).
+#include "sei_common.h"
+
+namespace {
+
+// =================================================================================================
+// depthwise 7x7
+// =================================================================================================
+constexpr int DW_THREADS = 256;
+constexpr int DW_SEG = 16;      // output columns per worker segment
+
+// One thread = one channel; a "worker" (Cc consecutive threads) walks a segment of one output row with
+// a 7x7 register window that slides by one column per step (7 new loads + 49 FMA per output).
+template <bool WEIGHT_GRAD>
+__global__ __launch_bounds__(DW_THREADS) void dwconv7_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    const float *__restrict__ res, float res_scale, float *__restrict__ y, const float *__restrict__ gy,
+    float *__restrict__ gw, float *__restrict__ gbias, int B, int H, int W, int C, int flip, int Cc, int nseg,
+    int total_rowsegs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int workers = DW_THREADS / Cc;
+    const int cl = threadIdx.x % Cc, worker = threadIdx.x / Cc;
+    const int c = blockIdx.y * Cc + cl;
+    const bool c_ok = c < C;
+
+    float wr[49];
+    float acc_w[49];
+    float acc_b = 0.f;
+    if (!WEIGHT_GRAD) {
+#pragma unroll
+        for (int t = 0; t < 49; ++t) wr[t] = c_ok ? w[(size_t)c * 49 + (flip ? 48 - t : t)] : 0.f;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 49; ++t) acc_w[t] = 0.f;
+    }
+    const float bv = (!WEIGHT_GRAD && bias && c_ok) ? bias[c] : 0.f;
+
+    for (int rs = blockIdx.x * workers + worker; rs < total_rowsegs; rs += gridDim.x * workers) {
+        if (!c_ok) continue;
+        const int seg = rs % nseg;
+        const int bi = rs / nseg;
+        const int i = bi % H, b = bi / H;
+        const int j0 = seg * DW_SEG, j1 = min(W, j0 + DW_SEG);
+        const float *xb = x + (size_t)b * H * W * C + c;
+        float win[7][7];   // win[di][slot]
+        // preload input columns j0-3 .. j0+2 into slots 0..5
+#pragma unroll
+        for (int dj = 0; dj < 6; ++dj) {
+            const int jj = j0 - 3 + dj;
+#pragma unroll
+            for (int di = 0; di < 7; ++di) {
+                const int ii = i - 3 + di;
+                win[di][dj] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? xb[((size_t)ii * W + jj) * C] : 0.f;
+            }
+        }
+        for (int jb = j0; jb < j1; jb += 7) {
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                const int j = jb + s;
+                if (j < j1) {
+                    const int jj = j + 3;
+#pragma unroll
+                    for (int di = 0; di < 7; ++di) {
+                        const int ii = i - 3 + di;
+                        win[di][(s + 6) % 7] =
+                            (ii >= 0 && ii < H && jj < W) ? xb[((size_t)ii * W + jj) * C] : 0.f;
+                    }
+                    const size_t o = (((size_t)b * H + i) * W + j) * C + c;
+                    if (!WEIGHT_GRAD) {
+                        float a = bv;
+#pragma unroll
+                        for (int di = 0; di < 7; ++di)
+#pragma unroll
+                            for (int dj = 0; dj < 7; ++dj) a = fmaf(wr[di * 7 + dj], win[di][(s + dj) % 7], a);
+                        if (res) a = fmaf(res_scale, res[o], a);
+                        y[o] = a;
+                    } else {
+                        const float g = gy[o];
+                        acc_b += g;
+#pragma unroll
+                        for (int di = 0; di < 7; ++di)
+#pragma unroll
+                            for (int dj = 0; dj < 7; ++dj)
+                                acc_w[di * 7 + dj] = fmaf(g, win[di][(s + dj) % 7], acc_w[di * 7 + dj]);
+                    }
+                }
+            }
+        }
+    }
+    if (WEIGHT_GRAD) {
+        // reduce the workers of this block through LDS, then one atomic per (channel, tap) per block
+        float *red = smem;   // [worker][50][Cc]
+#pragma unroll
+        for (int t = 0; t < 49; ++t) red[(worker * 50 + t) * Cc + cl] = acc_w[t];
+        red[(worker * 50 + 49) * Cc + cl] = acc_b;
+        __syncthreads();
+        for (int e = threadIdx.x; e < 50 * Cc; e += DW_THREADS) {
+            const int t = e / Cc, c2 = e % Cc;
+            const int cg = blockIdx.y * Cc + c2;
+            if (cg >= C) continue;
+            float s = 0.f;
+            for (int wk = 0; wk < workers; ++wk) s += red[(wk * 50 + t) * Cc + c2];
+            if (t < 49) atomicAdd(gw + (size_t)cg * 49 + t, s);
+            else if (gbias) atomicAdd(gbias + cg, s);
+        }
+    }
+}
+
+// =================================================================================================
+// LayerNorm over the channel (contiguous) axis
+// =================================================================================================
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+constexpr int LN_THREADS = 256;
+constexpr int LN_EPL = 8;   // max elements per lane in the group kernels (C <= G*LN_EPL)
+
+// G lanes per row, C <= 8*G. Row data lives in registers (one HBM read), statistics by shuffles.
+template <int G>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_group_kernel(
+    const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float *__restrict__ y, float *__restrict__ mean, float *__restrict__ rstd, size_t rows, int C, float eps) {
+    const int lg = threadIdx.x % G, rsub = threadIdx.x / G;
+    constexpr int RPB = LN_THREADS / G;
+    const float invC = 1.0f / (float)C;
+    for (size_t row = (size_t)blockIdx.x * RPB + rsub; row < rows; row += (size_t)gridDim.x * RPB) {
+        const float *xr = x + row * C;
+        float v[LN_EPL];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < LN_EPL; ++e) {
+            const int c = lg + e * G;
+            v[e] = c < C ? xr[c] : 0.f;
+            s += v[e];
+        }
+        const float mu = group_sum<G>(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < LN_EPL; ++e) {
+            const int c = lg + e * G;
+            const float d = c < C ? v[e] - mu : 0.f;
+            q = fmaf(d, d, q);
+        }
+        const float rs = 1.0f / sqrtf(group_sum<G>(q) * invC + eps);
+        float *yr = y + row * C;
+#pragma unroll
+        for (int e = 0; e < LN_EPL; ++e) {
+            const int c = lg + e * G;
+            if (c < C) yr[c] = fmaf((v[e] - mu) * rs, gamma[c], beta[c]);
+        }
+        if (lg == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+// One workgroup per row for wide rows: element c = tid + k*256, up to LN_WIDE_EPT per thread.
+constexpr int LN_WIDE_EPT = 32;   // C <= 8192
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_wide_kernel(
+    const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float *__restrict__ y, float *__restrict__ mean, float *__restrict__ rstd, size_t rows, int C, float eps) {
+    __shared__ float scratch[LN_THREADS / 64];
+    __shared__ float bc[2];
+    const float invC = 1.0f / (float)C;
+    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float *xr = x + row * C;
+        float v[LN_WIDE_EPT];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < LN_WIDE_EPT; ++e) {
+            const int c = threadIdx.x + e * LN_THREADS;
+            v[e] = c < C ? xr[c] : 0.f;
+            s += v[e];
+        }
+        s = sei_block_sum<LN_THREADS>(s, scratch);
+        if (threadIdx.x == 0) bc[0] = s * invC;
+        __syncthreads();
+        const float mu = bc[0];
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < LN_WIDE_EPT; ++e) {
+            const int c = threadIdx.x + e * LN_THREADS;
+            const float d = c < C ? v[e] - mu : 0.f;
+            q = fmaf(d, d, q);
+        }
+        q = sei_block_sum<LN_THREADS>(q, scratch);
+        if (threadIdx.x == 0) bc[1] = 1.0f / sqrtf(q * invC + eps);
+        __syncthreads();
+        const float rs = bc[1];
+        float *yr = y + row * C;
+#pragma unroll
+        for (int e = 0; e < LN_WIDE_EPT; ++e) {
+            const int c = threadIdx.x + e * LN_THREADS;
+            if (c < C) yr[c] = fmaf((v[e] - mu) * rs, gamma[c], beta[c]);
+        }
+        if (threadIdx.x == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+        __syncthreads();
+    }
+}
+
+// backward: gx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = gy*gamma;
+//           ggamma[c] += sum_rows gy*xhat; gbeta[c] += sum_rows gy.
+template <int G>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_group_kernel(
+    const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gy, float *__restrict__ gx,
+    float *__restrict__ ggamma, float *__restrict__ gbeta, size_t rows, int C) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][C]
+    const int lg = threadIdx.x % G, rsub = threadIdx.x / G;
+    constexpr int RPB = LN_THREADS / G;
+    for (int e = threadIdx.x; e < 2 * C; e += LN_THREADS) smem[e] = 0.f;
+    __syncthreads();
+    const float invC = 1.0f / (float)C;
+    float gam[LN_EPL], dg[LN_EPL], db[LN_EPL];
+#pragma unroll
+    for (int e = 0; e < LN_EPL; ++e) {
+        const int c = lg + e * G;
+        gam[e] = c < C ? gamma[c] : 0.f;
+        dg[e] = 0.f;
+        db[e] = 0.f;
+    }
+    for (size_t row = (size_t)blockIdx.x * RPB + rsub; row < rows; row += (size_t)gridDim.x * RPB) {
+        const float mu = mean[row], rs = rstd[row];
+        const float *xr = x + row * C, *gr = gy + row * C;
+        float xh[LN_EPL], g[LN_EPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < LN_EPL; ++e) {
+            const int c = lg + e * G;
+            const float gyv = c < C ? gr[c] : 0.f;
+            xh[e] = c < C ? (xr[c] - mu) * rs : 0.f;
+            g[e] = gyv * gam[e];
+            s1 += g[e];
+            s2 = fmaf(g[e], xh[e], s2);
+            dg[e] = fmaf(gyv, xh[e], dg[e]);
+            db[e] += gyv;
+        }
+        s1 = group_sum<G>(s1) * invC;
+        s2 = group_sum<G>(s2) * invC;
+        float *gxr = gx + row * C;
+#pragma unroll
+        for (int e = 0; e < LN_EPL; ++e) {
+            const int c = lg + e * G;
+            if (c < C) gxr[c] = rs * (g[e] - s1 - xh[e] * s2);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < LN_EPL; ++e) {
+        const int c = lg + e * G;
+        if (c < C) {
+            atomicAdd(&smem[c], dg[e]);
+            atomicAdd(&smem[C + c], db[e]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += LN_THREADS) {
+        atomicAdd(ggamma + c, smem[c]);
+        atomicAdd(gbeta + c, smem[C + c]);
+    }
+}
+
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_wide_kernel(
+    const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gy, float *__restrict__ gx,
+    float *__restrict__ ggamma, float *__restrict__ gbeta, size_t rows, int C) {
+    __shared__ float scratch[LN_THREADS / 64];
+    __shared__ float bc[2];
+    const float invC = 1.0f / (float)C;
+    float gam[LN_WIDE_EPT], dg[LN_WIDE_EPT], db[LN_WIDE_EPT];
+#pragma unroll
+    for (int e = 0; e < LN_WIDE_EPT; ++e) {
+        const int c = threadIdx.x + e * LN_THREADS;
+        gam[e] = c < C ? gamma[c] : 0.f;
+        dg[e] = 0.f;
+        db[e] = 0.f;
+    }
+    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float mu = mean[row], rs = rstd[row];
+        const float *xr = x + row * C, *gr = gy + row * C;
+        float xh[LN_WIDE_EPT], g[LN_WIDE_EPT];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < LN_WIDE_EPT; ++e) {
+            const int c = threadIdx.x + e * LN_THREADS;
+            const float gyv = c < C ? gr[c] : 0.f;
+            xh[e] = c < C ? (xr[c] - mu) * rs : 0.f;
+            g[e] = gyv * gam[e];
+            s1 += g[e];
+            s2 = fmaf(g[e], xh[e], s2);
+            dg[e] = fmaf(gyv, xh[e], dg[e]);
+            db[e] += gyv;
+        }
+        s1 = sei_block_sum<LN_THREADS>(s1, scratch);
+        s2 = sei_block_sum<LN_THREADS>(s2, scratch);
+        if (threadIdx.x == 0) {
+            bc[0] = s1 * invC;
+            bc[1] = s2 * invC;
+        }
+        __syncthreads();
+        const float m1 = bc[0], m2 = bc[1];
+        float *gxr = gx + row * C;
+#pragma unroll
+        for (int e = 0; e < LN_WIDE_EPT; ++e) {
+            const int c = threadIdx.x + e * LN_THREADS;
+            if (c < C) gxr[c] = rs * (g[e] - m1 - xh[e] * m2);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < LN_WIDE_EPT; ++e) {
+        const int c = threadIdx.x + e * LN_THREADS;
+        if (c < C) {
+            atomicAdd(ggamma + c, dg[e]);
+            atomicAdd(gbeta + c, db[e]);
+        }
+    }
+}
+
+// =================================================================================================
+// 3x3 convolution with small channel counts (in_conv 3->hidden, out_conv hidden->3)
+// =================================================================================================
+constexpr int C3_THREADS = 256;
+
+__device__ __forceinline__ size_t img_index(int nchw, int b, int c, int i, int j, int C, int H, int W) {
+    return nchw ? (((size_t)b * C + c) * H + i) * W + j : (((size_t)b * H + i) * W + j) * C + c;
+}
+
+// y[p, co] = bias[co] + sum_{ci,ky,kx} wq(co,ci,ky,kx) * x[p + (ky-1, kx-1), ci]  (+ res[p, co])
+// transposed=0: wq = w[co][ci][ky][kx]                    (forward)
+// transposed=1: wq = w[ci][co][2-ky][2-kx], w is (Cin_of_fwd=Cout here ... ) i.e. the data gradient:
+//               the caller passes Cin = forward Cout and Cout = forward Cin.
+__global__ __launch_bounds__(C3_THREADS) void conv3x3_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    const float *__restrict__ res, float *__restrict__ y, int B, int H, int W, int Cin, int Cout,
+    int nchw_in, int nchw_out, int transposed) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];   // [ci][tap][co]
+    const int nw = Cin * Cout * 9;
+    for (int e = threadIdx.x; e < nw; e += C3_THREADS) {
+        const int co = e % Cout, t = (e / Cout) % 9, ci = e / (Cout * 9);
+        const int ky = t / 3, kx = t % 3;
+        sw[e] = transposed ? w[(((size_t)ci * Cout + co) * 3 + (2 - ky)) * 3 + (2 - kx)]
+                           : w[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx];
+    }
+    __syncthreads();
+    const size_t total = (size_t)B * H * W * Cout;
+    for (size_t idx = (size_t)blockIdx.x * C3_THREADS + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * C3_THREADS) {
+        // thread order follows the OUTPUT layout so stores coalesce
+        int b, i, j, co;
+        if (nchw_out) {
+            j = (int)(idx % W); i = (int)((idx / W) % H); co = (int)((idx / ((size_t)W * H)) % Cout);
+            b = (int)(idx / ((size_t)W * H * Cout));
+        } else {
+            co = (int)(idx % Cout); j = (int)((idx / Cout) % W); i = (int)((idx / ((size_t)Cout * W)) % H);
+            b = (int)(idx / ((size_t)Cout * W * H));
+        }
+        float a = bias ? bias[co] : 0.f;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ii = i + ky - 1;
+            if (ii < 0 || ii >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int jj = j + kx - 1;
+                if (jj < 0 || jj >= W) continue;
+                const int t = ky * 3 + kx;
+                for (int ci = 0; ci < Cin; ++ci)
+                    a = fmaf(sw[(ci * 9 + t) * Cout + co], x[img_index(nchw_in, b, ci, ii, jj, Cin, H, W)], a);
+            }
+        }
+        const size_t o = img_index(nchw_out, b, co, i, j, Cout, H, W);
+        if (res) a += res[o];
+        y[o] = a;
+    }
+}
+
+// gw[co][ci][ky][kx] += sum_p gy[p,co] * x[p + (ky-1,kx-1), ci];  gb[co] += sum_p gy[p,co]
+// Each thread owns a set of (co,ci,tap) outputs and walks this block's pixel range.
+__global__ __launch_bounds__(C3_THREADS) void conv3x3_bwd_weight_kernel(
+    const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gw,
+    float *__restrict__ gb, int B, int H, int W, int Cin, int Cout, int nchw_x, int nchw_gy,
+    int pix_per_block) {
+    const size_t npix = (size_t)B * H * W;
+    const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+    const size_t p1 = min(npix, p0 + pix_per_block);
+    const int nw = Cin * Cout * 9;
+    for (int e = threadIdx.x; e < nw + Cout; e += C3_THREADS) {
+        float acc = 0.f;
+        if (e < nw) {
+            const int kx = e % 3, ky = (e / 3) % 3, ci = (e / 9) % Cin, co = e / (9 * Cin);
+            for (size_t p = p0; p < p1; ++p) {
+                const int j = (int)(p % W), i = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+                const int ii = i + ky - 1, jj = j + kx - 1;
+                if (ii < 0 || ii >= H || jj < 0 || jj >= W) continue;
+                acc = fmaf(gy[img_index(nchw_gy, b, co, i, j, Cout, H, W)],
+                           x[img_index(nchw_x, b, ci, ii, jj, Cin, H, W)], acc);
+            }
+            atomicAdd(gw + e, acc);
+        } else if (gb) {
+            const int co = e - nw;
+            for (size_t p = p0; p < p1; ++p) {
+                const int j = (int)(p % W), i = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+                acc += gy[img_index(nchw_gy, b, co, i, j, Cout, H, W)];
+            }
+            atomicAdd(gb + co, acc);
+        }
+    }
+}
+
+// =================================================================================================
+// separable rank-2 spatial map, NHWC:  y[b,i',j',c] = sum_t sum_i L_t[i',i] sum_j R_t[j',j] x[b,i,j,c]
+// pass W: T[b][t][i][j'][c] = sum_j R_t[j',j] x[b,i,j,c]      (workspace, 2*B*Hi*Wo*C floats)
+// pass H: y[b,i',j',c]      = sum_t sum_i L_t[i',i] T[b][t][i][j'][c]
+// =================================================================================================
+constexpr int SM_THREADS = 256;
+
+__global__ __launch_bounds__(SM_THREADS) void sepmap_w_kernel(const float *__restrict__ x, float *__restrict__ T,
+                                                              const float *__restrict__ R1,
+                                                              const float *__restrict__ R2, int B, int Hi,
+                                                              int Wi, int Wo, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sR[];   // R1 | R2, each Wo*Wi
+    for (int e = threadIdx.x; e < Wo * Wi; e += SM_THREADS) {
+        sR[e] = R1[e];
+        sR[Wo * Wi + e] = R2[e];
+    }
+    __syncthreads();
+    const size_t total = (size_t)B * Hi * Wo * C;
+    for (size_t idx = (size_t)blockIdx.x * SM_THREADS + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * SM_THREADS) {
+        const int c = (int)(idx % C);
+        const int jo = (int)((idx / C) % Wo);
+        const int i = (int)((idx / ((size_t)C * Wo)) % Hi);
+        const int b = (int)(idx / ((size_t)C * Wo * Hi));
+        const float *xr = x + (((size_t)b * Hi + i) * Wi) * C + c;
+        const float *r1 = sR + jo * Wi, *r2 = sR + Wo * Wi + jo * Wi;
+        float a1 = 0.f, a2 = 0.f;
+        for (int j = 0; j < Wi; ++j) {
+            const float v = xr[(size_t)j * C];
+            a1 = fmaf(r1[j], v, a1);
+            a2 = fmaf(r2[j], v, a2);
+        }
+        const size_t plane = (size_t)Hi * Wo * C;
+        const size_t o = ((size_t)b * 2) * plane + ((size_t)i * Wo + jo) * C + c;
+        T[o] = a1;
+        T[o + plane] = a2;
+    }
+}
+
+__global__ __launch_bounds__(SM_THREADS) void sepmap_h_kernel(const float *__restrict__ T, float *__restrict__ y,
+                                                              const float *__restrict__ L1,
+                                                              const float *__restrict__ L2, int B, int Hi,
+                                                              int Ho, int Wo, int C) {
+    extern __shared__ __attribute__((aligned(16))) float sL[];   // L1 | L2, each Ho*Hi
+    for (int e = threadIdx.x; e < Ho * Hi; e += SM_THREADS) {
+        sL[e] = L1[e];
+        sL[Ho * Hi + e] = L2[e];
+    }
+    __syncthreads();
+    const size_t total = (size_t)B * Ho * Wo * C;
+    const size_t row = (size_t)Wo * C, plane = (size_t)Hi * row;
+    for (size_t idx = (size_t)blockIdx.x * SM_THREADS + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * SM_THREADS) {
+        const size_t jc = idx % row;
+        const int io = (int)((idx / row) % Ho);
+        const int b = (int)(idx / (row * Ho));
+        const float *t1 = T + ((size_t)b * 2) * plane + jc, *t2 = t1 + plane;
+        const float *l1 = sL + io * Hi, *l2 = sL + Ho * Hi + io * Hi;
+        float a = 0.f;
+        for (int i = 0; i < Hi; ++i) {
+            a = fmaf(l1[i], t1[(size_t)i * row], a);
+            a = fmaf(l2[i], t2[(size_t)i * row], a);
+        }
+        y[idx] = a;
+    }
+}
+
+// =================================================================================================
+// column sums and Adam
+// =================================================================================================
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, float *__restrict__ out,
+                                                     size_t M, int N, size_t rows_per_block) {
+    // threads tile columns; each block owns a row range; in-block reduce over the row sub-groups via LDS
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [rsubs][cw]
+    const int cw = min(N, 256);
+    const int rsubs = 256 / cw;
+    const int cl = threadIdx.x % cw, rsub = threadIdx.x / cw;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int cb = 0; cb < N; cb += cw) {
+        const int c = cb + cl;
+        float s = 0.f;
+        if (c < N && rsub < rsubs)
+            for (size_t r = r0 + rsub; r < r1; r += rsubs) s += X[r * N + c];
+        if (rsub < rsubs) red[rsub * cw + cl] = s;
+        __syncthreads();
+        if (rsub == 0 && c < N) {
+            float t = 0.f;
+            for (int k = 0; k < rsubs; ++k) t += red[k * cw + cl];
+            atomicAdd(out + c, t);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v, size_t n,
+                                                   float beta1, float beta2, float eps, float wd,
+                                                   float step_size, float inv_bc2_sqrt, float gscale) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        // torch.optim.Adam (single-tensor form): lerp for exp_avg, addcmul for exp_avg_sq
+        const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+        const float vi = fmaf(beta2, v[i], (1.f - beta2) * gi * gi);
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+inline unsigned capped_grid(size_t work_items, int per_block, unsigned cap) {
+    size_t g = sei_ceil_div(work_items, (size_t)per_block);
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+extern "C" int sei_dwconv7_fwd(const float *x, const float *w, const float *bias, const float *res,
+                               float res_scale, float *y, int B, int H, int W, int C, int flip, void *stream) {
+    SEI_REQUIRE(x && w && y && x != y && B > 0 && H > 0 && W > 0 && C > 0);
+    const int Cc = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
+    const int workers = DW_THREADS / Cc;
+    const int nseg = (int)sei_ceil_div(W, DW_SEG);
+    const size_t total = (size_t)B * H * nseg;
+    SEI_REQUIRE(total < (size_t)1 << 31);
+    dim3 grid(capped_grid(total, workers, 65535), (unsigned)sei_ceil_div(C, Cc));
+    hipLaunchKernelGGL(dwconv7_kernel<false>, grid, dim3(DW_THREADS), 0, (hipStream_t)stream, x, w, bias, res,
+                       res_scale, y, (const float *)nullptr, (float *)nullptr, (float *)nullptr, B, H, W, C,
+                       flip ? 1 : 0, Cc, nseg, (int)total);
+    return sei_launch_status();
+}
+
+extern "C" int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
+                                      int W, int C, void *stream) {
+    SEI_REQUIRE(x && gy && gw && B > 0 && H > 0 && W > 0 && C > 0);
+    const int Cc = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
+    const int workers = DW_THREADS / Cc;
+    const int nseg = (int)sei_ceil_div(W, DW_SEG);
+    const size_t total = (size_t)B * H * nseg;
+    SEI_REQUIRE(total < (size_t)1 << 31);
+    // each worker walks several row segments so that the atomics per (channel, tap) stay few
+    const unsigned chunks = (unsigned)sei_ceil_div(C, Cc);
+    unsigned gx = capped_grid(total, workers * 8, 65535);
+    const unsigned max_gx = 2048 / chunks > 0 ? 2048 / chunks : 1;
+    if (gx > max_gx) gx = max_gx;
+    const size_t lds = sizeof(float) * (size_t)workers * 50 * Cc;
+    hipLaunchKernelGGL(dwconv7_kernel<true>, dim3(gx, chunks), dim3(DW_THREADS), lds, (hipStream_t)stream, x,
+                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f,
+                       (float *)nullptr, gy, gw, gbias, B, H, W, C, 0, Cc, nseg, (int)total);
+    return sei_launch_status();
+}
+
+namespace {
+template <int G>
+int launch_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                  size_t rows, int C, float eps, hipStream_t s) {
+    const unsigned grid = capped_grid(rows, LN_THREADS / G, 4096);
+    hipLaunchKernelGGL(ln_fwd_group_kernel<G>, dim3(grid), dim3(LN_THREADS), 0, s, x, gamma, beta, y, mean, rstd,
+                       rows, C, eps);
+    return sei_launch_status();
+}
+template <int G>
+int launch_ln_bwd(const float *x, const float *gamma, const float *mean, const float *rstd, const float *gy,
+                  float *gx, float *ggamma, float *gbeta, size_t rows, int C, hipStream_t s) {
+    // few blocks, many rows each: keeps the global atomics per column low
+    const unsigned grid = capped_grid(rows, (LN_THREADS / G) * 4, 1024);
+    hipLaunchKernelGGL(ln_bwd_group_kernel<G>, dim3(grid), dim3(LN_THREADS), sizeof(float) * 2 * C, s, x, gamma,
+                       mean, rstd, gy, gx, ggamma, gbeta, rows, C);
+    return sei_launch_status();
+}
+inline int ln_group(int C) {
+    int g = 1;
+    while (g < 64 && g < C) g <<= 1;   // consecutive lanes = consecutive channels
+    return g;
+}
+}  // namespace
+
+extern "C" int sei_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+                          float *rstd, size_t rows, int C, float eps, void *stream) {
+    SEI_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0);
+    if (C > LN_WIDE_EPT * LN_THREADS) return SEI_ERR_TOO_LARGE;
+    hipStream_t s = (hipStream_t)stream;
+    if (C > 64 * LN_EPL) {
+        hipLaunchKernelGGL(ln_fwd_wide_kernel, dim3(capped_grid(rows, 1, 8192)), dim3(LN_THREADS), 0, s, x, gamma,
+                           beta, y, mean, rstd, rows, C, eps);
+        return sei_launch_status();
+    }
+    switch (ln_group(C)) {
+        case 1: return launch_ln_fwd<1>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        case 2: return launch_ln_fwd<2>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        case 4: return launch_ln_fwd<4>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        case 8: return launch_ln_fwd<8>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        case 16: return launch_ln_fwd<16>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        case 32: return launch_ln_fwd<32>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        default: return launch_ln_fwd<64>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+    }
+}
+
+extern "C" int sei_ln_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
+                          const float *gy, float *gx, float *ggamma, float *gbeta, size_t rows, int C,
+                          void *stream) {
+    SEI_REQUIRE(x && gamma && mean && rstd && gy && gx && ggamma && gbeta && rows > 0 && C > 0);
+    if (C > LN_WIDE_EPT * LN_THREADS) return SEI_ERR_TOO_LARGE;
+    hipStream_t s = (hipStream_t)stream;
+    if (C > 64 * LN_EPL) {
+        hipLaunchKernelGGL(ln_bwd_wide_kernel, dim3(capped_grid(rows, 2, 512)), dim3(LN_THREADS), 0, s, x, gamma,
+                           mean, rstd, gy, gx, ggamma, gbeta, rows, C);
+        return sei_launch_status();
+    }
+    switch (ln_group(C)) {
+        case 1: return launch_ln_bwd<1>(x, gamma, mean, rstd, gy, gx, ggamma, gbeta, rows, C, s);
+        case 2: return launch_ln_bwd<2>(x, gamma, mean, rstd, gy, gx, ggamma, gbeta, rows, C, s);
+        case 4: return launch_ln_bwd<4>(x, gamma, mean, rstd, gy, gx, ggamma, gbeta, rows, C, s);
+        case 8: return launch_ln_bwd<8>(x, gamma, mean, rstd, gy, gx, ggamma, gbeta, rows, C, s);
+        case 16: return launch_ln_bwd<16>(x, gamma, mean, rstd, gy, gx, ggamma, gbeta, rows, C, s);
+        case 32: return launch_ln_bwd<32>(x, gamma, mean, rstd, gy, gx, ggamma, gbeta, rows, C, s);
+        default: return launch_ln_bwd<64>(x, gamma, mean, rstd, gy, gx, ggamma, gbeta, rows, C, s);
+    }
+}
+
+extern "C" int sei_conv3x3_fwd(const float *x, const float *w, const float *bias, const float *res, float *y,
+                               int B, int H, int W, int Cin, int Cout, int nchw_in, int nchw_out,
+                               int transposed, void *stream) {
+    SEI_REQUIRE(x && w && y && x != y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+    const size_t lds = sizeof(float) * (size_t)Cin * Cout * 9;
+    if (lds > 64 * 1024) return SEI_ERR_TOO_LARGE;
+    const size_t total = (size_t)B * H * W * Cout;
+    hipLaunchKernelGGL(conv3x3_kernel, dim3(capped_grid(total, C3_THREADS, 4096)), dim3(C3_THREADS), lds,
+                       (hipStream_t)stream, x, w, bias, res, y, B, H, W, Cin, Cout, nchw_in ? 1 : 0,
+                       nchw_out ? 1 : 0, transposed ? 1 : 0);
+    return sei_launch_status();
+}
+
+extern "C" int sei_conv3x3_bwd_weight(const float *x, const float *gy, float *gw, float *gb, int B, int H,
+                                      int W, int Cin, int Cout, int nchw_x, int nchw_gy, void *stream) {
+    SEI_REQUIRE(x && gy && gw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+    const size_t npix = (size_t)B * H * W;
+    int ppb = 64;
+    while (sei_ceil_div(npix, ppb) > 2048) ppb *= 2;
+    hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3((unsigned)sei_ceil_div(npix, ppb)), dim3(C3_THREADS), 0,
+                       (hipStream_t)stream, x, gy, gw, gb, B, H, W, Cin, Cout, nchw_x ? 1 : 0, nchw_gy ? 1 : 0,
+                       ppb);
+    return sei_launch_status();
+}
+
+extern "C" int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                           const float *L1, const float *R1, const float *L2, const float *R2, float *work,
+                           size_t work_floats, void *stream) {
+    SEI_REQUIRE(x && y && L1 && R1 && L2 && R2 && work && x != y);
+    SEI_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0);
+    const size_t need = (size_t)2 * B * Hi * Wo * C;
+    SEI_REQUIRE(work_floats >= need);
+    const size_t lds_w = sizeof(float) * 2 * (size_t)Wo * Wi, lds_h = sizeof(float) * 2 * (size_t)Ho * Hi;
+    if (lds_w > 160 * 1024 || lds_h > 160 * 1024) return SEI_ERR_TOO_LARGE;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sepmap_w_kernel, dim3(capped_grid((size_t)B * Hi * Wo * C, SM_THREADS * 4, 4096)),
+                       dim3(SM_THREADS), lds_w, s, x, work, R1, R2, B, Hi, Wi, Wo, C);
+    hipLaunchKernelGGL(sepmap_h_kernel, dim3(capped_grid((size_t)B * Ho * Wo * C, SM_THREADS * 4, 4096)),
+                       dim3(SM_THREADS), lds_h, s, (const float *)work, y, L1, L2, B, Hi, Ho, Wo, C);
+    return sei_launch_status();
+}
+
+extern "C" int sei_colsum_f32(const float *X, float *out, size_t M, int N, void *stream) {
+    SEI_REQUIRE(X && out && M > 0 && N > 0);
+    size_t rpb = 64;
+    while (sei_ceil_div(M, rpb) > 1024) rpb *= 2;
+    const int cw = N < 256 ? N : 256;
+    const size_t lds = sizeof(float) * (size_t)(256 / cw) * cw;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sei_ceil_div(M, rpb)), dim3(256), lds, (hipStream_t)stream, X,
+                       out, M, N, rpb);
+    return sei_launch_status();
+}
+
+extern "C" int sei_adam_fused(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                              float grad_scale, void *stream) {
+    SEI_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    hipLaunchKernelGGL(adam_kernel, dim3(capped_grid(n, 256 * 4, 8192)), dim3(256), 0, (hipStream_t)stream, param,
+                       grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
+                       grad_scale);
+    return sei_launch_status();
+}

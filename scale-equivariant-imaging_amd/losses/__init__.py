@@ -1,0 +1,173 @@
+"""Training losses (reference call surface: src/losses/__init__.py).
+
+`get_loss(args, physics)` -> module with forward(x, y, model) -> 0-dim tensor. The hot path is
+method "proposed": crop the batch to 48x48 (Loss.forward), then SURE + scale-equivariant loss
+(ProposedLoss). `supervised`, `css`, `noise2inverse` and `sure` keep their surface (thin model(y) + one
+loss term); the R2R alternative and the Rotate/Shift transforms are outside this build's scope.
+
+One build-side optimisation, on by default and exactly equivalent per image: the two network passes
+that do not depend on each other -- model(y) and model(y + tau*b) -- run as ONE batch of 2B images
+(`fuse_passes`), doubling the row count of every weight-bandwidth-bound GEMM. `fuse_passes=False`
+(env SEI_NO_FUSED_PASSES=1) issues the reference's literal call sequence.
+"""
+from os import environ
+
+import torch
+from torch.nn import Module
+from torch.nn.functional import l1_loss
+
+from crop import CropPair
+from physics._ops import axpy
+from transforms import ScalingTransform
+from .ei import EILoss, SupLoss, mse
+from .sure import SureGaussianLoss, draw_probe
+
+
+class _ModelPlusOneLoss(Module):
+    """x_net = model(y); one deepinv-style loss term (reference :13-64)."""
+
+    def __init__(self, physics, loss):
+        super().__init__()
+        self.physics = physics
+        self.loss = loss
+
+    def forward(self, x, y, model):
+        x_net = model(y)
+        return self.loss(x=x, x_net=x_net, y=y, physics=self.physics, model=model)
+
+
+class SupervisedLoss(_ModelPlusOneLoss):
+    def __init__(self, physics):
+        metric = mse()
+        if "SUPERVISED_L1" in environ:
+            print("SUPERVISED_L1")
+            metric = l1_loss
+        super().__init__(physics, SupLoss(metric=metric))
+
+
+class CSSLoss(_ModelPlusOneLoss):
+    def __init__(self, physics):
+        super().__init__(physics, SupLoss(metric=mse()))
+
+
+class Noise2InverseLoss(_ModelPlusOneLoss):
+    def __init__(self, physics):
+        super().__init__(physics, SupLoss(metric=mse()))
+
+
+class SURELoss(_ModelPlusOneLoss):
+    def __init__(self, noise_level, cropped_div, averaged_cst, margin, physics):
+        super().__init__(physics, SureGaussianLoss(sigma=noise_level / 255, cropped_div=cropped_div,
+                                                   averaged_cst=averaged_cst, margin=margin))
+
+
+class ProposedLoss(Module):
+    def __init__(self, blueprint, sure_alternative, noise_level, stop_gradient, sure_cropped_div,
+                 sure_averaged_cst, sure_margin, alpha_tradeoff, transforms, physics, fuse_passes=None):
+        super().__init__()
+        self.physics = physics
+        if transforms == "Scaling_Transforms":
+            ei_transform = ScalingTransform(**blueprint[ScalingTransform.__name__])
+        elif transforms in ("Rotations+Shifts", "Rotations", "Shifts"):
+            raise NotImplementedError(f"--ProposedLoss__transforms {transforms} (deepinv Rotate/Shift) is "
+                                      "outside the hot path of this build; use Scaling_Transforms")
+        else:
+            raise ValueError(f"Unknown transforms: {transforms}")
+        assert sure_alternative in [None, "r2r"]
+        if sure_alternative == "r2r":
+            raise NotImplementedError("--ProposedLoss__sure_alternative r2r is outside the hot path of this build")
+        self.sure = SureGaussianLoss(sigma=noise_level / 255, cropped_div=sure_cropped_div,
+                                     averaged_cst=sure_averaged_cst, margin=sure_margin)
+        self.ei = EILoss(metric=mse(), transform=ei_transform, no_grad=stop_gradient, weight=alpha_tradeoff)
+        self.loss_fns = [self.sure, self.ei]
+        self.compute_x_net = True
+        if fuse_passes is None:
+            fuse_passes = "SEI_NO_FUSED_PASSES" not in environ
+        self.fuse_passes = fuse_passes
+
+    def forward(self, x, y, model):
+        if not self.fuse_passes:
+            x_net = model(y)
+            loss = 0
+            for loss_fn in self.loss_fns:
+                loss = loss + loss_fn(x=x, x_net=x_net, y=y, physics=self.physics, model=model)
+            return loss
+        # Same arithmetic and the same RNG draw order (probe b first: the network consumes no random
+        # numbers), but model(y) and model(y + tau b) share one pass of 2B images.
+        y = y.contiguous()
+        B = y.shape[0]
+        b = draw_probe(y, self.sure.div_margin)
+        both = model(torch.cat([y, axpy(y, b, self.sure.tau)], dim=0))
+        y12 = self.physics.A(both)
+        x_net = both[:B]
+        loss = self.sure(y=y, x_net=x_net, physics=self.physics, model=model, b=b, y1=y12[:B], y2=y12[B:])
+        return loss + self.ei(x=x, x_net=x_net, y=y, physics=self.physics, model=model)
+
+
+class Loss(Module):
+    def __init__(self, physics, blueprint, noise_level, sure_cropped_div, sure_averaged_cst, sure_margin,
+                 method, crop_training_pairs, crop_size):
+        super().__init__()
+        if method == "supervised":
+            self.loss = SupervisedLoss(physics=physics)
+        elif method == "css":
+            self.loss = CSSLoss(physics=physics)
+        elif method == "noise2inverse":
+            self.loss = Noise2InverseLoss(physics=physics)
+        elif method == "sure":
+            self.loss = SURELoss(physics=physics, noise_level=noise_level, cropped_div=sure_cropped_div,
+                                 averaged_cst=sure_averaged_cst, margin=sure_margin)
+        elif method == "proposed":
+            self.loss = ProposedLoss(physics=physics, blueprint=blueprint, noise_level=noise_level,
+                                     sure_cropped_div=sure_cropped_div, sure_averaged_cst=sure_averaged_cst,
+                                     sure_margin=sure_margin, **blueprint[ProposedLoss.__name__])
+        else:
+            raise ValueError(f"Unknwon method: {method}")
+
+        if crop_training_pairs:
+            self.xy_size_ratio = physics.rate if hasattr(physics, "rate") else 1
+            self.crop_fn = CropPair(location="random", size=crop_size)
+        else:
+            self.crop_fn = None
+        if "HOMOGENEOUS_SWINIR" in environ:
+            self.crop_fn = None
+
+    def forward(self, x, y, model):
+        if self.crop_fn is not None:
+            x, y = self.crop_fn(x, y, xy_size_ratio=self.xy_size_ratio)
+        return self.loss(x=x, y=y, model=model)
+
+
+def get_loss(args, physics):
+    if args.partial_sure:
+        if args.sure_margin is not None:
+            sure_margin = args.sure_margin
+        elif args.task == "deblurring":
+            assert physics.task == "deblurring"
+            kernel = physics.filter
+            sure_margin = (max(kernel.shape[-2], kernel.shape[-1]) - 1) // 2
+        elif args.task == "sr":
+            sure_margin = 2 if args.partial_sure_sr else 0
+    else:
+        assert args.sure_margin is None
+        sure_margin = 0
+
+    blueprint = {
+        Loss.__name__: {
+            "crop_training_pairs": args.Loss__crop_training_pairs,
+            "crop_size": args.Loss__crop_size,
+        },
+        ProposedLoss.__name__: {
+            "stop_gradient": args.ProposedLoss__stop_gradient,
+            "sure_alternative": args.ProposedLoss__sure_alternative,
+            "alpha_tradeoff": args.ProposedLoss__alpha_tradeoff,
+            "transforms": args.ProposedLoss__transforms,
+        },
+        ScalingTransform.__name__: {
+            "kind": args.ScalingTransform__kind,
+            "antialias": args.ScalingTransform__antialias,
+        },
+    }
+    return Loss(physics=physics, blueprint=blueprint, method=args.method, noise_level=args.noise_level,
+                sure_cropped_div=args.sure_cropped_div, sure_averaged_cst=args.sure_averaged_cst,
+                sure_margin=sure_margin, **blueprint[Loss.__name__])

@@ -1,0 +1,274 @@
+"""Autograd functions of the U-Net blocks, each a short sequence of HIP kernel launches.
+
+Activations are NHWC float32 tensors (B, H, W, C); a 1x1 convolution is then a row-major GEMM over
+the (B*H*W, C) view. Parameter gradients are not returned to autograd: every backward ACCUMULATES
+straight into `param.grad` (a view of the model's flat gradient bucket when the model has been
+flattened), which is what lets the kernels fuse "grad += ..." and keeps one contiguous buffer for the
+fused Adam step and the RCCL all-reduce. `optimizer.zero_grad()` (either flavour) is honoured.
+"""
+import torch
+
+import _native as N
+from . import _mats
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_ACCUM, EPI_BIAS_ROWSCALE = range(7)
+LN_EPS = 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# gradient buckets
+# ---------------------------------------------------------------------------------------------
+def grad_of(p):
+    """The tensor to accumulate p's gradient into (zeroed on first touch after zero_grad)."""
+    if p.grad is None:
+        view = getattr(p, "_sei_grad_view", None)
+        if view is None or view.shape != p.shape or view.device != p.device:
+            view = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        else:
+            view.zero_()
+        p.grad = view
+    return p.grad
+
+
+# ---------------------------------------------------------------------------------------------
+# thin launch helpers (pointers + sizes only; shapes are checked here, on the host)
+# ---------------------------------------------------------------------------------------------
+_GEMM_PROFILE = None     # bench.py: list of (flops, start_event, end_event) while enabled
+
+
+def profile_gemms(enable):
+    """Bracket every GEMM launch with HIP events on the launch stream (bench.py's roofline leg)."""
+    global _GEMM_PROFILE
+    records, _GEMM_PROFILE = _GEMM_PROFILE, ([] if enable else None)
+    return records
+
+
+def gemm(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2=None, allow_splitk=True):
+    if out is None:
+        out = torch.empty((M, Nn), dtype=torch.float32, device=A.device)
+    if _GEMM_PROFILE is not None:
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+    N.call("sei_gemm_f32_ex", A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K, ta, tb, epi,
+           N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2), 1, 0, 0, 0, int(allow_splitk))
+    if _GEMM_PROFILE is not None:
+        t1.record()
+        _GEMM_PROFILE.append((2.0 * M * Nn * K, t0, t1))
+    return out
+
+
+def layer_norm(x2d, gamma, beta):
+    rows, C = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty_like(mean)
+    N.call("sei_ln_fwd", x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+           rstd.data_ptr(), rows, C, LN_EPS)
+    return y, mean, rstd
+
+
+def layer_norm_bwd(x2d, gamma, mean, rstd, gy, ggamma, gbeta):
+    rows, C = x2d.shape
+    gx = torch.empty_like(x2d)
+    N.call("sei_ln_bwd", x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gy.data_ptr(),
+           gx.data_ptr(), ggamma.data_ptr(), gbeta.data_ptr(), rows, C)
+    return gx
+
+
+def colsum_into(acc, x2d):
+    M, Nn = x2d.shape
+    N.call("sei_colsum_f32", x2d.data_ptr(), acc.data_ptr(), M, Nn)
+
+
+def dwconv7(x, w, bias, flip=False, res=None, res_scale=1.0):
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    N.call("sei_dwconv7_fwd", x.data_ptr(), w.data_ptr(), N.ptr(bias), N.ptr(res), float(res_scale),
+           y.data_ptr(), B, H, W, C, int(flip))
+    return y
+
+
+def sepmap2(x, mats, Ho, Wo):
+    B, Hi, Wi, C = x.shape
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    work = torch.empty(2 * B * Hi * Wo * C, dtype=torch.float32, device=x.device)
+    L1, R1, L2, R2 = mats
+    N.call("sei_sepmap2", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, L1.data_ptr(), R1.data_ptr(),
+           L2.data_ptr(), R2.data_ptr(), work.data_ptr(), work.numel())
+    return y
+
+
+def _nhwc(x):
+    N.check_tensor(x, "activation")
+    if x.dim() != 4:
+        raise ValueError("expected an NHWC activation (B, H, W, C)")
+    return x
+
+
+# ---------------------------------------------------------------------------------------------
+# ConvBlock: x + conv3(gelu(conv2(LN(dwconv7(x)))))   (reference convolutional.py:33-51)
+# `twice` adds the block input a second time: the encoder's inner residual x + xb with xb == x
+# (convolutional.py:226-231) fused into the last GEMM's epilogue.
+# ---------------------------------------------------------------------------------------------
+class ConvBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, gamma, beta, w2, b2, w3, b3, twice):
+        x = _nhwc(x)
+        B, H, W, C = x.shape
+        M = B * H * W
+        h1 = dwconv7(x, w1, b1)
+        h2, mean, rstd = layer_norm(h1.view(M, C), gamma, beta)
+        h4 = torch.empty((M, 4 * C), dtype=torch.float32, device=x.device)
+        h3 = gemm(h2, w2, M, 4 * C, C, 0, 1, EPI_BIAS_GELU, bias=b2, D2=h4)
+        out = gemm(h4, w3, M, C, 4 * C, 0, 1, EPI_BIAS_RES, bias=b3, R1=x, R2=x if twice else None)
+        ctx.save_for_backward(x, h1, mean, rstd, h2, h3, h4)
+        ctx.params = (w1, b1, gamma, beta, w2, b2, w3, b3)
+        ctx.twice = twice
+        return out.view(B, H, W, C)
+
+    @staticmethod
+    def backward(ctx, go):
+        x, h1, mean, rstd, h2, h3, h4 = ctx.saved_tensors
+        w1, b1, gamma, beta, w2, b2, w3, b3 = ctx.params
+        B, H, W, C = x.shape
+        M = B * H * W
+        go = go.contiguous()
+        go2 = go.view(M, C)
+        # conv3
+        colsum_into(grad_of(b3), go2)
+        gemm(go2, h4, C, 4 * C, M, 1, 0, EPI_ACCUM, out=grad_of(w3).view(C, 4 * C))
+        gh3 = gemm(go2, w3, M, 4 * C, C, 0, 0, EPI_MUL_DGELU, R1=h3)          # (go W3) * gelu'(h3)
+        # conv2
+        colsum_into(grad_of(b2), gh3)
+        gemm(gh3, h2, 4 * C, C, M, 1, 0, EPI_ACCUM, out=grad_of(w2).view(4 * C, C))
+        gh2 = gemm(gh3, w2, M, C, 4 * C, 0, 0, EPI_NONE)
+        # LayerNorm, depthwise conv
+        gh1 = layer_norm_bwd(h1.view(M, C), gamma, mean, rstd, gh2, grad_of(gamma), grad_of(beta))
+        gh1 = gh1.view(B, H, W, C)
+        N.call("sei_dwconv7_bwd_weight", x.data_ptr(), gh1.data_ptr(), grad_of(w1).data_ptr(),
+               grad_of(b1).data_ptr(), B, H, W, C)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = dwconv7(gh1, w1, None, flip=True, res=go, res_scale=2.0 if ctx.twice else 1.0)
+        return (gx,) + (None,) * 9
+
+
+# ---------------------------------------------------------------------------------------------
+# Downsample: LN -> 1x1 conv C -> 4C -> ideal downsample    (reference convolutional.py:136-150)
+# ---------------------------------------------------------------------------------------------
+class DownsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w, b, rate):
+        x = _nhwc(x)
+        B, H, W, C = x.shape
+        M, Co = B * H * W, w.shape[0]
+        h, mean, rstd = layer_norm(x.view(M, C), gamma, beta)
+        z = gemm(h, w, M, Co, C, 0, 1, EPI_BIAS, bias=b)
+        fwd, bwd = _mats.resample_matrices("down", H, W, rate, x.device)
+        Ho, Wo = fwd[0].shape[0], fwd[1].shape[0]
+        out = sepmap2(z.view(B, H, W, Co), fwd, Ho, Wo)
+        ctx.save_for_backward(x, mean, rstd, h)
+        ctx.params, ctx.mats_t, ctx.hw = (gamma, beta, w, b), bwd, (H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, mean, rstd, h = ctx.saved_tensors
+        gamma, beta, w, b = ctx.params
+        B, H, W, C = x.shape
+        M, Co = B * H * W, w.shape[0]
+        gz = sepmap2(go.contiguous(), ctx.mats_t, H, W).view(M, Co)
+        colsum_into(grad_of(b), gz)
+        gemm(gz, h, Co, C, M, 1, 0, EPI_ACCUM, out=grad_of(w).view(Co, C))
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gh = gemm(gz, w, M, C, Co, 0, 0, EPI_NONE)
+            gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
+        else:
+            gh = gemm(gz, w, M, C, Co, 0, 0, EPI_NONE)
+            layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta))
+        return gx, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# Upsample: ideal upsample -> LN -> 1x1 conv (+ skip)       (reference convolutional.py:95-110,236-240)
+# ---------------------------------------------------------------------------------------------
+class UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, skip, gamma, beta, w, b, rate):
+        x = _nhwc(x)
+        B, H, W, C = x.shape
+        Co = w.shape[0]
+        fwd, bwd = _mats.resample_matrices("up", H, W, rate, x.device)
+        Ho, Wo = fwd[0].shape[0], fwd[1].shape[0]
+        u = sepmap2(x, fwd, Ho, Wo)
+        M = B * Ho * Wo
+        h, mean, rstd = layer_norm(u.view(M, C), gamma, beta)
+        if skip is not None:
+            skip = _nhwc(skip)
+            if tuple(skip.shape) != (B, Ho, Wo, Co):
+                raise ValueError("skip connection shape mismatch")
+            out = gemm(h, w, M, Co, C, 0, 1, EPI_BIAS_RES, bias=b, R1=skip)
+        else:
+            out = gemm(h, w, M, Co, C, 0, 1, EPI_BIAS, bias=b)
+        ctx.save_for_backward(u, mean, rstd, h)
+        ctx.params, ctx.mats_t, ctx.in_hw = (gamma, beta, w, b), bwd, (H, W)
+        return out.view(B, Ho, Wo, Co)
+
+    @staticmethod
+    def backward(ctx, go):
+        u, mean, rstd, h = ctx.saved_tensors
+        gamma, beta, w, b = ctx.params
+        B, Ho, Wo, C = u.shape
+        M, Co = B * Ho * Wo, w.shape[0]
+        go = go.contiguous()
+        go2 = go.view(M, Co)
+        colsum_into(grad_of(b), go2)
+        gemm(go2, h, Co, C, M, 1, 0, EPI_ACCUM, out=grad_of(w).view(Co, C))
+        gh = gemm(go2, w, M, C, Co, 0, 0, EPI_NONE)
+        gu = layer_norm_bwd(u.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta))
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = sepmap2(gu.view(B, Ho, Wo, C), ctx.mats_t, *ctx.in_hw)
+        gskip = go if ctx.needs_input_grad[1] else None
+        return gx, gskip, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# 3x3 convolutions at the ends of the U-Net                 (reference convolutional.py:174-176)
+# ---------------------------------------------------------------------------------------------
+class Conv3x3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, res, nchw_in, nchw_out):
+        N.check_tensor(x, "conv3x3 input")
+        Co, Ci = w.shape[0], w.shape[1]
+        if nchw_in:
+            B, _, H, W = x.shape
+        else:
+            B, H, W, _ = x.shape
+        y = torch.empty((B, Co, H, W) if nchw_out else (B, H, W, Co), dtype=torch.float32, device=x.device)
+        if res is not None:
+            N.check_tensor(res, "conv3x3 residual")
+            if res.shape != y.shape:
+                raise ValueError("conv3x3: residual shape mismatch")
+        N.call("sei_conv3x3_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), N.ptr(res), y.data_ptr(), B, H, W,
+               Ci, Co, int(nchw_in), int(nchw_out), 0)
+        ctx.save_for_backward(x)
+        ctx.params, ctx.cfg = (w, b), (B, H, W, Ci, Co, nchw_in, nchw_out)
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        (x,) = ctx.saved_tensors
+        w, b = ctx.params
+        B, H, W, Ci, Co, nchw_in, nchw_out = ctx.cfg
+        go = go.contiguous()
+        N.call("sei_conv3x3_bwd_weight", x.data_ptr(), go.data_ptr(), grad_of(w).data_ptr(),
+               grad_of(b).data_ptr(), B, H, W, Ci, Co, int(nchw_in), int(nchw_out))
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            N.call("sei_conv3x3_fwd", go.data_ptr(), w.data_ptr(), None, None, gx.data_ptr(), B, H, W, Co, Ci,
+                   int(nchw_out), int(nchw_in), 1)
+        gres = go if ctx.needs_input_grad[3] else None
+        return gx, None, None, gres, None, None

@@ -1,0 +1,143 @@
+"""Scale transforms of the equivariant-imaging loss (reference call surface: src/transforms.py).
+
+The default ("padded") transform zooms each image out by a random rate about a random centre with
+bicubic grid sampling and reflection padding. The reference materialises a (B,H,W,2) grid and calls
+F.grid_sample; here `sei_scale_resample_fwd` generates the grid in-kernel from (rate, centre).
+Random draws keep the reference's order and distributions (rand(B) then rand(B,2) on x's device).
+"""
+import torch
+from torch.nn import Module
+
+import _native as N
+from physics import _bands
+from physics._ops import SeparableResampleOp, apply_linear
+
+
+def sample_from(values, shape=(1,), dtype=torch.float32, device="cpu"):
+    """Uniform draw from `values` (reference :5-12)."""
+    table = torch.tensor(values, device=device, dtype=dtype)
+    u = torch.rand(shape, device=device, dtype=dtype)
+    return table[torch.floor(len(values) * u).to(torch.int)]
+
+
+def sample_downsampling_parameters(image_count, device, dtype, rates):
+    """Per-image (rate, centre in [-1,1]^2) (reference :15-24)."""
+    rate = sample_from(rates, shape=(image_count,), dtype=dtype, device=device)
+    center = 2 * torch.rand((image_count, 2), dtype=dtype, device=device) - 1
+    return rate, center.view(image_count, 1, 1, 2)
+
+
+class _ScaleResample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rate, center, out_hw):
+        N.check_tensor(x, "x")
+        B, C, Hi, Wi = x.shape
+        H, W = out_hw
+        rate = N.check_tensor(rate.reshape(B).contiguous(), "downsampling_rate")
+        center = N.check_tensor(center.reshape(B, 2).contiguous(), "center")
+        y = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device)
+        N.call("sei_scale_resample_fwd", x.data_ptr(), y.data_ptr(), rate.data_ptr(), center.data_ptr(),
+               B, C, Hi, Wi, H, W)
+        ctx.save_for_backward(rate, center)
+        ctx.in_hw = (Hi, Wi)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        rate, center = ctx.saved_tensors
+        g = g.contiguous()
+        B, C, H, W = g.shape
+        Hi, Wi = ctx.in_hw
+        gx = torch.zeros((B, C, Hi, Wi), dtype=g.dtype, device=g.device)
+        N.call("sei_scale_resample_bwd", g.data_ptr(), gx.data_ptr(), rate.data_ptr(), center.data_ptr(),
+               B, C, Hi, Wi, H, W)
+        return gx, None, None, None
+
+
+_AA_OPS = {}
+
+
+def _aa_resize(x, scale_factor, antialias=True):
+    """F.interpolate(x, scale_factor, 'bicubic', antialias) as a banded separable product."""
+    key = (float(scale_factor), bool(antialias))
+    if key not in _AA_OPS:
+        build = _bands.aa_bicubic_matrix if antialias else _bands.plain_bicubic_matrix
+        _AA_OPS[key] = SeparableResampleOp(lambda n, s=key[0], f=build: f(n, s))
+    return apply_linear(_AA_OPS[key], x.contiguous())
+
+
+def alias_free_interpolate(x, downsampling_rate, interpolation_mode):
+    """Reference :46-57: a per-image antialiased resize, then torch.stack -- which, as in the
+    reference, only succeeds when every image of the batch drew the same rate."""
+    if interpolation_mode != "bicubic":
+        raise ValueError("only mode='bicubic' is supported")
+    rates = [float(r) for r in downsampling_rate.reshape(-1).tolist()]    # host sync, as .item() does
+    return torch.stack([_aa_resize(x[i:i + 1], rates[i])[0] for i in range(x.shape[0])])
+
+
+def padded_downsampling_transform(x, downsampling_rate, center, mode, padding_mode, antialiased):
+    """Reference :60-83. With `antialiased` the pre-filtered (smaller) image is sampled on the grid
+    of the ORIGINAL shape, as the reference does (the output keeps the original size)."""
+    if mode != "bicubic" or padding_mode != "reflection":
+        raise ValueError("only mode='bicubic', padding_mode='reflection' are supported")
+    out_hw = tuple(x.shape[-2:])
+    if antialiased:
+        x = alias_free_interpolate(x, downsampling_rate=downsampling_rate, interpolation_mode=mode)
+    return _ScaleResample.apply(x.contiguous(), downsampling_rate, center, out_hw)
+
+
+class PaddedDownsamplingTransform(Module):
+    def __init__(self, antialias, downsampling_rates):
+        super().__init__()
+        self.antialias = antialias
+        self.downsampling_rates = downsampling_rates
+
+    def forward(self, x):
+        rate, center = sample_downsampling_parameters(
+            image_count=x.shape[0], device=x.device, dtype=x.dtype, rates=self.downsampling_rates)
+        return padded_downsampling_transform(x, downsampling_rate=rate, center=center,
+                                             antialiased=self.antialias, mode="bicubic",
+                                             padding_mode="reflection")
+
+
+def normal_downsampling_transform(x, downsampling_rate, mode, antialiased):
+    """Reference :112-123: every image resized by the same python-float rate."""
+    if mode != "bicubic":
+        raise ValueError("only mode='bicubic' is supported")
+    return _aa_resize(x, downsampling_rate, antialiased)
+
+
+class NormalDownsamplingTransform(Module):
+    def __init__(self, antialias, downsampling_rates):
+        super().__init__()
+        self.antialias = antialias
+        self.downsampling_rates = downsampling_rates
+
+    def forward(self, x):
+        rate = sample_from(self.downsampling_rates, shape=(), dtype=x.dtype, device=x.device).item()
+        return normal_downsampling_transform(x, downsampling_rate=rate, mode="bicubic",
+                                             antialiased=self.antialias)
+
+
+class ScalingTransform(Module):
+    def __init__(self, kind, antialias):
+        super().__init__()
+        rates = [0.75, 0.5]
+        kinds = {"padded": PaddedDownsamplingTransform, "normal": NormalDownsamplingTransform}
+        if kind not in kinds:
+            raise ValueError(f"Unknown kind: {kind}")
+        self.transform = kinds[kind](antialias=antialias, downsampling_rates=rates)
+
+    def forward(self, x):
+        return self.transform(x)
+
+
+class CombinedTransform(Module):
+    def __init__(self, transforms):
+        super().__init__()
+        self.transforms = transforms
+
+    def forward(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x

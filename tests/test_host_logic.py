@@ -1,0 +1,222 @@
+"""CPU tests of the host layer: flags, crop quirk, samplers, schedules, checkpoints, band builders,
+resampler matrices, and the N>1 gradient exchange over gloo (world_size 2)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import closed_form as cf
+from oracle import torch_path as tp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def test_kernel_table_matches_golden(golden):
+    import physics
+    g = golden("g1_kernels")
+    for name in g.files:
+        k = physics.get_kernel(name)
+        assert k.dtype == torch.float64
+        np.testing.assert_array_equal(k.numpy(), g[name])          # bit for bit
+        t = physics.kernels.taps_1d(name)
+        np.testing.assert_allclose(torch.outer(t, t).numpy() / float(t.sum()) ** 2, g[name], atol=1e-17)
+    with pytest.raises(AssertionError):
+        physics.get_kernel("Box_R9")
+    bk = physics.BlurKernel("Gaussian_R2").to_tensor("cpu")
+    assert tuple(bk.shape) == (1, 1, 13, 13) and bk.dtype == torch.float64
+
+
+def test_blur_kernel_from_file(tmp_path):
+    import physics
+    k = torch.rand(5, 5, dtype=torch.float64)
+    path = str(tmp_path / "k.pt")
+    torch.save(k, path)
+    assert torch.equal(physics.BlurKernel(path).to_tensor("cpu")[0, 0], k)
+
+
+def test_band_matrices_match_closed_form():
+    from physics import _bands
+    for n, r in [(96, 2), (96, 3), (96, 4), (48, 4), (130, 2)]:
+        dense = _bands.aa_bicubic_matrix(n, 1 / r)
+        np.testing.assert_allclose(dense, cf.aa_weights(n, r), atol=1e-15)
+        for mat in (dense, dense.T):
+            w, lo, nb, step = _bands.to_band(np.ascontiguousarray(mat))
+            rebuilt = np.zeros_like(mat)
+            for o in range(mat.shape[0]):
+                n_ok = min(nb, mat.shape[1] - lo[o])
+                rebuilt[o, lo[o]:lo[o] + n_ok] = w[o, :n_ok]
+            np.testing.assert_allclose(rebuilt, mat, atol=1e-7)
+            assert np.all(np.diff(lo) >= 0) and (np.diff(lo).max() if len(lo) > 1 else 0) == step
+    for n, r in [(12, 2), (12, 3), (16, 4)]:
+        np.testing.assert_allclose(_bands.plain_bicubic_matrix(n, r), cf.plain_bicubic_up_weights(n, r), atol=1e-15)
+    # antialias pre-filter of the EI transform at rate 0.75 == torch's own antialiased resize
+    x = torch.rand(1, 1, 48, 48, dtype=torch.float64)
+    m = torch.from_numpy(_bands.aa_bicubic_matrix(48, 0.75))
+    ref = torch.nn.functional.interpolate(x, scale_factor=0.75, mode="bicubic", antialias=True)
+    assert (m @ x[0, 0] @ m.T - ref[0, 0]).abs().max() < 1e-12
+
+
+def test_resampler_matrices_match_fft_oracle():
+    from models import _mats
+    for kind, H, W, r in [("down", 48, 48, 2), ("down", 16, 32, 2), ("up", 24, 24, 2), ("up", 12, 12, 4), ("up", 3, 3, 2)]:
+        L1, R1, L2, R2 = (m.astype(np.float64) for m in _mats._host_matrices(kind, H, W, r))
+        x = torch.rand(2, 3, H, W, dtype=torch.float64)
+        ref = tp.ideal_downsample(x, r) if kind == "down" else tp.ideal_upsample(x, r)
+        got = cf.sepmap2(x.numpy(), L1, R1, L2, R2)
+        assert np.abs(got - ref.numpy()).max() < 5e-7
+    with pytest.raises(RuntimeError):
+        _mats._host_matrices("up", 16, 16, 3)
+
+
+def test_crop_pair_reproduces_batched_quirk():
+    import crop
+    torch.manual_seed(3)
+    x, y = torch.rand(2, 3, 256, 256), torch.rand(2, 3, 256, 256)
+    torch.manual_seed(9)
+    xc, yc = crop.CropPair("random", 48)(x, y, xy_size_ratio=1)
+    torch.manual_seed(9)
+    xr, yr = tp.crop_pair(x, y, 48, 1)
+    assert torch.equal(xc, xr) and torch.equal(yc, yr)
+    # offsets are drawn over the padded height 301 (quirk) unless the fix is requested
+    pad = crop.MinSizePadding(48)(y)
+    assert pad.shape == (2, 3, 301, 256)
+    assert crop.MinSizePadding(48, fix_batched_crop=True)(y).shape == (2, 3, 256, 256)
+    assert crop.MinSizePadding(48)(torch.rand(3, 30, 60)).shape == (3, 48, 60)      # 3-D item: as intended
+    xs, ys = crop.CropPair("center", 48)(torch.rand(3, 200, 200), torch.rand(3, 100, 100))
+    assert xs.shape == (3, 96, 96) and ys.shape == (3, 48, 48)
+
+
+def test_scale_parameter_draws_match_reference(golden):
+    import transforms
+    g = golden("g4_scale_transform")
+    for k in range(4):
+        torch.manual_seed(k)
+        r, c = transforms.sample_downsampling_parameters(4, "cpu", torch.float32, [0.75, 0.5])
+        np.testing.assert_array_equal(r.numpy(), g[f"draw.seed{k}.rate"])
+        np.testing.assert_array_equal(c.numpy(), g[f"draw.seed{k}.center"])
+
+
+def test_lr_schedules_match_reference():
+    import warnings
+    import scheduler
+    want = json.load(open(os.path.join(GOLDEN, "g9_lr_schedule.json")))
+    for key, lrs in want.items():
+        kind, epochs = key.rsplit(".", 1)
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=1e-4)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sch = scheduler.get_lr_scheduler(opt, int(epochs), kind)
+            got = []
+            for _ in range(int(epochs)):
+                got.append(opt.param_groups[0]["lr"])
+                opt.step()
+                sch.step()
+        np.testing.assert_allclose(got, lrs, rtol=1e-12)
+    with pytest.raises(ValueError):
+        scheduler.get_lr_scheduler(opt, 10, "nope")
+
+
+def test_flags_and_defaults_match_reference():
+    sys.path.insert(0, ROOT)
+    import train
+    a = train.build_parser().parse_args(["--task", "deblurring", "--method", "proposed", "--out_dir", "o"])
+    assert (a.device, a.noise_level, a.batch_size, a.Loss__crop_size) == ("cpu", 5, 8, 48)
+    assert a.ProposedModel__architecture == "Transformer" and a.physics_v2 and a.ProposedLoss__stop_gradient
+    assert a.ConvolutionalModel__hidden_channels == 32 and a.ConvolutionalModel__scales == 5
+    assert a.sure_averaged_cst is None and a.sure_cropped_div and a.partial_sure and a.sure_margin is None
+    assert a.ScalingTransform__kind == "padded" and not a.ScalingTransform__antialias
+    assert a.lr_scheduler_kind == "delayed_linear_decay" and a.optimizer_beta2 == 0.999
+    b = train.build_parser().parse_args(["--no-physics_v2", "--GroundTruthDataset__no_resize", "--download"])
+    assert not b.physics_v2 and b.GroundTruthDataset__size is None and b.GroundTruthDataset__download
+
+
+def test_state_dict_layout_and_seeded_init_match_reference():
+    from models.convolutional import ConvolutionalModel
+    man = json.load(open(os.path.join(GOLDEN, "g8_state_dict_manifest.json")))
+    for tag, up in [("deblur", 1), ("sr2", 2), ("sr4", 4)]:
+        with torch.device("meta"):
+            m = ConvolutionalModel(in_channels=3, upsampling_rate=up, residual=True, inner_residual=True,
+                                   num_conv_blocks=1, hidden_channels=32, inout_convs=True, scales=5)
+        assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == man[tag]["keys"]
+        assert sum(p.numel() for p in m.parameters()) == man[tag]["num_parameters"]
+    g = np.load(os.path.join(GOLDEN, "g7_unet_h8s3_deblur.npz"))
+    torch.manual_seed(0)
+    m = ConvolutionalModel(in_channels=3, upsampling_rate=1, residual=True, inner_residual=True,
+                           num_conv_blocks=1, hidden_channels=8, inout_convs=True, scales=3)
+    for k, v in m.state_dict().items():
+        if ".ln." not in k:                       # the golden's norm parameters were perturbed after init
+            np.testing.assert_array_equal(v.numpy(), g["sd." + k])
+
+
+def test_checkpoint_format(tmp_path):
+    import training
+
+    class M:
+        def get_weights(self):
+            return {"seq.0.in_conv.weight": torch.ones(2)}
+
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-4)
+    sch = torch.optim.lr_scheduler.LinearLR(opt)
+    path = str(tmp_path / "a" / "ckp_1.pt")
+    training.save_training_state(0, M(), opt, sch, path)
+    st = torch.load(path)
+    assert set(st) == {"epoch", "params", "optimizer", "scheduler"}
+    assert torch.equal(training.get_weights(path, "cpu")["seq.0.in_conv.weight"], torch.ones(2))
+
+
+def test_psnr_metric():
+    import metrics
+    a, b = torch.rand(3, 20, 20), torch.rand(3, 20, 20)
+    assert abs(float(metrics.psnr_fn(a, b)) - float(tp.psnr_y(a, b))) < 1e-5
+    assert float(metrics.psnr_fn(a, a + 1e-3)) == pytest.approx(60.0, abs=1e-3)
+
+
+# ------------------------------------------------------------------ N>1 over gloo
+def _reducer_worker(rank, world, port, numel, chunk_mib, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, os.path.join(ROOT, "scale-equivariant-imaging_amd"))
+    import torch.distributed as dist
+    import parallel
+    r, _, w = parallel.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(100 + r)
+    grads = torch.randn(numel, generator=g)
+    params = torch.full((numel,), float(r))
+    parallel.broadcast_parameters(params)
+    red = parallel.FlatGradientReducer(grads, chunk_mib=chunk_mib)
+    red.reduce_async()
+    for k in range(len(red.bounds)):
+        red.wait(k)
+    loss = parallel.all_reduce_mean_scalar(torch.tensor(float(r + 1)))
+    want = sum(torch.randn(numel, generator=torch.Generator().manual_seed(100 + k)) for k in range(w))
+    # plain floats only: tensors sent through the queue would outlive this process's shared memory
+    q.put((r, float((grads - want).abs().max()), float(params.abs().max()), float(loss), len(red.bounds)))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_reducer_gloo_world2():
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "scale-equivariant-imaging_amd"))
+    import parallel
+    assert parallel.chunk_bounds(10, 4) == [(0, 4), (4, 8), (8, 10)]
+    numel = 1_000_003
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, numel, 1, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, grad_err, param_max, loss, nchunks in res:
+        assert grad_err < 1e-6                     # every rank holds the sum of both ranks' gradients
+        assert param_max == 0                      # rank 0's weights everywhere
+        assert loss == pytest.approx(1.5) and nchunks == 4

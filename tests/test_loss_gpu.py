@@ -1,0 +1,257 @@
+"""GPU parity of the loss layer and of whole training steps against the oracle and the goldens."""
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_path as tp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rel(a, b):
+    a, b = float(a), float(b)
+    return abs(a - b) / max(abs(b), 1e-30)
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def ref_args(**over):
+    import bench
+    a = bench.reference_args("cuda", hidden=8, scales=3)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+# ------------------------------------------------------------------ SURE vs golden G6
+@pytest.mark.parametrize("margin", [0, 6])
+@pytest.mark.parametrize("cst", [False, True])
+def test_sure_vs_golden(golden, margin, cst):
+    import physics
+    from losses.sure import SureGaussianLoss, embed_probe
+    g = golden("g6_sure")
+    op = physics.BlurV2(kernel=physics.get_kernel("Gaussian_R2")[None, None])
+    y = dev(g["y"])
+    w = torch.tensor(0.9, device="cuda", requires_grad=True)
+    model = lambda v: w * v + 0.05 * v * v
+    lf = SureGaussianLoss(sigma=5 / 255, margin=margin, cropped_div=True, averaged_cst=cst)
+    val = lf(y=y, x_net=model(y), physics=op, model=model, b=embed_probe(y, dev(g[f"m{margin}.b"]), margin))
+    (gw,) = torch.autograd.grad(val, w)
+    assert rel(val, g[f"m{margin}.cst{int(cst)}.loss"]) < 1e-5
+    assert rel(gw, g[f"m{margin}.cst{int(cst)}.gw"]) < 1e-4
+
+
+def test_sure_uncropped_divergence_and_random_probe():
+    import physics
+    from losses.sure import SureGaussianLoss, draw_probe
+    op = physics.BlurV2(kernel=physics.get_kernel("Gaussian_R2")[None, None])
+    y = torch.rand(3, 3, 48, 48, device="cuda")
+    b = draw_probe(y, 6)
+    assert b[:, :, :6].abs().max() == 0 and b[:, :, :, -6:].abs().max() == 0 and abs(float(b[:, :, 6:-6, 6:-6].std()) - 1) < 0.05
+    model = lambda v: 0.8 * v
+    k = tp.blur_kernel("Gaussian_R2")
+    for cropped in (True, False):
+        lf = SureGaussianLoss(sigma=5 / 255, margin=6, cropped_div=cropped)
+        bb = draw_probe(y, lf.div_margin)
+        val = lf(y=y, x_net=model(y), physics=op, model=model, b=bb)
+        m = 6 if cropped else 0
+        b_int = bb[:, :, m:48 - m, m:48 - m].cpu() if m else bb.cpu()
+        ref = tp.sure_loss(y.cpu(), model(y.cpu()), lambda v: tp.blur_fft(v, k), model, 5 / 255, margin=6,
+                           cropped_div=cropped, b=b_int)
+        assert rel(val, ref) < 2e-5
+
+
+# ------------------------------------------------------------------ composite proposed loss vs golden G11
+def _proposed_manual(model, physics, y, b, noise, rate, center, margin):
+    """The product's loss layer driven with injected randomness (b, noise, rate, centre)."""
+    import transforms
+    from losses.ei import mse
+    from losses.sure import SureGaussianLoss
+    x_net = model(y)
+    sure = SureGaussianLoss(sigma=5 / 255, margin=margin, cropped_div=True, averaged_cst=None)
+    l_sure = sure(y=y, x_net=x_net, physics=physics, model=model, b=b)
+    with torch.no_grad():
+        x2 = transforms.padded_downsampling_transform(x_net.contiguous(), rate, center, "bicubic", "reflection", False)
+    y2 = physics.noise_model(physics.A(x2), noise=noise)
+    x3 = model(y2)
+    l_ei = mse()(x3, x2)
+    return l_sure + l_ei, dict(x_net=x_net, x2=x2, x3=x3, loss_sure=l_sure, loss_ei=l_ei)
+
+
+@pytest.mark.parametrize("tag", ["deblur", "sr2"])
+def test_proposed_loss_vs_golden(golden, tag):
+    import physics
+    from losses.sure import embed_probe
+    from models.convolutional import ConvolutionalModel
+    g = golden(f"g11_proposed_{tag}")
+    up, margin = (1, 6) if tag == "deblur" else (2, 0)
+    m = ConvolutionalModel(in_channels=3, upsampling_rate=up, residual=True, inner_residual=True,
+                           num_conv_blocks=1, hidden_channels=8, inout_convs=True, scales=3)
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("sd.")})
+    m = m.cuda()
+    if tag == "deblur":
+        op = physics.BlurV2(kernel=physics.get_kernel("Gaussian_R2")[None, None])
+    else:
+        op = physics.Downsampling(rate=2, antialias=True)
+    op.noise_model = physics.GaussianNoise(sigma=5 / 255)
+    y = dev(g["y"])
+    loss, aux = _proposed_manual(m, op, y, embed_probe(y, dev(g["b"]), margin), dev(g["n"]), dev(g["rate"]),
+                                 dev(g["center"]), margin)
+    assert relerr(aux["x_net"], g["x_net"]) < 2e-5
+    assert relerr(aux["x2"], g["x2"]) < 2e-5
+    assert relerr(aux["x3"], g["x3"]) < 5e-5
+    assert rel(aux["loss_sure"], g["loss_sure"]) < 1e-4
+    assert rel(aux["loss_ei"], g["loss_ei"]) < 1e-4
+    assert rel(loss, g["loss"]) < 1e-4
+    m.zero_grad_flat()
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert relerr(p.grad, g[f"grad.{k}"]) < 5e-4, (k, relerr(p.grad, g[f"grad.{k}"]))
+
+
+def test_fused_and_literal_pass_orders_agree():
+    import physics
+    import models
+    from losses import get_loss
+    args = ref_args()
+    p = physics.get_physics(args, "cuda")
+    torch.manual_seed(0)
+    model = models.get_model(args, p, "cuda").to("cuda")
+    x = torch.rand(4, 3, 256, 256, device="cuda")
+    y = p(x)
+    out = {}
+    for fuse in (True, False):
+        lf = get_loss(args, p)
+        lf.loss.fuse_passes = fuse
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        model.get_backbone().zero_grad_flat()
+        val = lf(x=x, y=y, model=model)
+        val.backward()
+        out[fuse] = (float(val), model.get_backbone().flat_grads.clone())
+    assert rel(out[True][0], out[False][0]) < 1e-6
+    assert relerr(out[True][1], out[False][1]) < 1e-5
+
+
+def test_loss_surface_and_methods():
+    import physics
+    import models
+    from losses import get_loss
+    args = ref_args()
+    p = physics.get_physics(args, "cuda")
+    model = models.get_model(args, p, "cuda").to("cuda")
+    x = torch.rand(2, 3, 256, 256, device="cuda")
+    y = p(x)
+    for method in ["proposed", "supervised", "sure", "css", "noise2inverse"]:
+        args.method = method
+        val = get_loss(args, p)(x=x, y=y, model=model)
+        assert val.dim() == 0 and torch.isfinite(val)
+    args.method = "nope"
+    with pytest.raises(ValueError):
+        get_loss(args, p)
+    args.method = "proposed"
+    args.ProposedLoss__transforms = "Rotations"
+    with pytest.raises(NotImplementedError):
+        get_loss(args, p)
+    # SR: margin 0, x/y size ratio from physics.rate, 48 -> 96 crops
+    args = ref_args(task="sr", sr_factor=2, kernel=None)
+    p = physics.get_physics(args, "cuda")
+    model = models.get_model(args, p, "cuda").to("cuda")
+    lf = get_loss(args, p)
+    assert lf.loss.sure.margin == 0 and lf.xy_size_ratio == 2
+    xs = torch.rand(2, 3, 96, 96, device="cuda")
+    val = lf(x=xs, y=p(xs), model=model)
+    assert torch.isfinite(val)
+    val.backward()
+
+
+# ------------------------------------------------------------------ full-size network: config[1] parity
+def test_default_unet_step_vs_oracle():
+    """The benchmarked network (hidden 32, 5 scales, 645 M parameters) at the training crop size:
+    restored images within 1e-4 relative and 0.01 dB PSNR of the float32 CPU path; loss and gradient
+    norms within 1e-4 (SURVEY 8d 'parity check in the same run')."""
+    import bench
+    import metrics
+    import models
+    import physics
+    from losses.sure import embed_probe
+    args = bench.reference_args("cuda")
+    p = physics.get_physics(args, "cuda")
+    torch.manual_seed(0)
+    model = models.get_model(args, p, "cuda")
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.get_weights().items()}   # CPU, f32
+    model.to("cuda")
+    gen = torch.Generator().manual_seed(11)
+    B = 2
+    xgt = torch.rand((B, 3, 48, 48), generator=gen)
+    b_int = torch.randn((B, 3, 36, 36), generator=gen)
+    noise = torch.randn((B, 3, 48, 48), generator=gen)
+    rate, center = torch.tensor([0.75, 0.5]), torch.tensor([[0.3, -0.2], [-0.5, 0.6]])
+    k = tp.blur_kernel("Gaussian_R2")
+    A = lambda v: tp.blur_fft(v, k)
+    y = A(xgt) + 5 / 255 * torch.randn((B, 3, 48, 48), generator=gen)
+    ref_model = lambda v: tp.unet_forward(sd, v, scales=5)
+    ref, aux = tp.proposed_loss(y, A, ref_model, 5 / 255, margin=6, rate=rate, center=center.view(-1, 1, 1, 2),
+                                b=b_int, n=noise)
+    ref.backward()
+    yd = y.cuda()
+    loss, got = _proposed_manual(model, p, yd, embed_probe(yd, b_int.cuda(), 6), noise.cuda(), rate.cuda(),
+                                 center.cuda(), 6)
+    assert relerr(got["x_net"], aux["x_net"]) < 1e-4
+    for i in range(B):
+        d = abs(float(metrics.psnr_fn(got["x_net"][i].cpu(), xgt[i])) - float(tp.psnr_y(aux["x_net"][i].detach(), xgt[i])))
+        assert d < 0.01
+    assert rel(loss, ref) < 1e-4
+    model.get_backbone().zero_grad_flat()
+    loss.backward()
+    params = dict(model.get_backbone().named_parameters())
+    worst = 0.0
+    for kname, v in sd.items():
+        gn, rn = float(params[kname].grad.double().norm()), float(v.grad.double().norm())
+        worst = max(worst, abs(gn - rn) / rn)
+    assert worst < 1e-4, worst
+
+
+# ------------------------------------------------------------------ drivers
+def test_train_script_end_to_end(tmp_path):
+    out = tmp_path / "run"
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--device", "cuda", "--method", "proposed", "--task",
+           "deblurring", "--kernel", "Gaussian_R2", "--ProposedModel__architecture", "Convolutional",
+           "--ConvolutionalModel__hidden_channels", "8", "--ConvolutionalModel__scales", "3", "--dataset",
+           "synthetic", "--batch_size", "4", "--epochs", "4", "--max_steps", "2", "--checkpoint_interval", "2",
+           "--out_dir", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = open(out / "training.csv").read().strip().splitlines()
+    assert rows[0] == "Epoch,Training Loss" and len(rows) == 5
+    assert all(np.isfinite(float(r_.split(",")[1])) for r_ in rows[1:])
+    names = sorted(os.listdir(out / "checkpoints"))
+    assert names == ["ckp_0.pt", "ckp_1.pt", "ckp_3.pt", "ckp_4.pt"]
+    ckp = torch.load(out / "checkpoints" / "ckp_4.pt", map_location="cpu")
+    assert set(ckp) == {"epoch", "params", "optimizer", "scheduler"} and ckp["epoch"] == 3
+    w = torch.load(out / "weights.pt", map_location="cpu")
+    assert "seq.0.in_conv.weight" in w and set(w) == set(ckp["params"])
+    # resume: loads model/optimizer/scheduler, requires --lr (as upstream)
+    r = subprocess.run(cmd[:-1] + [str(tmp_path / "run2"), "--RESUME", str(out / "checkpoints" / "ckp_4.pt"),
+                                   "--lr", "1e-5", "--epochs", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_graft_smoke():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.smoke()
