@@ -146,7 +146,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     records = _ops.profile_gemms(False) if opt.profile_gemms else None
-    loss_value = float(last)
+    loss_value = float(last.detach())
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:

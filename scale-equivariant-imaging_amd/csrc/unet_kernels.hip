@@ -496,25 +496,23 @@ __global__ __launch_bounds__(SM_THREADS) void sepmap_h_kernel(const float *__res
 // =================================================================================================
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, float *__restrict__ out,
                                                      size_t M, int N, size_t rows_per_block) {
-    // threads tile columns; each block owns a row range; in-block reduce over the row sub-groups via LDS
+    // blockIdx.y tiles the columns (cw = min(N,256) per block, lanes = consecutive columns),
+    // blockIdx.x tiles the rows; the 256/cw row sub-groups of a block are reduced through LDS.
     extern __shared__ __attribute__((aligned(16))) float red[];   // [rsubs][cw]
     const int cw = min(N, 256);
     const int rsubs = 256 / cw;
     const int cl = threadIdx.x % cw, rsub = threadIdx.x / cw;
     const size_t r0 = (size_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (int cb = 0; cb < N; cb += cw) {
-        const int c = cb + cl;
-        float s = 0.f;
-        if (c < N && rsub < rsubs)
-            for (size_t r = r0 + rsub; r < r1; r += rsubs) s += X[r * N + c];
-        if (rsub < rsubs) red[rsub * cw + cl] = s;
-        __syncthreads();
-        if (rsub == 0 && c < N) {
-            float t = 0.f;
-            for (int k = 0; k < rsubs; ++k) t += red[k * cw + cl];
-            atomicAdd(out + c, t);
-        }
-        __syncthreads();
+    const int c = blockIdx.y * cw + cl;
+    float s = 0.f;
+    if (c < N && rsub < rsubs)
+        for (size_t r = r0 + rsub; r < r1; r += rsubs) s += X[r * N + c];
+    if (rsub < rsubs) red[rsub * cw + cl] = s;
+    __syncthreads();
+    if (rsub == 0 && c < N) {
+        float t = 0.f;
+        for (int k = 0; k < rsubs; ++k) t += red[k * cw + cl];
+        atomicAdd(out + c, t);
     }
 }
 
@@ -694,12 +692,14 @@ extern "C" int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int 
 
 extern "C" int sei_colsum_f32(const float *X, float *out, size_t M, int N, void *stream) {
     SEI_REQUIRE(X && out && M > 0 && N > 0);
-    size_t rpb = 64;
-    while (sei_ceil_div(M, rpb) > 1024) rpb *= 2;
     const int cw = N < 256 ? N : 256;
+    const unsigned col_blocks = (unsigned)sei_ceil_div(N, cw);
+    // ~2048 workgroups in all: enough to fill 256 CUs, few enough to keep the atomics per column low
+    size_t rpb = 16;
+    while (sei_ceil_div(M, rpb) * col_blocks > 2048 && rpb < M) rpb *= 2;
     const size_t lds = sizeof(float) * (size_t)(256 / cw) * cw;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sei_ceil_div(M, rpb)), dim3(256), lds, (hipStream_t)stream, X,
-                       out, M, N, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sei_ceil_div(M, rpb), col_blocks), dim3(256), lds,
+                       (hipStream_t)stream, X, out, M, N, rpb);
     return sei_launch_status();
 }
 

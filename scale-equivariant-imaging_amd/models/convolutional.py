@@ -243,7 +243,7 @@ class ConvolutionalModel(Module):
 
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, y):
-        N.check_tensor(y, "y")
+        y = N.check_tensor(y.contiguous(), "y")        # crops arrive as strided views
         div = 2 ** (self.scales - 1)
         pad_h = (div - y.shape[-2] % div) % div
         pad_w = (div - y.shape[-1] % div) % div
