@@ -29,7 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "scale-equivariant-imaging_amd"))
 sys.path.insert(1, ROOT)
 
-F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+# MI355X_MICROARCH.md, dense spec peaks: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 CROP, NOISE, KERNEL = 48, 5, "Gaussian_R2"
 
 
@@ -85,6 +86,8 @@ def main():
     ap.add_argument("--cpu-baseline", action=argparse.BooleanOptionalAction, default=True)
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--profile-gemms", action=argparse.BooleanOptionalAction, default=True)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="arithmetic type of the 1x1-conv GEMMs (f32 = parity mode, bf16 = throughput mode)")
     opt = ap.parse_args()
 
     import parallel
@@ -101,6 +104,7 @@ def main():
     from physics import get_physics
 
     args = reference_args(device, opt.hidden, opt.scales)
+    _ops.set_compute_dtype(opt.dtype)
     torch.manual_seed(0)
     physics = get_physics(args, device)
     model = get_model(args, physics, device)
@@ -158,8 +162,9 @@ def main():
         flops = sum(r[0] for r in records)
         ms = sum(r[1].elapsed_time(r[2]) for r in records)
         achieved = flops / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "sei_gemm_f32 (gemm_f32_kernel<*>)", "achieved": round(achieved, 2),
-                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+        peak = MFMA_PEAK_TFLOPS[opt.dtype]
+        roofline = {"bound": "mfma", "kernel": f"sei_gemm_{opt.dtype} (gemm_{opt.dtype}_kernel<*>)",
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": None, "launches_per_step": len(records) // opt.steps,
                     "avg_launch_us": round(1e3 * ms / len(records), 2),
                     "gemm_share_of_step": round(ms / (elapsed * 1e3), 3),
@@ -171,7 +176,7 @@ def main():
             "metric": "training images/sec (256x256 crops), proposed-loss deblur",
             "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": opt.steps,
             "warmup": opt.warmup, "ms_per_step": round(1e3 * elapsed / opt.steps, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": opt.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: deblurring Gaussian_R2 noise=5, proposed loss (SURE + "
                                    "scale-EI), 256x256 pairs cropped to 48 in Loss.forward, ConvolutionalModel "
                                    f"hidden={opt.hidden} scales={opt.scales}",

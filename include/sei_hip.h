@@ -167,6 +167,48 @@ int sei_gemm_f32_ex(const float *A, const float *B, float *D, int M, int N, int 
                     float *D2, int batch, long long strideA, long long strideB, long long strideD,
                     int allow_splitk, void *stream);
 
+/* Same contract on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): A and B are float32 in HBM and
+ * are rounded to bf16 (round-to-nearest-even) while being staged into LDS; accumulation, epilogue
+ * and D stay float32. Throughput mode (--compute_dtype bf16); parity claims are made with sei_gemm_f32. */
+int sei_gemm_bf16_ex(const float *A, const float *B, float *D, int M, int N, int K, int transA,
+                     int transB, int epilogue, const float *bias, const float *R1, const float *R2,
+                     float *D2, int batch, long long strideA, long long strideB, long long strideD,
+                     int allow_splitk, void *stream);
+
+/* sei_gemm_bf16_ex with per-operand storage types: a_is_bf16 / b_is_bf16 = the operand is bf16 in HBM. */
+int sei_gemm_bf16_mixed(const void *A, int a_is_bf16, const void *B, int b_is_bf16, float *D, int M, int N,
+                        int K, int transA, int transB, int epilogue, const float *bias, const float *R1,
+                        const float *R2, float *D2, int batch, long long strideA, long long strideB,
+                        long long strideD, int allow_splitk, void *stream);
+
+/* bf16-mode support (all streaming): f32 -> bf16 cast; weight shadows w16 (R,C) and its transpose
+ * wt16 (C,R) from the f32 master weight w (R,C) (either output may be NULL); channel LayerNorm with a
+ * bf16 output (same statistics as sei_ln_fwd); column sums of a bf16 matrix (out[n] += sum_m X[m,n]). */
+int sei_cast_bf16(const float *x, uint16_t *y, size_t n, void *stream);
+int sei_weight_shadow_bf16(const float *w, uint16_t *w16, uint16_t *wt16, int R, int C, void *stream);
+int sei_ln_fwd_bf16(const float *x, const float *gamma, const float *beta, uint16_t *y, float *mean,
+                    float *rstd, size_t rows, int C, float eps, void *stream);
+int sei_colsum_bf16(const uint16_t *X, float *out, size_t M, int N, void *stream);
+/* x (R,C) float32 or bf16 -> x16 (R,C) bf16 copy (optional, float32 input only) and xt16 (C,ldt) bf16
+ * transpose (optional) whose columns R..ldt-1 are zero: a K-padded operand for sei_gemm_bf16nt. */
+int sei_cast_transpose_bf16(const void *x, int x_is_bf16, uint16_t *x16, uint16_t *xt16, int R, int C,
+                            int ldt, void *stream);
+
+/* Large-shape bf16 GEMM with bf16 operands in HBM, both K-contiguous:  D[M,N] = A[M,K] * B[N,K]^T.
+ * Forward 1x1 convolutions (B = bf16 weight shadow) and data gradients (B = transposed shadow).
+ * Direct-to-LDS staging (global_load_lds), 8 waves, (128|192|256) x 256 tiles, f32 accumulation.
+ * D32 (float) and/or D16 (bf16) receive the epilogue result; SEI_EPI_BIAS_GELU also writes
+ * gelu(D) to D2_16 (bf16); SEI_EPI_ACCUM adds into D32 (weight gradients: A = dY^T, B = X^T, both
+ * transposed to K = pixels-contiguous by sei_cast_transpose_bf16). lda / ldb = row strides in elements
+ * (>= K, multiples of 8). Needs K % 64 == 0 and 16-byte aligned A, B. May split K (float atomics on D32,
+ * zero-filled first unless accumulating) when the output is narrow. */
+int sei_gemm_bf16nt(const uint16_t *A, int lda, const uint16_t *B, int ldb, float *D32, uint16_t *D16,
+                    int M, int N, int K, int epilogue, const float *bias, const float *R1, const float *R2,
+                    uint16_t *D2_16, void *stream);
+
+/* Tuning aid: force the tile of sei_gemm_bf16nt (0 = automatic). Process-global; not for production use. */
+int sei_debug_set_nt_tile(int code);
+
 int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
                 const float *L1, const float *R1, const float *L2, const float *R2, float *work,
                 size_t work_floats, void *stream);

@@ -1,0 +1,252 @@
+// Support kernels of the bf16 throughput mode: casts, weight shadows, bf16-output LayerNorm, bf16 column sums.
+// All HBM-bound streaming kernels.
+#include "sei_common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned short f2bf(float v) {
+    const __bf16 b = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict__ x, unsigned short *__restrict__ y,
+                                                        size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        ushort4 o;
+        o.x = f2bf(v.x); o.y = f2bf(v.y); o.z = f2bf(v.z); o.w = f2bf(v.w);
+        reinterpret_cast<ushort4 *>(y)[i] = o;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = f2bf(x[i]);
+}
+
+__device__ __forceinline__ unsigned short to_bf(float v) { return f2bf(v); }
+__device__ __forceinline__ unsigned short to_bf(unsigned short v) { return v; }
+
+// x (R, C) f32 or bf16 -> x16 (R, C) bf16 (optional) and xt16 (C, ldt) bf16 (optional; columns R..ldt-1
+// are zero-filled so that the transposed matrix can be a K-padded GEMM operand). 64x64 tiles through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const T *__restrict__ x,
+                                                             unsigned short *__restrict__ x16,
+                                                             unsigned short *__restrict__ xt16, int R, int C,
+                                                             int ldt) {
+    __shared__ unsigned short tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        unsigned short v = 0;
+        if (r0 + r < R && c0 + c < C) {
+            v = to_bf(x[(size_t)(r0 + r) * C + c0 + c]);
+            if (x16) x16[(size_t)(r0 + r) * C + c0 + c] = v;
+        }
+        tile[r][c] = v;
+    }
+    __syncthreads();
+    if (xt16)
+        for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+            const int c = e >> 6, r = e & 63;
+            if (r0 + r < ldt && c0 + c < C) xt16[(size_t)(c0 + c) * ldt + r0 + r] = tile[r][c];   // zeros past R
+        }
+}
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// LayerNorm over C with a bf16 output (and f32 mean / rstd for the backward). One workgroup row-group
+// layout as in unet_kernels.hip: G lanes per row for C <= 512, one workgroup per row above.
+template <int G>
+__global__ __launch_bounds__(256) void ln_fwd_bf16_group_kernel(const float *__restrict__ x,
+                                                                const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta,
+                                                                unsigned short *__restrict__ y,
+                                                                float *__restrict__ mean, float *__restrict__ rstd,
+                                                                size_t rows, int C, float eps) {
+    const int lg = threadIdx.x % G, rsub = threadIdx.x / G;
+    constexpr int RPB = 256 / G;
+    const float invC = 1.0f / (float)C;
+    for (size_t row = (size_t)blockIdx.x * RPB + rsub; row < rows; row += (size_t)gridDim.x * RPB) {
+        const float *xr = x + row * C;
+        float v[8];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = lg + e * G;
+            v[e] = c < C ? xr[c] : 0.f;
+            s += v[e];
+        }
+        const float mu = group_sum<G>(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = lg + e * G;
+            const float d = c < C ? v[e] - mu : 0.f;
+            q = fmaf(d, d, q);
+        }
+        const float rs = 1.0f / sqrtf(group_sum<G>(q) * invC + eps);
+        unsigned short *yr = y + row * C;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = lg + e * G;
+            if (c < C) yr[c] = f2bf(fmaf((v[e] - mu) * rs, gamma[c], beta[c]));
+        }
+        if (lg == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_bf16_wide_kernel(const float *__restrict__ x,
+                                                               const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta,
+                                                               unsigned short *__restrict__ y,
+                                                               float *__restrict__ mean, float *__restrict__ rstd,
+                                                               size_t rows, int C, float eps) {
+    __shared__ float scratch[4];
+    __shared__ float bc[2];
+    const float invC = 1.0f / (float)C;
+    for (size_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float *xr = x + row * C;
+        float v[32];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int c = threadIdx.x + e * 256;
+            v[e] = c < C ? xr[c] : 0.f;
+            s += v[e];
+        }
+        s = sei_block_sum<256>(s, scratch);
+        if (threadIdx.x == 0) bc[0] = s * invC;
+        __syncthreads();
+        const float mu = bc[0];
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int c = threadIdx.x + e * 256;
+            const float d = c < C ? v[e] - mu : 0.f;
+            q = fmaf(d, d, q);
+        }
+        q = sei_block_sum<256>(q, scratch);
+        if (threadIdx.x == 0) bc[1] = 1.0f / sqrtf(q * invC + eps);
+        __syncthreads();
+        const float rs = bc[1];
+        unsigned short *yr = y + row * C;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int c = threadIdx.x + e * 256;
+            if (c < C) yr[c] = f2bf(fmaf((v[e] - mu) * rs, gamma[c], beta[c]));
+        }
+        if (threadIdx.x == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short *__restrict__ X,
+                                                          float *__restrict__ out, size_t M, int N,
+                                                          size_t rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int cw = min(N, 256);
+    const int rsubs = 256 / cw;
+    const int cl = threadIdx.x % cw, rsub = threadIdx.x / cw;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const int c = blockIdx.y * cw + cl;
+    float s = 0.f;
+    if (c < N && rsub < rsubs)
+        for (size_t r = r0 + rsub; r < r1; r += rsubs) s += bf2f(X[r * N + c]);
+    if (rsub < rsubs) red[rsub * cw + cl] = s;
+    __syncthreads();
+    if (rsub == 0 && c < N) {
+        float t = 0.f;
+        for (int k = 0; k < rsubs; ++k) t += red[k * cw + cl];
+        atomicAdd(out + c, t);
+    }
+}
+
+template <int G>
+int launch_ln16(const float *x, const float *gamma, const float *beta, unsigned short *y, float *mean, float *rstd,
+                size_t rows, int C, float eps, hipStream_t s) {
+    size_t grid = sei_ceil_div(rows, 256 / G);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(ln_fwd_bf16_group_kernel<G>, dim3((unsigned)grid), dim3(256), 0, s, x, gamma, beta, y, mean,
+                       rstd, rows, C, eps);
+    return sei_launch_status();
+}
+
+}  // namespace
+
+extern "C" int sei_cast_bf16(const float *x, uint16_t *y, size_t n, void *stream) {
+    SEI_REQUIRE(x && y && n > 0);
+    SEI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0);
+    size_t grid = sei_ceil_div(n / 4 + 1, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return sei_launch_status();
+}
+
+extern "C" int sei_weight_shadow_bf16(const float *w, uint16_t *w16, uint16_t *wt16, int R, int C, void *stream) {
+    SEI_REQUIRE(w && (w16 || wt16) && R > 0 && C > 0);
+    hipLaunchKernelGGL(cast_transpose_kernel<float>, dim3((unsigned)sei_ceil_div(C, 64), (unsigned)sei_ceil_div(R, 64)),
+                       dim3(256), 0, (hipStream_t)stream, w, w16, wt16, R, C, R);
+    return sei_launch_status();
+}
+
+extern "C" int sei_cast_transpose_bf16(const void *x, int x_is_bf16, uint16_t *x16, uint16_t *xt16, int R, int C,
+                                       int ldt, void *stream) {
+    SEI_REQUIRE(x && (x16 || xt16) && R > 0 && C > 0 && ldt >= R);
+    SEI_REQUIRE(!(x_is_bf16 && x16));
+    // the grid covers ldt rows so that the zero padding of xt16 is written too
+    dim3 grid((unsigned)sei_ceil_div(C, 64), (unsigned)sei_ceil_div(xt16 ? ldt : R, 64));
+    if (x_is_bf16)
+        hipLaunchKernelGGL(cast_transpose_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short *)x, x16, xt16, R, C, ldt);
+    else
+        hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)x,
+                           x16, xt16, R, C, ldt);
+    return sei_launch_status();
+}
+
+extern "C" int sei_ln_fwd_bf16(const float *x, const float *gamma, const float *beta, uint16_t *y, float *mean,
+                               float *rstd, size_t rows, int C, float eps, void *stream) {
+    SEI_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0);
+    if (C > 8192) return SEI_ERR_TOO_LARGE;
+    hipStream_t s = (hipStream_t)stream;
+    if (C > 512) {
+        size_t grid = rows < 8192 ? rows : 8192;
+        hipLaunchKernelGGL(ln_fwd_bf16_wide_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd,
+                           rows, C, eps);
+        return sei_launch_status();
+    }
+    int gsz = 1;
+    while (gsz < 64 && gsz < C) gsz <<= 1;
+    switch (gsz) {
+        case 1: return launch_ln16<1>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        case 2: return launch_ln16<2>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        case 4: return launch_ln16<4>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        case 8: return launch_ln16<8>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        case 16: return launch_ln16<16>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        case 32: return launch_ln16<32>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        default: return launch_ln16<64>(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+    }
+}
+
+extern "C" int sei_colsum_bf16(const uint16_t *X, float *out, size_t M, int N, void *stream) {
+    SEI_REQUIRE(X && out && M > 0 && N > 0);
+    const int cw = N < 256 ? N : 256;
+    const unsigned col_blocks = (unsigned)sei_ceil_div(N, cw);
+    size_t rpb = 16;
+    while (sei_ceil_div(M, rpb) * col_blocks > 2048 && rpb < M) rpb *= 2;
+    const size_t lds = sizeof(float) * (size_t)(256 / cw) * cw;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)sei_ceil_div(M, rpb), col_blocks), dim3(256), lds,
+                       (hipStream_t)stream, X, out, M, N, rpb);
+    return sei_launch_status();
+}

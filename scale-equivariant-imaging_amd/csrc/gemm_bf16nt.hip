@@ -1,0 +1,266 @@
+// sei_gemm_bf16nt: the large 1x1-convolution GEMMs of the U-Net in throughput (bf16) mode.
+//
+//   D[M,N] = A[M,K] * B[N,K]^T      A, B: bf16 in HBM, both K-contiguous ("NT"); f32 accumulation
+//   outputs: D32 (float) and/or D16 (bf16), fused epilogues as sei_gemm_f32.
+//
+// Serves the forward 1x1 convolutions (A = activations, B = weight shadow in bf16) and the data
+// gradients (A = upstream gradient, B = the TRANSPOSED bf16 weight shadow), i.e. every GEMM whose
+// operands can be kept K-contiguous. Weight gradients (reduction over pixels) stay on the
+// register-staged kernel (gemm_bf16.hip): they are bound by the f32 gradient read-modify-write.
+//
+// Structure (cdna_hip_programming.md section 5, "minimum 2-phase" loop):
+//   * 8 waves (2 x 4), block tile (64*TM) x 256, BK = 64 -> one 128-byte line per row per k-tile.
+//   * HBM/L2 -> LDS by global_load_lds_dwordx4: each wave-instruction moves 8 rows x 128 B = 1 KiB
+//     (full lines), no VGPR staging. The LDS image is row-major [row][8 chunks of 16 B]; chunk c of row
+//     r is stored at chunk position c ^ ((r>>1)&7). Because the DMA destination is lane-linear, the
+//     swizzle is applied to the per-lane SOURCE address and again on the fragment read.
+//   * MFMA fragment (v_mfma_f32_32x32x16_bf16) of lane l = row l&31, k-chunk 2s + (l>>5) of k-step s:
+//     one ds_read_b128; with the swizzle every 16-lane group covers 16 distinct 16-B slots.
+//   * double-buffered LDS (2 x (BM+256) x 128 B <= 128 KiB, one workgroup per CU), one barrier per k-tile.
+//   * workgroup order: the m-tiles that share a B (weight) panel get ids congruent mod 8 and adjacent,
+//     so they run on one XCD at the same time and the panel is fetched from HBM once (speed only).
+//   * narrow outputs (few tiles, long K) split K over workgroups and combine with float atomics.
+//
+// Requirements checked by the host entry: K % 64 == 0, 16-byte aligned A and B.
+#include "sei_common.h"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+constexpr int BK = 64;
+constexpr int ROW_BYTES = 128;
+constexpr int NWAVES = 8, NT = 512;
+
+struct NtArgs {
+    const unsigned short *A, *B;
+    float *D32;
+    unsigned short *D16;
+    int M, N, K, lda, ldb;
+    int epilogue;
+    const float *bias, *R1, *R2;
+    unsigned short *D2_16;     // BIAS_GELU: gelu(D) in bf16
+    int splitk, k_per_split;
+    int tiles_m, tiles_n, xcd_order;
+};
+
+__device__ __forceinline__ unsigned short f2bf(float v) {
+    const __bf16 b = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+template <int ROWS>
+__device__ __forceinline__ void stage_tile(const unsigned short *__restrict__ G, int ld, int row0, int row_lim,
+                                           int k0, char *lds_tile, int wave, int lane) {
+    constexpr int NI = ROWS / 8;             // 1-KiB wave-instructions in the tile
+#pragma unroll
+    for (int q0 = 0; q0 < NI; q0 += NWAVES) {
+        const int q = q0 + wave;             // wave-uniform
+        if (q < NI) {
+            const int row = 8 * q + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);      // logical chunk this lane must fetch
+            const int grow = min(row0 + row, row_lim - 1);     // rows past the edge re-read the last row
+            const unsigned short *src = G + (size_t)grow * ld + k0 + 8 * c;
+            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
+        }
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
+    static_assert(WM * WN == NWAVES, "8 waves per workgroup");
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int STAGE = (BM + BN) * ROW_BYTES;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- tile / split assignment --------------------------------------------------------------
+    int bid = blockIdx.x;
+    const int ntile = g.tiles_m * g.tiles_n;
+    const int zs = bid / ntile;
+    bid -= zs * ntile;
+    int tm_i, tn_i;
+    if (g.xcd_order) {
+        const int xcd = bid & 7, j = bid >> 3;
+        tm_i = j % g.tiles_m;
+        tn_i = (j / g.tiles_m) * 8 + xcd;
+    } else {
+        tm_i = bid % g.tiles_m;
+        tn_i = bid / g.tiles_m;
+    }
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int M = g.M, N = g.N, K = g.K;
+    const int k_begin = zs * g.k_per_split;
+    const int k_end = min(K, k_begin + g.k_per_split);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage_tile<BM>(g.A, g.lda, m0, M, k_begin, smem, wave, lane);
+    stage_tile<BN>(g.B, g.ldb, n0, N, k_begin, smem + BM * ROW_BYTES, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int sw = (li >> 1) & 7;                              // swizzle key of this lane's rows
+    const int a_off = (wm * 32 * TM + li) * ROW_BYTES;
+    const int b_off = BM * ROW_BYTES + (wn * 32 * TN + li) * ROW_BYTES;
+
+    int cur = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        char *now = smem + cur * STAGE;
+        if (k0 + BK < k_end) {
+            char *nxt = smem + (cur ^ 1) * STAGE;
+            stage_tile<BM>(g.A, g.lda, m0, M, k0 + BK, nxt, wave, lane);
+            stage_tile<BN>(g.B, g.ldb, n0, N, k0 + BK, nxt + BM * ROW_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int pc = ((2 * s + lh) ^ sw) * 16;
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const bf16x8 *>(now + a_off + i * 32 * ROW_BYTES + pc);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const bf16x8 *>(now + b_off + j * 32 * ROW_BYTES + pc);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------
+    // Per 32x32 accumulator tile: first gather every auxiliary value the epilogue needs (16 independent
+    // loads in flight), then compute and store. Interleaving loads with the stores serialises them.
+    const int epi = g.epilogue;
+    const bool lead = zs == 0;          // with split-K, split 0 carries bias / residual terms
+    const bool split = g.splitk > 1;
+    const float *aux1p = nullptr, *aux2p = nullptr;
+    if (epi == SEI_EPI_BIAS_RES && (!split || lead)) { aux1p = g.R1; aux2p = g.R2; }
+    else if (epi == SEI_EPI_MUL_DGELU) aux1p = g.R1;
+    else if (epi == SEI_EPI_ACCUM && !split) aux1p = g.D32;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (32 * TN) + 32 * j + li;
+            const bool col_ok = col < N;
+            const int row_base = m0 + wm * (32 * TM) + 32 * i + 4 * lh;
+            const float bias = (col_ok && (!split || lead) &&
+                                (epi == SEI_EPI_BIAS || epi == SEI_EPI_BIAS_GELU || epi == SEI_EPI_BIAS_RES))
+                                   ? g.bias[col] : 0.f;
+            float a1[16], a2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + (r & 3) + 8 * (r >> 2);
+                const bool ok = col_ok && row < M;
+                const size_t o = (size_t)row * N + col;
+                a1[r] = (ok && aux1p) ? aux1p[o] : 0.f;
+                a2[r] = (ok && aux2p) ? aux2p[o] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + (r & 3) + 8 * (r >> 2);
+                if (!col_ok || row >= M) continue;
+                const size_t o = (size_t)row * N + col;
+                float v = acc[i][j][r] + bias;
+                if (split) {
+                    atomicAdd(g.D32 + o, v + a1[r] + a2[r]);
+                    continue;
+                }
+                if (epi == SEI_EPI_MUL_DGELU) v *= sei_dgelu(a1[r]);
+                else v += a1[r] + a2[r];
+                if (epi == SEI_EPI_BIAS_GELU) g.D2_16[o] = f2bf(sei_gelu(v));
+                if (g.D32) g.D32[o] = v;
+                if (g.D16) g.D16[o] = f2bf(v);
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int WM, int WN>
+int launch_nt(NtArgs &g, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    g.tiles_m = (int)sei_ceil_div(g.M, BM);
+    g.tiles_n = (int)sei_ceil_div(g.N, BN);
+    g.xcd_order = (g.tiles_n % 8 == 0) ? 1 : 0;
+    const size_t tiles = (size_t)g.tiles_m * g.tiles_n;
+    g.splitk = 1;
+    g.k_per_split = g.K;
+    const bool splittable = g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
+                            g.epilogue == SEI_EPI_BIAS_RES || g.epilogue == SEI_EPI_ACCUM;
+    if (splittable && g.D32 && !g.D16 && tiles < 160 && g.K >= 8 * BK) {
+        size_t sk = sei_ceil_div(256, tiles);
+        const size_t max_sk = (size_t)g.K / (4 * BK);
+        if (sk > max_sk) sk = max_sk;
+        if (sk > 1) {
+            g.k_per_split = (int)(sei_ceil_div(sei_ceil_div(g.K, sk), BK) * BK);
+            g.splitk = (int)sei_ceil_div(g.K, g.k_per_split);
+        }
+    }
+    if (g.splitk > 1 && g.epilogue != SEI_EPI_ACCUM) {      // ACCUM adds into the running gradient as it is
+        const hipError_t e = hipMemsetAsync(g.D32, 0, sizeof(float) * (size_t)g.M * g.N, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN>), dim3((unsigned)(tiles * g.splitk)), dim3(NT), 0, s, g);
+    return sei_launch_status();
+}
+
+int g_force_tile = 0;     // tuning aid only (sei_debug_set_nt_tile); 0 = automatic choice
+
+}  // namespace
+
+extern "C" int sei_debug_set_nt_tile(int code) {
+    g_force_tile = code;
+    return SEI_OK;
+}
+
+extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, const uint16_t *B, int ldb, float *D32, uint16_t *D16,
+                               int M, int N, int K, int epilogue, const float *bias, const float *R1,
+                               const float *R2, uint16_t *D2_16, void *stream) {
+    SEI_REQUIRE(A && B && (D32 || D16) && M > 0 && N > 0 && K > 0);
+    SEI_REQUIRE(K % BK == 0 && lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0);
+    SEI_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0);
+    SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU ||
+                epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_ACCUM);
+    if (epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU || epilogue == SEI_EPI_BIAS_RES) SEI_REQUIRE(bias);
+    if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D2_16);
+    if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU) SEI_REQUIRE(R1);
+    if (epilogue == SEI_EPI_ACCUM) SEI_REQUIRE(D32 && !D16);
+    NtArgs g;
+    g.A = A; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
+    g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
+    hipStream_t s = (hipStream_t)stream;
+    switch (g_force_tile) {
+        case 1: return launch_nt<2, 1, 2, 4>(g, s);      // 128 x 128
+        case 2: return launch_nt<2, 2, 2, 4>(g, s);      // 128 x 256
+        case 3: return launch_nt<3, 2, 2, 4>(g, s);      // 192 x 256
+        case 5: return launch_nt<3, 1, 1, 8>(g, s);      //  96 x 256
+        default: break;
+    }
+    // Tile choice (measured on MI355X, tools/exp_dw.py): 128x128 runs two workgroups per CU, which hides
+    // each block's load latency and epilogue behind the other's MFMAs, and is the best or within 2 % of
+    // the best on every U-Net shape except long-K GEMMs whose row count is a multiple of 192, where
+    // 192x256 wins by ~10 %. 96x256 avoids 25 % padding when M = 96 (mod 192) (the B-pass: 288 rows).
+    // A 256x256 tile (1 block/CU, 172 VGPRs) measured ~115 TFLOP/s on every shape and is not used.
+    if (N >= 256 && M % 192 == 0 && K >= 2048) return launch_nt<3, 2, 2, 4>(g, s);       // 192 x 256
+    if (N >= 256 && M % 128 != 0 && M % 96 == 0) return launch_nt<3, 1, 1, 8>(g, s);     //  96 x 256
+    return launch_nt<2, 1, 2, 4>(g, s);                                                  // 128 x 128
+}

@@ -34,6 +34,22 @@ def grad_of(p):
 # thin launch helpers (pointers + sizes only; shapes are checked here, on the host)
 # ---------------------------------------------------------------------------------------------
 _GEMM_PROFILE = None     # bench.py: list of (flops, start_event, end_event) while enabled
+_GEMM_ENTRY = {"f32": "sei_gemm_f32_ex", "bf16": "sei_gemm_bf16_ex"}
+_COMPUTE_DTYPE = "f32"
+
+
+def set_compute_dtype(name):
+    """Arithmetic type of the 1x1-convolution GEMMs: "f32" (exact-f32 MFMA; the parity mode) or "bf16"
+    (bf16 MFMA with f32 accumulation; operands stay f32 in HBM). Everything else is f32 either way."""
+    global _COMPUTE_DTYPE
+    if name not in _GEMM_ENTRY:
+        raise ValueError(f"compute dtype must be one of {sorted(_GEMM_ENTRY)}, got {name!r}")
+    previous, _COMPUTE_DTYPE = _COMPUTE_DTYPE, name
+    return previous
+
+
+def get_compute_dtype():
+    return _COMPUTE_DTYPE
 
 
 def profile_gemms(enable):
@@ -49,12 +65,25 @@ def gemm(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2
     if _GEMM_PROFILE is not None:
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0.record()
-    N.call("sei_gemm_f32_ex", A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K, ta, tb, epi,
+    N.call(_GEMM_ENTRY[_COMPUTE_DTYPE], A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K, ta, tb, epi,
            N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2), 1, 0, 0, 0, int(allow_splitk))
     if _GEMM_PROFILE is not None:
         t1.record()
         _GEMM_PROFILE.append((2.0 * M * Nn * K, t0, t1))
     return out
+
+
+def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=None, R2=None, D2_16=None,
+              lda=None, ldb=None):
+    """D = A16[M,K] @ B16[N,K]^T on the direct-to-LDS bf16 kernel (K % 64 == 0). Outputs as given."""
+    if _GEMM_PROFILE is not None:
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+    N.call("sei_gemm_bf16nt", A16.data_ptr(), K if lda is None else lda, B16.data_ptr(), K if ldb is None else ldb,
+           N.ptr(out32), N.ptr(out16), M, Nn, K, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2_16))
+    if _GEMM_PROFILE is not None:
+        t1.record()
+        _GEMM_PROFILE.append((2.0 * M * Nn * K, t0, t1))
 
 
 def layer_norm(x2d, gamma, beta):
@@ -226,6 +255,239 @@ class UpsampleFn(torch.autograd.Function):
         colsum_into(grad_of(b), go2)
         gemm(go2, h, Co, C, M, 1, 0, EPI_ACCUM, out=grad_of(w).view(Co, C))
         gh = gemm(go2, w, M, C, Co, 0, 0, EPI_NONE)
+        gu = layer_norm_bwd(u.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta))
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = sepmap2(gu.view(B, Ho, Wo, C), ctx.mats_t, *ctx.in_hw)
+        gskip = go if ctx.needs_input_grad[1] else None
+        return gx, gskip, None, None, None, None, None
+
+
+# =============================================================================================
+# bf16 throughput mode (--compute_dtype bf16): GEMM-only activations are STORED in bf16, weights get
+# bf16 shadows (plain + transposed) refreshed once per optimizer step, and every GEMM whose operands can
+# be K-contiguous runs on the direct-to-LDS kernel (sei_gemm_bf16nt). Weight gradients use the
+# register-staged kernel on the bf16 tensors and accumulate into the f32 gradient bucket. Everything
+# else (depthwise conv, LayerNorm statistics and backward, resamplers, residuals, Adam) stays f32.
+# =============================================================================================
+_SHADOW_GENERATION = 0
+
+
+def weights_updated():
+    """Tell the shadow cache that parameters changed behind torch's back (fused Adam kernel)."""
+    global _SHADOW_GENERATION
+    _SHADOW_GENERATION += 1
+
+
+def shadow(p):
+    """(w16 (R,C), wt16 (C,R)) bf16 shadows of a 1x1-conv weight p (R,C,1,1); cached per update."""
+    key = (_SHADOW_GENERATION, p._version, p.data_ptr())
+    st = getattr(p, "_sei_shadow", None)
+    if st is None or st[0] != key:
+        R, C = p.shape[0], p.shape[1]
+        if st is None or st[1].device != p.device:
+            w16 = torch.empty((R, C), dtype=torch.bfloat16, device=p.device)
+            wt16 = torch.empty((C, R), dtype=torch.bfloat16, device=p.device)
+        else:
+            w16, wt16 = st[1], st[2]
+        N.call("sei_weight_shadow_bf16", p.data_ptr(), w16.data_ptr(), wt16.data_ptr(), R, C)
+        st = (key, w16, wt16)
+        p._sei_shadow = st
+    return st[1], st[2]
+
+
+def nt16_ok(K):
+    return K % 64 == 0
+
+
+def to_bf16(x):
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    N.call("sei_cast_bf16", x.data_ptr(), y.data_ptr(), x.numel())
+    return y
+
+
+def layer_norm16(x2d, gamma, beta):
+    rows, C = x2d.shape
+    y = torch.empty((rows, C), dtype=torch.bfloat16, device=x2d.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty_like(mean)
+    N.call("sei_ln_fwd_bf16", x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+           rstd.data_ptr(), rows, C, LN_EPS)
+    return y, mean, rstd
+
+
+def colsum16_into(acc, x16):
+    M, Nn = x16.shape
+    N.call("sei_colsum_bf16", x16.data_ptr(), acc.data_ptr(), M, Nn)
+
+
+def gemm_mixed(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2=None, allow_splitk=True):
+    """Register-staged bf16-MFMA GEMM; each operand may be stored as float32 or bfloat16."""
+    if out is None:
+        out = torch.empty((M, Nn), dtype=torch.float32, device=A.device)
+    if _GEMM_PROFILE is not None:
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+    N.call("sei_gemm_bf16_mixed", A.data_ptr(), int(A.dtype == torch.bfloat16), Bm.data_ptr(),
+           int(Bm.dtype == torch.bfloat16), out.data_ptr(), M, Nn, K, ta, tb, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2),
+           N.ptr(D2), 1, 0, 0, 0, int(allow_splitk))
+    if _GEMM_PROFILE is not None:
+        t1.record()
+        _GEMM_PROFILE.append((2.0 * M * Nn * K, t0, t1))
+    return out
+
+
+def pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def transposed16(x2d, also_plain=False):
+    """x (R, C) f32 or bf16 -> xt16 (C, pad64(R)) bf16, zero padded (and x16 (R, C) when asked, f32 input)."""
+    R, C = x2d.shape
+    ldt = pad64(R)
+    xt = torch.empty((C, ldt), dtype=torch.bfloat16, device=x2d.device)
+    x16 = torch.empty((R, C), dtype=torch.bfloat16, device=x2d.device) if also_plain else None
+    N.call("sei_cast_transpose_bf16", x2d.data_ptr(), int(x2d.dtype == torch.bfloat16), N.ptr(x16), xt.data_ptr(),
+           R, C, ldt)
+    return (x16, xt) if also_plain else xt
+
+
+def weight_grad16(gy_t, x_t, grad2d, rows):
+    """grad (N', K') += gy^T x over `rows` pixels, both operands given transposed and K-padded."""
+    Np, Kp = grad2d.shape
+    ld = gy_t.shape[1]
+    gemm_nt16(gy_t, x_t, Np, Kp, ld, EPI_ACCUM, out32=grad2d, lda=ld, ldb=ld)
+
+
+def use_bf16_blocks(C):
+    """A block takes the bf16-storage path when the mode is bf16 and its GEMMs fit the NT kernel."""
+    return _COMPUTE_DTYPE == "bf16" and nt16_ok(C)
+
+
+class ConvBlockFn16(torch.autograd.Function):
+    """ConvBlockFn with bf16 storage of h2 / h4 / gh3 and the direct-to-LDS GEMMs (C % 64 == 0)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, gamma, beta, w2, b2, w3, b3, twice):
+        x = _nhwc(x)
+        B, H, W, C = x.shape
+        M = B * H * W
+        h1 = dwconv7(x, w1, b1)
+        h2, mean, rstd = layer_norm16(h1.view(M, C), gamma, beta)
+        w2_16, _ = shadow(w2)
+        w3_16, _ = shadow(w3)
+        h3 = torch.empty((M, 4 * C), dtype=torch.float32, device=x.device)
+        h4 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device)
+        gemm_nt16(h2, w2_16, M, 4 * C, C, EPI_BIAS_GELU, out32=h3, bias=b2, D2_16=h4)
+        out = torch.empty((M, C), dtype=torch.float32, device=x.device)
+        gemm_nt16(h4, w3_16, M, C, 4 * C, EPI_BIAS_RES, out32=out, bias=b3, R1=x, R2=x if twice else None)
+        ctx.save_for_backward(x, h1, mean, rstd, h2, h3, h4)
+        ctx.params = (w1, b1, gamma, beta, w2, b2, w3, b3)
+        ctx.twice = twice
+        return out.view(B, H, W, C)
+
+    @staticmethod
+    def backward(ctx, go):
+        x, h1, mean, rstd, h2, h3, h4 = ctx.saved_tensors
+        w1, b1, gamma, beta, w2, b2, w3, b3 = ctx.params
+        B, H, W, C = x.shape
+        M = B * H * W
+        go = go.contiguous()
+        go2 = go.view(M, C)
+        go16, go16_t = transposed16(go2, also_plain=True)
+        _, w3t_16 = shadow(w3)
+        _, w2t_16 = shadow(w2)
+        colsum_into(grad_of(b3), go2)
+        weight_grad16(go16_t, transposed16(h4), grad_of(w3).view(C, 4 * C), M)
+        gh3 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device)
+        gemm_nt16(go16, w3t_16, M, 4 * C, C, EPI_MUL_DGELU, out16=gh3, R1=h3)
+        colsum16_into(grad_of(b2), gh3)
+        weight_grad16(transposed16(gh3), transposed16(h2), grad_of(w2).view(4 * C, C), M)
+        gh2 = torch.empty((M, C), dtype=torch.float32, device=x.device)
+        gemm_nt16(gh3, w2t_16, M, C, 4 * C, EPI_NONE, out32=gh2)
+        gh1 = layer_norm_bwd(h1.view(M, C), gamma, mean, rstd, gh2, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
+        N.call("sei_dwconv7_bwd_weight", x.data_ptr(), gh1.data_ptr(), grad_of(w1).data_ptr(),
+               grad_of(b1).data_ptr(), B, H, W, C)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = dwconv7(gh1, w1, None, flip=True, res=go, res_scale=2.0 if ctx.twice else 1.0)
+        return (gx,) + (None,) * 9
+
+
+class DownsampleFn16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w, b, rate):
+        x = _nhwc(x)
+        B, H, W, C = x.shape
+        M, Co = B * H * W, w.shape[0]
+        h, mean, rstd = layer_norm16(x.view(M, C), gamma, beta)
+        w16, _ = shadow(w)
+        z = torch.empty((M, Co), dtype=torch.float32, device=x.device)
+        gemm_nt16(h, w16, M, Co, C, EPI_BIAS, out32=z, bias=b)
+        fwd, bwd = _mats.resample_matrices("down", H, W, rate, x.device)
+        out = sepmap2(z.view(B, H, W, Co), fwd, fwd[0].shape[0], fwd[1].shape[0])
+        ctx.save_for_backward(x, mean, rstd, h)
+        ctx.params, ctx.mats_t = (gamma, beta, w, b), bwd
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        x, mean, rstd, h = ctx.saved_tensors
+        gamma, beta, w, b = ctx.params
+        B, H, W, C = x.shape
+        M, Co = B * H * W, w.shape[0]
+        gz = sepmap2(go.contiguous(), ctx.mats_t, H, W).view(M, Co)
+        gz16, gz16_t = transposed16(gz, also_plain=True)
+        colsum_into(grad_of(b), gz)
+        weight_grad16(gz16_t, transposed16(h), grad_of(w).view(Co, C), M)
+        _, wt16 = shadow(w)
+        gh = torch.empty((M, C), dtype=torch.float32, device=x.device)
+        gemm_nt16(gz16, wt16, M, C, Co, EPI_NONE, out32=gh)
+        gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
+        return (gx if ctx.needs_input_grad[0] else None), None, None, None, None, None
+
+
+class UpsampleFn16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, skip, gamma, beta, w, b, rate):
+        x = _nhwc(x)
+        B, H, W, C = x.shape
+        Co = w.shape[0]
+        fwd, bwd = _mats.resample_matrices("up", H, W, rate, x.device)
+        Ho, Wo = fwd[0].shape[0], fwd[1].shape[0]
+        u = sepmap2(x, fwd, Ho, Wo)
+        M = B * Ho * Wo
+        h, mean, rstd = layer_norm16(u.view(M, C), gamma, beta)
+        w16, _ = shadow(w)
+        out = torch.empty((M, Co), dtype=torch.float32, device=x.device)
+        if skip is not None:
+            skip = _nhwc(skip)
+            if tuple(skip.shape) != (B, Ho, Wo, Co):
+                raise ValueError("skip connection shape mismatch")
+            gemm_nt16(h, w16, M, Co, C, EPI_BIAS_RES, out32=out, bias=b, R1=skip)
+        else:
+            gemm_nt16(h, w16, M, Co, C, EPI_BIAS, out32=out, bias=b)
+        ctx.save_for_backward(u, mean, rstd, h)
+        ctx.params, ctx.mats_t, ctx.in_hw = (gamma, beta, w, b), bwd, (H, W)
+        return out.view(B, Ho, Wo, Co)
+
+    @staticmethod
+    def backward(ctx, go):
+        u, mean, rstd, h = ctx.saved_tensors
+        gamma, beta, w, b = ctx.params
+        B, Ho, Wo, C = u.shape
+        M, Co = B * Ho * Wo, w.shape[0]
+        go = go.contiguous()
+        go2 = go.view(M, Co)
+        go16, go16_t = transposed16(go2, also_plain=True)
+        colsum_into(grad_of(b), go2)
+        weight_grad16(go16_t, transposed16(h), grad_of(w).view(Co, C), M)
+        if nt16_ok(Co):
+            _, wt16 = shadow(w)
+            gh = torch.empty((M, C), dtype=torch.float32, device=u.device)
+            gemm_nt16(go16, wt16, M, C, Co, EPI_NONE, out32=gh)
+        else:
+            gh = gemm_mixed(go16, w, M, C, Co, 0, 0, EPI_NONE)
         gu = layer_norm_bwd(u.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta))
         gx = None
         if ctx.needs_input_grad[0]:

@@ -59,7 +59,8 @@ class ConvBlock(Module):
         self.conv3 = Conv2d(in_channels=4 * dim, out_channels=dim, kernel_size=1)
 
     def forward(self, x, twice=False):
-        return _ops.ConvBlockFn.apply(x, self.conv1.weight, self.conv1.bias, self.ln.ln.weight, self.ln.ln.bias,
+        fn = _ops.ConvBlockFn16 if _ops.use_bf16_blocks(x.shape[-1]) else _ops.ConvBlockFn
+        return fn.apply(x, self.conv1.weight, self.conv1.bias, self.ln.ln.weight, self.ln.ln.bias,
                                       self.conv2.weight, self.conv2.bias, self.conv3.weight, self.conv3.bias,
                                       twice)
 
@@ -108,7 +109,8 @@ class Upsample(Module):
 
     def forward(self, x, skip=None):
         ln, conv = self.seq[1].ln, self.seq[2]
-        return _ops.UpsampleFn.apply(x, skip, ln.weight, ln.bias, conv.weight, conv.bias, self.rate)
+        fn = _ops.UpsampleFn16 if _ops.use_bf16_blocks(x.shape[-1]) else _ops.UpsampleFn
+        return fn.apply(x, skip, ln.weight, ln.bias, conv.weight, conv.bias, self.rate)
 
 
 class Downsample(Module):
@@ -122,8 +124,8 @@ class Downsample(Module):
         self.ideal_downsample = IdealDownsample(rate=self.rate)
 
     def forward(self, x):
-        return _ops.DownsampleFn.apply(x, self.ln.ln.weight, self.ln.ln.bias, self.conv.weight, self.conv.bias,
-                                       self.rate)
+        fn = _ops.DownsampleFn16 if _ops.use_bf16_blocks(x.shape[-1]) else _ops.DownsampleFn
+        return fn.apply(x, self.ln.ln.weight, self.ln.ln.bias, self.conv.weight, self.conv.bias, self.rate)
 
 
 class UNet(Module):

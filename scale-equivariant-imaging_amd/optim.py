@@ -44,3 +44,5 @@ class FlatAdam(torch.optim.Optimizer):
             N.call("sei_adam_fused", flat[s:e].data_ptr(), grads[s:e].data_ptr(), st["exp_avg"][s:e].data_ptr(),
                    st["exp_avg_sq"][s:e].data_ptr(), e - s, float(group["lr"]), float(b1), float(b2),
                    float(group["eps"]), float(group["weight_decay"]), int(st["step"]), 1.0 / world)
+        from models import _ops
+        _ops.weights_updated()          # bf16 weight shadows must be rebuilt before the next forward

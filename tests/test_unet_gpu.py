@@ -321,3 +321,108 @@ def test_model_factory_surface():
     args.ProposedModel__architecture = "Nope"
     with pytest.raises(ValueError):
         models.get_model(args, p, "cuda")
+
+
+# ------------------------------------------------------------------ bf16 throughput mode
+@pytest.mark.parametrize("M,N,K", [(288, 512, 128), (2304, 128, 32), (37, 29, 19), (130, 260, 70), (576, 2048, 512),
+                                    (4608, 32, 128), (300, 96, 1000), (1, 3, 3)])
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_bf16_layouts(ops, M, N, K, ta, tb):
+    """bf16 MFMA path: exact for bf16-representable inputs up to f32 accumulation order."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=gen).bfloat16().float()
+    Bm = torch.randn((N, K) if tb else (K, N), generator=gen).bfloat16().float()
+    ref = (A.double().T if ta else A.double()) @ (Bm.double().T if tb else Bm.double())
+    prev = ops.set_compute_dtype("bf16")
+    try:
+        out = ops.gemm(A.cuda(), Bm.cuda(), M, N, K, ta, tb, ops.EPI_NONE)
+        bias = torch.randn(N, generator=gen)
+        d2 = torch.empty((M, N), device="cuda")
+        out2 = ops.gemm(A.cuda(), Bm.cuda(), M, N, K, ta, tb, ops.EPI_BIAS_GELU, bias=bias.cuda(), D2=d2)
+        # un-rounded inputs: the kernel rounds to bf16 (RNE) itself
+        A2 = torch.randn((K, M) if ta else (M, K), generator=gen)
+        ref2 = (A2.bfloat16().double().T if ta else A2.bfloat16().double()) @ (Bm.double().T if tb else Bm.double())
+        out3 = ops.gemm(A2.cuda(), Bm.cuda(), M, N, K, ta, tb, ops.EPI_NONE)
+    finally:
+        ops.set_compute_dtype(prev)
+    assert relerr(out, ref) < 3e-6
+    assert relerr(out2, ref + bias.double()) < 3e-6 and relerr(d2, F.gelu(ref + bias.double())) < 3e-6
+    assert relerr(out3, ref2) < 3e-6
+
+
+def test_bf16_mode_model_quality():
+    """Same weights, bf16 GEMMs vs f32 GEMMs: restored images agree to bf16 rounding and their PSNR
+    against a clean target differs by < 0.01 dB."""
+    import metrics
+    from models import _ops
+    from models.convolutional import ConvolutionalModel
+    torch.manual_seed(0)
+    m = ConvolutionalModel(in_channels=3, upsampling_rate=1, residual=True, inner_residual=True, num_conv_blocks=1,
+                           hidden_channels=32, inout_convs=True, scales=4).cuda()
+    gen = torch.Generator().manual_seed(2)
+    x = torch.rand((4, 3, 48, 48), generator=gen)
+    y = (x + 5 / 255 * torch.randn((4, 3, 48, 48), generator=gen)).cuda()
+    with torch.no_grad():
+        ref = m(y)
+        prev = _ops.set_compute_dtype("bf16")
+        try:
+            got = m(y)
+        finally:
+            _ops.set_compute_dtype(prev)
+    assert relerr(got, ref) < 2e-2
+    for i in range(4):
+        assert abs(float(metrics.psnr_fn(got[i].cpu(), x[i])) - float(metrics.psnr_fn(ref[i].cpu(), x[i]))) < 0.01
+    # and the backward runs in bf16 mode with gradients close to the f32 ones
+    ct = torch.randn(ref.shape, generator=gen).cuda()
+    m.zero_grad_flat()
+    m(y).backward(ct)
+    g32 = m.flat_grads.clone()
+    prev = _ops.set_compute_dtype("bf16")
+    try:
+        m.zero_grad_flat()
+        m(y).backward(ct)
+    finally:
+        _ops.set_compute_dtype(prev)
+    cos = torch.nn.functional.cosine_similarity(g32, m.flat_grads, dim=0)
+    assert cos > 0.999, float(cos)
+
+
+@pytest.mark.parametrize("M,N,K", [(576, 2048, 512), (288, 512, 128), (192, 256, 64), (100, 300, 192), (1152, 8192, 2048),
+                                    (576, 512, 8192), (2304, 128, 512), (700, 260, 128)])
+def test_gemm_bf16nt(ops, M, N, K):
+    """Direct-to-LDS bf16 kernel: exact for bf16 inputs up to f32 accumulation order; all epilogues."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((M, K), generator=gen).bfloat16()
+    Bm = torch.randn((N, K), generator=gen).bfloat16()
+    bias, R1 = torch.randn(N, generator=gen), torch.randn((M, N), generator=gen)
+    ref = A.double() @ Bm.double().T
+    Ad, Bd = A.cuda(), Bm.cuda()
+    o32 = torch.empty((M, N), device="cuda")
+    ops.gemm_nt16(Ad, Bd, M, N, K, ops.EPI_NONE, out32=o32)
+    assert relerr(o32, ref) < 3e-6
+    o16 = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    g16 = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    ops.gemm_nt16(Ad, Bd, M, N, K, ops.EPI_BIAS_GELU, out32=o32, out16=o16, bias=bias.cuda(), D2_16=g16)
+    assert relerr(o32, ref + bias.double()) < 3e-6
+    assert relerr(o16.float(), (ref + bias.double())) < 5e-3 and relerr(g16.float(), F.gelu(ref + bias.double())) < 5e-3
+    ops.gemm_nt16(Ad, Bd, M, N, K, ops.EPI_BIAS_RES, out32=o32, bias=bias.cuda(), R1=R1.cuda(), R2=R1.cuda())
+    assert relerr(o32, ref + bias.double() + 2 * R1.double()) < 3e-6
+    z = R1.double().requires_grad_(True)
+    (dg,) = torch.autograd.grad(F.gelu(z).sum(), z)
+    ops.gemm_nt16(Ad, Bd, M, N, K, ops.EPI_MUL_DGELU, out16=o16, R1=R1.cuda())
+    assert relerr(o16.float(), ref * dg) < 5e-3
+
+
+@pytest.mark.parametrize("M,Np,Kp", [(576, 512, 128), (288, 2048, 512), (9216, 128, 32), (300, 130, 70)])
+def test_weight_gradient_via_transposes(ops, M, Np, Kp):
+    """dW += dY^T X through cast/transpose (K padded to 64) + the NT kernel's accumulate epilogue."""
+    gen = torch.Generator().manual_seed(M + Np)
+    dY, X = torch.randn((M, Np), generator=gen), torch.randn((M, Kp), generator=gen).bfloat16()
+    base = torch.randn((Np, Kp), generator=gen)
+    ref = base.double() + dY.bfloat16().double().T @ X.double()
+    acc = base.clone().cuda()
+    dY16, dYt = ops.transposed16(dY.cuda(), also_plain=True)
+    assert torch.equal(dY16.cpu(), dY.bfloat16()) and dYt.shape == (Np, ops.pad64(M))
+    assert torch.equal(dYt[:, :M].cpu(), dY.bfloat16().T) and (dYt[:, M:] == 0).all()
+    ops.weight_grad16(dYt, ops.transposed16(X.cuda()), acc, M)
+    assert relerr(acc, ref) < 5e-6
