@@ -143,8 +143,11 @@ int sei_conv3x3_bwd_weight(const float *x, const float *gy, float *gw, float *gb
 
 int sei_dwconv7_fwd(const float *x, const float *w, const float *bias, const float *res,
                     float res_scale, float *y, int B, int H, int W, int C, int flip, void *stream);
+/* `work` holds per-workgroup partial sums (two-stage reduction, no atomics); it must have at least
+ * sei_dwconv7_bwd_weight_workspace(B,H,W,C) floats. */
+size_t sei_dwconv7_bwd_weight_workspace(int B, int H, int W, int C);
 int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
-                           int W, int C, void *stream);
+                           int W, int C, float *work, size_t work_floats, void *stream);
 
 int sei_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
                float *rstd, size_t rows, int C, float eps, void *stream);

@@ -34,7 +34,7 @@ SIGNATURES = {
     "sei_conv3x3_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sei_conv3x3_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "sei_dwconv7_fwd": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
-    "sei_dwconv7_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sei_dwconv7_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P],
     "sei_ln_fwd": [_P, _P, _P, _P, _P, _P, _Z, _I, _F, _P],
     "sei_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P],
     "sei_gemm_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -75,6 +75,8 @@ def lib():
                 continue            # reported by tests/test_abi.py; a call would raise AttributeError
             fn.argtypes = argtypes
             fn.restype = _I
+        handle.sei_dwconv7_bwd_weight_workspace.argtypes = [_I, _I, _I, _I]
+        handle.sei_dwconv7_bwd_weight_workspace.restype = _Z
         if handle.sei_abi_version() != 1:
             raise NativeLibraryError("libsei_hip.so was built from a different include/sei_hip.h")
         _lib = handle

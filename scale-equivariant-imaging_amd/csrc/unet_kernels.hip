@@ -105,16 +105,30 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv7_kernel(
         for (int t = 0; t < 49; ++t) red[(worker * 50 + t) * Cc + cl] = acc_w[t];
         red[(worker * 50 + 49) * Cc + cl] = acc_b;
         __syncthreads();
+        // this workgroup's partial sums -> workspace row blockIdx.x: part[bx][t][c]  (gw aliases the workspace)
+        float *part = gw + (size_t)blockIdx.x * 50 * C;
         for (int e = threadIdx.x; e < 50 * Cc; e += DW_THREADS) {
             const int t = e / Cc, c2 = e % Cc;
             const int cg = blockIdx.y * Cc + c2;
             if (cg >= C) continue;
             float s = 0.f;
             for (int wk = 0; wk < workers; ++wk) s += red[(wk * 50 + t) * Cc + c2];
-            if (t < 49) atomicAdd(gw + (size_t)cg * 49 + t, s);
-            else if (gbias) atomicAdd(gbias + cg, s);
+            part[(size_t)t * C + cg] = s;
         }
     }
+}
+
+// stage 2 of the depthwise weight gradient: gw[c][t] += sum_bx part[bx][t][c]; gbias[c] += sum_bx part[bx][49][c]
+__global__ __launch_bounds__(256) void dwconv7_wgrad_finish_kernel(const float *__restrict__ part, int nparts,
+                                                                   int C, float *__restrict__ gw,
+                                                                   float *__restrict__ gbias) {
+    const int e = blockIdx.x * 256 + threadIdx.x;       // e = t*C + c : coalesced over c
+    if (e >= 50 * C) return;
+    const int t = e / C, c = e - t * C;
+    float s = 0.f;
+    for (int b = 0; b < nparts; ++b) s += part[(size_t)b * 50 * C + e];
+    if (t < 49) gw[(size_t)c * 49 + t] += s;
+    else if (gbias) gbias[c] += s;
 }
 
 // =================================================================================================
@@ -424,6 +438,129 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_bwd_weight_kernel(
     }
 }
 
+// Pixel-per-thread form for the two real cases (3 -> hidden and hidden -> 3): one thread owns one output
+// pixel and all COUT accumulators; every input value is loaded once and multiplied into the COUT
+// accumulators with weights read as LDS broadcasts. Stores follow the output layout.
+template <int COUT>
+__global__ __launch_bounds__(C3_THREADS) void conv3x3_pix_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    const float *__restrict__ res, float *__restrict__ y, int B, int H, int W, int Cin, int nchw_in,
+    int nchw_out, int transposed) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];   // [ci][tap][co]
+    const int nw = Cin * COUT * 9;
+    for (int e = threadIdx.x; e < nw; e += C3_THREADS) {
+        const int co = e % COUT, t = (e / COUT) % 9, ci = e / (COUT * 9);
+        const int ky = t / 3, kx = t % 3;
+        sw[e] = transposed ? w[(((size_t)ci * COUT + co) * 3 + (2 - ky)) * 3 + (2 - kx)]
+                           : w[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx];
+    }
+    __syncthreads();
+    const size_t npix = (size_t)B * H * W;
+    for (size_t p = (size_t)blockIdx.x * C3_THREADS + threadIdx.x; p < npix; p += (size_t)gridDim.x * C3_THREADS) {
+        const int j = (int)(p % W), i = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = bias ? bias[co] : 0.f;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ii = i + ky - 1;
+            if (ii < 0 || ii >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int jj = j + kx - 1;
+                if (jj < 0 || jj >= W) continue;
+                const int t = ky * 3 + kx;
+                if (nchw_in) {
+                    const float *xp = x + ((size_t)b * Cin * H + ii) * W + jj;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const float v = xp[(size_t)ci * H * W];
+                        const float *wr = sw + (ci * 9 + t) * COUT;
+#pragma unroll
+                        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wr[co], v, acc[co]);
+                    }
+                } else {
+                    const float *xp = x + (((size_t)b * H + ii) * W + jj) * Cin;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const float v = xp[ci];
+                        const float *wr = sw + (ci * 9 + t) * COUT;
+#pragma unroll
+                        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wr[co], v, acc[co]);
+                    }
+                }
+            }
+        }
+        if (nchw_out) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const size_t o = (((size_t)b * COUT + co) * H + i) * W + j;
+                y[o] = res ? acc[co] + res[o] : acc[co];
+            }
+        } else {
+            float *yp = y + p * COUT;
+            const float *rp = res ? res + p * COUT : nullptr;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) yp[co] = rp ? acc[co] + rp[co] : acc[co];
+        }
+    }
+}
+
+// Weight gradient, tiled: a workgroup stages P pixels of gy (P x Cout) and of the im2col'ed input
+// (P x Cin*9) in LDS, each thread owns a few of the Cout*Cin*9 outputs and reduces over the P pixels
+// out of LDS; one float atomic per output per workgroup.
+__global__ __launch_bounds__(C3_THREADS) void conv3x3_bwd_weight_tiled_kernel(
+    const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gw,
+    float *__restrict__ gb, int B, int H, int W, int Cin, int Cout, int nchw_x, int nchw_gy, int P,
+    int tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int KC = Cin * 9;
+    float *sG = sm;                 // [P][Cout]
+    float *sX = sm + P * Cout;      // [P][KC]
+    const size_t npix = (size_t)B * H * W;
+    const int nout = Cout * KC;
+    constexpr int MAXO = 8;         // outputs per thread (nout <= 8*256)
+    float acc[MAXO];
+#pragma unroll
+    for (int q = 0; q < MAXO; ++q) acc[q] = 0.f;
+    float accb = 0.f;
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const size_t p0 = ((size_t)blockIdx.x * tiles_per_block + tile) * P;
+        if (p0 >= npix) break;
+        const int np = (int)min((size_t)P, npix - p0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < np * Cout; e += C3_THREADS) {
+            const int pp = e / Cout, co = e % Cout;
+            const size_t p = p0 + pp;
+            const int j = (int)(p % W), i = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+            sG[e] = gy[img_index(nchw_gy, b, co, i, j, Cout, H, W)];
+        }
+        for (int e = threadIdx.x; e < np * KC; e += C3_THREADS) {
+            const int pp = e / KC, k = e % KC;
+            const int ci = k / 9, t = k % 9;
+            const size_t p = p0 + pp;
+            const int j = (int)(p % W), i = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+            const int ii = i + t / 3 - 1, jj = j + t % 3 - 1;
+            sX[e] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? x[img_index(nchw_x, b, ci, ii, jj, Cin, H, W)] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MAXO; ++q) {
+            const int e = threadIdx.x + q * C3_THREADS;
+            if (e < nout) {
+                const int co = e / KC, k = e % KC;
+                float a = acc[q];
+                for (int pp = 0; pp < np; ++pp) a = fmaf(sG[pp * Cout + co], sX[pp * KC + k], a);
+                acc[q] = a;
+            }
+        }
+        if (gb && threadIdx.x < Cout)
+            for (int pp = 0; pp < np; ++pp) accb += sG[pp * Cout + threadIdx.x];
+    }
+#pragma unroll
+    for (int q = 0; q < MAXO; ++q) {
+        const int e = threadIdx.x + q * C3_THREADS;
+        if (e < nout) atomicAdd(gw + e, acc[q]);      // e = (co*Cin + ci)*9 + t: the torch weight layout
+    }
+    if (gb && threadIdx.x < Cout) atomicAdd(gb + threadIdx.x, accb);
+}
+
 // =================================================================================================
 // separable rank-2 spatial map, NHWC:  y[b,i',j',c] = sum_t sum_i L_t[i',i] sum_j R_t[j',j] x[b,i,j,c]
 // pass W: T[b][t][i][j'][c] = sum_j R_t[j',j] x[b,i,j,c]      (workspace, 2*B*Hi*Wo*C floats)
@@ -560,23 +697,49 @@ extern "C" int sei_dwconv7_fwd(const float *x, const float *w, const float *bias
     return sei_launch_status();
 }
 
-extern "C" int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
-                                      int W, int C, void *stream) {
-    SEI_REQUIRE(x && gy && gw && B > 0 && H > 0 && W > 0 && C > 0);
-    const int Cc = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
+namespace {
+// grid of the depthwise weight-gradient pass: (row-segment groups, channel chunks)
+inline void dwconv7_wgrad_grid(int B, int H, int W, int C, int &Cc, int &nseg, size_t &total, unsigned &gx,
+                               unsigned &chunks) {
+    Cc = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
     const int workers = DW_THREADS / Cc;
-    const int nseg = (int)sei_ceil_div(W, DW_SEG);
-    const size_t total = (size_t)B * H * nseg;
-    SEI_REQUIRE(total < (size_t)1 << 31);
-    // each worker walks several row segments so that the atomics per (channel, tap) stay few
-    const unsigned chunks = (unsigned)sei_ceil_div(C, Cc);
-    unsigned gx = capped_grid(total, workers * 8, 65535);
-    const unsigned max_gx = 2048 / chunks > 0 ? 2048 / chunks : 1;
+    nseg = (int)sei_ceil_div(W, DW_SEG);
+    total = (size_t)B * H * nseg;
+    chunks = (unsigned)sei_ceil_div(C, Cc);
+    gx = capped_grid(total, workers * 2, 65535);
+    const unsigned max_gx = 4096 / chunks > 0 ? 4096 / chunks : 1;
     if (gx > max_gx) gx = max_gx;
+}
+}  // namespace
+
+extern "C" size_t sei_dwconv7_bwd_weight_workspace(int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    int Cc, nseg;
+    size_t total;
+    unsigned gx, chunks;
+    dwconv7_wgrad_grid(B, H, W, C, Cc, nseg, total, gx, chunks);
+    return (size_t)gx * 50 * C;
+}
+
+extern "C" int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
+                                      int W, int C, float *work, size_t work_floats, void *stream) {
+    SEI_REQUIRE(x && gy && gw && work && B > 0 && H > 0 && W > 0 && C > 0);
+    int Cc, nseg;
+    size_t total;
+    unsigned gx, chunks;
+    dwconv7_wgrad_grid(B, H, W, C, Cc, nseg, total, gx, chunks);
+    SEI_REQUIRE(total < (size_t)1 << 31);
+    SEI_REQUIRE(work_floats >= (size_t)gx * 50 * C);
+    const int workers = DW_THREADS / Cc;
     const size_t lds = sizeof(float) * (size_t)workers * 50 * Cc;
-    hipLaunchKernelGGL(dwconv7_kernel<true>, dim3(gx, chunks), dim3(DW_THREADS), lds, (hipStream_t)stream, x,
-                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f,
-                       (float *)nullptr, gy, gw, gbias, B, H, W, C, 0, Cc, nseg, (int)total);
+    hipStream_t s = (hipStream_t)stream;
+    // stage 1: per-workgroup partial sums into the workspace (passed through the kernel's gw argument)
+    hipLaunchKernelGGL(dwconv7_kernel<true>, dim3(gx, chunks), dim3(DW_THREADS), lds, s, x, (const float *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, 0.f, (float *)nullptr, gy, work,
+                       (float *)nullptr, B, H, W, C, 0, Cc, nseg, (int)total);
+    // stage 2: fold the partials into the running gradient (no atomics: bitwise reproducible)
+    hipLaunchKernelGGL(dwconv7_wgrad_finish_kernel, dim3((unsigned)sei_ceil_div((size_t)50 * C, 256)), dim3(256), 0, s,
+                       (const float *)work, (int)gx, C, gw, gbias);
     return sei_launch_status();
 }
 
@@ -654,10 +817,24 @@ extern "C" int sei_conv3x3_fwd(const float *x, const float *w, const float *bias
     SEI_REQUIRE(x && w && y && x != y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
     const size_t lds = sizeof(float) * (size_t)Cin * Cout * 9;
     if (lds > 64 * 1024) return SEI_ERR_TOO_LARGE;
-    const size_t total = (size_t)B * H * W * Cout;
-    hipLaunchKernelGGL(conv3x3_kernel, dim3(capped_grid(total, C3_THREADS, 4096)), dim3(C3_THREADS), lds,
-                       (hipStream_t)stream, x, w, bias, res, y, B, H, W, Cin, Cout, nchw_in ? 1 : 0,
-                       nchw_out ? 1 : 0, transposed ? 1 : 0);
+    const size_t npix = (size_t)B * H * W;
+    const unsigned pgrid = capped_grid(npix, C3_THREADS, 8192);
+    hipStream_t s = (hipStream_t)stream;
+#define SEI_C3_PIX(CO)                                                                                          \
+    hipLaunchKernelGGL(conv3x3_pix_kernel<CO>, dim3(pgrid), dim3(C3_THREADS), lds, s, x, w, bias, res, y, B, H, \
+                       W, Cin, nchw_in ? 1 : 0, nchw_out ? 1 : 0, transposed ? 1 : 0);                          \
+    return sei_launch_status();
+    switch (Cout) {
+        case 3: SEI_C3_PIX(3)
+        case 8: SEI_C3_PIX(8)
+        case 16: SEI_C3_PIX(16)
+        case 32: SEI_C3_PIX(32)
+        default: break;
+    }
+#undef SEI_C3_PIX
+    const size_t total = npix * Cout;
+    hipLaunchKernelGGL(conv3x3_kernel, dim3(capped_grid(total, C3_THREADS, 4096)), dim3(C3_THREADS), lds, s, x, w,
+                       bias, res, y, B, H, W, Cin, Cout, nchw_in ? 1 : 0, nchw_out ? 1 : 0, transposed ? 1 : 0);
     return sei_launch_status();
 }
 
@@ -665,6 +842,18 @@ extern "C" int sei_conv3x3_bwd_weight(const float *x, const float *gy, float *gw
                                       int W, int Cin, int Cout, int nchw_x, int nchw_gy, void *stream) {
     SEI_REQUIRE(x && gy && gw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
     const size_t npix = (size_t)B * H * W;
+    const int KC = Cin * 9;
+    if (Cout * KC <= 8 * C3_THREADS) {
+        int P = 128;
+        while (P > 8 && (size_t)P * (Cout + KC) * sizeof(float) > 48 * 1024) P /= 2;
+        int tpb = 1;                          // pixel tiles per workgroup: keep the atomics per output low
+        while (sei_ceil_div(npix, (size_t)P * tpb) > 1024) tpb *= 2;
+        const size_t lds = (size_t)P * (Cout + KC) * sizeof(float);
+        hipLaunchKernelGGL(conv3x3_bwd_weight_tiled_kernel, dim3((unsigned)sei_ceil_div(npix, (size_t)P * tpb)),
+                           dim3(C3_THREADS), lds, (hipStream_t)stream, x, gy, gw, gb, B, H, W, Cin, Cout,
+                           nchw_x ? 1 : 0, nchw_gy ? 1 : 0, P, tpb);
+        return sei_launch_status();
+    }
     int ppb = 64;
     while (sei_ceil_div(npix, ppb) > 2048) ppb *= 2;
     hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3((unsigned)sei_ceil_div(npix, ppb)), dim3(C3_THREADS), 0,

@@ -1,0 +1,62 @@
+"""hipGraph capture of the training step's device work.
+
+One proposed-loss step is ~620 kernel launches of 5-500 us; launched eagerly from Python the GPU idles
+between them. `GraphedLossStep` captures zero_grad + loss forward + backward ONCE (torch.cuda.graph =
+hipGraph on ROCm) over static buffers and replays it per step:
+
+    graphed = GraphedLossStep(loss, model, optimizer, y_shape)
+    loss_value = graphed(x, y)          # crop (host RNG, as the reference) -> copy -> replay
+    optimizer.step()                    # outside the graph: its bias corrections are host scalars
+
+What stays outside the graph: the random 48-crop of Loss.forward (two CPU randint draws + a strided
+copy into the static input), the gradient all-reduce and the fused Adam launch. Random draws on the
+device (probe b, measurement noise, scale rates/centres) are captured with torch's graph-safe
+generator, so every replay sees fresh numbers.
+"""
+import torch
+
+
+class GraphedLossStep:
+    def __init__(self, loss_module, model, optimizer, crop_shape, warmup=3):
+        """loss_module: a `losses.Loss`; crop_shape: (B, 3, S, S) of the cropped measurement y."""
+        self.loss_module = loss_module
+        self.inner = loss_module.loss                # method-level loss working on cropped tensors
+        self.model = model
+        self.optimizer = optimizer
+        backbone = model.get_backbone() if hasattr(model, "get_backbone") else model
+        if getattr(backbone, "flat_grads", None) is None:
+            raise ValueError("GraphedLossStep needs a flattened model")
+        self.backbone = backbone
+        device = backbone.flat_params.device
+        self.static_y = torch.zeros(crop_shape, dtype=torch.float32, device=device)
+        self.static_x = None
+
+        def fwd_bwd():
+            self.backbone.zero_grad_flat()
+            value = self.inner(x=self.static_x, y=self.static_y, model=self.model)
+            value.backward()
+            return value.detach()
+
+        from models import _ops
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                  # settle caches / allocator outside capture
+                fwd_bwd()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        _ops.weights_updated()                       # the captured step must rebuild the bf16 shadows itself
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = fwd_bwd()
+        self.backbone.zero_grad_flat()
+
+    def __call__(self, x, y):
+        crop = self.loss_module.crop_fn
+        if crop is not None:
+            x, y = crop(x, y, xy_size_ratio=self.loss_module.xy_size_ratio)
+        if tuple(y.shape) != tuple(self.static_y.shape):
+            raise ValueError(f"graphed step was captured for {tuple(self.static_y.shape)}, got {tuple(y.shape)}")
+        self.static_y.copy_(y)
+        self.graph.replay()
+        return self.static_loss

@@ -117,6 +117,14 @@ def dwconv7(x, w, bias, flip=False, res=None, res_scale=1.0):
     return y
 
 
+def dwconv7_weight_grad(x, gy, gw, gb):
+    B, H, W, C = x.shape
+    need = N.lib().sei_dwconv7_bwd_weight_workspace(B, H, W, C)
+    work = torch.empty(need, dtype=torch.float32, device=x.device)
+    N.call("sei_dwconv7_bwd_weight", x.data_ptr(), gy.data_ptr(), gw.data_ptr(), N.ptr(gb), B, H, W, C,
+           work.data_ptr(), need)
+
+
 def sepmap2(x, mats, Ho, Wo):
     B, Hi, Wi, C = x.shape
     y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
@@ -174,8 +182,7 @@ class ConvBlockFn(torch.autograd.Function):
         # LayerNorm, depthwise conv
         gh1 = layer_norm_bwd(h1.view(M, C), gamma, mean, rstd, gh2, grad_of(gamma), grad_of(beta))
         gh1 = gh1.view(B, H, W, C)
-        N.call("sei_dwconv7_bwd_weight", x.data_ptr(), gh1.data_ptr(), grad_of(w1).data_ptr(),
-               grad_of(b1).data_ptr(), B, H, W, C)
+        dwconv7_weight_grad(x, gh1, grad_of(w1), grad_of(b1))
         gx = None
         if ctx.needs_input_grad[0]:
             gx = dwconv7(gh1, w1, None, flip=True, res=go, res_scale=2.0 if ctx.twice else 1.0)
@@ -406,8 +413,7 @@ class ConvBlockFn16(torch.autograd.Function):
         gh2 = torch.empty((M, C), dtype=torch.float32, device=x.device)
         gemm_nt16(gh3, w2t_16, M, C, 4 * C, EPI_NONE, out32=gh2)
         gh1 = layer_norm_bwd(h1.view(M, C), gamma, mean, rstd, gh2, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
-        N.call("sei_dwconv7_bwd_weight", x.data_ptr(), gh1.data_ptr(), grad_of(w1).data_ptr(),
-               grad_of(b1).data_ptr(), B, H, W, C)
+        dwconv7_weight_grad(x, gh1, grad_of(w1), grad_of(b1))
         gx = None
         if ctx.needs_input_grad[0]:
             gx = dwconv7(gh1, w1, None, flip=True, res=go, res_scale=2.0 if ctx.twice else 1.0)

@@ -13,9 +13,20 @@ from physics import _bands
 from physics._ops import SeparableResampleOp, apply_linear
 
 
+_TABLES = {}
+
+
+def _table(values, device, dtype):
+    """Device-resident copy of `values`, built once (a host->device copy is illegal inside hipGraph capture)."""
+    key = (tuple(values), str(device), dtype)
+    if key not in _TABLES:
+        _TABLES[key] = torch.tensor(values, device=device, dtype=dtype)
+    return _TABLES[key]
+
+
 def sample_from(values, shape=(1,), dtype=torch.float32, device="cpu"):
     """Uniform draw from `values` (reference :5-12)."""
-    table = torch.tensor(values, device=device, dtype=dtype)
+    table = _table(values, device, dtype)
     u = torch.rand(shape, device=device, dtype=dtype)
     return table[torch.floor(len(values) * u).to(torch.int)]
 

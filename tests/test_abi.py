@@ -13,7 +13,7 @@ def declared():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\bint\s+(sei_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t)\s+(sei_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = [a.strip() for a in m.group(2).split(",")]
         decls[m.group(1)] = 0 if args == ["void"] else len(args)
     return decls
@@ -38,9 +38,11 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_table_matches_header():
     import _native
     d = declared()
-    assert set(_native.SIGNATURES) == set(d)
+    sized = {"sei_dwconv7_bwd_weight_workspace"}          # size queries: no stream argument, bound separately
+    assert set(_native.SIGNATURES) | sized == set(d)
     for name, nargs in d.items():
-        assert len(_native.SIGNATURES[name]) == nargs, name
+        if name not in sized:
+            assert len(_native.SIGNATURES[name]) == nargs, name
 
 
 def test_argument_errors_are_reported_not_launched():

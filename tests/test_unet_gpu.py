@@ -129,7 +129,7 @@ def test_dwconv7(ops, B, H, W, C):
     assert relerr(nchw(gx), rgx) < 5e-6
     gw, gb = torch.zeros_like(w).cuda(), torch.zeros(C, device="cuda")
     xd, gyd = nhwc(x).cuda(), nhwc(gy).cuda()        # keep the buffers alive across the launch
-    call("sei_dwconv7_bwd_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, H, W, C)
+    ops.dwconv7_weight_grad(xd, gyd, gw, gb)
     torch.cuda.synchronize()
     assert relerr(gw, rgw) < 2e-5 and relerr(gb, rgb) < 2e-5
 
