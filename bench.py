@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--profile-gemms", action=argparse.BooleanOptionalAction, default=True)
     ap.add_argument("--graph", action=argparse.BooleanOptionalAction, default=True,
                     help="replay forward+backward as one hipGraph (the eager launch path otherwise)")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                     help="arithmetic type of the 1x1-conv GEMMs (f32 = parity mode, bf16 = throughput mode)")
     opt = ap.parse_args()
 

@@ -134,6 +134,7 @@ int sei_mse_terms(const float *a, const float *b, size_t n, float scale, float *
  * sei_colsum_f32: out[n] += sum_m X[m,n]  (bias gradients of the 1x1 convolutions).
  * sei_adam_fused: torch.optim.Adam step (demo/train.py:157-186; amsgrad=False) over one flat bucket;
  *   grad is multiplied by grad_scale first (1/world_size after a summing all-reduce). step >= 1.
+ *   param_bf16 (optional): bf16 copy of the updated parameters, written in the same pass.
  * ------------------------------------------------------------------------------------------- */
 int sei_conv3x3_fwd(const float *x, const float *w, const float *bias, const float *res, float *y,
                     int B, int H, int W, int Cin, int Cout, int nchw_in, int nchw_out, int transposed,
@@ -193,9 +194,10 @@ int sei_ln_fwd_bf16(const float *x, const float *gamma, const float *beta, uint1
                     float *rstd, size_t rows, int C, float eps, void *stream);
 int sei_colsum_bf16(const uint16_t *X, float *out, size_t M, int N, void *stream);
 /* x (R,C) float32 or bf16 -> x16 (R,C) bf16 copy (optional, float32 input only) and xt16 (C,ldt) bf16
- * transpose (optional) whose columns R..ldt-1 are zero: a K-padded operand for sei_gemm_bf16nt. */
+ * transpose (optional) whose columns R..ldt-1 are zero: a K-padded operand for sei_gemm_bf16nt.
+ * colsum (optional): colsum[c] += sum_r x[r][c] in float32 -- the bias gradient, from the same pass. */
 int sei_cast_transpose_bf16(const void *x, int x_is_bf16, uint16_t *x16, uint16_t *xt16, int R, int C,
-                            int ldt, void *stream);
+                            int ldt, float *colsum, void *stream);
 
 /* Large-shape bf16 GEMM with bf16 operands in HBM, both K-contiguous:  D[M,N] = A[M,K] * B[N,K]^T.
  * Forward 1x1 convolutions (B = bf16 weight shadow) and data gradients (B = transposed shadow).
@@ -220,7 +222,7 @@ int sei_colsum_f32(const float *X, float *out, size_t M, int N, void *stream);
 
 int sei_adam_fused(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                   float grad_scale, void *stream);
+                   float grad_scale, uint16_t *param_bf16, void *stream);
 
 #ifdef __cplusplus
 }

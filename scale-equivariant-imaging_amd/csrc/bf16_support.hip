@@ -28,23 +28,36 @@ __device__ __forceinline__ unsigned short to_bf(unsigned short v) { return v; }
 
 // x (R, C) f32 or bf16 -> x16 (R, C) bf16 (optional) and xt16 (C, ldt) bf16 (optional; columns R..ldt-1
 // are zero-filled so that the transposed matrix can be a K-padded GEMM operand). 64x64 tiles through LDS.
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(unsigned short v) { return bf2f(v); }
+
+// colsum (optional): colsum[c] += sum_r x[r][c] in float32 from the UN-rounded input (bias gradients),
+// one atomic per column per 64-row tile.
 template <typename T>
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const T *__restrict__ x,
                                                              unsigned short *__restrict__ x16,
                                                              unsigned short *__restrict__ xt16, int R, int C,
-                                                             int ldt) {
+                                                             int ldt, float *__restrict__ colsum) {
     __shared__ unsigned short tile[64][66];
+    __shared__ float csum[4][64];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    float part = 0.f;                      // this thread's column c = tid & 63, rows (tid >> 6) + 4k
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
         const int r = e >> 6, c = e & 63;
         unsigned short v = 0;
         if (r0 + r < R && c0 + c < C) {
-            v = to_bf(x[(size_t)(r0 + r) * C + c0 + c]);
+            const T raw = x[(size_t)(r0 + r) * C + c0 + c];
+            part += to_f(raw);
+            v = to_bf(raw);
             if (x16) x16[(size_t)(r0 + r) * C + c0 + c] = v;
         }
         tile[r][c] = v;
     }
+    if (colsum) csum[threadIdx.x >> 6][threadIdx.x & 63] = part;
     __syncthreads();
+    if (colsum && threadIdx.x < 64 && c0 + threadIdx.x < C && r0 < R)
+        atomicAdd(colsum + c0 + threadIdx.x,
+                  csum[0][threadIdx.x] + csum[1][threadIdx.x] + csum[2][threadIdx.x] + csum[3][threadIdx.x]);
     if (xt16)
         for (int e = threadIdx.x; e < 64 * 64; e += 256) {
             const int c = e >> 6, r = e & 63;
@@ -196,22 +209,22 @@ extern "C" int sei_cast_bf16(const float *x, uint16_t *y, size_t n, void *stream
 extern "C" int sei_weight_shadow_bf16(const float *w, uint16_t *w16, uint16_t *wt16, int R, int C, void *stream) {
     SEI_REQUIRE(w && (w16 || wt16) && R > 0 && C > 0);
     hipLaunchKernelGGL(cast_transpose_kernel<float>, dim3((unsigned)sei_ceil_div(C, 64), (unsigned)sei_ceil_div(R, 64)),
-                       dim3(256), 0, (hipStream_t)stream, w, w16, wt16, R, C, R);
+                       dim3(256), 0, (hipStream_t)stream, w, w16, wt16, R, C, R, (float *)nullptr);
     return sei_launch_status();
 }
 
 extern "C" int sei_cast_transpose_bf16(const void *x, int x_is_bf16, uint16_t *x16, uint16_t *xt16, int R, int C,
-                                       int ldt, void *stream) {
-    SEI_REQUIRE(x && (x16 || xt16) && R > 0 && C > 0 && ldt >= R);
+                                       int ldt, float *colsum, void *stream) {
+    SEI_REQUIRE(x && (x16 || xt16 || colsum) && R > 0 && C > 0 && ldt >= R);
     SEI_REQUIRE(!(x_is_bf16 && x16));
     // the grid covers ldt rows so that the zero padding of xt16 is written too
     dim3 grid((unsigned)sei_ceil_div(C, 64), (unsigned)sei_ceil_div(xt16 ? ldt : R, 64));
     if (x_is_bf16)
         hipLaunchKernelGGL(cast_transpose_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream,
-                           (const unsigned short *)x, x16, xt16, R, C, ldt);
+                           (const unsigned short *)x, x16, xt16, R, C, ldt, colsum);
     else
         hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)x,
-                           x16, xt16, R, C, ldt);
+                           x16, xt16, R, C, ldt, colsum);
     return sei_launch_status();
 }
 

@@ -656,7 +656,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, size_t n,
                                                    float beta1, float beta2, float eps, float wd,
-                                                   float step_size, float inv_bc2_sqrt, float gscale) {
+                                                   float step_size, float inv_bc2_sqrt, float gscale,
+                                                   unsigned short *__restrict__ p16) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float gi = g[i] * gscale;
@@ -668,7 +669,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
         m[i] = mi;
         v[i] = vi;
-        p[i] = pi - step_size * (mi / denom);
+        const float pn = pi - step_size * (mi / denom);
+        p[i] = pn;
+        if (p16) {                                  // bf16 shadow of the updated weight (throughput mode)
+            const __bf16 b = (__bf16)pn;
+            p16[i] = __builtin_bit_cast(unsigned short, b);
+        }
     }
 }
 
@@ -894,7 +900,7 @@ extern "C" int sei_colsum_f32(const float *X, float *out, size_t M, int N, void 
 
 extern "C" int sei_adam_fused(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
                               float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                              float grad_scale, void *stream) {
+                              float grad_scale, uint16_t *param_bf16, void *stream) {
     SEI_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -902,6 +908,6 @@ extern "C" int sei_adam_fused(float *param, const float *grad, float *exp_avg, f
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     hipLaunchKernelGGL(adam_kernel, dim3(capped_grid(n, 256 * 4, 8192)), dim3(256), 0, (hipStream_t)stream, param,
                        grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
-                       grad_scale);
+                       grad_scale, param_bf16);
     return sei_launch_status();
 }

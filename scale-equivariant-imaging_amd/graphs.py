@@ -45,7 +45,10 @@ class GraphedLossStep:
                 fwd_bwd()
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
-        _ops.weights_updated()                       # the captured step must rebuild the bf16 shadows itself
+        # The captured step rebuilds the TRANSPOSED bf16 weight shadows from the plain bf16 copy, which
+        # the fused Adam refreshes every step; make that copy current now, and re-check before each replay.
+        self._ops = _ops
+        _ops.refresh_plain_shadow(self.backbone)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_loss = fwd_bwd()
@@ -58,5 +61,7 @@ class GraphedLossStep:
         if tuple(y.shape) != tuple(self.static_y.shape):
             raise ValueError(f"graphed step was captured for {tuple(self.static_y.shape)}, got {tuple(y.shape)}")
         self.static_y.copy_(y)
+        if not self._ops.plain_shadow_is_current():   # weights changed by something other than FlatAdam
+            self._ops.refresh_plain_shadow(self.backbone)
         self.graph.replay()
         return self.static_loss

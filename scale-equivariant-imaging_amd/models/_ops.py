@@ -277,27 +277,51 @@ class UpsampleFn(torch.autograd.Function):
 # register-staged kernel on the bf16 tensors and accumulate into the f32 gradient bucket. Everything
 # else (depthwise conv, LayerNorm statistics and backward, resamplers, residuals, Adam) stays f32.
 # =============================================================================================
-_SHADOW_GENERATION = 0
+_SHADOW_GENERATION = 0      # bumped whenever parameters change behind torch's back (fused Adam kernel)
+_PLAIN_SHADOW_GENERATION = -1   # generation for which the flat bf16 bucket already holds the weights
 
 
-def weights_updated():
-    """Tell the shadow cache that parameters changed behind torch's back (fused Adam kernel)."""
-    global _SHADOW_GENERATION
+def weights_updated(plain_shadow_written=False):
+    """Parameters changed outside torch's version counters. `plain_shadow_written`: the optimizer kernel
+    has also refreshed the flat bf16 copy of every parameter (so only the transposes need rebuilding)."""
+    global _SHADOW_GENERATION, _PLAIN_SHADOW_GENERATION
     _SHADOW_GENERATION += 1
+    if plain_shadow_written:
+        _PLAIN_SHADOW_GENERATION = _SHADOW_GENERATION
+
+
+def plain_shadow_is_current():
+    return _PLAIN_SHADOW_GENERATION == _SHADOW_GENERATION
+
+
+def refresh_plain_shadow(backbone):
+    """Cast the whole flat parameter bucket to its bf16 copy (what the fused Adam does as a side output)."""
+    if getattr(backbone, "flat_shadow", None) is None:
+        return
+    N.call("sei_cast_bf16", backbone.flat_params.data_ptr(), backbone.flat_shadow.data_ptr(),
+           backbone.flat_params.numel())
+    weights_updated(plain_shadow_written=True)
 
 
 def shadow(p):
-    """(w16 (R,C), wt16 (C,R)) bf16 shadows of a 1x1-conv weight p (R,C,1,1); cached per update."""
+    """(w16 (R,C), wt16 (C,R)) bf16 shadows of a 1x1-conv weight p (R,C,1,1); rebuilt once per update.
+    w16 is a view of the model's flat bf16 bucket when there is one (the fused Adam writes it)."""
     key = (_SHADOW_GENERATION, p._version, p.data_ptr())
     st = getattr(p, "_sei_shadow", None)
     if st is None or st[0] != key:
         R, C = p.shape[0], p.shape[1]
-        if st is None or st[1].device != p.device:
-            w16 = torch.empty((R, C), dtype=torch.bfloat16, device=p.device)
-            wt16 = torch.empty((C, R), dtype=torch.bfloat16, device=p.device)
-        else:
+        flat16 = getattr(p, "_sei_shadow_view", None)
+        if st is not None and st[1].device == p.device:
             w16, wt16 = st[1], st[2]
-        N.call("sei_weight_shadow_bf16", p.data_ptr(), w16.data_ptr(), wt16.data_ptr(), R, C)
+        else:
+            w16 = flat16.view(R, C) if flat16 is not None else torch.empty((R, C), dtype=torch.bfloat16, device=p.device)
+            wt16 = torch.empty((C, R), dtype=torch.bfloat16, device=p.device)
+        if flat16 is not None and _PLAIN_SHADOW_GENERATION == _SHADOW_GENERATION \
+                and (st is None or st[0][1:] == key[1:]):
+            # plain copy already current: only the transpose, from the bf16 data (half the read traffic)
+            N.call("sei_cast_transpose_bf16", w16.data_ptr(), 1, None, wt16.data_ptr(), R, C, R, None)
+        else:
+            N.call("sei_weight_shadow_bf16", p.data_ptr(), w16.data_ptr(), wt16.data_ptr(), R, C)
         st = (key, w16, wt16)
         p._sei_shadow = st
     return st[1], st[2]
@@ -348,14 +372,15 @@ def pad64(n):
     return (n + 63) // 64 * 64
 
 
-def transposed16(x2d, also_plain=False):
-    """x (R, C) f32 or bf16 -> xt16 (C, pad64(R)) bf16, zero padded (and x16 (R, C) when asked, f32 input)."""
+def transposed16(x2d, also_plain=False, colsum_into_=None):
+    """x (R, C) f32 or bf16 -> xt16 (C, pad64(R)) bf16, zero padded (and x16 (R, C) when asked, f32 input).
+    colsum_into_: accumulate the column sums of x (a bias gradient) into this tensor in the same pass."""
     R, C = x2d.shape
     ldt = pad64(R)
     xt = torch.empty((C, ldt), dtype=torch.bfloat16, device=x2d.device)
     x16 = torch.empty((R, C), dtype=torch.bfloat16, device=x2d.device) if also_plain else None
     N.call("sei_cast_transpose_bf16", x2d.data_ptr(), int(x2d.dtype == torch.bfloat16), N.ptr(x16), xt.data_ptr(),
-           R, C, ldt)
+           R, C, ldt, N.ptr(colsum_into_))
     return (x16, xt) if also_plain else xt
 
 
@@ -401,15 +426,13 @@ class ConvBlockFn16(torch.autograd.Function):
         M = B * H * W
         go = go.contiguous()
         go2 = go.view(M, C)
-        go16, go16_t = transposed16(go2, also_plain=True)
+        go16, go16_t = transposed16(go2, also_plain=True, colsum_into_=grad_of(b3))
         _, w3t_16 = shadow(w3)
         _, w2t_16 = shadow(w2)
-        colsum_into(grad_of(b3), go2)
         weight_grad16(go16_t, transposed16(h4), grad_of(w3).view(C, 4 * C), M)
         gh3 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device)
         gemm_nt16(go16, w3t_16, M, 4 * C, C, EPI_MUL_DGELU, out16=gh3, R1=h3)
-        colsum16_into(grad_of(b2), gh3)
-        weight_grad16(transposed16(gh3), transposed16(h2), grad_of(w2).view(4 * C, C), M)
+        weight_grad16(transposed16(gh3, colsum_into_=grad_of(b2)), transposed16(h2), grad_of(w2).view(4 * C, C), M)
         gh2 = torch.empty((M, C), dtype=torch.float32, device=x.device)
         gemm_nt16(gh3, w2t_16, M, C, 4 * C, EPI_NONE, out32=gh2)
         gh1 = layer_norm_bwd(h1.view(M, C), gamma, mean, rstd, gh2, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
@@ -443,8 +466,7 @@ class DownsampleFn16(torch.autograd.Function):
         B, H, W, C = x.shape
         M, Co = B * H * W, w.shape[0]
         gz = sepmap2(go.contiguous(), ctx.mats_t, H, W).view(M, Co)
-        gz16, gz16_t = transposed16(gz, also_plain=True)
-        colsum_into(grad_of(b), gz)
+        gz16, gz16_t = transposed16(gz, also_plain=True, colsum_into_=grad_of(b))
         weight_grad16(gz16_t, transposed16(h), grad_of(w).view(Co, C), M)
         _, wt16 = shadow(w)
         gh = torch.empty((M, C), dtype=torch.float32, device=x.device)
@@ -485,8 +507,7 @@ class UpsampleFn16(torch.autograd.Function):
         M, Co = B * Ho * Wo, w.shape[0]
         go = go.contiguous()
         go2 = go.view(M, Co)
-        go16, go16_t = transposed16(go2, also_plain=True)
-        colsum_into(grad_of(b), go2)
+        go16, go16_t = transposed16(go2, also_plain=True, colsum_into_=grad_of(b))
         weight_grad16(go16_t, transposed16(h), grad_of(w).view(Co, C), M)
         if nt16_ok(Co):
             _, wt16 = shadow(w)

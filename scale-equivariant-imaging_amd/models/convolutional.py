@@ -209,6 +209,9 @@ class ConvolutionalModel(Module):
                              inner_residual=inner_residual, rate=2))
         self.flat_params = None
         self.flat_grads = None
+        self.flat_shadow = None
+        # load_state_dict copies into the parameters: cached bf16 shadows are stale afterwards
+        self.register_load_state_dict_post_hook(lambda module, incompatible: _ops.weights_updated())
 
     # -- parameter bucket ----------------------------------------------------------------------
     def _apply(self, fn, *args, **kwargs):
@@ -236,6 +239,13 @@ class ConvolutionalModel(Module):
             p.grad = None
             off += n
         self.flat_params, self.flat_grads = flat, grads
+        # bf16 copy of the whole bucket for the throughput mode (written by the fused Adam kernel)
+        self.flat_shadow = torch.empty(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
+        if self.flat_shadow is not None:
+            off = 0
+            for p in params:
+                p._sei_shadow_view = self.flat_shadow[off:off + p.numel()]
+                off += p.numel()
 
     def zero_grad_flat(self):
         """One memset for the whole model; leaves every p.grad attached to the bucket."""

@@ -38,11 +38,14 @@ class FlatAdam(torch.optim.Optimizer):
             from parallel import world_size
             world = world_size()
             bounds = self.reducer.bounds
+        from models import _ops
+        shadow = getattr(self.backbone, "flat_shadow", None) if _ops.get_compute_dtype() == "bf16" else None
         for k, (s, e) in enumerate(bounds):
             if self.reducer is not None:
                 self.reducer.wait(k)
             N.call("sei_adam_fused", flat[s:e].data_ptr(), grads[s:e].data_ptr(), st["exp_avg"][s:e].data_ptr(),
                    st["exp_avg_sq"][s:e].data_ptr(), e - s, float(group["lr"]), float(b1), float(b2),
-                   float(group["eps"]), float(group["weight_decay"]), int(st["step"]), 1.0 / world)
-        from models import _ops
-        _ops.weights_updated()          # bf16 weight shadows must be rebuilt before the next forward
+                   float(group["eps"]), float(group["weight_decay"]), int(st["step"]), 1.0 / world,
+                   None if shadow is None else shadow[s:e].data_ptr())
+        # bf16 weight shadows must be rebuilt before the next forward (the plain copy just was, if asked)
+        _ops.weights_updated(plain_shadow_written=shadow is not None)

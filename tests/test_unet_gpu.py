@@ -174,10 +174,12 @@ def test_colsum_and_adam(ops):
         ref_p.grad = gs.clone()
         opt.step()
         gd = gs.cuda()
+        p16 = torch.empty(n, dtype=torch.bfloat16, device="cuda")
         call("sei_adam_fused", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999,
-             1e-8, 0.0, step, 1.0)
+             1e-8, 0.0, step, 1.0, p16.data_ptr())
         torch.cuda.synchronize()
         assert relerr(p, ref_p) < 1e-6
+        assert torch.equal(p16, p.bfloat16())
 
 
 # ------------------------------------------------------------------ ideal resamplers
@@ -421,7 +423,9 @@ def test_weight_gradient_via_transposes(ops, M, Np, Kp):
     base = torch.randn((Np, Kp), generator=gen)
     ref = base.double() + dY.bfloat16().double().T @ X.double()
     acc = base.clone().cuda()
-    dY16, dYt = ops.transposed16(dY.cuda(), also_plain=True)
+    cs = torch.ones(Np, device="cuda")
+    dY16, dYt = ops.transposed16(dY.cuda(), also_plain=True, colsum_into_=cs)
+    assert relerr(cs, dY.double().sum(0) + 1) < 1e-5
     assert torch.equal(dY16.cpu(), dY.bfloat16()) and dYt.shape == (Np, ops.pad64(M))
     assert torch.equal(dYt[:, :M].cpu(), dY.bfloat16().T) and (dYt[:, M:] == 0).all()
     ops.weight_grad16(dYt, ops.transposed16(X.cuda()), acc, M)
