@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--cpu-baseline", action=argparse.BooleanOptionalAction, default=True)
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--profile-gemms", action=argparse.BooleanOptionalAction, default=True)
+    ap.add_argument("--grad-comm", choices=["auto", "f32", "bf16"], default="auto",
+                    help="dtype of the all-reduced gradient bucket (auto: bf16 in bf16 mode, f32 in f32 mode)")
     ap.add_argument("--graph", action=argparse.BooleanOptionalAction, default=True,
                     help="replay forward+backward as one hipGraph (the eager launch path otherwise)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
@@ -96,7 +98,7 @@ def main():
     rank, local_rank, world = parallel.init_from_env()
     if world != opt.gpus:
         raise SystemExit(f"--gpus {opt.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    device = f"cuda:{local_rank}"
+    device = f"cuda:{local_rank % torch.cuda.device_count()}"     # (% only matters for shared-GPU rehearsals)
     torch.cuda.set_device(device)
 
     import torch.distributed as dist
@@ -117,7 +119,9 @@ def main():
     if world > 1:
         parallel.broadcast_parameters(backbone.flat_params)
     loss_fn = get_loss(args, physics)
-    reducer = parallel.FlatGradientReducer(backbone.flat_grads) if world > 1 else None
+    comm_dtype = torch.bfloat16 if (opt.dtype == "bf16" and opt.grad_comm == "auto") or opt.grad_comm == "bf16" \
+        else torch.float32
+    reducer = parallel.FlatGradientReducer(backbone.flat_grads, comm_dtype=comm_dtype) if world > 1 else None
     optimizer = FlatAdam(model, lr=1e-4, betas=(0.9, 0.999), reducer=reducer)
 
     # synthetic 256x256 pairs, resident in HBM before the timed region
@@ -156,27 +160,38 @@ def main():
     for _ in range(opt.warmup):
         step()
     fence()
-    live_events = opt.profile_gemms and not opt.graph     # HIP events cannot be recorded inside a graph
-    if live_events:
-        _ops.profile_gemms(True)
     t0 = time.perf_counter()
     for _ in range(opt.steps):
         last = step()
     fence()
     elapsed = time.perf_counter() - t0
-    records = _ops.profile_gemms(False) if live_events else None
     loss_value = float(last.detach())
-    roofline_source = "HIP events on the launch stream, during the timed steps"
-    if opt.profile_gemms and opt.graph:
-        # same kernels, same shapes, same process: the timed steps' launches replayed eagerly with events
-        _ops.profile_gemms(True)
-        for _ in range(max(2, opt.steps // 2)):
-            eager_step()
-        fence()
-        records = _ops.profile_gemms(False)
-        roofline_source = ("HIP events on the launch stream over eager launches of the same step right after the "
-                           "timed region (events cannot be recorded inside the replayed hipGraph)")
 
+    # Roofline leg: the dominant kernel family (all GEMM launches of one step). One eager step records each
+    # launch's entry point and arguments (the tensors stay alive in the autograd graph / local scope), then
+    # every recorded launch is re-issued back to back between HIP events on the launch stream: device time
+    # per launch with a full queue, free of host-side gaps, same shapes and data as the timed steps.
+    records = None
+    if opt.profile_gemms:
+        import _native
+        _ops.profile_gemms(True)
+        optimizer.zero_grad()
+        keep = loss_fn(x=x, y=y, model=model)
+        keep.backward(retain_graph=True)       # keeps the saved activations (GEMM operands) alive for the replay
+        records = _ops.profile_gemms(False)
+        torch.cuda.synchronize()
+        reps, total_ms, flops = 3, 0.0, 0.0
+        for fl, entry, cargs in records:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            _native.call(entry, *cargs)                 # warm
+            e0.record()
+            for _ in range(reps):
+                _native.call(entry, *cargs)
+            e1.record()
+            e1.synchronize()
+            total_ms += e0.elapsed_time(e1) / reps
+            flops += fl
+        del keep
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,17 +199,17 @@ def main():
 
     roofline = None
     if records:
-        flops = sum(r[0] for r in records)
-        ms = sum(r[1].elapsed_time(r[2]) for r in records)
-        achieved = flops / (ms * 1e-3) / 1e12
+        achieved = flops / (total_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[opt.dtype]
-        roofline = {"bound": "mfma", "kernel": f"sei_gemm_{opt.dtype} (gemm_{opt.dtype}_kernel<*>)",
-                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": None, "launches_per_step": 156,
-                    "avg_launch_us": round(1e3 * ms / len(records), 2),
-                    "gemm_ms_per_step": round(ms / (len(records) / 156), 2),
-                    "algorithmic_gflop_per_step": round(flops / (len(records) / 156) / 1e9, 1),
-                    "timed_with": roofline_source}
+        kernels = ("gemm_bf16nt_kernel<*> (direct-to-LDS NT, all large GEMMs) + gemm_bf16_kernel<*> (K<64 layers)"
+                   if opt.dtype == "bf16" else "gemm_f32_kernel<*>")
+        roofline = {"bound": "mfma", "kernel": kernels, "achieved": round(achieved, 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "launches_per_step": len(records), "avg_launch_us": round(1e3 * total_ms / len(records), 2),
+                    "gemm_ms_per_step": round(total_ms, 2),
+                    "algorithmic_gflop_per_step": round(flops / 1e9, 1),
+                    "timed_with": "HIP events on the launch stream around back-to-back re-issues of every GEMM "
+                                  "launch of one step (recorded arguments), right after the timed region"}
 
     if rank == 0:
         images = opt.batch * world * opt.steps
@@ -208,6 +223,7 @@ def main():
                                    f"hidden={opt.hidden} scales={opt.scales}",
                        "parameters": nparams, "batch_per_gpu": opt.batch, "global_batch": opt.batch * world,
                        "parallelism": f"dp{world}", "optimizer": "Adam (fused, flat bucket)",
+                       "grad_allreduce": None if world == 1 else str(comm_dtype).replace("torch.", ""),
                        "launch": "hipGraph replay of forward+backward" if opt.graph else "eager",
                        "final_loss": loss_value},
             "roofline": roofline,

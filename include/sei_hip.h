@@ -134,6 +134,7 @@ int sei_mse_terms(const float *a, const float *b, size_t n, float scale, float *
  * sei_colsum_f32: out[n] += sum_m X[m,n]  (bias gradients of the 1x1 convolutions).
  * sei_adam_fused: torch.optim.Adam step (demo/train.py:157-186; amsgrad=False) over one flat bucket;
  *   grad is multiplied by grad_scale first (1/world_size after a summing all-reduce). step >= 1.
+ *   grad may be bf16 (grad_is_bf16: the all-reduced, bf16-compressed gradient bucket of parallel.py).
  *   param_bf16 (optional): bf16 copy of the updated parameters, written in the same pass.
  * ------------------------------------------------------------------------------------------- */
 int sei_conv3x3_fwd(const float *x, const float *w, const float *bias, const float *res, float *y,
@@ -220,8 +221,8 @@ int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo,
 
 int sei_colsum_f32(const float *X, float *out, size_t M, int N, void *stream);
 
-int sei_adam_fused(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
-                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, float *exp_avg, float *exp_avg_sq,
+                   size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float grad_scale, uint16_t *param_bf16, void *stream);
 
 #ifdef __cplusplus

@@ -195,6 +195,16 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
     }
 }
 
+// Zero-fill of a split-K output. A kernel (not hipMemsetAsync): a memset issued from inside the library was
+// observed not to be replayed reliably as part of a captured hipGraph, which left stale partial sums.
+__global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<float4 *>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+}
+
 template <int TM, int TN, int WM, int WN>
 int launch_nt(NtArgs &g, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -216,8 +226,11 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         }
     }
     if (g.splitk > 1 && g.epilogue != SEI_EPI_ACCUM) {      // ACCUM adds into the running gradient as it is
-        const hipError_t e = hipMemsetAsync(g.D32, 0, sizeof(float) * (size_t)g.M * g.N, s);
-        if (e != hipSuccess) return (int)e;
+        const size_t n = (size_t)g.M * g.N;
+        size_t zg = sei_ceil_div(n / 4 + 1, 256);
+        if (zg > 2048) zg = 2048;
+        if ((reinterpret_cast<uintptr_t>(g.D32) & 15) != 0) return SEI_ERR_BAD_ARG;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
     hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN>), dim3((unsigned)(tiles * g.splitk)), dim3(NT), 0, s, g);
     return sei_launch_status();

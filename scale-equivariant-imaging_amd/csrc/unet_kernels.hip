@@ -653,14 +653,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
     }
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+__device__ __forceinline__ float grad_value(const float *g, size_t i) { return g[i]; }
+__device__ __forceinline__ float grad_value(const unsigned short *g, size_t i) {
+    return __uint_as_float((unsigned)g[i] << 16);
+}
+
+template <typename G>
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const G *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, size_t n,
                                                    float beta1, float beta2, float eps, float wd,
                                                    float step_size, float inv_bc2_sqrt, float gscale,
                                                    unsigned short *__restrict__ p16) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float gi = g[i] * gscale;
+        float gi = grad_value(g, i) * gscale;
         const float pi = p[i];
         if (wd != 0.f) gi = fmaf(wd, pi, gi);
         // torch.optim.Adam (single-tensor form): lerp for exp_avg, addcmul for exp_avg_sq
@@ -898,16 +904,22 @@ extern "C" int sei_colsum_f32(const float *X, float *out, size_t M, int N, void 
     return sei_launch_status();
 }
 
-extern "C" int sei_adam_fused(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
-                              float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+extern "C" int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, float *exp_avg, float *exp_avg_sq,
+                              size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                               float grad_scale, uint16_t *param_bf16, void *stream) {
     SEI_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    hipLaunchKernelGGL(adam_kernel, dim3(capped_grid(n, 256 * 4, 8192)), dim3(256), 0, (hipStream_t)stream, param,
-                       grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
-                       grad_scale, param_bf16);
+    const dim3 grid(capped_grid(n, 256 * 4, 8192));
+    if (grad_is_bf16)
+        hipLaunchKernelGGL(adam_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, param,
+                           (const unsigned short *)grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay,
+                           step_size, inv_bc2_sqrt, grad_scale, param_bf16);
+    else
+        hipLaunchKernelGGL(adam_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, param, (const float *)grad,
+                           exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
+                           grad_scale, param_bf16);
     return sei_launch_status();
 }

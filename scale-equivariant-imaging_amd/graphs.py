@@ -61,7 +61,7 @@ class GraphedLossStep:
         if tuple(y.shape) != tuple(self.static_y.shape):
             raise ValueError(f"graphed step was captured for {tuple(self.static_y.shape)}, got {tuple(y.shape)}")
         self.static_y.copy_(y)
-        if not self._ops.plain_shadow_is_current():   # weights changed by something other than FlatAdam
+        if not self._ops.plain_shadow_is_current(self.backbone):   # weights changed by something other than FlatAdam
             self._ops.refresh_plain_shadow(self.backbone)
         self.graph.replay()
         return self.static_loss

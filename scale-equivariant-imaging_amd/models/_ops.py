@@ -33,7 +33,7 @@ def grad_of(p):
 # ---------------------------------------------------------------------------------------------
 # thin launch helpers (pointers + sizes only; shapes are checked here, on the host)
 # ---------------------------------------------------------------------------------------------
-_GEMM_PROFILE = None     # bench.py: list of (flops, start_event, end_event) while enabled
+_GEMM_PROFILE = None     # bench.py: list of (flops, entry point, ctypes args) recorded while enabled
 _GEMM_ENTRY = {"f32": "sei_gemm_f32_ex", "bf16": "sei_gemm_bf16_ex"}
 _COMPUTE_DTYPE = "f32"
 
@@ -53,37 +53,33 @@ def get_compute_dtype():
 
 
 def profile_gemms(enable):
-    """Bracket every GEMM launch with HIP events on the launch stream (bench.py's roofline leg)."""
+    """Record every GEMM launch (entry point + arguments + algorithmic FLOPs) while enabled, so that
+    bench.py can re-issue exactly those launches back to back between HIP events (roofline leg)."""
     global _GEMM_PROFILE
     records, _GEMM_PROFILE = _GEMM_PROFILE, ([] if enable else None)
     return records
 
 
+def _gemm_call(flops, entry, *args):
+    if _GEMM_PROFILE is not None:
+        _GEMM_PROFILE.append((flops, entry, args))
+    N.call(entry, *args)
+
+
 def gemm(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2=None, allow_splitk=True):
     if out is None:
         out = torch.empty((M, Nn), dtype=torch.float32, device=A.device)
-    if _GEMM_PROFILE is not None:
-        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0.record()
-    N.call(_GEMM_ENTRY[_COMPUTE_DTYPE], A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K, ta, tb, epi,
-           N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2), 1, 0, 0, 0, int(allow_splitk))
-    if _GEMM_PROFILE is not None:
-        t1.record()
-        _GEMM_PROFILE.append((2.0 * M * Nn * K, t0, t1))
+    _gemm_call(2.0 * M * Nn * K, _GEMM_ENTRY[_COMPUTE_DTYPE], A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K,
+               ta, tb, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2), 1, 0, 0, 0, int(allow_splitk))
     return out
 
 
 def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=None, R2=None, D2_16=None,
               lda=None, ldb=None):
     """D = A16[M,K] @ B16[N,K]^T on the direct-to-LDS bf16 kernel (K % 64 == 0). Outputs as given."""
-    if _GEMM_PROFILE is not None:
-        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0.record()
-    N.call("sei_gemm_bf16nt", A16.data_ptr(), K if lda is None else lda, B16.data_ptr(), K if ldb is None else ldb,
-           N.ptr(out32), N.ptr(out16), M, Nn, K, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2_16))
-    if _GEMM_PROFILE is not None:
-        t1.record()
-        _GEMM_PROFILE.append((2.0 * M * Nn * K, t0, t1))
+    _gemm_call(2.0 * M * Nn * K, "sei_gemm_bf16nt", A16.data_ptr(), K if lda is None else lda, B16.data_ptr(),
+               K if ldb is None else ldb, N.ptr(out32), N.ptr(out16), M, Nn, K, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2),
+               N.ptr(D2_16))
 
 
 def layer_norm(x2d, gamma, beta):
@@ -278,20 +274,20 @@ class UpsampleFn(torch.autograd.Function):
 # else (depthwise conv, LayerNorm statistics and backward, resamplers, residuals, Adam) stays f32.
 # =============================================================================================
 _SHADOW_GENERATION = 0      # bumped whenever parameters change behind torch's back (fused Adam kernel)
-_PLAIN_SHADOW_GENERATION = -1   # generation for which the flat bf16 bucket already holds the weights
 
 
-def weights_updated(plain_shadow_written=False):
+def weights_updated(backbone=None, plain_shadow_written=False):
     """Parameters changed outside torch's version counters. `plain_shadow_written`: the optimizer kernel
-    has also refreshed the flat bf16 copy of every parameter (so only the transposes need rebuilding)."""
-    global _SHADOW_GENERATION, _PLAIN_SHADOW_GENERATION
+    also refreshed `backbone.flat_shadow` (the bf16 copy of every parameter), so only the transposed
+    shadows of that model need rebuilding."""
+    global _SHADOW_GENERATION
     _SHADOW_GENERATION += 1
-    if plain_shadow_written:
-        _PLAIN_SHADOW_GENERATION = _SHADOW_GENERATION
+    if plain_shadow_written and backbone is not None:
+        backbone._sei_plain_state["gen"] = _SHADOW_GENERATION
 
 
-def plain_shadow_is_current():
-    return _PLAIN_SHADOW_GENERATION == _SHADOW_GENERATION
+def plain_shadow_is_current(backbone):
+    return backbone._sei_plain_state["gen"] == _SHADOW_GENERATION
 
 
 def refresh_plain_shadow(backbone):
@@ -300,28 +296,32 @@ def refresh_plain_shadow(backbone):
         return
     N.call("sei_cast_bf16", backbone.flat_params.data_ptr(), backbone.flat_shadow.data_ptr(),
            backbone.flat_params.numel())
-    weights_updated(plain_shadow_written=True)
+    weights_updated(backbone, plain_shadow_written=True)
 
 
 def shadow(p):
     """(w16 (R,C), wt16 (C,R)) bf16 shadows of a 1x1-conv weight p (R,C,1,1); rebuilt once per update.
-    w16 is a view of the model's flat bf16 bucket when there is one (the fused Adam writes it)."""
+    w16 is a view of the owning model's flat bf16 bucket when there is one (the fused Adam writes it)."""
     key = (_SHADOW_GENERATION, p._version, p.data_ptr())
     st = getattr(p, "_sei_shadow", None)
     if st is None or st[0] != key:
         R, C = p.shape[0], p.shape[1]
         flat16 = getattr(p, "_sei_shadow_view", None)
+        plain = getattr(p, "_sei_plain_state", None)
         if st is not None and st[1].device == p.device:
             w16, wt16 = st[1], st[2]
         else:
             w16 = flat16.view(R, C) if flat16 is not None else torch.empty((R, C), dtype=torch.bfloat16, device=p.device)
             wt16 = torch.empty((C, R), dtype=torch.bfloat16, device=p.device)
-        if flat16 is not None and _PLAIN_SHADOW_GENERATION == _SHADOW_GENERATION \
-                and (st is None or st[0][1:] == key[1:]):
+        plain_current = (flat16 is not None and plain is not None and plain["gen"] == _SHADOW_GENERATION
+                         and plain["version"].get(id(p)) == p._version)
+        if plain_current:
             # plain copy already current: only the transpose, from the bf16 data (half the read traffic)
             N.call("sei_cast_transpose_bf16", w16.data_ptr(), 1, None, wt16.data_ptr(), R, C, R, None)
         else:
             N.call("sei_weight_shadow_bf16", p.data_ptr(), w16.data_ptr(), wt16.data_ptr(), R, C)
+        if plain is not None:
+            plain["version"][id(p)] = p._version
         st = (key, w16, wt16)
         p._sei_shadow = st
     return st[1], st[2]
@@ -356,15 +356,9 @@ def gemm_mixed(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=No
     """Register-staged bf16-MFMA GEMM; each operand may be stored as float32 or bfloat16."""
     if out is None:
         out = torch.empty((M, Nn), dtype=torch.float32, device=A.device)
-    if _GEMM_PROFILE is not None:
-        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0.record()
-    N.call("sei_gemm_bf16_mixed", A.data_ptr(), int(A.dtype == torch.bfloat16), Bm.data_ptr(),
-           int(Bm.dtype == torch.bfloat16), out.data_ptr(), M, Nn, K, ta, tb, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2),
-           N.ptr(D2), 1, 0, 0, 0, int(allow_splitk))
-    if _GEMM_PROFILE is not None:
-        t1.record()
-        _GEMM_PROFILE.append((2.0 * M * Nn * K, t0, t1))
+    _gemm_call(2.0 * M * Nn * K, "sei_gemm_bf16_mixed", A.data_ptr(), int(A.dtype == torch.bfloat16), Bm.data_ptr(),
+               int(Bm.dtype == torch.bfloat16), out.data_ptr(), M, Nn, K, ta, tb, epi, N.ptr(bias), N.ptr(R1),
+               N.ptr(R2), N.ptr(D2), 1, 0, 0, 0, int(allow_splitk))
     return out
 
 

@@ -210,6 +210,7 @@ class ConvolutionalModel(Module):
         self.flat_params = None
         self.flat_grads = None
         self.flat_shadow = None
+        self._sei_plain_state = {"gen": -1, "version": {}}
         # load_state_dict copies into the parameters: cached bf16 shadows are stale afterwards
         self.register_load_state_dict_post_hook(lambda module, incompatible: _ops.weights_updated())
 
@@ -241,10 +242,15 @@ class ConvolutionalModel(Module):
         self.flat_params, self.flat_grads = flat, grads
         # bf16 copy of the whole bucket for the throughput mode (written by the fused Adam kernel)
         self.flat_shadow = torch.empty(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
+        # validity of the bf16 bucket is tracked per model: {"gen": generation it was written for,
+        # "version": torch version counter of each parameter at that time}
+        self._sei_plain_state = {"gen": -1, "version": {}}
         if self.flat_shadow is not None:
             off = 0
             for p in params:
                 p._sei_shadow_view = self.flat_shadow[off:off + p.numel()]
+                p._sei_plain_state = self._sei_plain_state
+                p._sei_shadow = None
                 off += p.numel()
 
     def zero_grad_flat(self):

@@ -34,18 +34,22 @@ class FlatAdam(torch.optim.Optimizer):
         b1, b2 = group["betas"]
         world = 1
         bounds = [(0, flat.numel())]
+        grads_16 = False
         if self.reducer is not None:
             from parallel import world_size
             world = world_size()
             bounds = self.reducer.bounds
+            grads = self.reducer.comm                     # the (possibly bf16-compressed) reduced bucket
+            grads_16 = grads.dtype == torch.bfloat16
         from models import _ops
         shadow = getattr(self.backbone, "flat_shadow", None) if _ops.get_compute_dtype() == "bf16" else None
         for k, (s, e) in enumerate(bounds):
             if self.reducer is not None:
                 self.reducer.wait(k)
-            N.call("sei_adam_fused", flat[s:e].data_ptr(), grads[s:e].data_ptr(), st["exp_avg"][s:e].data_ptr(),
+            N.call("sei_adam_fused", flat[s:e].data_ptr(), grads[s:e].data_ptr(), int(grads_16),
+                   st["exp_avg"][s:e].data_ptr(),
                    st["exp_avg_sq"][s:e].data_ptr(), e - s, float(group["lr"]), float(b1), float(b2),
                    float(group["eps"]), float(group["weight_decay"]), int(st["step"]), 1.0 / world,
                    None if shadow is None else shadow[s:e].data_ptr())
         # bf16 weight shadows must be rebuilt before the next forward (the plain copy just was, if asked)
-        _ops.weights_updated(plain_shadow_written=shadow is not None)
+        _ops.weights_updated(self.backbone, plain_shadow_written=shadow is not None)

@@ -26,7 +26,8 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SEI_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL refuses that)
+            backend = os.environ.get("SEI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -53,18 +54,28 @@ class FlatGradientReducer:
     which lets the optimizer consume chunks in order while later ones are still on the wire.
     """
 
-    def __init__(self, flat_grads, chunk_mib=256, group=None):
+    def __init__(self, flat_grads, chunk_mib=256, group=None, comm_dtype=torch.float32):
+        """comm_dtype=torch.bfloat16 compresses the exchanged gradients (half the xGMI bytes): the f32
+        bucket is cast once into `self.comm`, which is what gets summed and what the optimizer reads."""
         self.flat = flat_grads
         self.group = group
-        self.bounds = chunk_bounds(flat_grads.numel(), max(1, (chunk_mib << 20) // flat_grads.element_size()))
+        self.comm_dtype = comm_dtype
+        self.comm = flat_grads if comm_dtype == flat_grads.dtype else torch.empty_like(flat_grads, dtype=comm_dtype)
+        self.bounds = chunk_bounds(flat_grads.numel(), max(1, (chunk_mib << 20) // self.comm.element_size()))
         self._work = []
 
     def reduce_async(self):
         self._work = []
+        if self.comm is not self.flat:
+            if self.flat.is_cuda:
+                import _native as N
+                N.call("sei_cast_bf16", self.flat.data_ptr(), self.comm.data_ptr(), self.flat.numel())
+            else:
+                self.comm.copy_(self.flat)
         if world_size() == 1:
             return
         for s, e in self.bounds:
-            self._work.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._work.append(dist.all_reduce(self.comm[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self, k):
         if self._work:

@@ -193,6 +193,13 @@ def _reducer_worker(rank, world, port, numel, chunk_mib, q):
     red.reduce_async()
     for k in range(len(red.bounds)):
         red.wait(k)
+    # bf16-compressed exchange: the f32 bucket is left alone, the reduced values land in red16.comm
+    g2 = torch.randn(numel, generator=torch.Generator().manual_seed(200 + r))
+    red16 = parallel.FlatGradientReducer(g2, chunk_mib=chunk_mib, comm_dtype=torch.bfloat16)
+    red16.reduce_async()
+    red16.wait_all()
+    want16 = sum(torch.randn(numel, generator=torch.Generator().manual_seed(200 + k)).bfloat16().float() for k in range(w))
+    assert red16.comm.dtype == torch.bfloat16 and (red16.comm.float() - want16).abs().max() < 0.05
     loss = parallel.all_reduce_mean_scalar(torch.tensor(float(r + 1)))
     want = sum(torch.randn(numel, generator=torch.Generator().manual_seed(100 + k)) for k in range(w))
     # plain floats only: tensors sent through the queue would outlive this process's shared memory

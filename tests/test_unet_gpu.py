@@ -175,11 +175,22 @@ def test_colsum_and_adam(ops):
         opt.step()
         gd = gs.cuda()
         p16 = torch.empty(n, dtype=torch.bfloat16, device="cuda")
-        call("sei_adam_fused", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999,
+        call("sei_adam_fused", p.data_ptr(), gd.data_ptr(), 0, m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999,
              1e-8, 0.0, step, 1.0, p16.data_ptr())
         torch.cuda.synchronize()
         assert relerr(p, ref_p) < 1e-6
         assert torch.equal(p16, p.bfloat16())
+    # bf16-compressed gradients (the multi-GPU exchange format): same update as the f32 kernel fed the rounded grads
+    pa, pb = p0.clone().cuda(), p0.clone().cuda()
+    ma, va, mb, vb = (torch.zeros(n, device="cuda") for _ in range(4))
+    g16 = g.cuda().bfloat16()
+    g16f = g16.float()
+    call("sei_adam_fused", pa.data_ptr(), g16.data_ptr(), 1, ma.data_ptr(), va.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.0,
+         1, 0.5, None)
+    call("sei_adam_fused", pb.data_ptr(), g16f.data_ptr(), 0, mb.data_ptr(), vb.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.0,
+         1, 0.5, None)
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(ma, mb)
 
 
 # ------------------------------------------------------------------ ideal resamplers
@@ -430,3 +441,22 @@ def test_weight_gradient_via_transposes(ops, M, Np, Kp):
     assert torch.equal(dYt[:, :M].cpu(), dY.bfloat16().T) and (dYt[:, M:] == 0).all()
     ops.weight_grad16(dYt, ops.transposed16(X.cuda()), acc, M)
     assert relerr(acc, ref) < 5e-6
+
+
+def test_splitk_gemm_inside_hipgraph(ops):
+    """A split-K GEMM (zero-fill + atomics) replayed from a captured graph must not accumulate stale sums."""
+    gen = torch.Generator().manual_seed(5)
+    M, N, K = 2304, 128, 512                      # 18 tiles, long K: the split-K path
+    A = torch.randn((M, K), generator=gen).bfloat16().cuda()
+    Bm = torch.randn((N, K), generator=gen).bfloat16().cuda()
+    ref = A.double().cpu() @ Bm.double().cpu().T
+    out = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm_nt16(A, Bm, M, N, K, ops.EPI_NONE, out32=out)          # warm up outside capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.gemm_nt16(A, Bm, M, N, K, ops.EPI_NONE, out32=out)
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert relerr(out, ref) < 3e-6

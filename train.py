@@ -73,6 +73,9 @@ def build_parser():
     flag("--fused_optimizer", default=True, **onoff)
     flag("--fix_batched_crop", default=False, **onoff)
     flag("--max_steps", type=int, default=None, help="stop each epoch after this many steps (smoke runs)")
+    flag("--compute_dtype", choices=["f32", "bf16"], default="f32",
+         help="1x1-conv GEMM arithmetic: f32 (reference precision) or bf16 MFMA with f32 accumulation")
+    flag("--hip_graph", default=True, **onoff)
     return parser
 
 
@@ -118,7 +121,11 @@ def main(argv=None):
         print(f"\nSelected learning rate: {lr:e}\n")
         print(f"\nSelected optimizer: {optimizer_kind}\n")
 
-    reducer = parallel.FlatGradientReducer(backbone.flat_grads) if world > 1 else None
+    from models import _ops as model_ops
+    model_ops.set_compute_dtype(args.compute_dtype)
+    fused_adam = optimizer_kind == "Adam" and args.fused_optimizer
+    comm_dtype = torch.bfloat16 if (args.compute_dtype == "bf16" and fused_adam) else torch.float32
+    reducer = parallel.FlatGradientReducer(backbone.flat_grads, comm_dtype=comm_dtype) if world > 1 else None
     if optimizer_kind == "Adam" and args.fused_optimizer:
         optimizer = FlatAdam(model, lr=lr, betas=(0.9, args.optimizer_beta2), reducer=reducer)
     elif optimizer_kind == "Adam":
@@ -161,6 +168,7 @@ def main(argv=None):
         save_training_state(epoch=0, model=model, optimizer=optimizer, scheduler=scheduler,
                             state_path=checkpoint_name(0))
 
+    graphed = None
     for epoch in range(epochs):
         if sampler is not None:
             sampler.set_epoch(epoch)
@@ -168,9 +176,18 @@ def main(argv=None):
         steps = 0
         for x, y in dataloader:
             x, y = x.to(args.device), y.to(args.device)
-            optimizer.zero_grad()
-            training_loss = loss(x=x, y=y, model=model)
-            training_loss.backward()
+            can_graph = (args.hip_graph and isinstance(optimizer, FlatAdam) and loss.crop_fn is not None
+                         and y.shape[0] == args.batch_size)
+            if can_graph:
+                if graphed is None:                   # capture once; short last batches run eagerly
+                    from graphs import GraphedLossStep
+                    graphed = GraphedLossStep(loss, model, optimizer,
+                                              (args.batch_size, y.shape[1], args.Loss__crop_size, args.Loss__crop_size))
+                training_loss = graphed(x, y)
+            else:
+                optimizer.zero_grad()
+                training_loss = loss(x=x, y=y, model=model)
+                training_loss.backward()
             if reducer is not None:
                 reducer.reduce_async()
                 if not isinstance(optimizer, FlatAdam):
