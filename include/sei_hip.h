@@ -200,17 +200,25 @@ int sei_colsum_bf16(const uint16_t *X, float *out, size_t M, int N, void *stream
 int sei_cast_transpose_bf16(const void *x, int x_is_bf16, uint16_t *x16, uint16_t *xt16, int R, int C,
                             int ldt, float *colsum, void *stream);
 
-/* Large-shape bf16 GEMM with bf16 operands in HBM, both K-contiguous:  D[M,N] = A[M,K] * B[N,K]^T.
- * Forward 1x1 convolutions (B = bf16 weight shadow) and data gradients (B = transposed shadow).
- * Direct-to-LDS staging (global_load_lds), 8 waves, (128|192|256) x 256 tiles, f32 accumulation.
- * D32 (float) and/or D16 (bf16) receive the epilogue result; SEI_EPI_BIAS_GELU also writes
- * gelu(D) to D2_16 (bf16); SEI_EPI_ACCUM adds into D32 (weight gradients: A = dY^T, B = X^T, both
- * transposed to K = pixels-contiguous by sei_cast_transpose_bf16). lda / ldb = row strides in elements
- * (>= K, multiples of 8). Needs K % 64 == 0 and 16-byte aligned A, B. May split K (float atomics on D32,
- * zero-filled first unless accumulating) when the output is narrow. */
-int sei_gemm_bf16nt(const uint16_t *A, int lda, const uint16_t *B, int ldb, float *D32, uint16_t *D16,
-                    int M, int N, int K, int epilogue, const float *bias, const float *R1, const float *R2,
-                    uint16_t *D2_16, void *stream);
+/* Large-shape bf16 GEMM with bf16 operands in HBM:  D[M,N] = op(A) * op(B),  f32 accumulation.
+ * Each operand is stored either K-contiguous (a_rmajor = 0: A is (M,K) row-major, b_rmajor = 0: B is (N,K)
+ * row-major -- the "NT" form) or reduction-major (a_rmajor = 1: A is (K,M) row-major; b_rmajor = 1: B is
+ * (K,N) row-major). lda / ldb = row strides in elements of the operand as stored (multiples of 8).
+ * Forward 1x1 convolutions: A = activations, B = bf16 weight (N,K): both K-contiguous.
+ * Data gradients dX = dY W: A = dY K-contiguous, B = the SAME bf16 weight read reduction-major.
+ * Weight gradients dW += dY^T X (SEI_EPI_ACCUM): both operands reduction-major (reduction over pixels).
+ * Direct-to-LDS staging (global_load_lds); reduction-major tiles are consumed with the transposing LDS
+ * read ds_read_b64_tr_b16, so no transposed copies exist anywhere. 8 waves, 128x128 / 192x256 / 96x256
+ * tiles. D32 (float) and/or D16 (bf16) receive the epilogue result; SEI_EPI_BIAS_GELU also writes gelu(D)
+ * to D2_16 (bf16). Needs K % 8 == 0 (K tails are fed from a zero page), M % 8 == 0 / N % 8 == 0 for a
+ * reduction-major A / B, 16-byte aligned operands. May split K (float atomics on D32, zero-filled first
+ * unless accumulating) when the output is narrow. */
+int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                    float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
+                    const float *R1, const float *R2, uint16_t *D2_16, void *stream);
+
+/* Development probe (tools/probe_tr_read.py): what ds_read_b64_tr_b16 delivers for a 64x128 LDS image. */
+int sei_debug_tr_probe(const uint16_t *in, uint16_t *out, int r0, int c0, void *stream);
 
 /* Tuning aid: force the tile of sei_gemm_bf16nt (0 = automatic). Process-global; not for production use. */
 int sei_debug_set_nt_tile(int code);

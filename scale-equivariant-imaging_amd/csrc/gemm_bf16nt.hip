@@ -31,15 +31,21 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+
 constexpr int BK = 64;
 constexpr int ROW_BYTES = 128;
 constexpr int NWAVES = 8, NT = 512;
+
+// 16 bytes of zeros: the DMA source of every lane whose chunk lies past the K (or row) edge.
+__device__ __attribute__((aligned(16))) unsigned short g_zero_chunk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 struct NtArgs {
     const unsigned short *A, *B;
     float *D32;
     unsigned short *D16;
-    int M, N, K, lda, ldb;
+    int M, N, K, lda, ldb;     // lda / ldb: row strides in elements of A / B as stored
     int epilogue;
     const float *bias, *R1, *R2;
     unsigned short *D2_16;     // BIAS_GELU: gelu(D) in bf16
@@ -52,9 +58,10 @@ __device__ __forceinline__ unsigned short f2bf(float v) {
     return __builtin_bit_cast(unsigned short, b);
 }
 
+// ---- operand stored K-contiguous: element (o, k) at G[o*ld + k]; LDS image [o][128 B], chunk swizzle (r>>1)&7
 template <int ROWS>
 __device__ __forceinline__ void stage_tile(const unsigned short *__restrict__ G, int ld, int row0, int row_lim,
-                                           int k0, char *lds_tile, int wave, int lane) {
+                                           int k0, int k_lim, char *lds_tile, int wave, int lane) {
     constexpr int NI = ROWS / 8;             // 1-KiB wave-instructions in the tile
 #pragma unroll
     for (int q0 = 0; q0 < NI; q0 += NWAVES) {
@@ -63,16 +70,52 @@ __device__ __forceinline__ void stage_tile(const unsigned short *__restrict__ G,
             const int row = 8 * q + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);      // logical chunk this lane must fetch
             const int grow = min(row0 + row, row_lim - 1);     // rows past the edge re-read the last row
-            const unsigned short *src = G + (size_t)grow * ld + k0 + 8 * c;
+            const int k = k0 + 8 * c;
+            const unsigned short *src = k < k_lim ? G + (size_t)grow * ld + k : g_zero_chunk;
             __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
         }
     }
 }
 
-template <int TM, int TN, int WM, int WN>
+// ---- operand stored reduction-major: element (o, k) at G[k*ld + o]; LDS image [64 k-rows][256 B = 128 o],
+// 16-byte chunk ch of row r at chunk position ch ^ swz(r) (cdna_hip_programming.md T10, image (b)); consumed
+// with ds_read_b64_tr_b16. Rows past K and chunks past the o edge are fed from the zero chunk.
+__device__ __forceinline__ int swz_rmajor(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ void stage_tile_rmajor(const unsigned short *__restrict__ G, int ld, int o0, int o_lim,
+                                                  int k0, int k_lim, char *lds_tile, int wave, int lane) {
+#pragma unroll
+    for (int q0 = 0; q0 < 16; q0 += NWAVES) {            // 64 rows x 256 B = 16 wave-instructions of 4 rows
+        const int q = q0 + wave;
+        const int row = 4 * q + (lane >> 4);
+        const int ch = (lane & 15) ^ swz_rmajor(row);
+        const int k = k0 + row, o = o0 + 8 * ch;
+        const unsigned short *src = (k < k_lim && o < o_lim) ? G + (size_t)k * ld + o : g_zero_chunk;
+        __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
+    }
+}
+
+// fragment of a reduction-major operand: 8 k-values (k = 16s + 8h + j) of column c0 + (lane & 15)
+__device__ __forceinline__ bf16x8 frag_rmajor(const char *tile, int s, int lane, int c0) {
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int col0 = c0 + 16 * (g & 1);
+    const int row = 16 * s + 8 * (g >> 1) + q;
+    const int chunk = (col0 >> 3) + (p >> 1);
+    auto addr = [&](int r) {
+        return (__attribute__((address_space(3))) v4s *)(tile + 256 * r + 16 * (chunk ^ swz_rmajor(r)) + 8 * (p & 1));
+    };
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(addr(row));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(addr(row + 4));
+    const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+template <int TM, int TN, int WM, int WN, bool ARM, bool BRM>
 __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
     static_assert(WM * WN == NWAVES, "8 waves per workgroup");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    static_assert(!ARM || BM == 128, "a reduction-major A tile is 64 x 128");
+    static_assert(!BRM || BN == 128, "a reduction-major B tile is 64 x 128");
     constexpr int STAGE = (BM + BN) * ROW_BYTES;
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
@@ -108,8 +151,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    stage_tile<BM>(g.A, g.lda, m0, M, k_begin, smem, wave, lane);
-    stage_tile<BN>(g.B, g.ldb, n0, N, k_begin, smem + BM * ROW_BYTES, wave, lane);
+    auto stage = [&](int k0, char *dst) {
+        if constexpr (ARM) stage_tile_rmajor(g.A, g.lda, m0, M, k0, k_end, dst, wave, lane);
+        else stage_tile<BM>(g.A, g.lda, m0, M, k0, k_end, dst, wave, lane);
+        if constexpr (BRM) stage_tile_rmajor(g.B, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
+        else stage_tile<BN>(g.B, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
+    };
+    stage(k_begin, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -120,21 +168,21 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
     int cur = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         char *now = smem + cur * STAGE;
-        if (k0 + BK < k_end) {
-            char *nxt = smem + (cur ^ 1) * STAGE;
-            stage_tile<BM>(g.A, g.lda, m0, M, k0 + BK, nxt, wave, lane);
-            stage_tile<BN>(g.B, g.ldb, n0, N, k0 + BK, nxt + BM * ROW_BYTES, wave, lane);
-        }
+        if (k0 + BK < k_end) stage(k0 + BK, smem + (cur ^ 1) * STAGE);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             const int pc = ((2 * s + lh) ^ sw) * 16;
             bf16x8 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const bf16x8 *>(now + a_off + i * 32 * ROW_BYTES + pc);
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (ARM) a[i] = frag_rmajor(now, s, lane, wm * 32 * TM + 32 * i);
+                else a[i] = *reinterpret_cast<const bf16x8 *>(now + a_off + i * 32 * ROW_BYTES + pc);
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const bf16x8 *>(now + b_off + j * 32 * ROW_BYTES + pc);
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (BRM) b[j] = frag_rmajor(now + BM * ROW_BYTES, s, lane, wn * 32 * TN + 32 * j);
+                else b[j] = *reinterpret_cast<const bf16x8 *>(now + b_off + j * 32 * ROW_BYTES + pc);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -205,7 +253,7 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, s
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.f;
 }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, bool ARM = false, bool BRM = false>
 int launch_nt(NtArgs &g, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     g.tiles_m = (int)sei_ceil_div(g.M, BM);
@@ -232,7 +280,8 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         if ((reinterpret_cast<uintptr_t>(g.D32) & 15) != 0) return SEI_ERR_BAD_ARG;
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
-    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN>), dim3((unsigned)(tiles * g.splitk)), dim3(NT), 0, s, g);
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM>), dim3((unsigned)(tiles * g.splitk)), dim3(NT), 0,
+                       s, g);
     return sei_launch_status();
 }
 
@@ -245,11 +294,14 @@ extern "C" int sei_debug_set_nt_tile(int code) {
     return SEI_OK;
 }
 
-extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, const uint16_t *B, int ldb, float *D32, uint16_t *D16,
-                               int M, int N, int K, int epilogue, const float *bias, const float *R1,
-                               const float *R2, uint16_t *D2_16, void *stream) {
+extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                               float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
+                               const float *R1, const float *R2, uint16_t *D2_16, void *stream) {
     SEI_REQUIRE(A && B && (D32 || D16) && M > 0 && N > 0 && K > 0);
-    SEI_REQUIRE(K % BK == 0 && lda >= K && ldb >= K && lda % 8 == 0 && ldb % 8 == 0);
+    SEI_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0);
+    SEI_REQUIRE(lda >= (a_rmajor ? M : K) && ldb >= (b_rmajor ? N : K));
+    if (a_rmajor) SEI_REQUIRE(M % 8 == 0);
+    if (b_rmajor) SEI_REQUIRE(N % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0);
     SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU ||
                 epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_ACCUM);
@@ -261,6 +313,10 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, const uint16_t *B, in
     g.A = A; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
     hipStream_t s = (hipStream_t)stream;
+    // a reduction-major operand fixes the tile at 128 x 128 (its LDS rows are 256 bytes = 128 columns)
+    if (a_rmajor && b_rmajor) return launch_nt<2, 1, 2, 4, true, true>(g, s);
+    if (a_rmajor) return launch_nt<2, 1, 2, 4, true, false>(g, s);
+    if (b_rmajor) return launch_nt<2, 1, 2, 4, false, true>(g, s);
     switch (g_force_tile) {
         case 1: return launch_nt<2, 1, 2, 4>(g, s);      // 128 x 128
         case 2: return launch_nt<2, 2, 2, 4>(g, s);      // 128 x 256

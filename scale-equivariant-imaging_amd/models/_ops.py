@@ -75,10 +75,15 @@ def gemm(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2
 
 
 def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=None, R2=None, D2_16=None,
-              lda=None, ldb=None):
-    """D = A16[M,K] @ B16[N,K]^T on the direct-to-LDS bf16 kernel (K % 64 == 0). Outputs as given."""
-    _gemm_call(2.0 * M * Nn * K, "sei_gemm_bf16nt", A16.data_ptr(), K if lda is None else lda, B16.data_ptr(),
-               K if ldb is None else ldb, N.ptr(out32), N.ptr(out16), M, Nn, K, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2),
+              lda=None, ldb=None, a_rmajor=False, b_rmajor=False):
+    """D[M,N] = op(A16) op(B16) on the direct-to-LDS bf16 kernel. A16 is (M,K) [or (K,M) when a_rmajor],
+    B16 is (N,K) [or (K,N) when b_rmajor]; K % 8 == 0. Outputs as given."""
+    if lda is None:
+        lda = M if a_rmajor else K
+    if ldb is None:
+        ldb = Nn if b_rmajor else K
+    _gemm_call(2.0 * M * Nn * K, "sei_gemm_bf16nt", A16.data_ptr(), lda, int(a_rmajor), B16.data_ptr(), ldb,
+               int(b_rmajor), N.ptr(out32), N.ptr(out16), M, Nn, K, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2),
                N.ptr(D2_16))
 
 
@@ -300,8 +305,9 @@ def refresh_plain_shadow(backbone):
 
 
 def shadow(p):
-    """(w16 (R,C), wt16 (C,R)) bf16 shadows of a 1x1-conv weight p (R,C,1,1); rebuilt once per update.
-    w16 is a view of the owning model's flat bf16 bucket when there is one (the fused Adam writes it)."""
+    """bf16 copy w16 (R,C) of a 1x1-conv weight p (R,C,1,1): a view of the owning model's flat bf16 bucket,
+    which the fused Adam kernel rewrites every step; cast here only when that copy is not current.
+    (No transposed copy exists: the data-gradient GEMM reads w16 reduction-major.)"""
     key = (_SHADOW_GENERATION, p._version, p.data_ptr())
     st = getattr(p, "_sei_shadow", None)
     if st is None or st[0] != key:
@@ -309,26 +315,22 @@ def shadow(p):
         flat16 = getattr(p, "_sei_shadow_view", None)
         plain = getattr(p, "_sei_plain_state", None)
         if st is not None and st[1].device == p.device:
-            w16, wt16 = st[1], st[2]
+            w16 = st[1]
         else:
             w16 = flat16.view(R, C) if flat16 is not None else torch.empty((R, C), dtype=torch.bfloat16, device=p.device)
-            wt16 = torch.empty((C, R), dtype=torch.bfloat16, device=p.device)
         plain_current = (flat16 is not None and plain is not None and plain["gen"] == _SHADOW_GENERATION
                          and plain["version"].get(id(p)) == p._version)
-        if plain_current:
-            # plain copy already current: only the transpose, from the bf16 data (half the read traffic)
-            N.call("sei_cast_transpose_bf16", w16.data_ptr(), 1, None, wt16.data_ptr(), R, C, R, None)
-        else:
-            N.call("sei_weight_shadow_bf16", p.data_ptr(), w16.data_ptr(), wt16.data_ptr(), R, C)
+        if not plain_current:
+            N.call("sei_cast_bf16", p.data_ptr(), w16.data_ptr(), p.numel())
         if plain is not None:
             plain["version"][id(p)] = p._version
-        st = (key, w16, wt16)
+        st = (key, w16)
         p._sei_shadow = st
-    return st[1], st[2]
+    return st[1]
 
 
 def nt16_ok(K):
-    return K % 64 == 0
+    return K % 8 == 0
 
 
 def to_bf16(x):
@@ -362,32 +364,24 @@ def gemm_mixed(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=No
     return out
 
 
-def pad64(n):
-    return (n + 63) // 64 * 64
-
-
-def transposed16(x2d, also_plain=False, colsum_into_=None):
-    """x (R, C) f32 or bf16 -> xt16 (C, pad64(R)) bf16, zero padded (and x16 (R, C) when asked, f32 input).
-    colsum_into_: accumulate the column sums of x (a bias gradient) into this tensor in the same pass."""
+def cast16(x2d, colsum_into_=None):
+    """f32 (R, C) -> bf16 copy; colsum_into_: accumulate the column sums (a bias gradient) in the same pass."""
     R, C = x2d.shape
-    ldt = pad64(R)
-    xt = torch.empty((C, ldt), dtype=torch.bfloat16, device=x2d.device)
-    x16 = torch.empty((R, C), dtype=torch.bfloat16, device=x2d.device) if also_plain else None
-    N.call("sei_cast_transpose_bf16", x2d.data_ptr(), int(x2d.dtype == torch.bfloat16), N.ptr(x16), xt.data_ptr(),
-           R, C, ldt, N.ptr(colsum_into_))
-    return (x16, xt) if also_plain else xt
+    x16 = torch.empty((R, C), dtype=torch.bfloat16, device=x2d.device)
+    N.call("sei_cast_transpose_bf16", x2d.data_ptr(), 0, x16.data_ptr(), None, R, C, R, N.ptr(colsum_into_))
+    return x16
 
 
-def weight_grad16(gy_t, x_t, grad2d, rows):
-    """grad (N', K') += gy^T x over `rows` pixels, both operands given transposed and K-padded."""
-    Np, Kp = grad2d.shape
-    ld = gy_t.shape[1]
-    gemm_nt16(gy_t, x_t, Np, Kp, ld, EPI_ACCUM, out32=grad2d, lda=ld, ldb=ld)
+def weight_grad16(gy16, x16, grad2d):
+    """grad (N', K') += gy^T x, gy16 (M, N') and x16 (M, K') bf16 as stored: both read reduction-major."""
+    M, Np = gy16.shape
+    Kp = x16.shape[1]
+    gemm_nt16(gy16, x16, Np, Kp, M, EPI_ACCUM, out32=grad2d, a_rmajor=True, b_rmajor=True)
 
 
 def use_bf16_blocks(C):
     """A block takes the bf16-storage path when the mode is bf16 and its GEMMs fit the NT kernel."""
-    return _COMPUTE_DTYPE == "bf16" and nt16_ok(C)
+    return _COMPUTE_DTYPE == "bf16" and C % 32 == 0
 
 
 class ConvBlockFn16(torch.autograd.Function):
@@ -400,8 +394,7 @@ class ConvBlockFn16(torch.autograd.Function):
         M = B * H * W
         h1 = dwconv7(x, w1, b1)
         h2, mean, rstd = layer_norm16(h1.view(M, C), gamma, beta)
-        w2_16, _ = shadow(w2)
-        w3_16, _ = shadow(w3)
+        w2_16, w3_16 = shadow(w2), shadow(w3)
         h3 = torch.empty((M, 4 * C), dtype=torch.float32, device=x.device)
         h4 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device)
         gemm_nt16(h2, w2_16, M, 4 * C, C, EPI_BIAS_GELU, out32=h3, bias=b2, D2_16=h4)
@@ -420,15 +413,14 @@ class ConvBlockFn16(torch.autograd.Function):
         M = B * H * W
         go = go.contiguous()
         go2 = go.view(M, C)
-        go16, go16_t = transposed16(go2, also_plain=True, colsum_into_=grad_of(b3))
-        _, w3t_16 = shadow(w3)
-        _, w2t_16 = shadow(w2)
-        weight_grad16(go16_t, transposed16(h4), grad_of(w3).view(C, 4 * C), M)
+        go16 = cast16(go2, colsum_into_=grad_of(b3))
+        weight_grad16(go16, h4, grad_of(w3).view(C, 4 * C))
         gh3 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device)
-        gemm_nt16(go16, w3t_16, M, 4 * C, C, EPI_MUL_DGELU, out16=gh3, R1=h3)
-        weight_grad16(transposed16(gh3, colsum_into_=grad_of(b2)), transposed16(h2), grad_of(w2).view(4 * C, C), M)
+        gemm_nt16(go16, shadow(w3), M, 4 * C, C, EPI_MUL_DGELU, out16=gh3, R1=h3, b_rmajor=True)   # (go W3) gelu'
+        colsum16_into(grad_of(b2), gh3)
+        weight_grad16(gh3, h2, grad_of(w2).view(4 * C, C))
         gh2 = torch.empty((M, C), dtype=torch.float32, device=x.device)
-        gemm_nt16(gh3, w2t_16, M, C, 4 * C, EPI_NONE, out32=gh2)
+        gemm_nt16(gh3, shadow(w2), M, C, 4 * C, EPI_NONE, out32=gh2, b_rmajor=True)
         gh1 = layer_norm_bwd(h1.view(M, C), gamma, mean, rstd, gh2, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
         dwconv7_weight_grad(x, gh1, grad_of(w1), grad_of(b1))
         gx = None
@@ -444,7 +436,7 @@ class DownsampleFn16(torch.autograd.Function):
         B, H, W, C = x.shape
         M, Co = B * H * W, w.shape[0]
         h, mean, rstd = layer_norm16(x.view(M, C), gamma, beta)
-        w16, _ = shadow(w)
+        w16 = shadow(w)
         z = torch.empty((M, Co), dtype=torch.float32, device=x.device)
         gemm_nt16(h, w16, M, Co, C, EPI_BIAS, out32=z, bias=b)
         fwd, bwd = _mats.resample_matrices("down", H, W, rate, x.device)
@@ -460,11 +452,10 @@ class DownsampleFn16(torch.autograd.Function):
         B, H, W, C = x.shape
         M, Co = B * H * W, w.shape[0]
         gz = sepmap2(go.contiguous(), ctx.mats_t, H, W).view(M, Co)
-        gz16, gz16_t = transposed16(gz, also_plain=True, colsum_into_=grad_of(b))
-        weight_grad16(gz16_t, transposed16(h), grad_of(w).view(Co, C), M)
-        _, wt16 = shadow(w)
+        gz16 = cast16(gz, colsum_into_=grad_of(b))
+        weight_grad16(gz16, h, grad_of(w).view(Co, C))
         gh = torch.empty((M, C), dtype=torch.float32, device=x.device)
-        gemm_nt16(gz16, wt16, M, C, Co, EPI_NONE, out32=gh)
+        gemm_nt16(gz16, shadow(w), M, C, Co, EPI_NONE, out32=gh, b_rmajor=True)
         gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
         return (gx if ctx.needs_input_grad[0] else None), None, None, None, None, None
 
@@ -480,7 +471,7 @@ class UpsampleFn16(torch.autograd.Function):
         u = sepmap2(x, fwd, Ho, Wo)
         M = B * Ho * Wo
         h, mean, rstd = layer_norm16(u.view(M, C), gamma, beta)
-        w16, _ = shadow(w)
+        w16 = shadow(w)
         out = torch.empty((M, Co), dtype=torch.float32, device=x.device)
         if skip is not None:
             skip = _nhwc(skip)
@@ -501,14 +492,10 @@ class UpsampleFn16(torch.autograd.Function):
         M, Co = B * Ho * Wo, w.shape[0]
         go = go.contiguous()
         go2 = go.view(M, Co)
-        go16, go16_t = transposed16(go2, also_plain=True, colsum_into_=grad_of(b))
-        weight_grad16(go16_t, transposed16(h), grad_of(w).view(Co, C), M)
-        if nt16_ok(Co):
-            _, wt16 = shadow(w)
-            gh = torch.empty((M, C), dtype=torch.float32, device=u.device)
-            gemm_nt16(go16, wt16, M, C, Co, EPI_NONE, out32=gh)
-        else:
-            gh = gemm_mixed(go16, w, M, C, Co, 0, 0, EPI_NONE)
+        go16 = cast16(go2, colsum_into_=grad_of(b))
+        weight_grad16(go16, h, grad_of(w).view(Co, C))
+        gh = torch.empty((M, C), dtype=torch.float32, device=u.device)
+        gemm_nt16(go16, shadow(w), M, C, Co, EPI_NONE, out32=gh, b_rmajor=True)
         gu = layer_norm_bwd(u.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta))
         gx = None
         if ctx.needs_input_grad[0]:

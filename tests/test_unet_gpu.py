@@ -426,20 +426,19 @@ def test_gemm_bf16nt(ops, M, N, K):
     assert relerr(o16.float(), ref * dg) < 5e-3
 
 
-@pytest.mark.parametrize("M,Np,Kp", [(576, 512, 128), (288, 2048, 512), (9216, 128, 32), (300, 130, 70)])
-def test_weight_gradient_via_transposes(ops, M, Np, Kp):
-    """dW += dY^T X through cast/transpose (K padded to 64) + the NT kernel's accumulate epilogue."""
+@pytest.mark.parametrize("M,Np,Kp", [(576, 512, 128), (288, 2048, 512), (9216, 128, 32), (304, 136, 72)])
+def test_weight_gradient_reduction_major(ops, M, Np, Kp):
+    """dW += dY^T X straight from the (M, .) bf16 tensors (no transposes), bias gradient from the cast pass."""
     gen = torch.Generator().manual_seed(M + Np)
     dY, X = torch.randn((M, Np), generator=gen), torch.randn((M, Kp), generator=gen).bfloat16()
     base = torch.randn((Np, Kp), generator=gen)
     ref = base.double() + dY.bfloat16().double().T @ X.double()
     acc = base.clone().cuda()
     cs = torch.ones(Np, device="cuda")
-    dY16, dYt = ops.transposed16(dY.cuda(), also_plain=True, colsum_into_=cs)
+    dY16 = ops.cast16(dY.cuda(), colsum_into_=cs)
     assert relerr(cs, dY.double().sum(0) + 1) < 1e-5
-    assert torch.equal(dY16.cpu(), dY.bfloat16()) and dYt.shape == (Np, ops.pad64(M))
-    assert torch.equal(dYt[:, :M].cpu(), dY.bfloat16().T) and (dYt[:, M:] == 0).all()
-    ops.weight_grad16(dYt, ops.transposed16(X.cuda()), acc, M)
+    assert torch.equal(dY16.cpu(), dY.bfloat16())
+    ops.weight_grad16(dY16, X.cuda(), acc)
     assert relerr(acc, ref) < 5e-6
 
 
@@ -460,3 +459,23 @@ def test_splitk_gemm_inside_hipgraph(ops):
         graph.replay()
         torch.cuda.synchronize()
         assert relerr(out, ref) < 3e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (576, 512, 128), (288, 2048, 512), (136, 264, 72), (2304, 128, 512),
+                                    (512, 128, 9216), (8, 16, 24)])
+@pytest.mark.parametrize("arm,brm", [(False, True), (True, True), (True, False)])
+def test_gemm_bf16nt_reduction_major_operands(ops, M, N, K, arm, brm):
+    """Operands stored reduction-major ((K,M) / (K,N)) are consumed through transposing LDS reads."""
+    gen = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn((M, K), generator=gen).bfloat16()
+    Bm = torch.randn((N, K), generator=gen).bfloat16()
+    ref = A.double() @ Bm.double().T
+    Ad = (A.t().contiguous() if arm else A).cuda()
+    Bd = (Bm.t().contiguous() if brm else Bm).cuda()
+    out = torch.empty((M, N), device="cuda")
+    ops.gemm_nt16(Ad, Bd, M, N, K, ops.EPI_NONE, out32=out, a_rmajor=arm, b_rmajor=brm)
+    assert relerr(out, ref) < 3e-6
+    base = torch.randn((M, N), generator=gen)
+    acc = base.clone().cuda()
+    ops.gemm_nt16(Ad, Bd, M, N, K, ops.EPI_ACCUM, out32=acc, a_rmajor=arm, b_rmajor=brm)
+    assert relerr(acc, ref + base.double()) < 3e-6

@@ -56,15 +56,11 @@ def main():
         o16 = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
         res["rb16"] = timeit(lambda: torch.matmul(A16, B16, out=o16))
         res["nt16"] = float("nan")
-        if ta and K % 64 == 0:          # weight gradient through transposes + NT accumulate
-            At = _ops.transposed16(A.bfloat16())
-            Bt = _ops.transposed16(B.bfloat16())
-            res["nt16"] = timeit(lambda: _ops.weight_grad16(At, Bt, out, K))
-        if not ta and K % 64 == 0:
-            Bk = (B if tb else B.t().contiguous()).bfloat16()       # [N, K]
-            Ak = A.bfloat16()
-            o32 = torch.empty((M, N), device="cuda")
-            res["nt16"] = timeit(lambda: _ops.gemm_nt16(Ak, Bk, M, N, K, _ops.EPI_NONE, out32=o32))
+        if K % 8 == 0 and M % 8 == 0 and N % 8 == 0:      # operands as the model stores them (no transposes)
+            A16, B16 = A.bfloat16(), B.bfloat16()
+            epi16 = _ops.EPI_ACCUM if ta else _ops.EPI_NONE
+            res["nt16"] = timeit(lambda: _ops.gemm_nt16(A16, B16, M, N, K, epi16, out32=out, a_rmajor=bool(ta),
+                                                        b_rmajor=not tb))
         fl = 2.0 * M * N * K
         for k in tot:
             tot[k] += res[k] if res[k] == res[k] else res["bf16"]
