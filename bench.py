@@ -203,8 +203,16 @@ def main():
         peak = MFMA_PEAK_TFLOPS[opt.dtype]
         kernels = ("gemm_bf16nt_kernel<*> (direct-to-LDS NT, all large GEMMs) + gemm_bf16_kernel<*> (K<64 layers)"
                    if opt.dtype == "bf16" else "gemm_f32_kernel<*>")
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_c_pmc_gemm.json")
+        if opt.dtype == "bf16" and opt.hidden == 32 and opt.scales == 5 and opt.batch == 32 and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))                 # PMC counters cannot be read live; see the file
+            traffic = round(pmc["traffic_bytes_per_launch"])
+            traffic_src = ("bytes beyond L2 per GEMM launch from committed rocprofv3 --pmc passes of this command "
+                           "(profiles/r01_c_pmc_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections)")
         roofline = {"bound": "mfma", "kernel": kernels, "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "launches_per_step": len(records), "avg_launch_us": round(1e3 * total_ms / len(records), 2),
                     "gemm_ms_per_step": round(total_ms, 2),
                     "algorithmic_gflop_per_step": round(flops / 1e9, 1),
