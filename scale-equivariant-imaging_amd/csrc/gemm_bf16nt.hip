@@ -264,12 +264,26 @@ int launch_nt(NtArgs &g, hipStream_t s) {
     g.k_per_split = g.K;
     const bool splittable = g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
                             g.epilogue == SEI_EPI_BIAS_RES || g.epilogue == SEI_EPI_ACCUM;
-    if (splittable && g.D32 && !g.D16 && tiles < 160 && g.K >= 8 * BK) {
-        size_t sk = sei_ceil_div(256, tiles);
-        const size_t max_sk = (size_t)g.K / (4 * BK);
-        if (sk > max_sk) sk = max_sk;
-        if (sk > 1) {
-            g.k_per_split = (int)(sei_ceil_div(sei_ceil_div(g.K, sk), BK) * BK);
+    if (splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
+        // Wave-quantisation-aware split: a launch takes ceil(tiles*sk / slots) rounds of workgroups, each
+        // round costing (k-tiles per split + a fixed prologue/epilogue/atomics overhead); pick the cheapest sk.
+        constexpr size_t STAGE_BYTES = 2 * (size_t)(BM + BN) * ROW_BYTES;
+        const size_t slots = 256 * (STAGE_BYTES <= 80 * 1024 ? 2 : 1);       // workgroups resident on 256 CUs
+        const size_t ktiles = sei_ceil_div(g.K, BK);
+        const size_t max_sk = ktiles / 4 < 16 ? ktiles / 4 : 16;
+        const double overhead = 6.0 + (g.epilogue == SEI_EPI_ACCUM ? 0.0 : 2.0);   // in k-tile units
+        double best = 1e30;
+        size_t best_sk = 1;
+        for (size_t sk = 1; sk <= max_sk; ++sk) {
+            const double rounds = (double)sei_ceil_div(tiles * sk, slots);
+            const double cost = rounds * ((double)sei_ceil_div(ktiles, sk) + overhead + (sk > 1 ? 2.0 : 0.0));
+            if (cost < best * 0.97) {            // prefer fewer splits unless the gain is real
+                best = cost;
+                best_sk = sk;
+            }
+        }
+        if (best_sk > 1) {
+            g.k_per_split = (int)(sei_ceil_div(ktiles, best_sk) * BK);
             g.splitk = (int)sei_ceil_div(g.K, g.k_per_split);
         }
     }
