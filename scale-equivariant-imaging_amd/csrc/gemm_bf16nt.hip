@@ -110,14 +110,27 @@ __device__ __forceinline__ bf16x8 frag_rmajor(const char *tile, int s, int lane,
     return __builtin_bit_cast(bf16x8, both);
 }
 
-template <int TM, int TN, int WM, int WN, bool ARM, bool BRM>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {          // counted wait: at most N LDS-DMA loads still in flight
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else static_assert(N < 0, "add the immediate");
+}
+
+template <int TM, int TN, int WM, int WN, bool ARM, bool BRM, int NSTAGE = 2>
 __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
     static_assert(WM * WN == NWAVES, "8 waves per workgroup");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static_assert(!ARM || BM == 128, "a reduction-major A tile is 64 x 128");
     static_assert(!BRM || BN == 128, "a reduction-major B tile is 64 x 128");
     constexpr int STAGE = (BM + BN) * ROW_BYTES;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -151,24 +164,60 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- epilogue inputs --------------------------------------------------------------------------
+    // The auxiliary values (running gradient for ACCUM, residuals, GELU' input) are independent of the main
+    // loop and could be loaded before it. MEASURED AND REJECTED: holding them costs 32-64 VGPRs, which takes
+    // the 128x128 tile from two resident workgroups per CU to one (101 -> 158 VGPRs), and the lost overlap
+    // between co-resident blocks outweighs the hidden latency (bench 1000 -> 883 images/s). Kept behind a
+    // constant for tiles that are register-rich.
+    constexpr bool PREFETCH_AUX = false;
+    const int epi = g.epilogue;
+    const bool lead = zs == 0;          // with split-K, split 0 carries bias / residual terms
+    const bool split = g.splitk > 1;
+    const float *aux1p = nullptr, *aux2p = nullptr;
+    if (epi == SEI_EPI_BIAS_RES && (!split || lead)) { aux1p = g.R1; aux2p = g.R2; }
+    else if (epi == SEI_EPI_MUL_DGELU) aux1p = g.R1;
+    else if (epi == SEI_EPI_ACCUM && !split) aux1p = g.D32;
+    float a1[TM][TN][16], a2[TM][TN][16];
+    auto gather_aux = [&](int i, int j) {
+        const int col = n0 + wn * (32 * TN) + 32 * j + li;
+        const int row_base = m0 + wm * (32 * TM) + 32 * i + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            const bool ok = col < N && row < M;
+            const size_t o = (size_t)row * N + col;
+            a1[i][j][r] = (ok && aux1p) ? aux1p[o] : 0.f;
+            a2[i][j][r] = (ok && aux2p) ? aux2p[o] : 0.f;
+        }
+    };
+    if constexpr (PREFETCH_AUX) {
+        if (aux1p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) gather_aux(i, j);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a1[i][j][r] = a2[i][j][r] = 0.f;
+        }
+    }
+
     auto stage = [&](int k0, char *dst) {
         if constexpr (ARM) stage_tile_rmajor(g.A, g.lda, m0, M, k0, k_end, dst, wave, lane);
         else stage_tile<BM>(g.A, g.lda, m0, M, k0, k_end, dst, wave, lane);
         if constexpr (BRM) stage_tile_rmajor(g.B, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
         else stage_tile<BN>(g.B, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
     };
-    stage(k_begin, smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     const int sw = (li >> 1) & 7;                              // swizzle key of this lane's rows
     const int a_off = (wm * 32 * TM + li) * ROW_BYTES;
     const int b_off = BM * ROW_BYTES + (wn * 32 * TN + li) * ROW_BYTES;
 
-    int cur = 0;
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        char *now = smem + cur * STAGE;
-        if (k0 + BK < k_end) stage(k0 + BK, smem + (cur ^ 1) * STAGE);
+    auto compute = [&](const char *now) {
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             const int pc = ((2 * s + lh) ^ sw) * 16;
@@ -189,21 +238,54 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+    };
+
+    if constexpr (NSTAGE == 2) {
+        // two stages, one workgroup's DMA in flight under its own MFMAs; relies on a second resident
+        // workgroup per CU for overlap (128x128 tile)
+        stage(k_begin, smem);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            if (k0 + BK < k_end) stage(k0 + BK, smem + (cur ^ 1) * STAGE);
+            compute(smem + cur * STAGE);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        // Ring of NSTAGE slots, NSTAGE-1 tiles of LDS-DMA in flight (cdna_hip_programming.md T3+T4): counted
+        // vmcnt (never 0 in steady state) and a raw s_barrier, so the DMA queue never drains at a barrier.
+        // Per wave and tile the DMA count is uniform: PER = (BM + BN) / 64 instructions.
+        constexpr int PER = (BM + BN) / 64;
+        static_assert((BM + BN) % 64 == 0, "uniform DMA count per wave");
+        const int nt = (k_end - k_begin + BK - 1) / BK;
+#pragma unroll
+        for (int t = 0; t < NSTAGE - 1; ++t)
+            if (t < nt) stage(k_begin + t * BK, smem + t * STAGE);
+        int slot = 0;
+        for (int t = 0; t < nt; ++t) {
+            // tile t must have landed: everything issued after it may still be in flight
+            if (t + NSTAGE - 2 < nt) wait_vmcnt<(NSTAGE - 2) * PER>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();          // every wave's share of tile t is in LDS; slot t-1 is free
+            const int tn = t + NSTAGE - 1;
+            if (tn < nt) {
+                int ns = slot + NSTAGE - 1;
+                if (ns >= NSTAGE) ns -= NSTAGE;
+                stage(k_begin + tn * BK, smem + ns * STAGE);
+            }
+            compute(smem + slot * STAGE);
+            if (++slot == NSTAGE) slot = 0;
+        }
+        wait_vmcnt<0>();
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
-    // Per 32x32 accumulator tile: first gather every auxiliary value the epilogue needs (16 independent
-    // loads in flight), then compute and store. Interleaving loads with the stores serialises them.
-    const int epi = g.epilogue;
-    const bool lead = zs == 0;          // with split-K, split 0 carries bias / residual terms
-    const bool split = g.splitk > 1;
-    const float *aux1p = nullptr, *aux2p = nullptr;
-    if (epi == SEI_EPI_BIAS_RES && (!split || lead)) { aux1p = g.R1; aux2p = g.R2; }
-    else if (epi == SEI_EPI_MUL_DGELU) aux1p = g.R1;
-    else if (epi == SEI_EPI_ACCUM && !split) aux1p = g.D32;
+    // Per 32x32 accumulator tile: the auxiliary values are already in registers (prefetched above) or are
+    // gathered first (16 independent loads in flight); then compute and store. Interleaving the loads with
+    // the stores would serialise them.
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -214,15 +296,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
             const float bias = (col_ok && (!split || lead) &&
                                 (epi == SEI_EPI_BIAS || epi == SEI_EPI_BIAS_GELU || epi == SEI_EPI_BIAS_RES))
                                    ? g.bias[col] : 0.f;
-            float a1[16], a2[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_base + (r & 3) + 8 * (r >> 2);
-                const bool ok = col_ok && row < M;
-                const size_t o = (size_t)row * N + col;
-                a1[r] = (ok && aux1p) ? aux1p[o] : 0.f;
-                a2[r] = (ok && aux2p) ? aux2p[o] : 0.f;
-            }
+            if constexpr (!PREFETCH_AUX) gather_aux(i, j);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row_base + (r & 3) + 8 * (r >> 2);
@@ -230,11 +304,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
                 const size_t o = (size_t)row * N + col;
                 float v = acc[i][j][r] + bias;
                 if (split) {
-                    atomicAdd(g.D32 + o, v + a1[r] + a2[r]);
+                    atomicAdd(g.D32 + o, v + a1[i][j][r] + a2[i][j][r]);
                     continue;
                 }
-                if (epi == SEI_EPI_MUL_DGELU) v *= sei_dgelu(a1[r]);
-                else v += a1[r] + a2[r];
+                if (epi == SEI_EPI_MUL_DGELU) v *= sei_dgelu(a1[i][j][r]);
+                else v += a1[i][j][r] + a2[i][j][r];
                 if (epi == SEI_EPI_BIAS_GELU) g.D2_16[o] = f2bf(sei_gelu(v));
                 if (g.D32) g.D32[o] = v;
                 if (g.D16) g.D16[o] = f2bf(v);
@@ -253,7 +327,7 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, s
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.f;
 }
 
-template <int TM, int TN, int WM, int WN, bool ARM = false, bool BRM = false>
+template <int TM, int TN, int WM, int WN, bool ARM = false, bool BRM = false, int NSTAGE = 2>
 int launch_nt(NtArgs &g, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     g.tiles_m = (int)sei_ceil_div(g.M, BM);
@@ -267,7 +341,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
     if (splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
         // Wave-quantisation-aware split: a launch takes ceil(tiles*sk / slots) rounds of workgroups, each
         // round costing (k-tiles per split + a fixed prologue/epilogue/atomics overhead); pick the cheapest sk.
-        constexpr size_t STAGE_BYTES = 2 * (size_t)(BM + BN) * ROW_BYTES;
+        constexpr size_t STAGE_BYTES = NSTAGE * (size_t)(BM + BN) * ROW_BYTES;
         const size_t slots = 256 * (STAGE_BYTES <= 80 * 1024 ? 2 : 1);       // workgroups resident on 256 CUs
         const size_t ktiles = sei_ceil_div(g.K, BK);
         const size_t max_sk = ktiles / 4 < 16 ? ktiles / 4 : 16;
@@ -294,8 +368,8 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         if ((reinterpret_cast<uintptr_t>(g.D32) & 15) != 0) return SEI_ERR_BAD_ARG;
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
-    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM>), dim3((unsigned)(tiles * g.splitk)), dim3(NT), 0,
-                       s, g);
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE>), dim3((unsigned)(tiles * g.splitk)),
+                       dim3(NT), 0, s, g);
     return sei_launch_status();
 }
 
@@ -327,6 +401,15 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     g.A = A; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
     hipStream_t s = (hipStream_t)stream;
+    if (!a_rmajor && !b_rmajor) {
+        switch (g_force_tile) {                          // ring-pipelined candidates (tuning aid)
+            case 11: return launch_nt<2, 1, 2, 4, false, false, 4>(g, s);      // 128 x 128, 4 stages
+            case 12: return launch_nt<4, 1, 2, 4, false, false, 3>(g, s);      // 256 x 128, 3 stages
+            case 13: return launch_nt<2, 2, 2, 4, false, false, 3>(g, s);      // 128 x 256, 3 stages
+            case 14: return launch_nt<2, 1, 2, 4, false, false, 3>(g, s);      // 128 x 128, 3 stages
+            default: break;
+        }
+    }
     // a reduction-major operand fixes the tile at 128 x 128 (its LDS rows are 256 bytes = 128 columns)
     if (a_rmajor && b_rmajor) return launch_nt<2, 1, 2, 4, true, true>(g, s);
     if (a_rmajor) return launch_nt<2, 1, 2, 4, true, false>(g, s);
