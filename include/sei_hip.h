@@ -223,6 +223,11 @@ int sei_debug_tr_probe(const uint16_t *in, uint16_t *out, int r0, int c0, void *
 /* Tuning aid: force the tile of sei_gemm_bf16nt (0 = automatic). Process-global; not for production use. */
 int sei_debug_set_nt_tile(int code);
 
+/* Tuning aid / test hook for the depthwise kernels (process-global): 1..64 = output columns per worker
+ * segment of the generic kernel (default 16); 0 = route every shape through the generic kernels; -1 = back
+ * to the automatic choice (LDS-tiled, whole-image or generic by shape). */
+int sei_debug_set_dw_seg(int seg);
+
 int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
                 const float *L1, const float *R1, const float *L2, const float *R2, float *work,
                 size_t work_floats, void *stream);

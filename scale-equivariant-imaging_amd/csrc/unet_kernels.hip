@@ -1,6 +1,6 @@
 // U-Net streaming kernels for gfx950 (reference: src/models/convolutional.py), NHWC float32.
 //
-//   sei_dwconv7_fwd / _bwd_weight : ConvBlock.conv1, depthwise 7x7, zero pad 3            (:36-38,46)
+//   (the depthwise 7x7 of ConvBlock.conv1 lives in dwconv_kernels.hip)
 //   sei_ln_fwd / sei_ln_bwd       : LayerNorm over channels, eps 1e-6, biased variance     (:21-30)
 //   sei_conv3x3_fwd / _bwd_weight : UNet.in_conv / out_conv, 3x3 'same'                    (:174-176)
 //   sei_sepmap2                   : IdealDownsample / IdealUpsample as L1 X R1^T + L2 X R2^T (:54-133)
@@ -13,123 +13,6 @@
 #include "sei_common.h"
 
 namespace {
-
-// =================================================================================================
-// depthwise 7x7
-// =================================================================================================
-constexpr int DW_THREADS = 256;
-constexpr int DW_SEG = 16;      // output columns per worker segment
-
-// One thread = one channel; a "worker" (Cc consecutive threads) walks a segment of one output row with
-// a 7x7 register window that slides by one column per step (7 new loads + 49 FMA per output).
-template <bool WEIGHT_GRAD>
-__global__ __launch_bounds__(DW_THREADS) void dwconv7_kernel(
-    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-    const float *__restrict__ res, float res_scale, float *__restrict__ y, const float *__restrict__ gy,
-    float *__restrict__ gw, float *__restrict__ gbias, int B, int H, int W, int C, int flip, int Cc, int nseg,
-    int total_rowsegs) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int workers = DW_THREADS / Cc;
-    const int cl = threadIdx.x % Cc, worker = threadIdx.x / Cc;
-    const int c = blockIdx.y * Cc + cl;
-    const bool c_ok = c < C;
-
-    float wr[49];
-    float acc_w[49];
-    float acc_b = 0.f;
-    if (!WEIGHT_GRAD) {
-#pragma unroll
-        for (int t = 0; t < 49; ++t) wr[t] = c_ok ? w[(size_t)c * 49 + (flip ? 48 - t : t)] : 0.f;
-    } else {
-#pragma unroll
-        for (int t = 0; t < 49; ++t) acc_w[t] = 0.f;
-    }
-    const float bv = (!WEIGHT_GRAD && bias && c_ok) ? bias[c] : 0.f;
-
-    for (int rs = blockIdx.x * workers + worker; rs < total_rowsegs; rs += gridDim.x * workers) {
-        if (!c_ok) continue;
-        const int seg = rs % nseg;
-        const int bi = rs / nseg;
-        const int i = bi % H, b = bi / H;
-        const int j0 = seg * DW_SEG, j1 = min(W, j0 + DW_SEG);
-        const float *xb = x + (size_t)b * H * W * C + c;
-        float win[7][7];   // win[di][slot]
-        // preload input columns j0-3 .. j0+2 into slots 0..5
-#pragma unroll
-        for (int dj = 0; dj < 6; ++dj) {
-            const int jj = j0 - 3 + dj;
-#pragma unroll
-            for (int di = 0; di < 7; ++di) {
-                const int ii = i - 3 + di;
-                win[di][dj] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? xb[((size_t)ii * W + jj) * C] : 0.f;
-            }
-        }
-        for (int jb = j0; jb < j1; jb += 7) {
-#pragma unroll
-            for (int s = 0; s < 7; ++s) {
-                const int j = jb + s;
-                if (j < j1) {
-                    const int jj = j + 3;
-#pragma unroll
-                    for (int di = 0; di < 7; ++di) {
-                        const int ii = i - 3 + di;
-                        win[di][(s + 6) % 7] =
-                            (ii >= 0 && ii < H && jj < W) ? xb[((size_t)ii * W + jj) * C] : 0.f;
-                    }
-                    const size_t o = (((size_t)b * H + i) * W + j) * C + c;
-                    if (!WEIGHT_GRAD) {
-                        float a = bv;
-#pragma unroll
-                        for (int di = 0; di < 7; ++di)
-#pragma unroll
-                            for (int dj = 0; dj < 7; ++dj) a = fmaf(wr[di * 7 + dj], win[di][(s + dj) % 7], a);
-                        if (res) a = fmaf(res_scale, res[o], a);
-                        y[o] = a;
-                    } else {
-                        const float g = gy[o];
-                        acc_b += g;
-#pragma unroll
-                        for (int di = 0; di < 7; ++di)
-#pragma unroll
-                            for (int dj = 0; dj < 7; ++dj)
-                                acc_w[di * 7 + dj] = fmaf(g, win[di][(s + dj) % 7], acc_w[di * 7 + dj]);
-                    }
-                }
-            }
-        }
-    }
-    if (WEIGHT_GRAD) {
-        // reduce the workers of this block through LDS, then one atomic per (channel, tap) per block
-        float *red = smem;   // [worker][50][Cc]
-#pragma unroll
-        for (int t = 0; t < 49; ++t) red[(worker * 50 + t) * Cc + cl] = acc_w[t];
-        red[(worker * 50 + 49) * Cc + cl] = acc_b;
-        __syncthreads();
-        // this workgroup's partial sums -> workspace row blockIdx.x: part[bx][t][c]  (gw aliases the workspace)
-        float *part = gw + (size_t)blockIdx.x * 50 * C;
-        for (int e = threadIdx.x; e < 50 * Cc; e += DW_THREADS) {
-            const int t = e / Cc, c2 = e % Cc;
-            const int cg = blockIdx.y * Cc + c2;
-            if (cg >= C) continue;
-            float s = 0.f;
-            for (int wk = 0; wk < workers; ++wk) s += red[(wk * 50 + t) * Cc + c2];
-            part[(size_t)t * C + cg] = s;
-        }
-    }
-}
-
-// stage 2 of the depthwise weight gradient: gw[c][t] += sum_bx part[bx][t][c]; gbias[c] += sum_bx part[bx][49][c]
-__global__ __launch_bounds__(256) void dwconv7_wgrad_finish_kernel(const float *__restrict__ part, int nparts,
-                                                                   int C, float *__restrict__ gw,
-                                                                   float *__restrict__ gbias) {
-    const int e = blockIdx.x * 256 + threadIdx.x;       // e = t*C + c : coalesced over c
-    if (e >= 50 * C) return;
-    const int t = e / C, c = e - t * C;
-    float s = 0.f;
-    for (int b = 0; b < nparts; ++b) s += part[(size_t)b * 50 * C + e];
-    if (t < 49) gw[(size_t)c * 49 + t] += s;
-    else if (gbias) gbias[c] += s;
-}
 
 // =================================================================================================
 // LayerNorm over the channel (contiguous) axis
@@ -566,66 +449,115 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_bwd_weight_tiled_kernel(
 // pass W: T[b][t][i][j'][c] = sum_j R_t[j',j] x[b,i,j,c]      (workspace, 2*B*Hi*Wo*C floats)
 // pass H: y[b,i',j',c]      = sum_t sum_i L_t[i',i] T[b][t][i][j'][c]
 // =================================================================================================
+// Register-blocked: a thread owns one (row, channel) and OT consecutive outputs along the mapped axis, so one
+// activation load feeds 2*OT FMAs; the matrix entries are wave-uniform (blockIdx.y picks the output tile) and
+// come through the scalar cache. Accumulation order per output is unchanged (j ascending; t=1 then t=2).
 constexpr int SM_THREADS = 256;
+constexpr int SM_LOADS = 6;            // activation loads issued together (extents are 3 * 2^k)
 
+template <int OT>
 __global__ __launch_bounds__(SM_THREADS) void sepmap_w_kernel(const float *__restrict__ x, float *__restrict__ T,
                                                               const float *__restrict__ R1,
-                                                              const float *__restrict__ R2, int B, int Hi,
+                                                              const float *__restrict__ R2, size_t rows, int Hi,
                                                               int Wi, int Wo, int C) {
-    extern __shared__ __attribute__((aligned(16))) float sR[];   // R1 | R2, each Wo*Wi
-    for (int e = threadIdx.x; e < Wo * Wi; e += SM_THREADS) {
-        sR[e] = R1[e];
-        sR[Wo * Wi + e] = R2[e];
+    const size_t idx = (size_t)blockIdx.x * SM_THREADS + threadIdx.x;      // (row = b*Hi + i, c)
+    if (idx >= rows * C) return;
+    const int jo0 = blockIdx.y * OT;
+    const size_t r = idx / C;
+    const int c = (int)(idx - r * C);
+    const float *xr = x + r * Wi * C + c;
+    const float *r1[OT], *r2[OT];
+#pragma unroll
+    for (int q = 0; q < OT; ++q) {
+        const int jo = min(jo0 + q, Wo - 1);                               // clamped rows are not stored
+        r1[q] = R1 + (size_t)jo * Wi;
+        r2[q] = R2 + (size_t)jo * Wi;
     }
-    __syncthreads();
-    const size_t total = (size_t)B * Hi * Wo * C;
-    for (size_t idx = (size_t)blockIdx.x * SM_THREADS + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * SM_THREADS) {
-        const int c = (int)(idx % C);
-        const int jo = (int)((idx / C) % Wo);
-        const int i = (int)((idx / ((size_t)C * Wo)) % Hi);
-        const int b = (int)(idx / ((size_t)C * Wo * Hi));
-        const float *xr = x + (((size_t)b * Hi + i) * Wi) * C + c;
-        const float *r1 = sR + jo * Wi, *r2 = sR + Wo * Wi + jo * Wi;
-        float a1 = 0.f, a2 = 0.f;
-        for (int j = 0; j < Wi; ++j) {
-            const float v = xr[(size_t)j * C];
-            a1 = fmaf(r1[j], v, a1);
-            a2 = fmaf(r2[j], v, a2);
+    float a1[OT], a2[OT];
+#pragma unroll
+    for (int q = 0; q < OT; ++q) a1[q] = a2[q] = 0.f;
+    int j = 0;
+    for (; j + SM_LOADS <= Wi; j += SM_LOADS) {                             // SM_LOADS loads in flight per thread
+        float v[SM_LOADS];
+#pragma unroll
+        for (int u = 0; u < SM_LOADS; ++u) v[u] = xr[(size_t)(j + u) * C];
+#pragma unroll
+        for (int u = 0; u < SM_LOADS; ++u)
+#pragma unroll
+            for (int q = 0; q < OT; ++q) {
+                a1[q] = fmaf(r1[q][j + u], v[u], a1[q]);
+                a2[q] = fmaf(r2[q][j + u], v[u], a2[q]);
+            }
+    }
+    for (; j < Wi; ++j) {
+        const float v = xr[(size_t)j * C];
+#pragma unroll
+        for (int q = 0; q < OT; ++q) {
+            a1[q] = fmaf(r1[q][j], v, a1[q]);
+            a2[q] = fmaf(r2[q][j], v, a2[q]);
         }
-        const size_t plane = (size_t)Hi * Wo * C;
-        const size_t o = ((size_t)b * 2) * plane + ((size_t)i * Wo + jo) * C + c;
-        T[o] = a1;
-        T[o + plane] = a2;
     }
+    const size_t b = r / Hi;
+    const int i = (int)(r - b * Hi);
+    const size_t plane = (size_t)Hi * Wo * C;
+    float *o = T + (b * 2) * plane + ((size_t)i * Wo + jo0) * C + c;
+#pragma unroll
+    for (int q = 0; q < OT; ++q)
+        if (jo0 + q < Wo) {
+            o[(size_t)q * C] = a1[q];
+            o[(size_t)q * C + plane] = a2[q];
+        }
 }
 
+template <int OT>
 __global__ __launch_bounds__(SM_THREADS) void sepmap_h_kernel(const float *__restrict__ T, float *__restrict__ y,
                                                               const float *__restrict__ L1,
                                                               const float *__restrict__ L2, int B, int Hi,
-                                                              int Ho, int Wo, int C) {
-    extern __shared__ __attribute__((aligned(16))) float sL[];   // L1 | L2, each Ho*Hi
-    for (int e = threadIdx.x; e < Ho * Hi; e += SM_THREADS) {
-        sL[e] = L1[e];
-        sL[Ho * Hi + e] = L2[e];
+                                                              int Ho, size_t row) {
+    const size_t idx = (size_t)blockIdx.x * SM_THREADS + threadIdx.x;      // (b, jc = j'*C + c)
+    if (idx >= (size_t)B * row) return;
+    const int io0 = blockIdx.y * OT;
+    const size_t b = idx / row, jc = idx - b * row;
+    const size_t plane = (size_t)Hi * row;
+    const float *t1 = T + (b * 2) * plane + jc, *t2 = t1 + plane;
+    const float *l1[OT], *l2[OT];
+#pragma unroll
+    for (int q = 0; q < OT; ++q) {
+        const int io = min(io0 + q, Ho - 1);
+        l1[q] = L1 + (size_t)io * Hi;
+        l2[q] = L2 + (size_t)io * Hi;
     }
-    __syncthreads();
-    const size_t total = (size_t)B * Ho * Wo * C;
-    const size_t row = (size_t)Wo * C, plane = (size_t)Hi * row;
-    for (size_t idx = (size_t)blockIdx.x * SM_THREADS + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * SM_THREADS) {
-        const size_t jc = idx % row;
-        const int io = (int)((idx / row) % Ho);
-        const int b = (int)(idx / (row * Ho));
-        const float *t1 = T + ((size_t)b * 2) * plane + jc, *t2 = t1 + plane;
-        const float *l1 = sL + io * Hi, *l2 = sL + Ho * Hi + io * Hi;
-        float a = 0.f;
-        for (int i = 0; i < Hi; ++i) {
-            a = fmaf(l1[i], t1[(size_t)i * row], a);
-            a = fmaf(l2[i], t2[(size_t)i * row], a);
+    float a[OT];
+#pragma unroll
+    for (int q = 0; q < OT; ++q) a[q] = 0.f;
+    int i = 0;
+    for (; i + SM_LOADS <= Hi; i += SM_LOADS) {
+        float v1[SM_LOADS], v2[SM_LOADS];
+#pragma unroll
+        for (int u = 0; u < SM_LOADS; ++u) {
+            v1[u] = t1[(size_t)(i + u) * row];
+            v2[u] = t2[(size_t)(i + u) * row];
         }
-        y[idx] = a;
+#pragma unroll
+        for (int u = 0; u < SM_LOADS; ++u)
+#pragma unroll
+            for (int q = 0; q < OT; ++q) {
+                a[q] = fmaf(l1[q][i + u], v1[u], a[q]);
+                a[q] = fmaf(l2[q][i + u], v2[u], a[q]);
+            }
     }
+    for (; i < Hi; ++i) {
+        const float v1 = t1[(size_t)i * row], v2 = t2[(size_t)i * row];
+#pragma unroll
+        for (int q = 0; q < OT; ++q) {
+            a[q] = fmaf(l1[q][i], v1, a[q]);
+            a[q] = fmaf(l2[q][i], v2, a[q]);
+        }
+    }
+    float *o = y + (b * Ho + io0) * row + jc;
+#pragma unroll
+    for (int q = 0; q < OT; ++q)
+        if (io0 + q < Ho) o[(size_t)q * row] = a[q];
 }
 
 // =================================================================================================
@@ -694,67 +626,6 @@ inline unsigned capped_grid(size_t work_items, int per_block, unsigned cap) {
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
-extern "C" int sei_dwconv7_fwd(const float *x, const float *w, const float *bias, const float *res,
-                               float res_scale, float *y, int B, int H, int W, int C, int flip, void *stream) {
-    SEI_REQUIRE(x && w && y && x != y && B > 0 && H > 0 && W > 0 && C > 0);
-    const int Cc = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
-    const int workers = DW_THREADS / Cc;
-    const int nseg = (int)sei_ceil_div(W, DW_SEG);
-    const size_t total = (size_t)B * H * nseg;
-    SEI_REQUIRE(total < (size_t)1 << 31);
-    dim3 grid(capped_grid(total, workers, 65535), (unsigned)sei_ceil_div(C, Cc));
-    hipLaunchKernelGGL(dwconv7_kernel<false>, grid, dim3(DW_THREADS), 0, (hipStream_t)stream, x, w, bias, res,
-                       res_scale, y, (const float *)nullptr, (float *)nullptr, (float *)nullptr, B, H, W, C,
-                       flip ? 1 : 0, Cc, nseg, (int)total);
-    return sei_launch_status();
-}
-
-namespace {
-// grid of the depthwise weight-gradient pass: (row-segment groups, channel chunks)
-inline void dwconv7_wgrad_grid(int B, int H, int W, int C, int &Cc, int &nseg, size_t &total, unsigned &gx,
-                               unsigned &chunks) {
-    Cc = C >= 64 ? 64 : (C >= 32 ? 32 : (C >= 16 ? 16 : (C >= 8 ? 8 : (C >= 4 ? 4 : (C >= 2 ? 2 : 1)))));
-    const int workers = DW_THREADS / Cc;
-    nseg = (int)sei_ceil_div(W, DW_SEG);
-    total = (size_t)B * H * nseg;
-    chunks = (unsigned)sei_ceil_div(C, Cc);
-    gx = capped_grid(total, workers * 2, 65535);
-    const unsigned max_gx = 4096 / chunks > 0 ? 4096 / chunks : 1;
-    if (gx > max_gx) gx = max_gx;
-}
-}  // namespace
-
-extern "C" size_t sei_dwconv7_bwd_weight_workspace(int B, int H, int W, int C) {
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-    int Cc, nseg;
-    size_t total;
-    unsigned gx, chunks;
-    dwconv7_wgrad_grid(B, H, W, C, Cc, nseg, total, gx, chunks);
-    return (size_t)gx * 50 * C;
-}
-
-extern "C" int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
-                                      int W, int C, float *work, size_t work_floats, void *stream) {
-    SEI_REQUIRE(x && gy && gw && work && B > 0 && H > 0 && W > 0 && C > 0);
-    int Cc, nseg;
-    size_t total;
-    unsigned gx, chunks;
-    dwconv7_wgrad_grid(B, H, W, C, Cc, nseg, total, gx, chunks);
-    SEI_REQUIRE(total < (size_t)1 << 31);
-    SEI_REQUIRE(work_floats >= (size_t)gx * 50 * C);
-    const int workers = DW_THREADS / Cc;
-    const size_t lds = sizeof(float) * (size_t)workers * 50 * Cc;
-    hipStream_t s = (hipStream_t)stream;
-    // stage 1: per-workgroup partial sums into the workspace (passed through the kernel's gw argument)
-    hipLaunchKernelGGL(dwconv7_kernel<true>, dim3(gx, chunks), dim3(DW_THREADS), lds, s, x, (const float *)nullptr,
-                       (const float *)nullptr, (const float *)nullptr, 0.f, (float *)nullptr, gy, work,
-                       (float *)nullptr, B, H, W, C, 0, Cc, nseg, (int)total);
-    // stage 2: fold the partials into the running gradient (no atomics: bitwise reproducible)
-    hipLaunchKernelGGL(dwconv7_wgrad_finish_kernel, dim3((unsigned)sei_ceil_div((size_t)50 * C, 256)), dim3(256), 0, s,
-                       (const float *)work, (int)gx, C, gw, gbias);
-    return sei_launch_status();
-}
-
 namespace {
 template <int G>
 int launch_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
@@ -881,13 +752,22 @@ extern "C" int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int 
     SEI_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0);
     const size_t need = (size_t)2 * B * Hi * Wo * C;
     SEI_REQUIRE(work_floats >= need);
-    const size_t lds_w = sizeof(float) * 2 * (size_t)Wo * Wi, lds_h = sizeof(float) * 2 * (size_t)Ho * Hi;
-    if (lds_w > 160 * 1024 || lds_h > 160 * 1024) return SEI_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sepmap_w_kernel, dim3(capped_grid((size_t)B * Hi * Wo * C, SM_THREADS * 4, 4096)),
-                       dim3(SM_THREADS), lds_w, s, x, work, R1, R2, B, Hi, Wi, Wo, C);
-    hipLaunchKernelGGL(sepmap_h_kernel, dim3(capped_grid((size_t)B * Ho * Wo * C, SM_THREADS * 4, 4096)),
-                       dim3(SM_THREADS), lds_h, s, (const float *)work, y, L1, L2, B, Hi, Ho, Wo, C);
+    const size_t rows = (size_t)B * Hi, nw = rows * C, nh = (size_t)B * Wo * C;
+    SEI_REQUIRE(sei_ceil_div(nw, SM_THREADS) < (1u << 31) && sei_ceil_div(nh, SM_THREADS) < (1u << 31));
+    const dim3 gw((unsigned)sei_ceil_div(nw, SM_THREADS)), gh((unsigned)sei_ceil_div(nh, SM_THREADS));
+    if (Wo % 12 == 0)
+        hipLaunchKernelGGL(sepmap_w_kernel<12>, dim3(gw.x, Wo / 12), dim3(SM_THREADS), 0, s, x, work, R1, R2, rows, Hi,
+                           Wi, Wo, C);
+    else
+        hipLaunchKernelGGL(sepmap_w_kernel<8>, dim3(gw.x, (unsigned)sei_ceil_div(Wo, 8)), dim3(SM_THREADS), 0, s, x,
+                           work, R1, R2, rows, Hi, Wi, Wo, C);
+    if (Ho % 12 == 0)
+        hipLaunchKernelGGL(sepmap_h_kernel<12>, dim3(gh.x, Ho / 12), dim3(SM_THREADS), 0, s, (const float *)work, y, L1,
+                           L2, B, Hi, Ho, (size_t)Wo * C);
+    else
+        hipLaunchKernelGGL(sepmap_h_kernel<8>, dim3(gh.x, (unsigned)sei_ceil_div(Ho, 8)), dim3(SM_THREADS), 0, s,
+                           (const float *)work, y, L1, L2, B, Hi, Ho, (size_t)Wo * C);
     return sei_launch_status();
 }
 

@@ -112,8 +112,34 @@ def test_layernorm_fwd_bwd(ops, rows, C):
     assert relerr(gg, rgg) < 2e-5 and relerr(gb, rgb) < 2e-5
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 48, 48, 32), (3, 6, 6, 2048), (2, 3, 3, 8192), (1, 5, 7, 8), (2, 12, 12, 128),
-                                     (1, 20, 33, 12)])
+DW_SHAPES = [(2, 48, 48, 32), (3, 6, 6, 2048), (2, 3, 3, 8192), (1, 5, 7, 8), (2, 12, 12, 128), (1, 20, 33, 12),
+             (2, 24, 24, 36), (2, 16, 12, 6), (5, 6, 6, 40), (3, 3, 3, 5), (1, 8, 8, 4), (2, 14, 21, 64)]
+
+
+@pytest.mark.parametrize("B,H,W,C", DW_SHAPES)
+def test_dwconv7_paths_agree(ops, B, H, W, C):
+    """LDS-tiled / whole-image kernels against the generic kernel: same accumulation order, so the forward
+    and the data gradient (flip + residual) are bit-identical; the weight gradient sums in another order."""
+    from _native import lib
+    gen = torch.Generator().manual_seed(7 * B + H + C)
+    x, r = torch.randn((B, H, W, C), generator=gen).cuda(), torch.randn((B, H, W, C), generator=gen).cuda()
+    w, b = (torch.randn((C, 1, 7, 7), generator=gen) * 0.1).cuda(), torch.randn(C, generator=gen).cuda()
+    out = {}
+    try:
+        for mode in (0, -1):                     # 0: generic kernels, -1: automatic choice
+            assert lib().sei_debug_set_dw_seg(mode) == 0
+            gw, gb = torch.zeros_like(w), torch.zeros(C, device="cuda")
+            ops.dwconv7_weight_grad(x, r, gw, gb)
+            ops.dwconv7_weight_grad(x, r, gw, gb)                   # accumulates: twice the gradient
+            out[mode] = (ops.dwconv7(x, w, b), ops.dwconv7(x, w, None, flip=True, res=r, res_scale=2.0), gw, gb)
+            torch.cuda.synchronize()
+    finally:
+        lib().sei_debug_set_dw_seg(-1)
+    assert torch.equal(out[0][0], out[-1][0]) and torch.equal(out[0][1], out[-1][1])
+    assert relerr(out[-1][2], out[0][2]) < 2e-6 and relerr(out[-1][3], out[0][3]) < 2e-6
+
+
+@pytest.mark.parametrize("B,H,W,C", DW_SHAPES[:6])
 def test_dwconv7(ops, B, H, W, C):
     from _native import call
     gen = torch.Generator().manual_seed(B + H + C)
