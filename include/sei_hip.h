@@ -32,7 +32,7 @@ extern "C" {
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
-#define SEI_ABI_VERSION 1
+#define SEI_ABI_VERSION 2
 int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
@@ -153,9 +153,14 @@ int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw, float *gb
 
 int sei_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
                float *rstd, size_t rows, int C, float eps, void *stream);
+/* bwd: gx is written, ggamma/gbeta are accumulated (+=). `work` holds per-row statistics and the
+ * per-workgroup parameter-gradient partials that are folded in a fixed order (bitwise reproducible);
+ * it needs sei_ln_bwd_workspace(rows, C) floats (0 for shapes served by the scalar kernels, which
+ * accumulate with float atomics: C not 4*2^k below 512, or not a multiple of 4 above). */
+size_t sei_ln_bwd_workspace(size_t rows, int C);
 int sei_ln_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
                const float *gy, float *gx, float *ggamma, float *gbeta, size_t rows, int C,
-               void *stream);
+               float *work, size_t work_floats, void *stream);
 
 #define SEI_EPI_NONE 0
 #define SEI_EPI_BIAS 1            /* D = acc + bias[n]                                        */

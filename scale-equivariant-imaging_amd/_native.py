@@ -36,7 +36,7 @@ SIGNATURES = {
     "sei_dwconv7_fwd": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
     "sei_dwconv7_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P],
     "sei_ln_fwd": [_P, _P, _P, _P, _P, _P, _Z, _I, _F, _P],
-    "sei_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P],
+    "sei_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P, _Z, _P],
     "sei_gemm_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sei_gemm_f32_ex": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _L, _L, _L, _I, _P],
     "sei_gemm_bf16_ex": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _L, _L, _L, _I, _P],
@@ -58,6 +58,14 @@ SIGNATURES = {
 _lib = None
 
 
+# size queries: return size_t, take no stream
+SIZE_QUERIES = {
+    "sei_dwconv7_bwd_weight_workspace": [_I, _I, _I, _I],
+    "sei_ln_bwd_workspace": [_Z, _I],
+}
+ABI_VERSION = 2       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
+
+
 class NativeLibraryError(RuntimeError):
     pass
 
@@ -77,9 +85,11 @@ def lib():
                 continue            # reported by tests/test_abi.py; a call would raise AttributeError
             fn.argtypes = argtypes
             fn.restype = _I
-        handle.sei_dwconv7_bwd_weight_workspace.argtypes = [_I, _I, _I, _I]
-        handle.sei_dwconv7_bwd_weight_workspace.restype = _Z
-        if handle.sei_abi_version() != 1:
+        for name, argtypes in SIZE_QUERIES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = _Z
+        if handle.sei_abi_version() != ABI_VERSION:
             raise NativeLibraryError("libsei_hip.so was built from a different include/sei_hip.h")
         _lib = handle
     return _lib

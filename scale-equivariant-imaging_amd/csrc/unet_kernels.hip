@@ -232,6 +232,173 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_wide_kernel(
     }
 }
 
+// ---- LayerNorm backward, vectorised (C % 4 == 0) -----------------------------------------------------------
+// Parameter gradients are written as per-workgroup partial rows into a workspace and folded by
+// ln_bwd_fold_kernel in a fixed order (no atomics, bitwise reproducible).
+//
+// narrow rows (C = 4*G*NV, G a power of two <= 64): G lanes own one row, NV float4 each; 256/G rows per sweep.
+template <int G, int NV>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_vec_kernel(
+    const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gy, float *__restrict__ gx,
+    float *__restrict__ part, size_t rows) {
+    constexpr int C = 4 * G * NV, RPB = LN_THREADS / G;
+    __shared__ __attribute__((aligned(16))) float red[RPB * 2 * C];
+    const int lg = threadIdx.x % G, rsub = threadIdx.x / G;
+    const float invC = 1.0f / (float)C;
+    float4 gam[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        gam[e] = *reinterpret_cast<const float4 *>(gamma + 4 * (lg + e * G));
+        dg[e] = db[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (size_t row = (size_t)blockIdx.x * RPB + rsub; row < rows; row += (size_t)gridDim.x * RPB) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const size_t o = row * C + 4 * (lg + e * G);
+            const float4 xv = *reinterpret_cast<const float4 *>(x + o);
+            const float4 gv = *reinterpret_cast<const float4 *>(gy + o);
+#define SEI_LN_BWD_LANE(f)                              \
+    xh[e].f = (xv.f - mu) * rs;                         \
+    g[e].f = gv.f * gam[e].f;                           \
+    s1 += g[e].f;                                       \
+    s2 = fmaf(g[e].f, xh[e].f, s2);                     \
+    dg[e].f = fmaf(gv.f, xh[e].f, dg[e].f);             \
+    db[e].f += gv.f;
+            SEI_LN_BWD_LANE(x) SEI_LN_BWD_LANE(y) SEI_LN_BWD_LANE(z) SEI_LN_BWD_LANE(w)
+#undef SEI_LN_BWD_LANE
+        }
+        s1 = group_sum<G>(s1) * invC;
+        s2 = group_sum<G>(s2) * invC;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            float4 o4;
+            o4.x = rs * (g[e].x - s1 - xh[e].x * s2);
+            o4.y = rs * (g[e].y - s1 - xh[e].y * s2);
+            o4.z = rs * (g[e].z - s1 - xh[e].z * s2);
+            o4.w = rs * (g[e].w - s1 - xh[e].w * s2);
+            *reinterpret_cast<float4 *>(gx + row * C + 4 * (lg + e * G)) = o4;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        *reinterpret_cast<float4 *>(red + (rsub * 2 + 0) * C + 4 * (lg + e * G)) = dg[e];
+        *reinterpret_cast<float4 *>(red + (rsub * 2 + 1) * C + 4 * (lg + e * G)) = db[e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += LN_THREADS) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < RPB; ++r) s += red[r * 2 * C + e];
+        part[(size_t)blockIdx.x * 2 * C + e] = s;
+    }
+}
+
+// wide rows, pass 1: stats[row] = (mean_c(gy*gamma), mean_c(gy*gamma*xhat)); one workgroup per row.
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_rowstats_kernel(
+    const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gy, float2 *__restrict__ stats, int C) {
+    __shared__ float scratch[2][LN_THREADS / 64];
+    const size_t row = blockIdx.x;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 4 * threadIdx.x; c < C; c += 4 * LN_THREADS) {
+        const float4 xv = *reinterpret_cast<const float4 *>(x + row * C + c);
+        const float4 gv = *reinterpret_cast<const float4 *>(gy + row * C + c);
+        const float4 gm = *reinterpret_cast<const float4 *>(gamma + c);
+        float g;
+        g = gv.x * gm.x; s1 += g; s2 = fmaf(g, (xv.x - mu) * rs, s2);
+        g = gv.y * gm.y; s1 += g; s2 = fmaf(g, (xv.y - mu) * rs, s2);
+        g = gv.z * gm.z; s1 += g; s2 = fmaf(g, (xv.z - mu) * rs, s2);
+        g = gv.w * gm.w; s1 += g; s2 = fmaf(g, (xv.w - mu) * rs, s2);
+    }
+    s1 = sei_wave_sum(s1);
+    s2 = sei_wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        scratch[0][wave] = s1;
+        scratch[1][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_THREADS / 64; ++k) {
+            a += scratch[0][k];
+            b += scratch[1][k];
+        }
+        const float invC = 1.0f / (float)C;
+        stats[row] = make_float2(a * invC, b * invC);
+    }
+}
+
+// wide rows, pass 2: a thread owns 4 consecutive channels and walks a chunk of rows (row scalars are
+// wave-uniform); gx elementwise, the parameter-gradient partial of the chunk in registers.
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_cols_kernel(
+    const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gy, const float2 *__restrict__ stats,
+    float *__restrict__ gx, float *__restrict__ part, size_t rows, int C, int rows_per_chunk) {
+    const int c = 4 * (blockIdx.x * LN_THREADS + threadIdx.x);
+    if (c >= C) return;
+    const float4 gm = *reinterpret_cast<const float4 *>(gamma + c);
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+    const size_t r0 = (size_t)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+#pragma unroll 4
+    for (size_t row = r0; row < r1; ++row) {
+        const float mu = mean[row], rs = rstd[row];
+        const float2 st = stats[row];
+        const float4 xv = *reinterpret_cast<const float4 *>(x + row * C + c);
+        const float4 gv = *reinterpret_cast<const float4 *>(gy + row * C + c);
+        float4 o4;
+#define SEI_LN_COL_LANE(f)                                   \
+    {                                                        \
+        const float xh = (xv.f - mu) * rs;                   \
+        o4.f = rs * (gv.f * gm.f - st.x - xh * st.y);        \
+        dg.f = fmaf(gv.f, xh, dg.f);                         \
+        db.f += gv.f;                                        \
+    }
+        SEI_LN_COL_LANE(x) SEI_LN_COL_LANE(y) SEI_LN_COL_LANE(z) SEI_LN_COL_LANE(w)
+#undef SEI_LN_COL_LANE
+        *reinterpret_cast<float4 *>(gx + row * C + c) = o4;
+    }
+    float *out = part + (size_t)blockIdx.y * 2 * C;
+    *reinterpret_cast<float4 *>(out + c) = dg;
+    *reinterpret_cast<float4 *>(out + C + c) = db;
+}
+
+// fold: ggamma[c] += sum_p part[p][c]; gbeta[c] += sum_p part[p][C + c]   (16 entries x 16 slices per workgroup)
+__global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float *__restrict__ part, int nparts, int C,
+                                                          float *__restrict__ ggamma,
+                                                          float *__restrict__ gbeta) {
+    __shared__ float red[16][16];
+    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const size_t stride = (size_t)2 * C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < 2 * C) {
+        int p = slice;
+        for (; p + 48 < nparts; p += 64) {
+            s0 += part[(size_t)p * stride + e];
+            s1 += part[(size_t)(p + 16) * stride + e];
+            s2 += part[(size_t)(p + 32) * stride + e];
+            s3 += part[(size_t)(p + 48) * stride + e];
+        }
+        for (; p < nparts; p += 16) s0 += part[(size_t)p * stride + e];
+    }
+    red[slice][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && e < 2 * C) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][el];
+        if (e < C) ggamma[e] += s;
+        else gbeta[e - C] += s;
+    }
+}
+
 // =================================================================================================
 // 3x3 convolution with small channel counts (in_conv 3->hidden, out_conv hidden->3)
 // =================================================================================================
@@ -672,12 +839,88 @@ extern "C" int sei_ln_fwd(const float *x, const float *gamma, const float *beta,
     }
 }
 
+namespace {
+// launch plan of sei_ln_bwd; workspace = [stats: 2*rows floats (wide only)] [partials: nparts * 2C floats]
+struct LnBwdPlan {
+    int kind;                 // 0 legacy (atomics, no workspace), 1 narrow vectorised, 2 wide two-pass
+    int G, NV;
+    unsigned grid, col_blocks, chunks;
+    int rows_per_chunk;
+    size_t stats_floats, nparts;
+};
+inline LnBwdPlan ln_bwd_plan(size_t rows, int C) {
+    LnBwdPlan p{};
+    if (C % 4 != 0 || C < 8) return p;
+    if (C <= 512) {
+        const int q = C / 4;                                  // float4 per row
+        if ((q & (q - 1)) != 0) return p;                     // power of two only
+        p.NV = q > 64 ? q / 64 : 1;
+        p.G = q / p.NV;
+        p.kind = 1;
+        const size_t sweeps = sei_ceil_div(rows, (size_t)(LN_THREADS / p.G));
+        size_t cap = ((size_t)1 << 20) / (2 * (size_t)C);     // <= 1M partial floats
+        if (cap > 2048) cap = 2048;
+        p.grid = (unsigned)(sweeps < cap ? sweeps : cap);
+        p.nparts = p.grid;
+        return p;
+    }
+    p.kind = 2;
+    p.col_blocks = (unsigned)sei_ceil_div((size_t)C, 4 * LN_THREADS);
+    size_t chunks = 768 / p.col_blocks > 0 ? 768 / p.col_blocks : 1;       // ~768 workgroups in pass 2
+    if (chunks > rows) chunks = rows;
+    p.rows_per_chunk = (int)sei_ceil_div(rows, chunks);
+    p.chunks = (unsigned)sei_ceil_div(rows, (size_t)p.rows_per_chunk);
+    p.stats_floats = 2 * rows;
+    p.nparts = p.chunks;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t sei_ln_bwd_workspace(size_t rows, int C) {
+    if (rows == 0 || C <= 0) return 0;
+    const LnBwdPlan p = ln_bwd_plan(rows, C);
+    return p.stats_floats + p.nparts * 2 * (size_t)C;
+}
+
 extern "C" int sei_ln_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
                           const float *gy, float *gx, float *ggamma, float *gbeta, size_t rows, int C,
-                          void *stream) {
+                          float *work, size_t work_floats, void *stream) {
     SEI_REQUIRE(x && gamma && mean && rstd && gy && gx && ggamma && gbeta && rows > 0 && C > 0);
     if (C > LN_WIDE_EPT * LN_THREADS) return SEI_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
+    const LnBwdPlan p = ln_bwd_plan(rows, C);
+    if (p.kind != 0) {
+        SEI_REQUIRE(work && work_floats >= p.stats_floats + p.nparts * 2 * (size_t)C);
+        SEI_REQUIRE(rows < ((size_t)1 << 31));
+        float *part = work + p.stats_floats;
+        if (p.kind == 1) {
+#define SEI_LN_VEC(GG, NN)                                                                                    \
+    hipLaunchKernelGGL((ln_bwd_vec_kernel<GG, NN>), dim3(p.grid), dim3(LN_THREADS), 0, s, x, gamma, mean, rstd, \
+                       gy, gx, part, rows);                                                                   \
+    break;
+            switch (p.G * 100 + p.NV) {
+                case 201: SEI_LN_VEC(2, 1)
+                case 401: SEI_LN_VEC(4, 1)
+                case 801: SEI_LN_VEC(8, 1)
+                case 1601: SEI_LN_VEC(16, 1)
+                case 3201: SEI_LN_VEC(32, 1)
+                case 6401: SEI_LN_VEC(64, 1)
+                case 6402: SEI_LN_VEC(64, 2)
+                default: return SEI_ERR_BAD_ARG;
+            }
+#undef SEI_LN_VEC
+        } else {
+            float2 *stats = reinterpret_cast<float2 *>(work);
+            hipLaunchKernelGGL(ln_bwd_rowstats_kernel, dim3((unsigned)rows), dim3(LN_THREADS), 0, s, x, gamma, mean,
+                               rstd, gy, stats, C);
+            hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3(p.col_blocks, p.chunks), dim3(LN_THREADS), 0, s, x, gamma,
+                               mean, rstd, gy, (const float2 *)stats, gx, part, rows, C, p.rows_per_chunk);
+        }
+        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((unsigned)sei_ceil_div((size_t)2 * C, 16)), dim3(256), 0, s,
+                           (const float *)part, (int)p.nparts, C, ggamma, gbeta);
+        return sei_launch_status();
+    }
+    // legacy shapes (C not a multiple of 4, or not 4 * 2^k below 512): scalar lanes, float atomics
     if (C > 64 * LN_EPL) {
         hipLaunchKernelGGL(ln_bwd_wide_kernel, dim3(capped_grid(rows, 2, 512)), dim3(LN_THREADS), 0, s, x, gamma,
                            mean, rstd, gy, gx, ggamma, gbeta, rows, C);

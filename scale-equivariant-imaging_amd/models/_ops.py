@@ -100,8 +100,10 @@ def layer_norm(x2d, gamma, beta):
 def layer_norm_bwd(x2d, gamma, mean, rstd, gy, ggamma, gbeta):
     rows, C = x2d.shape
     gx = torch.empty_like(x2d)
+    need = N.lib().sei_ln_bwd_workspace(rows, C)
+    work = torch.empty(max(need, 1), dtype=torch.float32, device=x2d.device)
     N.call("sei_ln_bwd", x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gy.data_ptr(),
-           gx.data_ptr(), ggamma.data_ptr(), gbeta.data_ptr(), rows, C)
+           gx.data_ptr(), ggamma.data_ptr(), gbeta.data_ptr(), rows, C, work.data_ptr(), need)
     return gx
 
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_native.LIB_PATH)       # loads on a GPU-less host: no HIP call at load time
     missing = [name for name in declared() if not hasattr(handle, name)]
     assert not missing, f"declared in sei_hip.h but not exported: {missing}"
-    assert handle.sei_abi_version() == 1
+    assert handle.sei_abi_version() == _native.ABI_VERSION == 2
     buf = ctypes.create_string_buffer(16)
     assert handle.sei_build_target(buf, 16) == 0 and buf.value == b"gfx950"
 
@@ -38,11 +38,11 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_table_matches_header():
     import _native
     d = declared()
-    sized = {"sei_dwconv7_bwd_weight_workspace"}          # size queries: no stream argument, bound separately
-    assert set(_native.SIGNATURES) | sized == set(d)
+    sized = _native.SIZE_QUERIES                          # size queries: no stream argument, size_t result
+    assert set(_native.SIGNATURES) | set(sized) == set(d)
     for name, nargs in d.items():
-        if name not in sized:
-            assert len(_native.SIGNATURES[name]) == nargs, name
+        table = sized if name in sized else _native.SIGNATURES
+        assert len(table[name]) == nargs, name
 
 
 def test_argument_errors_are_reported_not_launched():
