@@ -115,7 +115,7 @@ def main():
     model.to(device)
     model.train()
     backbone = model.get_backbone()
-    nparams = backbone.flat_params.numel()
+    nparams = sum(p.numel() for p in backbone.parameters())
     if world > 1:
         parallel.broadcast_parameters(backbone.flat_params)
     loss_fn = get_loss(args, physics)

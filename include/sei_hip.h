@@ -222,6 +222,15 @@ int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
                     float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
                     const float *R1, const float *R2, uint16_t *D2_16, void *stream);
 
+/* Weight gradient of two passes in one launch: D[M,N] (+)= A1^T B1 + A2^T B2, bf16 operands stored
+ * reduction-major (A1 (K1,M), A2 (K2,M), row stride lda; B1 (K1,N), B2 (K2,N), row stride ldb), f32 D.
+ * accumulate=0 stores D (the first write of a step into a gradient that need not be zeroed first);
+ * accumulate=1 adds. One pass over the 4*M*N-byte gradient instead of two read-modify-writes.
+ * (reference: the two model calls per step of ProposedLoss, src/losses/__init__.py, whose 1x1-conv weight
+ * gradients torch sums in AccumulateGrad.) */
+int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1, const uint16_t *B2,
+                        int ldb, float *D32, int M, int N, int K1, int K2, int accumulate, void *stream);
+
 /* Development probe (tools/probe_tr_read.py): what ds_read_b64_tr_b16 delivers for a 64x128 LDS image. */
 int sei_debug_tr_probe(const uint16_t *in, uint16_t *out, int r0, int c0, void *stream);
 

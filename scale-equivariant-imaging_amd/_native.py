@@ -48,6 +48,7 @@ SIGNATURES = {
     "sei_cast_transpose_bf16": [_P, _I, _P, _P, _I, _I, _I, _P, _P],
     "sei_gemm_bf16nt": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sei_debug_tr_probe": [_P, _P, _I, _I, _P],
+    "sei_gemm_bf16nt_dw2": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "sei_debug_set_nt_tile": [_I],
     "sei_debug_set_dw_seg": [_I],
     "sei_sepmap2": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P],

@@ -51,6 +51,9 @@ struct NtArgs {
     unsigned short *D2_16;     // BIAS_GELU: gelu(D) in bf16
     int splitk, k_per_split;
     int tiles_m, tiles_n, xcd_order;
+    // second reduction segment of reduction-major operands: rows k >= k_seg come from A2 / B2 (row k - k_seg)
+    const unsigned short *A2, *B2;
+    int k_seg;
 };
 
 __device__ __forceinline__ unsigned short f2bf(float v) {
@@ -82,15 +85,17 @@ __device__ __forceinline__ void stage_tile(const unsigned short *__restrict__ G,
 // with ds_read_b64_tr_b16. Rows past K and chunks past the o edge are fed from the zero chunk.
 __device__ __forceinline__ int swz_rmajor(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-__device__ __forceinline__ void stage_tile_rmajor(const unsigned short *__restrict__ G, int ld, int o0, int o_lim,
-                                                  int k0, int k_lim, char *lds_tile, int wave, int lane) {
+__device__ __forceinline__ void stage_tile_rmajor(const unsigned short *__restrict__ G,
+                                                  const unsigned short *__restrict__ G2, int k_seg, int ld, int o0,
+                                                  int o_lim, int k0, int k_lim, char *lds_tile, int wave, int lane) {
 #pragma unroll
     for (int q0 = 0; q0 < 16; q0 += NWAVES) {            // 64 rows x 256 B = 16 wave-instructions of 4 rows
         const int q = q0 + wave;
         const int row = 4 * q + (lane >> 4);
         const int ch = (lane & 15) ^ swz_rmajor(row);
         const int k = k0 + row, o = o0 + 8 * ch;
-        const unsigned short *src = (k < k_lim && o < o_lim) ? G + (size_t)k * ld + o : g_zero_chunk;
+        const unsigned short *rowp = k < k_seg ? G + (size_t)k * ld : G2 + (size_t)(k - k_seg) * ld;
+        const unsigned short *src = (k < k_lim && o < o_lim) ? rowp + o : g_zero_chunk;
         __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
     }
 }
@@ -208,9 +213,10 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
     }
 
     auto stage = [&](int k0, char *dst) {
-        if constexpr (ARM) stage_tile_rmajor(g.A, g.lda, m0, M, k0, k_end, dst, wave, lane);
+        if constexpr (ARM) stage_tile_rmajor(g.A, g.A2, g.k_seg, g.lda, m0, M, k0, k_end, dst, wave, lane);
         else stage_tile<BM>(g.A, g.lda, m0, M, k0, k_end, dst, wave, lane);
-        if constexpr (BRM) stage_tile_rmajor(g.B, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
+        if constexpr (BRM)
+            stage_tile_rmajor(g.B, g.B2, g.k_seg, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
         else stage_tile<BN>(g.B, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
     };
     const int sw = (li >> 1) & 7;                              // swizzle key of this lane's rows
@@ -400,6 +406,7 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     NtArgs g;
     g.A = A; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
+    g.A2 = A; g.B2 = B; g.k_seg = K;                       // one reduction segment
     hipStream_t s = (hipStream_t)stream;
     if (!a_rmajor && !b_rmajor) {
         switch (g_force_tile) {                          // ring-pipelined candidates (tuning aid)
@@ -429,4 +436,19 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     if (N >= 256 && M % 192 == 0 && K >= 2048) return launch_nt<3, 2, 2, 4>(g, s);       // 192 x 256
     if (N >= 256 && M % 128 != 0 && M % 96 == 0) return launch_nt<3, 1, 1, 8>(g, s);     //  96 x 256
     return launch_nt<2, 1, 2, 4>(g, s);                                                  // 128 x 128
+}
+
+extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
+                                   const uint16_t *B2, int ldb, float *D32, int M, int N, int K1, int K2,
+                                   int accumulate, void *stream) {
+    SEI_REQUIRE(A1 && A2 && B1 && B2 && D32 && M > 0 && N > 0 && K1 > 0 && K2 > 0);
+    SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
+    SEI_REQUIRE((K1 + K2) % 8 == 0);
+    SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
+    NtArgs g;
+    g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
+    g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
+    g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
+    g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
+    return launch_nt<2, 1, 2, 4, true, true>(g, (hipStream_t)stream);
 }

@@ -8,6 +8,10 @@ hipGraph on ROCm) over static buffers and replays it per step:
     loss_value = graphed(x, y)          # crop (host RNG, as the reference) -> copy -> replay
     optimizer.step()                    # outside the graph: its bias corrections are host scalars
 
+Inside the graph the 1x1-convolution weight gradients of the step's two model calls are produced by one
+GEMM each that STORES its result (models/_ops.py), so only the small remainder of the gradient bucket is
+zeroed per step.
+
 What stays outside the graph: the random 48-crop of Loss.forward (two CPU randint draws + a strided
 copy into the static input), the gradient all-reduce and the fused Adam launch. Random draws on the
 device (probe b, measurement noise, scale rates/centres) are captured with torch's graph-safe
@@ -17,7 +21,7 @@ import torch
 
 
 class GraphedLossStep:
-    def __init__(self, loss_module, model, optimizer, crop_shape, warmup=3):
+    def __init__(self, loss_module, model, optimizer, crop_shape, warmup=3, store_weight_grads=True):
         """loss_module: a `losses.Loss`; crop_shape: (B, 3, S, S) of the cropped measurement y."""
         self.loss_module = loss_module
         self.inner = loss_module.loss                # method-level loss working on cropped tensors
@@ -31,13 +35,16 @@ class GraphedLossStep:
         self.static_y = torch.zeros(crop_shape, dtype=torch.float32, device=device)
         self.static_x = None
 
+        self.store_weight_grads = False
+
         def fwd_bwd():
-            self.backbone.zero_grad_flat()
+            self.backbone.zero_grad_flat(store_weight_grads=self.store_weight_grads)
             value = self.inner(x=self.static_x, y=self.static_y, model=self.model)
             value.backward()
             return value.detach()
 
         from models import _ops
+        _ops.weight_grad_views(reset=True)           # record this model's weight-gradient views only
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
@@ -49,6 +56,9 @@ class GraphedLossStep:
         # the fused Adam refreshes every step; make that copy current now, and re-check before each replay.
         self._ops = _ops
         _ops.refresh_plain_shadow(self.backbone)
+        # The warm-up steps showed which gradients are written by the merged weight-gradient GEMMs; the
+        # captured step stores those instead of accumulating and zeroes only the rest of the bucket.
+        self.store_weight_grads = store_weight_grads and self.backbone.plan_weight_grad_store() is not None
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_loss = fwd_bwd()

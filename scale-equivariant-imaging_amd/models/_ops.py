@@ -374,11 +374,104 @@ def cast16(x2d, colsum_into_=None):
     return x16
 
 
+# ---------------------------------------------------------------------------------------------
+# weight gradients of the 1x1 convolutions, merged across the model calls of one step
+#
+# ProposedLoss calls the model twice per step (the fused SURE pass on 2B crops and the EI pass on B); each
+# call's backward used to read-modify-write every weight gradient, which at the deep levels (268 M weights,
+# 1.07 GB of float32 gradient each) is HBM traffic, not arithmetic. Instead the first backward to reach a
+# weight parks its (gy, x) pair, and the second one issues ONE GEMM whose reduction runs over both pairs
+# (sei_gemm_bf16nt_dw2). Pairs still parked when autograd finishes are flushed by an engine callback, so
+# `p.grad` is complete whenever .backward() returns, whoever consumes it.
+#
+# "Store" mode (opt-in, GraphedLossStep): the first launch of a step into a weight gradient stores instead
+# of accumulating, and zero_grad skips those gradients -- valid because the captured step writes every one
+# of them exactly this way on every replay.
+# ---------------------------------------------------------------------------------------------
+_DW = {"uses": 0, "arrivals": {}, "parked": {}, "written": set(), "store": False, "flush_queued": False,
+       "merge": True, "seen": {}}
+
+
+def note_forward():
+    """A model call that autograd will differentiate (ConvolutionalModel.forward)."""
+    if torch.is_grad_enabled():
+        _DW["uses"] += 1
+
+
+def begin_step(store=False):
+    """Start of a step (zero_grad): nothing parked, no model call counted, no gradient written yet."""
+    flush_weight_grads()
+    _DW["uses"] = 0
+    _DW["arrivals"].clear()
+    _DW["written"].clear()
+    _DW["store"] = bool(store)
+
+
+def set_weight_grad_merging(enabled):
+    previous, _DW["merge"] = _DW["merge"], bool(enabled)
+    return previous
+
+
+def weight_grad_views(reset=False):
+    """{data_ptr: numel} of every gradient view written through weight_grad16 since the last reset."""
+    seen = dict(_DW["seen"])
+    if reset:
+        _DW["seen"].clear()
+    return seen
+
+
+def _launch_weight_grad(grad2d, pairs):
+    key = grad2d.data_ptr()
+    store = _DW["store"] and key not in _DW["written"]
+    _DW["written"].add(key)
+    Np, Kp = grad2d.shape
+    if len(pairs) == 2:
+        (g1, x1), (g2, x2) = pairs
+        K1, K2 = g1.shape[0], g2.shape[0]
+        if (K1 + K2) % 8 == 0:
+            _gemm_call(2.0 * Np * Kp * (K1 + K2), "sei_gemm_bf16nt_dw2", g1.data_ptr(), g2.data_ptr(), Np,
+                       x1.data_ptr(), x2.data_ptr(), Kp, grad2d.data_ptr(), Np, Kp, K1, K2, 0 if store else 1)
+            return
+    for gy16, x16 in pairs:
+        gemm_nt16(gy16, x16, Np, Kp, gy16.shape[0], EPI_NONE if store else EPI_ACCUM, out32=grad2d, a_rmajor=True,
+                  b_rmajor=True)
+        store = False
+
+
+def flush_weight_grads():
+    """Issue every parked weight gradient on its own (no partner arrived)."""
+    _DW["flush_queued"] = False
+    parked, _DW["parked"] = _DW["parked"], {}
+    for gy16, x16, grad2d in parked.values():
+        _launch_weight_grad(grad2d, [(gy16, x16)])
+
+
 def weight_grad16(gy16, x16, grad2d):
-    """grad (N', K') += gy^T x, gy16 (M, N') and x16 (M, K') bf16 as stored: both read reduction-major."""
-    M, Np = gy16.shape
-    Kp = x16.shape[1]
-    gemm_nt16(gy16, x16, Np, Kp, M, EPI_ACCUM, out32=grad2d, a_rmajor=True, b_rmajor=True)
+    """grad (N', K') += gy^T x, gy16 (M, N') and x16 (M, K') bf16 as stored: both read reduction-major.
+    May park the pair until the step's other model call reaches the same weight (see above)."""
+    key = grad2d.data_ptr()
+    _DW["seen"][key] = grad2d.numel()
+    n = _DW["arrivals"].get(key, 0) + 1
+    _DW["arrivals"][key] = n
+    partner = _DW["parked"].pop(key, None)
+    if partner is not None:
+        _launch_weight_grad(grad2d, [partner[:2], (gy16, x16)])
+    elif _DW["merge"] and n < _DW["uses"] and _queue_flush():
+        _DW["parked"][key] = (gy16, x16, grad2d)
+    else:
+        _launch_weight_grad(grad2d, [(gy16, x16)])
+
+
+def _queue_flush():
+    """Ask autograd to flush parked pairs when the running backward ends; False outside a backward pass
+    (then nothing may be parked: nobody would flush it)."""
+    if not _DW["flush_queued"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
+        except RuntimeError:
+            return False
+        _DW["flush_queued"] = True
+    return True
 
 
 def use_bf16_blocks(C):

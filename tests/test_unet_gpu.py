@@ -507,3 +507,21 @@ def test_gemm_bf16nt_reduction_major_operands(ops, M, N, K, arm, brm):
     acc = base.clone().cuda()
     ops.gemm_nt16(Ad, Bd, M, N, K, ops.EPI_ACCUM, out32=acc, a_rmajor=arm, b_rmajor=brm)
     assert relerr(acc, ref + base.double()) < 3e-6
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [(128, 32, 147456, 73728), (512, 2048, 576, 288), (2048, 512, 2304, 1152),
+                                       (96, 160, 1000, 24), (32, 128, 40, 8)])
+def test_gemm_bf16nt_two_segment_weight_gradient(ops, M, N, K1, K2):
+    """sei_gemm_bf16nt_dw2: D (+)= A1^T B1 + A2^T B2 on reduction-major operands, store and accumulate."""
+    from _native import call
+    gen = torch.Generator().manual_seed(M + N + K1)
+    A1, A2 = torch.randn((K1, M), generator=gen).bfloat16().cuda(), torch.randn((K2, M), generator=gen).bfloat16().cuda()
+    B1, B2 = torch.randn((K1, N), generator=gen).bfloat16().cuda(), torch.randn((K2, N), generator=gen).bfloat16().cuda()
+    ref = A1.double().T @ B1.double() + A2.double().T @ B2.double()
+    D = torch.full((M, N), float("nan"), device="cuda")                # store must not read D
+    call("sei_gemm_bf16nt_dw2", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), N, D.data_ptr(), M, N,
+         K1, K2, 0)
+    assert relerr(D, ref) < 2e-5
+    call("sei_gemm_bf16nt_dw2", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), N, D.data_ptr(), M, N,
+         K1, K2, 1)
+    assert relerr(D, 2 * ref) < 2e-5
