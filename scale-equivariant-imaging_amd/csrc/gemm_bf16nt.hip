@@ -50,7 +50,8 @@ struct NtArgs {
     const float *bias, *R1, *R2;
     unsigned short *D2_16;     // BIAS_GELU: gelu(D) in bf16
     int splitk, k_per_split;
-    int tiles_m, tiles_n, xcd_order;
+    int tiles_m, tiles_n;
+    int tiles_per_xcd, band;   // tile order: see the kernel prologue
     // second reduction segment of reduction-major operands: rows k >= k_seg come from A2 / B2 (row k - k_seg)
     const unsigned short *A2, *B2;
     int k_seg;
@@ -143,18 +144,24 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
     const int li = lane & 31, lh = lane >> 5;
 
     // ---- tile / split assignment --------------------------------------------------------------
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so XCD x runs blocks
+    // x, x+8, x+16, ... in order. Those blocks walk a CONTIGUOUS range of a band-major tile order (bands of
+    // `band` tile columns, row by row inside a band): the ~32-64 tiles an XCD has in flight then form a
+    // near-square patch sharing A rows and B columns through its L2. (A strip order -- one tile column per
+    // XCD -- measured 52 % L2 hits on a 4096^3 GEMM: 16x the unique bytes through the fabric.)
     int bid = blockIdx.x;
-    const int ntile = g.tiles_m * g.tiles_n;
-    const int zs = bid / ntile;
-    bid -= zs * ntile;
+    const int per_split = 8 * g.tiles_per_xcd;
+    const int zs = bid / per_split;
+    bid -= zs * per_split;
+    const int ord = (bid & 7) * g.tiles_per_xcd + (bid >> 3);
+    if ((bid >> 3) >= g.tiles_per_xcd || ord >= g.tiles_m * g.tiles_n) return;   // block-uniform, before any barrier
     int tm_i, tn_i;
-    if (g.xcd_order) {
-        const int xcd = bid & 7, j = bid >> 3;
-        tm_i = j % g.tiles_m;
-        tn_i = (j / g.tiles_m) * 8 + xcd;
-    } else {
-        tm_i = bid % g.tiles_m;
-        tn_i = bid / g.tiles_m;
+    {
+        const int band_tiles = g.tiles_m * g.band;
+        const int b = ord / band_tiles, r = ord - b * band_tiles;
+        const int width = min(g.band, g.tiles_n - b * g.band);
+        tm_i = r / width;
+        tn_i = b * g.band + (r - tm_i * width);
     }
     const int m0 = tm_i * BM, n0 = tn_i * BN;
     const int M = g.M, N = g.N, K = g.K;
@@ -333,13 +340,24 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, s
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.f;
 }
 
+int g_force_band = 0;     // tuning aid (sei_debug_set_nt_tile codes 100 + band); 0 = automatic
+
 template <int TM, int TN, int WM, int WN, bool ARM = false, bool BRM = false, int NSTAGE = 2>
 int launch_nt(NtArgs &g, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     g.tiles_m = (int)sei_ceil_div(g.M, BM);
     g.tiles_n = (int)sei_ceil_div(g.N, BN);
-    g.xcd_order = (g.tiles_n % 8 == 0) ? 1 : 0;
     const size_t tiles = (size_t)g.tiles_m * g.tiles_n;
+    SEI_REQUIRE(tiles < ((size_t)1 << 27));
+    {
+        constexpr size_t STAGE_BYTES = NSTAGE * (size_t)(BM + BN) * ROW_BYTES;
+        const double conc = 32.0 * (STAGE_BYTES <= 80 * 1024 ? 2 : 1);        // tiles in flight per XCD
+        int band = g_force_band > 0 ? g_force_band : (int)(sqrt(conc * BM / BN) + 0.5);   // square patch in elements
+        if (band < 1) band = 1;
+        if (band > g.tiles_n) band = g.tiles_n;
+        g.band = band;
+        g.tiles_per_xcd = (int)sei_ceil_div(tiles, 8);
+    }
     g.splitk = 1;
     g.k_per_split = g.K;
     const bool splittable = g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
@@ -374,8 +392,8 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         if ((reinterpret_cast<uintptr_t>(g.D32) & 15) != 0) return SEI_ERR_BAD_ARG;
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
-    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE>), dim3((unsigned)(tiles * g.splitk)),
-                       dim3(NT), 0, s, g);
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE>),
+                       dim3((unsigned)(8 * (size_t)g.tiles_per_xcd * g.splitk)), dim3(NT), 0, s, g);
     return sei_launch_status();
 }
 
@@ -384,6 +402,10 @@ int g_force_tile = 0;     // tuning aid only (sei_debug_set_nt_tile); 0 = automa
 }  // namespace
 
 extern "C" int sei_debug_set_nt_tile(int code) {
+    if (code >= 100) {                 // 100 + band: force the band width of the tile order (100 = automatic)
+        g_force_band = code - 100;
+        return SEI_OK;
+    }
     g_force_tile = code;
     return SEI_OK;
 }
