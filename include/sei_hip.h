@@ -234,7 +234,9 @@ int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int lda, const u
 /* Development probe (tools/probe_tr_read.py): what ds_read_b64_tr_b16 delivers for a 64x128 LDS image. */
 int sei_debug_tr_probe(const uint16_t *in, uint16_t *out, int r0, int c0, void *stream);
 
-/* Tuning aid: force the tile of sei_gemm_bf16nt (0 = automatic). Process-global; not for production use. */
+/* Tuning aid: force the tile / schedule of sei_gemm_bf16nt (0 = automatic; 1, 2, 3, 5 = 128x128, 128x256,
+ * 192x256, 96x256; 11-14 = LDS-ring variants; 20 = the 256x256 ping-pong schedule of gemm_bf16pp.h;
+ * 100 + b = band width b of the tile order, 100 = automatic). Process-global; not for production use. */
 int sei_debug_set_nt_tile(int code);
 
 /* Tuning aid / test hook for the depthwise kernels (process-global): 1..64 = output columns per worker

@@ -63,22 +63,25 @@ __device__ __forceinline__ unsigned short f2bf(float v) {
 }
 
 // ---- operand stored K-contiguous: element (o, k) at G[o*ld + k]; LDS image [o][128 B], chunk swizzle (r>>1)&7
+// One 1-KiB wave-instruction ("piece") of a ROWS-row tile: piece q covers rows 8q .. 8q+7.
+template <int ROWS>
+__device__ __forceinline__ void stage_piece(const unsigned short *__restrict__ G, int ld, int row0, int row_lim,
+                                            int k0, int k_lim, char *lds_tile, int q, int lane) {
+    if (q < ROWS / 8) {                      // wave-uniform
+        const int row = 8 * q + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);      // logical chunk this lane must fetch
+        const int grow = min(row0 + row, row_lim - 1);     // rows past the edge re-read the last row
+        const int k = k0 + 8 * c;
+        const unsigned short *src = k < k_lim ? G + (size_t)grow * ld + k : g_zero_chunk;
+        __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
+    }
+}
 template <int ROWS>
 __device__ __forceinline__ void stage_tile(const unsigned short *__restrict__ G, int ld, int row0, int row_lim,
                                            int k0, int k_lim, char *lds_tile, int wave, int lane) {
-    constexpr int NI = ROWS / 8;             // 1-KiB wave-instructions in the tile
 #pragma unroll
-    for (int q0 = 0; q0 < NI; q0 += NWAVES) {
-        const int q = q0 + wave;             // wave-uniform
-        if (q < NI) {
-            const int row = 8 * q + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);      // logical chunk this lane must fetch
-            const int grow = min(row0 + row, row_lim - 1);     // rows past the edge re-read the last row
-            const int k = k0 + 8 * c;
-            const unsigned short *src = k < k_lim ? G + (size_t)grow * ld + k : g_zero_chunk;
-            __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
-        }
-    }
+    for (int q0 = 0; q0 < ROWS / 8; q0 += NWAVES)
+        stage_piece<ROWS>(G, ld, row0, row_lim, k0, k_lim, lds_tile, q0 + wave, lane);
 }
 
 // ---- operand stored reduction-major: element (o, k) at G[k*ld + o]; LDS image [64 k-rows][256 B = 128 o],
@@ -86,19 +89,22 @@ __device__ __forceinline__ void stage_tile(const unsigned short *__restrict__ G,
 // with ds_read_b64_tr_b16. Rows past K and chunks past the o edge are fed from the zero chunk.
 __device__ __forceinline__ int swz_rmajor(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
+__device__ __forceinline__ void stage_piece_rmajor(const unsigned short *__restrict__ G,
+                                                   const unsigned short *__restrict__ G2, int k_seg, int ld, int o0,
+                                                   int o_lim, int k0, int k_lim, char *lds_tile, int q, int lane) {
+    const int row = 4 * q + (lane >> 4);                  // 64 rows x 256 B = 16 pieces of 4 rows
+    const int ch = (lane & 15) ^ swz_rmajor(row);
+    const int k = k0 + row, o = o0 + 8 * ch;
+    const unsigned short *rowp = k < k_seg ? G + (size_t)k * ld : G2 + (size_t)(k - k_seg) * ld;
+    const unsigned short *src = (k < k_lim && o < o_lim) ? rowp + o : g_zero_chunk;
+    __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
+}
 __device__ __forceinline__ void stage_tile_rmajor(const unsigned short *__restrict__ G,
                                                   const unsigned short *__restrict__ G2, int k_seg, int ld, int o0,
                                                   int o_lim, int k0, int k_lim, char *lds_tile, int wave, int lane) {
 #pragma unroll
-    for (int q0 = 0; q0 < 16; q0 += NWAVES) {            // 64 rows x 256 B = 16 wave-instructions of 4 rows
-        const int q = q0 + wave;
-        const int row = 4 * q + (lane >> 4);
-        const int ch = (lane & 15) ^ swz_rmajor(row);
-        const int k = k0 + row, o = o0 + 8 * ch;
-        const unsigned short *rowp = k < k_seg ? G + (size_t)k * ld : G2 + (size_t)(k - k_seg) * ld;
-        const unsigned short *src = (k < k_lim && o < o_lim) ? rowp + o : g_zero_chunk;
-        __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
-    }
+    for (int q0 = 0; q0 < 16; q0 += NWAVES)
+        stage_piece_rmajor(G, G2, k_seg, ld, o0, o_lim, k0, k_lim, lds_tile, q0 + wave, lane);
 }
 
 // fragment of a reduction-major operand: 8 k-values (k = 16s + 8h + j) of column c0 + (lane & 15)
@@ -342,6 +348,8 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, s
 
 int g_force_band = 0;     // tuning aid (sei_debug_set_nt_tile codes 100 + band); 0 = automatic
 
+#include "gemm_bf16pp.h"  // 256 x 256 ping-pong schedule on the same LDS images
+
 template <int TM, int TN, int WM, int WN, bool ARM = false, bool BRM = false, int NSTAGE = 2>
 int launch_nt(NtArgs &g, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -430,6 +438,12 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
     g.A2 = A; g.B2 = B; g.k_seg = K;                       // one reduction segment
     hipStream_t s = (hipStream_t)stream;
+    if (g_force_tile == 20) {                            // 256 x 256 ping-pong schedule (tuning aid)
+        if (a_rmajor && b_rmajor) return launch_pp<true, true>(g, s);
+        if (a_rmajor) return launch_pp<true, false>(g, s);
+        if (b_rmajor) return launch_pp<false, true>(g, s);
+        return launch_pp<false, false>(g, s);
+    }
     if (!a_rmajor && !b_rmajor) {
         switch (g_force_tile) {                          // ring-pipelined candidates (tuning aid)
             case 11: return launch_nt<2, 1, 2, 4, false, false, 4>(g, s);      // 128 x 128, 4 stages
@@ -448,6 +462,7 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
         case 2: return launch_nt<2, 2, 2, 4>(g, s);      // 128 x 256
         case 3: return launch_nt<3, 2, 2, 4>(g, s);      // 192 x 256
         case 5: return launch_nt<3, 1, 1, 8>(g, s);      //  96 x 256
+        case 4: return launch_nt<4, 2, 2, 4>(g, s);      // 256 x 256 (tuning aid)
         default: break;
     }
     // Tile choice (measured on MI355X, tools/exp_dw.py): 128x128 runs two workgroups per CU, which hides

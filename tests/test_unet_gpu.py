@@ -525,3 +525,48 @@ def test_gemm_bf16nt_two_segment_weight_gradient(ops, M, N, K1, K2):
     call("sei_gemm_bf16nt_dw2", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), N, D.data_ptr(), M, N,
          K1, K2, 1)
     assert relerr(D, 2 * ref) < 2e-5
+
+
+@pytest.mark.parametrize("ar,br", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(512, 768, 1024), (264, 776, 200), (2304, 2048, 448), (4096, 4096, 1024)])
+def test_gemm_bf16_pingpong_schedule(ops, M, N, K, ar, br):
+    """The opt-in 256x256 ping-pong schedule (gemm_bf16pp.h, tile code 20): every operand layout, ragged edges,
+    a K tail, and the fused epilogues, against float64; repeated launches must agree bit for bit (the schedule
+    synchronises its LDS-DMA by counted waits and raw barriers: a race would show as run-to-run differences)."""
+    from _native import lib
+    gen = torch.Generator().manual_seed(M + N + K + ar + 2 * br)
+    A = torch.randn((K, M) if ar else (M, K), generator=gen).bfloat16().cuda()
+    B = torch.randn((K, N) if br else (N, K), generator=gen).bfloat16().cuda()
+    bias, R1 = torch.randn(N, generator=gen).cuda(), torch.randn((M, N), generator=gen).cuda()
+    Ad = (A.double().t() if ar else A.double())
+    Bd = (B.double() if br else B.double().t())
+    ref = (Ad @ Bd).cpu()
+    try:
+        assert lib().sei_debug_set_nt_tile(20) == 0
+        outs = []
+        for _ in range(3):
+            out = torch.full((M, N), float("nan"), device="cuda")
+            ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out32=out, a_rmajor=bool(ar), b_rmajor=bool(br))
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert relerr(outs[0], ref) < 2e-5
+        if K < 512 or M * N >= 256 * 256 * 256:      # launches that do not split K (no float atomics)
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        # bias + residual, GELU pair (f32 + bf16), GELU' product with a bf16 output, accumulate
+        out = torch.empty((M, N), device="cuda")
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_RES, out32=out, bias=bias, R1=R1, a_rmajor=bool(ar), b_rmajor=bool(br))
+        assert relerr(out, ref + bias.double().cpu() + R1.double().cpu()) < 2e-5
+        h3, h4 = torch.empty((M, N), device="cuda"), torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_GELU, out32=h3, bias=bias, D2_16=h4, a_rmajor=bool(ar), b_rmajor=bool(br))
+        pre = ref + bias.double().cpu()
+        assert relerr(h3, pre) < 2e-5 and relerr(h4.float(), F.gelu(pre)) < 1e-2
+        g16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_MUL_DGELU, out16=g16, R1=R1, a_rmajor=bool(ar), b_rmajor=bool(br))
+        x = R1.double().cpu().requires_grad_(True)
+        dg, = torch.autograd.grad(F.gelu(x).sum(), x)
+        assert relerr(g16.float(), ref * dg) < 1e-2
+        acc = R1.clone()
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_ACCUM, out32=acc, a_rmajor=bool(ar), b_rmajor=bool(br))
+        assert relerr(acc, ref + R1.double().cpu()) < 2e-5
+    finally:
+        lib().sei_debug_set_nt_tile(0)
