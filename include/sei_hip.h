@@ -249,6 +249,10 @@ int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo,
                 size_t work_floats, void *stream);
 
 int sei_colsum_f32(const float *X, float *out, size_t M, int N, void *stream);
+/* out[n] += sum_m row_weight[m] * X[m,n]: the bias gradient of a 1x1 convolution applied AFTER the ideal
+ * downsampler (models/_ops.py, DownsampleFn: the bias enters as bias[n] * s[m], s = the resampler's response
+ * to a constant image). */
+int sei_colsum_weighted_f32(const float *X, const float *row_weight, float *out, size_t M, int N, void *stream);
 
 int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, float *exp_avg, float *exp_avg_sq,
                    size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

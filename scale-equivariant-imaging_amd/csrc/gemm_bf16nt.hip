@@ -312,10 +312,19 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
             const int col = n0 + wn * (32 * TN) + 32 * j + li;
             const bool col_ok = col < N;
             const int row_base = m0 + wm * (32 * TM) + 32 * i + 4 * lh;
-            const float bias = (col_ok && (!split || lead) &&
-                                (epi == SEI_EPI_BIAS || epi == SEI_EPI_BIAS_GELU || epi == SEI_EPI_BIAS_RES))
-                                   ? g.bias[col] : 0.f;
+            float bias = (col_ok && (!split || lead) &&
+                          (epi == SEI_EPI_BIAS || epi == SEI_EPI_BIAS_GELU || epi == SEI_EPI_BIAS_RES ||
+                           epi == SEI_EPI_BIAS_ROWSCALE))
+                             ? g.bias[col] : 0.f;
             if constexpr (!PREFETCH_AUX) gather_aux(i, j);
+            if (epi == SEI_EPI_BIAS_ROWSCALE) {          // D = acc + bias[n] * R1[m]   (R1: one value per row)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + (r & 3) + 8 * (r >> 2);
+                    a1[i][j][r] = row < M ? bias * g.R1[row] : 0.f;
+                }
+                bias = 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row_base + (r & 3) + 8 * (r >> 2);
@@ -428,8 +437,12 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     if (b_rmajor) SEI_REQUIRE(N % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0);
     SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU ||
-                epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_ACCUM);
-    if (epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU || epilogue == SEI_EPI_BIAS_RES) SEI_REQUIRE(bias);
+                epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_ACCUM ||
+                epilogue == SEI_EPI_BIAS_ROWSCALE);
+    if (epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU || epilogue == SEI_EPI_BIAS_RES ||
+        epilogue == SEI_EPI_BIAS_ROWSCALE)
+        SEI_REQUIRE(bias);
+    if (epilogue == SEI_EPI_BIAS_ROWSCALE) SEI_REQUIRE(R1);
     if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D2_16);
     if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU) SEI_REQUIRE(R1);
     if (epilogue == SEI_EPI_ACCUM) SEI_REQUIRE(D32 && !D16);

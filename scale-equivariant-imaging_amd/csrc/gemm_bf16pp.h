@@ -224,9 +224,10 @@ __global__ __launch_bounds__(NT) void gemm_bf16pp_kernel(NtArgs g) {
         const int col = n0 + wc * 64 + 32 * j + li;
         const bool col_ok = col < N;
         const int row_base = m0 + wr * 128 + 32 * i + 4 * lh;
-        const float bias = (col_ok && (!split || lead) &&
-                            (epi == SEI_EPI_BIAS || epi == SEI_EPI_BIAS_GELU || epi == SEI_EPI_BIAS_RES))
-                               ? g.bias[col] : 0.f;
+        float bias = (col_ok && (!split || lead) &&
+                      (epi == SEI_EPI_BIAS || epi == SEI_EPI_BIAS_GELU || epi == SEI_EPI_BIAS_RES ||
+                       epi == SEI_EPI_BIAS_ROWSCALE))
+                         ? g.bias[col] : 0.f;
         // Auxiliary inputs: ONE uniform decision per sub-tile, then 16 unconditional loads in flight together
         // (clamped address, masked afterwards). A per-row "load or not" branch makes hipcc wait vmcnt(0) per
         // row, and stores count on vmcnt too: every store of the previous rows was drained one by one
@@ -260,6 +261,14 @@ __global__ __launch_bounds__(NT) void gemm_bf16pp_kernel(NtArgs g) {
                 const float v = aux2[ok ? (size_t)row * N + col : 0];
                 a2[r] = ok ? v : 0.f;
             }
+        }
+        if (epi == SEI_EPI_BIAS_ROWSCALE) {              // D = acc + bias[n] * R1[m]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + (r & 3) + 8 * (r >> 2);
+                a1[r] = bias * g.R1[row < M ? row : 0];
+            }
+            bias = 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
         // values first (this consumes every gathered input: one wait), stores afterwards with nothing to wait for

@@ -730,8 +730,9 @@ __global__ __launch_bounds__(SM_THREADS) void sepmap_h_kernel(const float *__res
 // =================================================================================================
 // column sums and Adam
 // =================================================================================================
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, float *__restrict__ out,
-                                                     size_t M, int N, size_t rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, const float *__restrict__ wrow,
+                                                     float *__restrict__ out, size_t M, int N,
+                                                     size_t rows_per_block) {
     // blockIdx.y tiles the columns (cw = min(N,256) per block, lanes = consecutive columns),
     // blockIdx.x tiles the rows; the 256/cw row sub-groups of a block are reduced through LDS.
     extern __shared__ __attribute__((aligned(16))) float red[];   // [rsubs][cw]
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
     const int c = blockIdx.y * cw + cl;
     float s = 0.f;
     if (c < N && rsub < rsubs)
-        for (size_t r = r0 + rsub; r < r1; r += rsubs) s += X[r * N + c];
+        for (size_t r = r0 + rsub; r < r1; r += rsubs) s += wrow ? wrow[r] * X[r * N + c] : X[r * N + c];
     if (rsub < rsubs) red[rsub * cw + cl] = s;
     __syncthreads();
     if (rsub == 0 && c < N) {
@@ -1014,8 +1015,8 @@ extern "C" int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int 
     return sei_launch_status();
 }
 
-extern "C" int sei_colsum_f32(const float *X, float *out, size_t M, int N, void *stream) {
-    SEI_REQUIRE(X && out && M > 0 && N > 0);
+namespace {
+int launch_colsum(const float *X, const float *wrow, float *out, size_t M, int N, void *stream) {
     const int cw = N < 256 ? N : 256;
     const unsigned col_blocks = (unsigned)sei_ceil_div(N, cw);
     // ~2048 workgroups in all: enough to fill 256 CUs, few enough to keep the atomics per column low
@@ -1023,8 +1024,20 @@ extern "C" int sei_colsum_f32(const float *X, float *out, size_t M, int N, void 
     while (sei_ceil_div(M, rpb) * col_blocks > 2048 && rpb < M) rpb *= 2;
     const size_t lds = sizeof(float) * (size_t)(256 / cw) * cw;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)sei_ceil_div(M, rpb), col_blocks), dim3(256), lds,
-                       (hipStream_t)stream, X, out, M, N, rpb);
+                       (hipStream_t)stream, X, wrow, out, M, N, rpb);
     return sei_launch_status();
+}
+}  // namespace
+
+extern "C" int sei_colsum_f32(const float *X, float *out, size_t M, int N, void *stream) {
+    SEI_REQUIRE(X && out && M > 0 && N > 0);
+    return launch_colsum(X, nullptr, out, M, N, stream);
+}
+
+extern "C" int sei_colsum_weighted_f32(const float *X, const float *row_weight, float *out, size_t M, int N,
+                                       void *stream) {
+    SEI_REQUIRE(X && row_weight && out && M > 0 && N > 0);
+    return launch_colsum(X, row_weight, out, M, N, stream);
 }
 
 extern "C" int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, float *exp_avg, float *exp_avg_sq,

@@ -93,3 +93,18 @@ def resample_matrices(kind, H, W, rate, device):
         bwd = tuple(torch.from_numpy(np.ascontiguousarray(m.T)).to(device) for m in host)
         _DEVICE_CACHE[key] = (fwd, bwd)
     return _DEVICE_CACHE[key]
+
+
+def constant_response(kind, H, W, rate, device, batch):
+    """s[b, i', j'] = the map's output for an all-ones image, flattened to (batch * Ho * Wo,) float32.
+
+    A bias added BEFORE the (linear, per-channel) resampler comes out as bias[c] * s[i', j']; it is not a
+    constant because the reference's discarded ifftshift leaves the spectrum shifted (reference
+    convolutional.py:131). Used to apply the 1x1 convolution after the ideal downsampler (_ops.DownsampleFn)."""
+    key = ("ones", kind, H, W, rate, str(device), batch)
+    if key not in _DEVICE_CACHE:
+        L1, R1, L2, R2 = (m.astype(np.float64) for m in _host_matrices(kind, H, W, rate))
+        resp = np.outer(L1.sum(1), R1.sum(1)) + np.outer(L2.sum(1), R2.sum(1))
+        full = np.tile(resp.reshape(-1), batch).astype(np.float32)
+        _DEVICE_CACHE[key] = torch.from_numpy(full).to(device)
+    return _DEVICE_CACHE[key]

@@ -107,9 +107,13 @@ def layer_norm_bwd(x2d, gamma, mean, rstd, gy, ggamma, gbeta):
     return gx
 
 
-def colsum_into(acc, x2d):
+def colsum_into(acc, x2d, row_weight=None):
+    """acc[n] += sum_m x2d[m, n] (times row_weight[m] if given)."""
     M, Nn = x2d.shape
-    N.call("sei_colsum_f32", x2d.data_ptr(), acc.data_ptr(), M, Nn)
+    if row_weight is None:
+        N.call("sei_colsum_f32", x2d.data_ptr(), acc.data_ptr(), M, Nn)
+    else:
+        N.call("sei_colsum_weighted_f32", x2d.data_ptr(), row_weight.data_ptr(), acc.data_ptr(), M, Nn)
 
 
 def dwconv7(x, w, bias, flip=False, res=None, res_scale=1.0):
@@ -196,37 +200,44 @@ class ConvBlockFn(torch.autograd.Function):
 # Downsample: LN -> 1x1 conv C -> 4C -> ideal downsample    (reference convolutional.py:136-150)
 # ---------------------------------------------------------------------------------------------
 class DownsampleFn(torch.autograd.Function):
+    """LN -> 1x1 conv C->Co -> ideal downsample, evaluated as LN -> ideal downsample -> 1x1 conv.
+
+    The resampler is linear and acts per channel, the convolution is linear and acts per pixel, so they
+    commute exactly; only the bias needs care: it comes out of the resampler as bias[c] * s[pixel], s = the
+    resampler's response to a constant image (`_mats.constant_response`), which is the BIAS_ROWSCALE epilogue.
+    The resampler then runs on C channels instead of Co = 4C, the three GEMMs on a quarter of the rows, and the
+    full-resolution Co-channel tensor (75 MB per level at B = 32) never exists."""
+
     @staticmethod
     def forward(ctx, x, gamma, beta, w, b, rate):
         x = _nhwc(x)
         B, H, W, C = x.shape
         M, Co = B * H * W, w.shape[0]
         h, mean, rstd = layer_norm(x.view(M, C), gamma, beta)
-        z = gemm(h, w, M, Co, C, 0, 1, EPI_BIAS, bias=b)
         fwd, bwd = _mats.resample_matrices("down", H, W, rate, x.device)
         Ho, Wo = fwd[0].shape[0], fwd[1].shape[0]
-        out = sepmap2(z.view(B, H, W, Co), fwd, Ho, Wo)
-        ctx.save_for_backward(x, mean, rstd, h)
-        ctx.params, ctx.mats_t, ctx.hw = (gamma, beta, w, b), bwd, (H, W)
-        return out
+        u = sepmap2(h.view(B, H, W, C), fwd, Ho, Wo)
+        Mo = B * Ho * Wo
+        s = _mats.constant_response("down", H, W, rate, x.device, B)
+        out = gemm(u.view(Mo, C), w, Mo, Co, C, 0, 1, EPI_BIAS_ROWSCALE, bias=b, R1=s)
+        ctx.save_for_backward(x, mean, rstd, u, s)
+        ctx.params, ctx.mats_t, ctx.hw = (gamma, beta, w, b), bwd, (H, W, Ho, Wo)
+        return out.view(B, Ho, Wo, Co)
 
     @staticmethod
     def backward(ctx, go):
-        x, mean, rstd, h = ctx.saved_tensors
+        x, mean, rstd, u, s = ctx.saved_tensors
         gamma, beta, w, b = ctx.params
         B, H, W, C = x.shape
-        M, Co = B * H * W, w.shape[0]
-        gz = sepmap2(go.contiguous(), ctx.mats_t, H, W).view(M, Co)
-        colsum_into(grad_of(b), gz)
-        gemm(gz, h, Co, C, M, 1, 0, EPI_ACCUM, out=grad_of(w).view(Co, C))
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gh = gemm(gz, w, M, C, Co, 0, 0, EPI_NONE)
-            gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
-        else:
-            gh = gemm(gz, w, M, C, Co, 0, 0, EPI_NONE)
-            layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta))
-        return gx, None, None, None, None, None
+        Ho, Wo = ctx.hw[2], ctx.hw[3]
+        M, Mo, Co = B * H * W, B * Ho * Wo, w.shape[0]
+        go2 = go.contiguous().view(Mo, Co)
+        colsum_into(grad_of(b), go2, row_weight=s)
+        gemm(go2, u.view(Mo, C), Co, C, Mo, 1, 0, EPI_ACCUM, out=grad_of(w).view(Co, C))
+        gu = gemm(go2, w, Mo, C, Co, 0, 0, EPI_NONE)
+        gh = sepmap2(gu.view(B, Ho, Wo, C), ctx.mats_t, H, W).view(M, C)
+        gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
+        return (gx if ctx.needs_input_grad[0] else None), None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -525,32 +536,40 @@ class ConvBlockFn16(torch.autograd.Function):
 
 
 class DownsampleFn16(torch.autograd.Function):
+    """DownsampleFn (resampler before the convolution) with the three GEMMs on bf16 operands."""
+
     @staticmethod
     def forward(ctx, x, gamma, beta, w, b, rate):
         x = _nhwc(x)
         B, H, W, C = x.shape
         M, Co = B * H * W, w.shape[0]
-        h, mean, rstd = layer_norm16(x.view(M, C), gamma, beta)
-        w16 = shadow(w)
-        z = torch.empty((M, Co), dtype=torch.float32, device=x.device)
-        gemm_nt16(h, w16, M, Co, C, EPI_BIAS, out32=z, bias=b)
+        h, mean, rstd = layer_norm(x.view(M, C), gamma, beta)
         fwd, bwd = _mats.resample_matrices("down", H, W, rate, x.device)
-        out = sepmap2(z.view(B, H, W, Co), fwd, fwd[0].shape[0], fwd[1].shape[0])
-        ctx.save_for_backward(x, mean, rstd, h)
-        ctx.params, ctx.mats_t = (gamma, beta, w, b), bwd
-        return out
+        Ho, Wo = fwd[0].shape[0], fwd[1].shape[0]
+        u = sepmap2(h.view(B, H, W, C), fwd, Ho, Wo)
+        Mo = B * Ho * Wo
+        s = _mats.constant_response("down", H, W, rate, x.device, B)
+        u16 = cast16(u.view(Mo, C))
+        out = torch.empty((Mo, Co), dtype=torch.float32, device=x.device)
+        gemm_nt16(u16, shadow(w), Mo, Co, C, EPI_BIAS_ROWSCALE, out32=out, bias=b, R1=s)
+        ctx.save_for_backward(x, mean, rstd, u16, s)
+        ctx.params, ctx.mats_t, ctx.hw = (gamma, beta, w, b), bwd, (H, W, Ho, Wo)
+        return out.view(B, Ho, Wo, Co)
 
     @staticmethod
     def backward(ctx, go):
-        x, mean, rstd, h = ctx.saved_tensors
+        x, mean, rstd, u16, s = ctx.saved_tensors
         gamma, beta, w, b = ctx.params
         B, H, W, C = x.shape
-        M, Co = B * H * W, w.shape[0]
-        gz = sepmap2(go.contiguous(), ctx.mats_t, H, W).view(M, Co)
-        gz16 = cast16(gz, colsum_into_=grad_of(b))
-        weight_grad16(gz16, h, grad_of(w).view(Co, C))
-        gh = torch.empty((M, C), dtype=torch.float32, device=x.device)
-        gemm_nt16(gz16, shadow(w), M, C, Co, EPI_NONE, out32=gh, b_rmajor=True)
+        Ho, Wo = ctx.hw[2], ctx.hw[3]
+        M, Mo, Co = B * H * W, B * Ho * Wo, w.shape[0]
+        go2 = go.contiguous().view(Mo, Co)
+        colsum_into(grad_of(b), go2, row_weight=s)
+        go16 = cast16(go2)
+        weight_grad16(go16, u16, grad_of(w).view(Co, C))
+        gu = torch.empty((Mo, C), dtype=torch.float32, device=x.device)
+        gemm_nt16(go16, shadow(w), Mo, C, Co, EPI_NONE, out32=gu, b_rmajor=True)
+        gh = sepmap2(gu.view(B, Ho, Wo, C), ctx.mats_t, H, W).view(M, C)
         gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
         return (gx if ctx.needs_input_grad[0] else None), None, None, None, None, None
 

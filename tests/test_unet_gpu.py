@@ -570,3 +570,21 @@ def test_gemm_bf16_pingpong_schedule(ops, M, N, K, ar, br):
         assert relerr(acc, ref + R1.double().cpu()) < 2e-5
     finally:
         lib().sei_debug_set_nt_tile(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(2304, 8192, 2048), (300, 520, 72)])
+def test_gemm_bf16nt_bias_rowscale_and_weighted_colsum(ops, M, N, K):
+    """D = A B^T + bias[n] * s[m] (the bias of a 1x1 convolution that was moved behind the ideal downsampler)
+    and its gradient, the row-weighted column sum."""
+    from _native import call
+    gen = torch.Generator().manual_seed(M + K)
+    A, B = torch.randn((M, K), generator=gen).bfloat16().cuda(), torch.randn((N, K), generator=gen).bfloat16().cuda()
+    bias, s = torch.randn(N, generator=gen).cuda(), torch.randn(M, generator=gen).cuda()
+    out = torch.empty((M, N), device="cuda")
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_ROWSCALE, out32=out, bias=bias, R1=s)
+    ref = A.double() @ B.double().t() + s.double()[:, None] * bias.double()[None, :]
+    assert relerr(out, ref) < 2e-5
+    go = torch.randn((M, N), generator=gen).cuda()
+    gb = torch.ones(N, device="cuda")
+    ops.colsum_into(gb, go, row_weight=s)
+    assert relerr(gb, 1.0 + (go.double() * s.double()[:, None]).sum(0)) < 2e-5
