@@ -758,6 +758,16 @@ __device__ __forceinline__ float grad_value(const unsigned short *g, size_t i) {
     return __uint_as_float((unsigned)g[i] << 16);
 }
 
+// One element of torch.optim.Adam (single-tensor form): lerp for exp_avg, addcmul for exp_avg_sq.
+__device__ __forceinline__ float adam_element(float pi, float gi, float &mi, float &vi, float beta1, float beta2,
+                                              float eps, float wd, float step_size, float inv_bc2_sqrt) {
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    mi = mi + (gi - mi) * (1.f - beta1);
+    vi = fmaf(beta2, vi, (1.f - beta2) * gi * gi);
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    return pi - step_size * (mi / denom);
+}
+
 template <typename G>
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const G *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, size_t n,
@@ -766,20 +776,52 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
                                                    unsigned short *__restrict__ p16) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float gi = grad_value(g, i) * gscale;
-        const float pi = p[i];
-        if (wd != 0.f) gi = fmaf(wd, pi, gi);
-        // torch.optim.Adam (single-tensor form): lerp for exp_avg, addcmul for exp_avg_sq
-        const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
-        const float vi = fmaf(beta2, v[i], (1.f - beta2) * gi * gi);
-        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        float mi = m[i], vi = v[i];
+        const float pn = adam_element(p[i], grad_value(g, i) * gscale, mi, vi, beta1, beta2, eps, wd, step_size,
+                                      inv_bc2_sqrt);
         m[i] = mi;
         v[i] = vi;
-        const float pn = pi - step_size * (mi / denom);
         p[i] = pn;
         if (p16) {                                  // bf16 shadow of the updated weight (throughput mode)
             const __bf16 b = (__bf16)pn;
             p16[i] = __builtin_bit_cast(unsigned short, b);
+        }
+    }
+}
+
+// The same update on 4 consecutive elements per thread: 16-byte accesses on every float32 stream, 8-byte on
+// the bf16 ones (identical per-element arithmetic, so bit-identical to adam_kernel).
+__device__ __forceinline__ float4 grad_quad(const float *g, size_t q) { return reinterpret_cast<const float4 *>(g)[q]; }
+__device__ __forceinline__ float4 grad_quad(const unsigned short *g, size_t q) {
+    const uint2 r = reinterpret_cast<const uint2 *>(g)[q];
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xffff0000u));
+}
+template <typename G>
+__global__ __launch_bounds__(256) void adam_vec_kernel(float *__restrict__ p, const G *__restrict__ g,
+                                                       float *__restrict__ m, float *__restrict__ v, size_t nquads,
+                                                       float beta1, float beta2, float eps, float wd,
+                                                       float step_size, float inv_bc2_sqrt, float gscale,
+                                                       unsigned short *__restrict__ p16) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += stride) {
+        const float4 pq = reinterpret_cast<float4 *>(p)[q];
+        float4 mq = reinterpret_cast<float4 *>(m)[q], vq = reinterpret_cast<float4 *>(v)[q];
+        const float4 gq = grad_quad(g, q);
+        float4 o;
+        o.x = adam_element(pq.x, gq.x * gscale, mq.x, vq.x, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+        o.y = adam_element(pq.y, gq.y * gscale, mq.y, vq.y, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+        o.z = adam_element(pq.z, gq.z * gscale, mq.z, vq.z, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+        o.w = adam_element(pq.w, gq.w * gscale, mq.w, vq.w, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+        reinterpret_cast<float4 *>(m)[q] = mq;
+        reinterpret_cast<float4 *>(v)[q] = vq;
+        reinterpret_cast<float4 *>(p)[q] = o;
+        if (p16) {
+            const __bf16 b0 = (__bf16)o.x, b1 = (__bf16)o.y, b2 = (__bf16)o.z, b3 = (__bf16)o.w;
+            uint2 w;
+            w.x = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+            w.y = (unsigned)__builtin_bit_cast(unsigned short, b2) | ((unsigned)__builtin_bit_cast(unsigned short, b3) << 16);
+            reinterpret_cast<uint2 *>(p16)[q] = w;
         }
     }
 }
@@ -1048,14 +1090,28 @@ extern "C" int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, 
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    const dim3 grid(capped_grid(n, 256 * 4, 8192));
-    if (grad_is_bf16)
-        hipLaunchKernelGGL(adam_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, param,
-                           (const unsigned short *)grad, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay,
-                           step_size, inv_bc2_sqrt, grad_scale, param_bf16);
-    else
-        hipLaunchKernelGGL(adam_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, param, (const float *)grad,
-                           exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
-                           grad_scale, param_bf16);
+    hipStream_t s = (hipStream_t)stream;
+    // 16-byte-aligned streams take the 4-wide kernel; a ragged tail (and unaligned views) the scalar one
+    const size_t gsz = grad_is_bf16 ? 2 : 4;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(exp_avg) |
+                           reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(grad) & (4 * gsz - 1)) == 0 &&
+                         (!param_bf16 || (reinterpret_cast<uintptr_t>(param_bf16) & 7) == 0);
+    const size_t nq = aligned ? n / 4 : 0, done = 4 * nq;
+#define SEI_ADAM(KERNEL, G, COUNT, OFF)                                                                              \
+    hipLaunchKernelGGL(KERNEL<G>, dim3(capped_grid(COUNT, 256 * 2, 8192)), dim3(256), 0, s, param + (OFF),          \
+                       reinterpret_cast<const G *>(grad) + (OFF), exp_avg + (OFF), exp_avg_sq + (OFF), COUNT, beta1, \
+                       beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale,                                \
+                       param_bf16 ? param_bf16 + (OFF) : nullptr)
+    if (nq > 0) {
+        if (grad_is_bf16) SEI_ADAM(adam_vec_kernel, unsigned short, nq, 0);
+        else SEI_ADAM(adam_vec_kernel, float, nq, 0);
+    }
+    if (done < n) {
+        const size_t rest = n - done;
+        if (grad_is_bf16) SEI_ADAM(adam_kernel, unsigned short, rest, done);
+        else SEI_ADAM(adam_kernel, float, rest, done);
+    }
+#undef SEI_ADAM
     return sei_launch_status();
 }
