@@ -1,27 +1,28 @@
-// sei_gemm_bf16nt: the large 1x1-convolution GEMMs of the U-Net in throughput (bf16) mode.
+// sei_gemm_bf16nt / sei_gemm_bf16nt_dw2: the large 1x1-convolution GEMMs of the U-Net in throughput (bf16) mode.
 //
-//   D[M,N] = A[M,K] * B[N,K]^T      A, B: bf16 in HBM, both K-contiguous ("NT"); f32 accumulation
-//   outputs: D32 (float) and/or D16 (bf16), fused epilogues as sei_gemm_f32.
+//   D[M,N] = op(A) op(B)      A, B: bf16 in HBM, read as the model stores them; f32 accumulation
+//   outputs: D32 (float) and/or D16 (bf16), fused epilogues as sei_gemm_f32 (+ BIAS_ROWSCALE).
 //
-// Serves the forward 1x1 convolutions (A = activations, B = weight shadow in bf16) and the data
-// gradients (A = upstream gradient, B = the TRANSPOSED bf16 weight shadow), i.e. every GEMM whose
-// operands can be kept K-contiguous. Weight gradients (reduction over pixels) stay on the
-// register-staged kernel (gemm_bf16.hip): they are bound by the f32 gradient read-modify-write.
+//   forward           Y  = X W^T     X (M,K) and W (N,K) both K-contiguous
+//   data gradient     dX = dY W      W read REDUCTION-MAJOR (b_rmajor): its rows are the reduction index
+//   weight gradient   dW = dY^T X    both operands reduction-major (a_rmajor, b_rmajor); sei_gemm_bf16nt_dw2 runs
+//                                    the reduction over the (dY, X) pairs of two model calls in one launch
 //
 // Structure (cdna_hip_programming.md section 5, "minimum 2-phase" loop):
-//   * 8 waves (2 x 4), block tile (64*TM) x 256, BK = 64 -> one 128-byte line per row per k-tile.
-//   * HBM/L2 -> LDS by global_load_lds_dwordx4: each wave-instruction moves 8 rows x 128 B = 1 KiB
-//     (full lines), no VGPR staging. The LDS image is row-major [row][8 chunks of 16 B]; chunk c of row
-//     r is stored at chunk position c ^ ((r>>1)&7). Because the DMA destination is lane-linear, the
-//     swizzle is applied to the per-lane SOURCE address and again on the fragment read.
-//   * MFMA fragment (v_mfma_f32_32x32x16_bf16) of lane l = row l&31, k-chunk 2s + (l>>5) of k-step s:
-//     one ds_read_b128; with the swizzle every 16-lane group covers 16 distinct 16-B slots.
-//   * double-buffered LDS (2 x (BM+256) x 128 B <= 128 KiB, one workgroup per CU), one barrier per k-tile.
-//   * workgroup order: the m-tiles that share a B (weight) panel get ids congruent mod 8 and adjacent,
-//     so they run on one XCD at the same time and the panel is fetched from HBM once (speed only).
-//   * narrow outputs (few tiles, long K) split K over workgroups and combine with float atomics.
+//   * 8 waves, block tile 128x128 (2 workgroups per CU) / 192x256 / 96x256, BK = 64.
+//   * HBM/L2 -> LDS by global_load_lds_dwordx4: each wave-instruction ("piece") moves 1 KiB of full lines, no
+//     VGPR staging. K-contiguous operand: LDS image [row][128 B], 16-byte chunk c of row r at chunk position
+//     c ^ ((r>>1)&7), fragment = one ds_read_b128. Reduction-major operand: image [64 k-rows][256 B = 128
+//     columns], chunk swizzle swz_rmajor(row), fragment = two ds_read_b64_tr_b16 (the transposing LDS read).
+//     Because the DMA destination is lane-linear, each swizzle is applied to the per-lane SOURCE address and
+//     again on the fragment read; SQ_LDS_BANK_CONFLICT = 0 on every variant.
+//   * double-buffered LDS, one barrier per k-tile (NSTAGE = 2); NSTAGE > 2 = ring with counted vmcnt and raw
+//     barriers (tuning variants: measured no better than two co-resident 2-stage workgroups).
+//   * tile order: each XCD walks a contiguous range of a band-major order (see the kernel prologue).
+//   * narrow outputs split K over workgroups (zero-fill kernel + float atomics), split chosen by rounds.
+//   * gemm_bf16pp.h: an opt-in 256x256 ping-pong schedule on the same LDS images.
 //
-// Requirements checked by the host entry: K % 64 == 0, 16-byte aligned A and B.
+// Requirements checked by the host entries: K % 8 == 0, leading dimensions % 8 == 0, 16-byte aligned A and B.
 #include "sei_common.h"
 
 namespace {
