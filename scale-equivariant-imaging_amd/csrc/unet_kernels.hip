@@ -611,6 +611,208 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_bwd_weight_tiled_kernel(
     if (gb && threadIdx.x < Cout) atomicAdd(gb + threadIdx.x, accb);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Lane-per-channel forms for the default network (hidden = 32): the 32 lanes of a half-wave are the 32
+// hidden channels, so every access to the NHWC hidden tensor is a coalesced 128-byte row (the pixel-per-thread
+// kernels above read it with a 128-byte stride ACROSS lanes: 64 cache lines per load). A half-wave walks a
+// run of C3L_RUN pixels of one image row with a 3x3 register window sliding by one column per pixel.
+// -------------------------------------------------------------------------------------------------
+constexpr int C3L_RUN = 16;
+
+__device__ __forceinline__ float half_wave_sum(float v) {        // over the 32 lanes of this half-wave
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// forward hidden(32, NHWC) -> CS <= 4 channels: y[p, co] = bias[co] + sum_{t, ci} w[co][ci][t] x[p + t, ci] (+ res)
+template <int CS>
+__global__ __launch_bounds__(C3_THREADS) void conv3x3_c32_to_small_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    const float *__restrict__ res, float *__restrict__ y, int B, int H, int W, int nchw_out, int nruns_row,
+    int total_runs) {
+    const int ci = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    float wr[CS][9];
+#pragma unroll
+    for (int co = 0; co < CS; ++co)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[co][t] = w[((size_t)co * 32 + ci) * 9 + t];
+    for (int run = blockIdx.x * (C3_THREADS / 32) + grp; run < total_runs; run += gridDim.x * (C3_THREADS / 32)) {
+        const int jr = run % nruns_row, bi = run / nruns_row;
+        const int i = bi % H, b = bi / H;
+        const int j0 = jr * C3L_RUN, jn = min(C3L_RUN, W - j0);
+        const float *xb = x + (size_t)b * H * W * 32 + ci;
+        auto load = [&](int ii, int jj) -> float {
+            return (ii >= 0 && ii < H && jj >= 0 && jj < W) ? xb[((size_t)ii * W + jj) * 32] : 0.f;
+        };
+        float win[3][3];                                  // win[ky][slot], slot rotates with the column
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            win[ky][0] = load(i + ky - 1, j0 - 1);
+            win[ky][1] = load(i + ky - 1, j0);
+        }
+        float outv[C3L_RUN];                              // lane co < CS keeps channel co of the run
+#pragma unroll
+        for (int jb = 0; jb < C3L_RUN + 2; jb += 3) {
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int jl = jb + s3;
+                if (jl < C3L_RUN) {
+                    if (jl < jn) {
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) win[ky][(s3 + 2) % 3] = load(i + ky - 1, j0 + jl + 1);
+                    }
+                    float mine = 0.f;
+#pragma unroll
+                    for (int co = 0; co < CS; ++co) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) a = fmaf(wr[co][ky * 3 + kx], win[ky][(s3 + kx) % 3], a);
+                        a = half_wave_sum(a);
+                        if (ci == co) mine = a;
+                    }
+                    outv[jl] = mine;
+                }
+            }
+        }
+        if (ci < CS) {
+            const float bv = bias ? bias[ci] : 0.f;
+#pragma unroll
+            for (int jl = 0; jl < C3L_RUN; ++jl)
+                if (jl < jn) {
+                    const size_t o = img_index(nchw_out, b, ci, i, j0 + jl, CS, H, W);
+                    const float v = outv[jl] + bv;
+                    y[o] = res ? v + res[o] : v;
+                }
+        }
+    }
+}
+
+// weight gradient with the 32-channel tensor on the lanes:
+//   SMALL_IS_OUT = true : x hidden (NHWC, 32), gy small (CS channels, either layout): gw[co][lane][t], lane = ci
+//   SMALL_IS_OUT = false: gy hidden (NHWC, 32), x small (CS channels, either layout): gw[lane][ci][t], lane = co
+// Per workgroup: 8 half-wave partials folded through LDS, then one float atomic per output.
+template <int CS, bool SMALL_IS_OUT>
+__global__ __launch_bounds__(C3_THREADS) void conv3x3_wgrad_c32_kernel(
+    const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gw, float *__restrict__ gb,
+    int B, int H, int W, int nchw_small, int nruns_row, int total_runs) {
+    __shared__ float red[C3_THREADS / 32][CS * 9 + CS][32];
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    float acc[CS][9];
+#pragma unroll
+    for (int c = 0; c < CS; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    float accb[CS];                                      // bias gradient: SMALL_IS_OUT -> per co (lane 0 only);
+#pragma unroll                                           //                else -> accb[0] per lane (= co)
+    for (int c = 0; c < CS; ++c) accb[c] = 0.f;
+    const float *big = SMALL_IS_OUT ? x : gy, *small = SMALL_IS_OUT ? gy : x;
+    for (int run = blockIdx.x * (C3_THREADS / 32) + grp; run < total_runs; run += gridDim.x * (C3_THREADS / 32)) {
+        const int jr = run % nruns_row, bi = run / nruns_row;
+        const int i = bi % H, b = bi / H;
+        const int j0 = jr * C3L_RUN, jn = min(C3L_RUN, W - j0);
+        if (SMALL_IS_OUT) {
+            // window of x (hidden, per lane); gy values of the pixel are uniform over the lanes
+            const float *xb = big + (size_t)b * H * W * 32 + lane;
+            auto load = [&](int ii, int jj) -> float {
+                return (ii >= 0 && ii < H && jj >= 0 && jj < W) ? xb[((size_t)ii * W + jj) * 32] : 0.f;
+            };
+            float win[3][3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                win[ky][0] = load(i + ky - 1, j0 - 1);
+                win[ky][1] = load(i + ky - 1, j0);
+            }
+#pragma unroll
+            for (int jb = 0; jb < C3L_RUN + 2; jb += 3) {
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) {
+                    const int jl = jb + s3;
+                    if (jl < C3L_RUN && jl < jn) {
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) win[ky][(s3 + 2) % 3] = load(i + ky - 1, j0 + jl + 1);
+#pragma unroll
+                        for (int co = 0; co < CS; ++co) {
+                            const float g = small[img_index(nchw_small, b, co, i, j0 + jl, CS, H, W)];
+                            accb[co] += g;
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                                for (int kx = 0; kx < 3; ++kx)
+                                    acc[co][ky * 3 + kx] = fmaf(g, win[ky][(s3 + kx) % 3], acc[co][ky * 3 + kx]);
+                        }
+                    }
+                }
+            }
+        } else {
+            // gy (hidden, per lane = co) at the pixel; the 3x3xCS window of x is uniform over the lanes
+            const float *gb_ = big + ((size_t)(b * H + i) * W) * 32 + lane;
+            auto load = [&](int c, int ii, int jj) -> float {
+                return (ii >= 0 && ii < H && jj >= 0 && jj < W) ? small[img_index(nchw_small, b, c, ii, jj, CS, H, W)]
+                                                                : 0.f;
+            };
+            float win[CS][3][3];
+#pragma unroll
+            for (int c = 0; c < CS; ++c)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    win[c][ky][0] = load(c, i + ky - 1, j0 - 1);
+                    win[c][ky][1] = load(c, i + ky - 1, j0);
+                }
+#pragma unroll
+            for (int jb = 0; jb < C3L_RUN + 2; jb += 3) {
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) {
+                    const int jl = jb + s3;
+                    if (jl < C3L_RUN && jl < jn) {
+#pragma unroll
+                        for (int c = 0; c < CS; ++c)
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky) win[c][ky][(s3 + 2) % 3] = load(c, i + ky - 1, j0 + jl + 1);
+                        const float g = gb_[(size_t)(j0 + jl) * 32];
+                        accb[0] += g;
+#pragma unroll
+                        for (int c = 0; c < CS; ++c)
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                                for (int kx = 0; kx < 3; ++kx)
+                                    acc[c][ky * 3 + kx] = fmaf(g, win[c][ky][(s3 + kx) % 3], acc[c][ky * 3 + kx]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[grp][c * 9 + t][lane] = acc[c][t];
+        red[grp][CS * 9 + c][lane] = accb[c];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < (CS * 9 + CS) * 32; e += C3_THREADS) {
+        const int k = e >> 5, l = e & 31;
+        float s = 0.f;
+#pragma unroll
+        for (int gI = 0; gI < C3_THREADS / 32; ++gI) s += red[gI][k][l];
+        if (k < CS * 9) {
+            const int c = k / 9, t = k % 9;
+            // torch layout gw[co][ci][t]: SMALL_IS_OUT -> co = c, ci = l (Cin = 32); else co = l, ci = c (Cin = CS)
+            const size_t o = SMALL_IS_OUT ? ((size_t)c * 32 + l) * 9 + t : ((size_t)l * CS + c) * 9 + t;
+            atomicAdd(gw + o, s);
+        } else if (gb) {
+            const int c = k - CS * 9;
+            if (SMALL_IS_OUT) {
+                if (l == 0) atomicAdd(gb + c, s);          // every lane accumulated the same gy: take lane 0
+            } else if (c == 0) {
+                atomicAdd(gb + l, s);
+            }
+        }
+    }
+}
+
 // =================================================================================================
 // separable rank-2 spatial map, NHWC:  y[b,i',j',c] = sum_t sum_i L_t[i',i] sum_j R_t[j',j] x[b,i,j,c]
 // pass W: T[b][t][i][j'][c] = sum_j R_t[j',j] x[b,i,j,c]      (workspace, 2*B*Hi*Wo*C floats)
@@ -989,6 +1191,23 @@ extern "C" int sei_conv3x3_fwd(const float *x, const float *w, const float *bias
     const size_t npix = (size_t)B * H * W;
     const unsigned pgrid = capped_grid(npix, C3_THREADS, 8192);
     hipStream_t s = (hipStream_t)stream;
+    if (Cin == 32 && Cout <= 4 && !nchw_in && !transposed) {      // hidden -> image: lanes = hidden channels
+        const int nruns_row = (int)sei_ceil_div(W, C3L_RUN);
+        const size_t runs = (size_t)B * H * nruns_row;
+        SEI_REQUIRE(runs < ((size_t)1 << 31));
+        const dim3 grid(capped_grid(runs, C3_THREADS / 32, 65535));
+#define SEI_C3_LANES(CS)                                                                                            \
+    hipLaunchKernelGGL(conv3x3_c32_to_small_kernel<CS>, grid, dim3(C3_THREADS), 0, s, x, w, bias, res, y, B, H, W, \
+                       nchw_out ? 1 : 0, nruns_row, (int)runs);                                                     \
+    return sei_launch_status();
+        switch (Cout) {
+            case 1: SEI_C3_LANES(1)
+            case 2: SEI_C3_LANES(2)
+            case 3: SEI_C3_LANES(3)
+            default: SEI_C3_LANES(4)
+        }
+#undef SEI_C3_LANES
+    }
 #define SEI_C3_PIX(CO)                                                                                          \
     hipLaunchKernelGGL(conv3x3_pix_kernel<CO>, dim3(pgrid), dim3(C3_THREADS), lds, s, x, w, bias, res, y, B, H, \
                        W, Cin, nchw_in ? 1 : 0, nchw_out ? 1 : 0, transposed ? 1 : 0);                          \
@@ -1012,6 +1231,38 @@ extern "C" int sei_conv3x3_bwd_weight(const float *x, const float *gy, float *gw
     SEI_REQUIRE(x && gy && gw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
     const size_t npix = (size_t)B * H * W;
     const int KC = Cin * 9;
+    {   // the two real layers of the default network: lanes = the 32 hidden channels
+        const bool small_out = Cin == 32 && Cout <= 4 && !nchw_x, small_in = Cout == 32 && Cin <= 4 && !nchw_gy;
+        if (small_out || small_in) {
+            const int nruns_row = (int)sei_ceil_div(W, C3L_RUN);
+            const size_t runs = (size_t)B * H * nruns_row;
+            SEI_REQUIRE(runs < ((size_t)1 << 31));
+            // ~512 workgroups: every CU busy, few atomics per output
+            const dim3 grid(capped_grid(runs, (C3_THREADS / 32) * (int)sei_ceil_div(runs, (size_t)512 * 8), 65535));
+            hipStream_t st = (hipStream_t)stream;
+            const int CSv = small_out ? Cout : Cin, lay = small_out ? (nchw_gy ? 1 : 0) : (nchw_x ? 1 : 0);
+#define SEI_C3_WG(CS, OUT)                                                                                          \
+    hipLaunchKernelGGL((conv3x3_wgrad_c32_kernel<CS, OUT>), grid, dim3(C3_THREADS), 0, st, x, gy, gw, gb, B, H, W, \
+                       lay, nruns_row, (int)runs);                                                                  \
+    return sei_launch_status();
+            if (small_out) {
+                switch (CSv) {
+                    case 1: SEI_C3_WG(1, true)
+                    case 2: SEI_C3_WG(2, true)
+                    case 3: SEI_C3_WG(3, true)
+                    default: SEI_C3_WG(4, true)
+                }
+            } else {
+                switch (CSv) {
+                    case 1: SEI_C3_WG(1, false)
+                    case 2: SEI_C3_WG(2, false)
+                    case 3: SEI_C3_WG(3, false)
+                    default: SEI_C3_WG(4, false)
+                }
+            }
+#undef SEI_C3_WG
+        }
+    }
     if (Cout * KC <= 8 * C3_THREADS) {
         int P = 128;
         while (P > 8 && (size_t)P * (Cout + KC) * sizeof(float) > 48 * 1024) P /= 2;
