@@ -1,0 +1,17 @@
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scale-equivariant-imaging_amd"))
+import _native as N
+def timeit(fn, iters=30):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+for lvl in range(5):
+    M = 64 * (48 >> lvl if lvl < 4 else 3) ** 2; Nn = 128 << (2 * lvl)
+    X = torch.randn((M, Nn), device="cuda").bfloat16(); out = torch.zeros(Nn, device="cuda")
+    t = timeit(lambda: N.call("sei_colsum_bf16", X.data_ptr(), out.data_ptr(), M, Nn))
+    ref = X.double().sum(0); out.zero_(); N.call("sei_colsum_bf16", X.data_ptr(), out.data_ptr(), M, Nn)
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    print(f"M={M} N={Nn}: {t:6.1f} us  {M*Nn*2/t/1e6:6.2f} TB/s  err {err:.1e}")
