@@ -65,6 +65,54 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const T *__restrict
         }
 }
 
+// f32 (R, C) -> bf16 copy (+ optional column sums of the un-rounded input), no transpose: a lane owns 4
+// consecutive columns (float4 in, 8 bytes out) and walks rows, 4 in flight; the row sub-groups of a workgroup
+// are folded through LDS and the column sums leave as coalesced atomics (one per column per workgroup).
+__global__ __launch_bounds__(256) void cast_colsum_kernel(const float *__restrict__ x,
+                                                          unsigned short *__restrict__ x16,
+                                                          float *__restrict__ colsum, size_t R, int C, int tpr,
+                                                          size_t rows_per_block) {
+    __shared__ float red[256 * 4];
+    const int rsubs = 256 / tpr;
+    const int cl = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const int cq = blockIdx.y * tpr + cl;                       // column quad: columns 4*cq .. 4*cq+3
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto emit = [&](size_t r, const float4 v) {
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        uint2 o;
+        o.x = (unsigned)to_bf(v.x) | ((unsigned)to_bf(v.y) << 16);
+        o.y = (unsigned)to_bf(v.z) | ((unsigned)to_bf(v.w) << 16);
+        *reinterpret_cast<uint2 *>(x16 + r * C + 4 * (size_t)cq) = o;
+    };
+    if (4 * cq < C) {
+        const float *col = x + 4 * (size_t)cq;
+        size_t r = r0 + rsub;
+        for (; r + 3 * (size_t)rsubs < r1; r += 4 * (size_t)rsubs) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(col + r * C);
+            const float4 v1 = *reinterpret_cast<const float4 *>(col + (r + rsubs) * C);
+            const float4 v2 = *reinterpret_cast<const float4 *>(col + (r + 2 * (size_t)rsubs) * C);
+            const float4 v3 = *reinterpret_cast<const float4 *>(col + (r + 3 * (size_t)rsubs) * C);
+            emit(r, v0); emit(r + rsubs, v1); emit(r + 2 * (size_t)rsubs, v2); emit(r + 3 * (size_t)rsubs, v3);
+        }
+        for (; r < r1; r += rsubs) emit(r, *reinterpret_cast<const float4 *>(col + r * C));
+    }
+    if (!colsum) return;                                        // uniform over the workgroup
+    const int width = tpr * 4;
+    red[rsub * width + cl * 4 + 0] = s.x;
+    red[rsub * width + cl * 4 + 1] = s.y;
+    red[rsub * width + cl * 4 + 2] = s.z;
+    red[rsub * width + cl * 4 + 3] = s.w;
+    __syncthreads();
+    const int c0 = blockIdx.y * width;
+    for (int e = threadIdx.x; e < width; e += 256) {
+        if (c0 + e >= C) break;
+        float t = 0.f;
+        for (int q = 0; q < rsubs; ++q) t += red[q * width + e];
+        atomicAdd(colsum + c0 + e, t);
+    }
+}
+
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -264,6 +312,18 @@ extern "C" int sei_cast_transpose_bf16(const void *x, int x_is_bf16, uint16_t *x
                                        int ldt, float *colsum, void *stream) {
     SEI_REQUIRE(x && (x16 || xt16 || colsum) && R > 0 && C > 0 && ldt >= R);
     SEI_REQUIRE(!(x_is_bf16 && x16));
+    if (!x_is_bf16 && x16 && !xt16 && C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(x16) & 7) == 0) {            // plain cast (+ column sums): streaming kernel
+        const int quads = C / 4;
+        int tpr = 1;
+        while (tpr < quads && tpr < 256) tpr <<= 1;
+        const unsigned col_blocks = (unsigned)sei_ceil_div(quads, tpr);
+        size_t rpb = (size_t)(256 / tpr) * 4;
+        while (sei_ceil_div((size_t)R, rpb) * col_blocks > 512 && rpb < (size_t)R) rpb *= 2;
+        hipLaunchKernelGGL(cast_colsum_kernel, dim3((unsigned)sei_ceil_div((size_t)R, rpb), col_blocks), dim3(256), 0,
+                           (hipStream_t)stream, (const float *)x, x16, colsum, (size_t)R, C, tpr, rpb);
+        return sei_launch_status();
+    }
     // the grid covers ldt rows so that the zero padding of xt16 is written too
     dim3 grid((unsigned)sei_ceil_div(C, 64), (unsigned)sei_ceil_div(xt16 ? ldt : R, 64));
     if (x_is_bf16)

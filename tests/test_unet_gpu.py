@@ -588,3 +588,19 @@ def test_gemm_bf16nt_bias_rowscale_and_weighted_colsum(ops, M, N, K):
     gb = torch.ones(N, device="cuda")
     ops.colsum_into(gb, go, row_weight=s)
     assert relerr(gb, 1.0 + (go.double() * s.double()[:, None]).sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("M,N", [(147456, 128), (9216, 2048), (576, 32768), (1000, 24), (333, 50), (77, 7)])
+def test_bf16_cast_and_column_sums(ops, M, N):
+    """sei_colsum_bf16 (16-byte lanes / scalar fallback) and the streaming cast + column-sum pass."""
+    gen = torch.Generator().manual_seed(M + N)
+    X = torch.randn((M, N), generator=gen)
+    X16 = X.bfloat16().cuda()
+    acc = torch.full((N,), 2.0, device="cuda")
+    ops.colsum16_into(acc, X16)
+    assert relerr(acc, 2.0 + X16.double().sum(0)) < 2e-6
+    cs = torch.full((N,), -1.0, device="cuda")
+    Y16 = ops.cast16(X.cuda(), colsum_into_=cs)
+    assert torch.equal(Y16.cpu(), X.bfloat16())
+    assert relerr(cs, -1.0 + X.double().sum(0)) < 2e-6
+    assert torch.equal(ops.cast16(X.cuda()).cpu(), X.bfloat16())

@@ -15,3 +15,13 @@ for lvl in range(5):
     ref = X.double().sum(0); out.zero_(); N.call("sei_colsum_bf16", X.data_ptr(), out.data_ptr(), M, Nn)
     err = float((out.double() - ref).abs().max() / ref.abs().max())
     print(f"M={M} N={Nn}: {t:6.1f} us  {M*Nn*2/t/1e6:6.2f} TB/s  err {err:.1e}")
+print("cast16 + colsum (f32 -> bf16):")
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scale-equivariant-imaging_amd"))
+for lvl in range(5):
+    M = 64 * (48 >> lvl if lvl < 4 else 3) ** 2
+    for mult in (1, 4):
+        C = (32 << (2 * lvl)) * mult
+        X = torch.randn((M, C), device="cuda"); Y = torch.empty((M, C), dtype=torch.bfloat16, device="cuda"); cs = torch.zeros(C, device="cuda")
+        t1 = timeit(lambda: N.call("sei_cast_transpose_bf16", X.data_ptr(), 0, Y.data_ptr(), None, M, C, M, cs.data_ptr()))
+        t2 = timeit(lambda: N.call("sei_cast_transpose_bf16", X.data_ptr(), 0, Y.data_ptr(), None, M, C, M, None))
+        print(f"M={M} C={C}: with colsum {t1:6.1f} us ({M*C*6/t1/1e6:5.2f} TB/s), cast only {t2:6.1f} us")
