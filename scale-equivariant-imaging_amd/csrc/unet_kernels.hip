@@ -792,23 +792,32 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_wgrad_c32_kernel(
         red[grp][CS * 9 + c][lane] = accb[c];
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < (CS * 9 + CS) * 32; e += C3_THREADS) {
-        const int k = e >> 5, l = e & 31;
-        float s = 0.f;
+    // consecutive threads own consecutive gw addresses (torch layout gw[co][ci][t]): contiguous float atomics --
+    // lane-strided ones cost one L2 round per instruction and cache line, serialised over all workgroups
+    constexpr int NOUT = CS * 32 * 9;
+    for (int o = threadIdx.x; o < NOUT; o += C3_THREADS) {
+        const int t = o % 9, rest = o / 9;
+        int c, l;                                         // c: the small channel, l: the lane (hidden channel)
+        if (SMALL_IS_OUT) {                               // o = (co * 32 + ci) * 9 + t, co = c, ci = l
+            l = rest & 31;
+            c = rest >> 5;
+        } else {                                          // o = (co * CS + ci) * 9 + t, co = l, ci = c
+            c = rest % CS;
+            l = rest / CS;
+        }
+        float sum = 0.f;
 #pragma unroll
-        for (int gI = 0; gI < C3_THREADS / 32; ++gI) s += red[gI][k][l];
-        if (k < CS * 9) {
-            const int c = k / 9, t = k % 9;
-            // torch layout gw[co][ci][t]: SMALL_IS_OUT -> co = c, ci = l (Cin = 32); else co = l, ci = c (Cin = CS)
-            const size_t o = SMALL_IS_OUT ? ((size_t)c * 32 + l) * 9 + t : ((size_t)l * CS + c) * 9 + t;
-            atomicAdd(gw + o, s);
-        } else if (gb) {
-            const int c = k - CS * 9;
-            if (SMALL_IS_OUT) {
-                if (l == 0) atomicAdd(gb + c, s);          // every lane accumulated the same gy: take lane 0
-            } else if (c == 0) {
-                atomicAdd(gb + l, s);
-            }
+        for (int gI = 0; gI < C3_THREADS / 32; ++gI) sum += red[gI][c * 9 + t][l];
+        atomicAdd(gw + o, sum);
+    }
+    if (gb) {
+        const int nb = SMALL_IS_OUT ? CS : 32;
+        if ((int)threadIdx.x < nb) {
+            float sum = 0.f;
+#pragma unroll
+            for (int gI = 0; gI < C3_THREADS / 32; ++gI)
+                sum += SMALL_IS_OUT ? red[gI][CS * 9 + threadIdx.x][0] : red[gI][CS * 9][threadIdx.x];
+            atomicAdd(gb + threadIdx.x, sum);
         }
     }
 }
