@@ -479,13 +479,13 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
         case 4: return launch_nt<4, 2, 2, 4>(g, s);      // 256 x 256 (tuning aid)
         default: break;
     }
-    // Tile choice (measured on MI355X, tools/exp_dw.py): 128x128 runs two workgroups per CU, which hides
-    // each block's load latency and epilogue behind the other's MFMAs, and is the best or within 2 % of
-    // the best on every U-Net shape except long-K GEMMs whose row count is a multiple of 192, where
-    // 192x256 wins by ~10 %. 96x256 avoids 25 % padding when M = 96 (mod 192) (the B-pass: 288 rows).
-    // A 256x256 tile (1 block/CU, 172 VGPRs) measured ~115 TFLOP/s on every shape and is not used.
-    if (N >= 256 && M % 192 == 0 && K >= 2048) return launch_nt<3, 2, 2, 4>(g, s);       // 192 x 256
-    if (N >= 256 && M % 128 != 0 && M % 96 == 0) return launch_nt<3, 1, 1, 8>(g, s);     //  96 x 256
+    // Tile choice (measured on MI355X with the band-major tile order, tools/exp_tiles576.py): 128x128 runs two
+    // workgroups per CU, which hides each block's load latency and epilogue behind the other's MFMAs, and is
+    // the best or within a few % of the best wherever there are many row tiles (M = 1152 / 2304 x 8192 x 2048:
+    // 110 vs 144 us for 192x256). Skinny outputs (the 8192-channel bottleneck: M = 288 or 576 rows against
+    // N = 8192 / 32768) are weight-streaming: there 192x256 wins (M = 288: 221 vs 309 us), padding included,
+    // and 96x256 never does. A 256x256 tile on this loop needs the rolled epilogue of gemm_bf16pp.h.
+    if (N >= 256 && K >= 2048 && M <= 768) return launch_nt<3, 2, 2, 4>(g, s);                // 192 x 256
     return launch_nt<2, 1, 2, 4>(g, s);                                                  // 128 x 128
 }
 
