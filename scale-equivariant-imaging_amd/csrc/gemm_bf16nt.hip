@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
     static_assert(WM * WN == NWAVES, "8 waves per workgroup");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static_assert(!ARM || BM == 128, "a reduction-major A tile is 64 x 128");
-    static_assert(!BRM || BN == 128, "a reduction-major B tile is 64 x 128");
+    static_assert(!BRM || BN % 128 == 0, "a reduction-major B tile is BN/128 images of 64 k-rows x 128 columns");
     constexpr int STAGE = (BM + BN) * ROW_BYTES;
     __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
 
@@ -229,9 +229,14 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
     auto stage = [&](int k0, char *dst) {
         if constexpr (ARM) stage_tile_rmajor(g.A, g.A2, g.k_seg, g.lda, m0, M, k0, k_end, dst, wave, lane);
         else stage_tile<BM>(g.A, g.lda, m0, M, k0, k_end, dst, wave, lane);
-        if constexpr (BRM)
-            stage_tile_rmajor(g.B, g.B2, g.k_seg, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
-        else stage_tile<BN>(g.B, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
+        if constexpr (BRM) {
+#pragma unroll
+            for (int im = 0; im < BN / 128; ++im)           // 16 KB image per 128 columns
+                stage_tile_rmajor(g.B, g.B2, g.k_seg, g.ldb, n0 + 128 * im, N, k0, k_end,
+                                  dst + BM * ROW_BYTES + im * 16384, wave, lane);
+        } else {
+            stage_tile<BN>(g.B, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
+        }
     };
     const int sw = (li >> 1) & 7;                              // swizzle key of this lane's rows
     const int a_off = (wm * 32 * TM + li) * ROW_BYTES;
@@ -249,7 +254,10 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if constexpr (BRM) b[j] = frag_rmajor(now + BM * ROW_BYTES, s, lane, wn * 32 * TN + 32 * j);
+                if constexpr (BRM) {
+                    const int c0 = wn * 32 * TN + 32 * j;
+                    b[j] = frag_rmajor(now + BM * ROW_BYTES + (c0 >> 7) * 16384, s, lane, c0 & 127);
+                }
                 else b[j] = *reinterpret_cast<const bf16x8 *>(now + b_off + j * 32 * ROW_BYTES + pc);
             }
 #pragma unroll
@@ -470,7 +478,12 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     // a reduction-major operand fixes the tile at 128 x 128 (its LDS rows are 256 bytes = 128 columns)
     if (a_rmajor && b_rmajor) return launch_nt<2, 1, 2, 4, true, true>(g, s);
     if (a_rmajor) return launch_nt<2, 1, 2, 4, true, false>(g, s);
-    if (b_rmajor) return launch_nt<2, 1, 2, 4, false, true>(g, s);
+    if (b_rmajor) {
+        // skinny data gradients (the bottleneck levels): 192 x 256 with two 128-column images of the weight
+        if (g_force_tile != 1 && N >= 2048 && K >= 2048 && M <= 768)
+            return launch_nt<3, 2, 2, 4, false, true>(g, s);
+        return launch_nt<2, 1, 2, 4, false, true>(g, s);
+    }
     switch (g_force_tile) {
         case 1: return launch_nt<2, 1, 2, 4>(g, s);      // 128 x 128
         case 2: return launch_nt<2, 2, 2, 4>(g, s);      // 128 x 256
@@ -485,7 +498,7 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     // 110 vs 144 us for 192x256). Skinny outputs (the 8192-channel bottleneck: M = 288 or 576 rows against
     // N = 8192 / 32768) are weight-streaming: there 192x256 wins (M = 288: 221 vs 309 us), padding included,
     // and 96x256 never does. A 256x256 tile on this loop needs the rolled epilogue of gemm_bf16pp.h.
-    if (N >= 256 && K >= 2048 && M <= 768) return launch_nt<3, 2, 2, 4>(g, s);                // 192 x 256
+    if (N >= 2048 && K >= 2048 && M <= 768) return launch_nt<3, 2, 2, 4>(g, s);               // 192 x 256
     return launch_nt<2, 1, 2, 4>(g, s);                                                  // 128 x 128
 }
 
