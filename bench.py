@@ -94,6 +94,9 @@ def main():
                     help="deblurring = BASELINE configs[1] (the headline); sr = configs[2] (x4 by default), a "
                          "secondary series: pairs (48r x 48r, 48 x 48) as the reference's dataset hands them over")
     ap.add_argument("--sr-factor", type=int, default=4)
+    ap.add_argument("--full256", action="store_true",
+                    help="secondary series of SURVEY 8d: --no-Loss__crop_training_pairs, the network sees the whole "
+                         "256x256 pair (28x the pixels of the default 48-crop); use a small --batch")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                     help="arithmetic type of the 1x1-conv GEMMs (f32 = parity mode, bf16 = throughput mode)")
     opt = ap.parse_args()
@@ -113,6 +116,8 @@ def main():
 
     sr = opt.task == "sr"
     args = reference_args(device, opt.hidden, opt.scales, opt.task, opt.sr_factor if sr else None)
+    if opt.full256:
+        args.Loss__crop_training_pairs = False
     _ops.set_compute_dtype(opt.dtype)
     torch.manual_seed(0)
     physics = get_physics(args, device)
@@ -149,7 +154,8 @@ def main():
     step = eager_step
     if opt.graph:
         from graphs import GraphedLossStep
-        graphed = GraphedLossStep(loss_fn, model, optimizer, (opt.batch, 3, CROP, CROP))
+        ys = 256 if opt.full256 else CROP
+        graphed = GraphedLossStep(loss_fn, model, optimizer, (opt.batch, 3, ys, ys))
 
         def step():
             loss = graphed(x, y)
@@ -211,7 +217,7 @@ def main():
                    if opt.dtype == "bf16" else "gemm_f32_kernel<*>")
         traffic, traffic_src = None, None
         pmc_file = os.path.join(ROOT, "profiles", "r01_e_pmc_gemm.json")
-        if opt.dtype == "bf16" and not sr and opt.hidden == 32 and opt.scales == 5 and opt.batch == 32 and os.path.exists(pmc_file):
+        if opt.dtype == "bf16" and not sr and not opt.full256 and opt.hidden == 32 and opt.scales == 5 and opt.batch == 32 and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))                 # PMC counters cannot be read live; see the file
             traffic = round(pmc["traffic_bytes_per_launch"])
             traffic_src = ("bytes beyond L2 per GEMM launch from committed rocprofv3 --pmc passes of this command "
@@ -237,8 +243,9 @@ def main():
                                     f"(SURE + scale-EI), pairs {side}x{side} / 48x48, ConvolutionalModel "
                                     f"hidden={opt.hidden} scales={opt.scales}") if sr else
                                    ("BASELINE configs[1]: deblurring Gaussian_R2 noise=5, proposed loss (SURE + "
-                                    "scale-EI), 256x256 pairs cropped to 48 in Loss.forward, ConvolutionalModel "
-                                    f"hidden={opt.hidden} scales={opt.scales}"),
+                                    "scale-EI), 256x256 pairs " +
+                                    ("NOT cropped (full-256 series)" if opt.full256 else "cropped to 48 in Loss.forward") +
+                                    f", ConvolutionalModel hidden={opt.hidden} scales={opt.scales}"),
                        "parameters": nparams, "batch_per_gpu": opt.batch, "global_batch": opt.batch * world,
                        "parallelism": f"dp{world}", "optimizer": "Adam (fused, flat bucket)",
                        "grad_allreduce": None if world == 1 else str(comm_dtype).replace("torch.", ""),
