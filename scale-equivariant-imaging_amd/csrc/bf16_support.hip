@@ -212,6 +212,87 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_wide_kernel(const float *__re
     }
 }
 
+// Wide rows with 16-byte lanes: RW waves (1, 2 or 4) own a row, each lane up to 8 float4 (C <= 2048 * RW,
+// C % 4 == 0); row data lives in registers (one HBM read), statistics by wave shuffles (+ one LDS exchange
+// when RW > 1). 4 / RW rows per workgroup.
+template <int RW>
+__global__ __launch_bounds__(256) void ln_fwd_bf16_vec_kernel(const float *__restrict__ x,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta,
+                                                              unsigned short *__restrict__ y,
+                                                              float *__restrict__ mean, float *__restrict__ rstd,
+                                                              size_t rows, int C, float eps) {
+    __shared__ float part[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave % RW, rsub = wave / RW;                 // wave within the row, row within the workgroup
+    constexpr int RPB = 4 / RW, STRIDE = 64 * RW;
+    const int nq = C / 4;
+    const float invC = 1.0f / (float)C;
+    for (size_t row0 = (size_t)blockIdx.x * RPB; row0 < rows; row0 += (size_t)gridDim.x * RPB) {
+        const size_t row = row0 + rsub;
+        const bool live = row < rows;
+        const float4 *xr = reinterpret_cast<const float4 *>(x + (live ? row : 0) * C);
+        float4 v[8];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int q = lane + 64 * wr + e * STRIDE;
+            v[e] = (live && q < nq) ? xr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+        }
+        s = sei_wave_sum(s);
+        s = __shfl(s, 0, 64);
+        if (RW > 1) {
+            if (lane == 0) part[0][wave] = s;
+            __syncthreads();
+            s = 0.f;
+#pragma unroll
+            for (int k = 0; k < RW; ++k) s += part[0][rsub * RW + k];
+        }
+        const float mu = s * invC;
+        float qq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int q = lane + 64 * wr + e * STRIDE;
+            if (q < nq) {
+                const float dx = v[e].x - mu, dy = v[e].y - mu, dz = v[e].z - mu, dw = v[e].w - mu;
+                qq = fmaf(dx, dx, qq); qq = fmaf(dy, dy, qq); qq = fmaf(dz, dz, qq); qq = fmaf(dw, dw, qq);
+            }
+        }
+        qq = sei_wave_sum(qq);
+        qq = __shfl(qq, 0, 64);
+        if (RW > 1) {
+            if (lane == 0) part[1][wave] = qq;
+            __syncthreads();
+            qq = 0.f;
+#pragma unroll
+            for (int k = 0; k < RW; ++k) qq += part[1][rsub * RW + k];
+        }
+        const float rs = 1.0f / sqrtf(qq * invC + eps);
+        if (live) {
+            uint2 *yr = reinterpret_cast<uint2 *>(y + row * C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int q = lane + 64 * wr + e * STRIDE;
+                if (q < nq) {
+                    const float4 gm = reinterpret_cast<const float4 *>(gamma)[q], bt = reinterpret_cast<const float4 *>(beta)[q];
+                    uint2 o;
+                    o.x = (unsigned)f2bf(fmaf((v[e].x - mu) * rs, gm.x, bt.x)) |
+                          ((unsigned)f2bf(fmaf((v[e].y - mu) * rs, gm.y, bt.y)) << 16);
+                    o.y = (unsigned)f2bf(fmaf((v[e].z - mu) * rs, gm.z, bt.z)) |
+                          ((unsigned)f2bf(fmaf((v[e].w - mu) * rs, gm.w, bt.w)) << 16);
+                    yr[q] = o;
+                }
+            }
+            if (lane == 0 && wr == 0) {
+                mean[row] = mu;
+                rstd[row] = rs;
+            }
+        }
+        if (RW > 1) __syncthreads();                            // part[] is reused by the next row group
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short *__restrict__ X,
                                                           float *__restrict__ out, size_t M, int N,
                                                           size_t rows_per_block) {
@@ -340,6 +421,21 @@ extern "C" int sei_ln_fwd_bf16(const float *x, const float *gamma, const float *
     SEI_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0);
     if (C > 8192) return SEI_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
+    if (C > 512 && C % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) |
+                                   reinterpret_cast<uintptr_t>(beta)) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(y) & 7) == 0) {
+        const int rw = C <= 2048 ? 1 : (C <= 4096 ? 2 : 4);
+        size_t grid = sei_ceil_div(rows, (size_t)(4 / rw));
+        if (grid > 8192) grid = 8192;
+#define SEI_LN_VEC16(RW)                                                                                          \
+    hipLaunchKernelGGL(ln_fwd_bf16_vec_kernel<RW>, dim3((unsigned)grid), dim3(256), 0, s, x, gamma, beta, y, mean, \
+                       rstd, rows, C, eps);                                                                        \
+    return sei_launch_status();
+        if (rw == 1) { SEI_LN_VEC16(1) }
+        if (rw == 2) { SEI_LN_VEC16(2) }
+        SEI_LN_VEC16(4)
+#undef SEI_LN_VEC16
+    }
     if (C > 512) {
         size_t grid = rows < 8192 ? rows : 8192;
         hipLaunchKernelGGL(ln_fwd_bf16_wide_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd,

@@ -604,3 +604,19 @@ def test_bf16_cast_and_column_sums(ops, M, N):
     assert torch.equal(Y16.cpu(), X.bfloat16())
     assert relerr(cs, -1.0 + X.double().sum(0)) < 2e-6
     assert torch.equal(ops.cast16(X.cuda()).cpu(), X.bfloat16())
+
+
+@pytest.mark.parametrize("rows,C", [(40, 2048), (9, 8192), (130, 4096), (701, 1024), (50, 520), (5, 700), (300, 512),
+                                    (500, 32), (2304, 2048), (577, 8192)])
+def test_layernorm_fwd_bf16_output(ops, rows, C):
+    """sei_ln_fwd_bf16 (group / 16-byte-lane / legacy wide kernels): bf16 output within one rounding of the
+    float64 LayerNorm, float32 statistics as the f32 kernel's."""
+    gen = torch.Generator().manual_seed(rows * 3 + C)
+    x = torch.randn((rows, C), generator=gen) * 2 + 0.5
+    gamma, beta = torch.randn(C, generator=gen), torch.randn(C, generator=gen)
+    y16, mean, rstd = ops.layer_norm16(x.cuda(), gamma.cuda(), beta.cuda())
+    ref = F.layer_norm(x.double(), (C,), gamma.double(), beta.double(), eps=1e-6)
+    assert y16.dtype == torch.bfloat16
+    assert float((y16.double().cpu() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) + 1e-6
+    assert relerr(mean, x.double().mean(1)) < 1e-5
+    assert relerr(rstd, 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-6)) < 1e-5
