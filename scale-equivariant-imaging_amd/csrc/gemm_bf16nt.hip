@@ -394,7 +394,9 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         constexpr size_t STAGE_BYTES = NSTAGE * (size_t)(BM + BN) * ROW_BYTES;
         const size_t slots = 256 * (STAGE_BYTES <= 80 * 1024 ? 2 : 1);       // workgroups resident on 256 CUs
         const size_t ktiles = sei_ceil_div(g.K, BK);
-        const size_t max_sk = ktiles / 4 < 16 ? ktiles / 4 : 16;
+        // up to 256 splits: a one-tile weight gradient of the shallow levels (128 x 32 outputs, K = 221,184 =
+        // 3456 k-tiles) capped at 16 splits kept 16 CUs busy for 147 us; its atomics are contiguous and few
+        const size_t max_sk = ktiles / 4 < 256 ? ktiles / 4 : 256;
         const double overhead = 6.0 + (g.epilogue == SEI_EPI_ACCUM ? 0.0 : 2.0);   // in k-tile units
         double best = 1e30;
         size_t best_sk = 1;
