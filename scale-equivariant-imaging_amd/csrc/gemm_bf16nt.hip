@@ -156,12 +156,22 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
     // `band` tile columns, row by row inside a band): the ~32-64 tiles an XCD has in flight then form a
     // near-square patch sharing A rows and B columns through its L2. (A strip order -- one tile column per
     // XCD -- measured 52 % L2 hits on a 4096^3 GEMM: 16x the unique bytes through the fabric.)
+    // Launches with few tiles (tiles_per_xcd == 0: one-tile weight gradients split 200-fold over K) use the
+    // plain order instead -- consecutive blocks = consecutive tiles, then the next K split -- so that the splits
+    // of a tile spread over all XCDs (with the XCD order every working block had bid % 8 == 0: one XCD).
     int bid = blockIdx.x;
-    const int per_split = 8 * g.tiles_per_xcd;
-    const int zs = bid / per_split;
-    bid -= zs * per_split;
-    const int ord = (bid & 7) * g.tiles_per_xcd + (bid >> 3);
-    if ((bid >> 3) >= g.tiles_per_xcd || ord >= g.tiles_m * g.tiles_n) return;   // block-uniform, before any barrier
+    int zs, ord;
+    if (g.tiles_per_xcd == 0) {
+        const int ntile = g.tiles_m * g.tiles_n;
+        zs = bid / ntile;
+        ord = bid - zs * ntile;
+    } else {
+        const int per_split = 8 * g.tiles_per_xcd;
+        zs = bid / per_split;
+        bid -= zs * per_split;
+        ord = (bid & 7) * g.tiles_per_xcd + (bid >> 3);
+        if ((bid >> 3) >= g.tiles_per_xcd || ord >= g.tiles_m * g.tiles_n) return;   // block-uniform, before any barrier
+    }
     int tm_i, tn_i;
     {
         const int band_tiles = g.tiles_m * g.band;
@@ -382,7 +392,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         if (band < 1) band = 1;
         if (band > g.tiles_n) band = g.tiles_n;
         g.band = band;
-        g.tiles_per_xcd = (int)sei_ceil_div(tiles, 8);
+        g.tiles_per_xcd = tiles < 64 ? 0 : (int)sei_ceil_div(tiles, 8);      // 0 = plain order (few tiles)
     }
     g.splitk = 1;
     g.k_per_split = g.K;
@@ -420,8 +430,9 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         if ((reinterpret_cast<uintptr_t>(g.D32) & 15) != 0) return SEI_ERR_BAD_ARG;
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
-    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE>),
-                       dim3((unsigned)(8 * (size_t)g.tiles_per_xcd * g.splitk)), dim3(NT), 0, s, g);
+    const size_t per_split = g.tiles_per_xcd ? 8 * (size_t)g.tiles_per_xcd : tiles;
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE>), dim3((unsigned)(per_split * g.splitk)),
+                       dim3(NT), 0, s, g);
     return sei_launch_status();
 }
 
