@@ -155,12 +155,17 @@ def main():
     if opt.graph:
         from graphs import GraphedLossStep
         ys = 256 if opt.full256 else CROP
-        graphed = GraphedLossStep(loss_fn, model, optimizer, (opt.batch, 3, ys, ys))
+        early = reducer is not None and os.environ.get("SEI_NO_EARLY_RELEASE") != "1"
+        graphed = GraphedLossStep(loss_fn, model, optimizer, (opt.batch, 3, ys, ys), early_release=early)
+        early_event = None
+        if early and graphed.early_grads is not None:        # the bottleneck block's gradients leave early
+            early_event = graphed.early_grads[0]
+            reducer.set_early_range(graphed.early_grads[1:])
 
         def step():
             loss = graphed(x, y)
             if reducer is not None:
-                reducer.reduce_async()
+                reducer.reduce_async(early=early_event)
             optimizer.step()
             return loss
 
@@ -249,7 +254,7 @@ def main():
                        "parameters": nparams, "batch_per_gpu": opt.batch, "global_batch": opt.batch * world,
                        "parallelism": f"dp{world}", "optimizer": "Adam (fused, flat bucket)",
                        "grad_allreduce": None if world == 1 else str(comm_dtype).replace("torch.", ""),
-                       "launch": "hipGraph replay of forward+backward" if opt.graph else "eager",
+                       "launch": ("hipGraph replay of forward+backward" + (", early gradient release" if opt.graph and world > 1 and early_event is not None else "")) if opt.graph else "eager",
                        "final_loss": loss_value},
             "roofline": roofline,
         }

@@ -37,6 +37,15 @@ int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
 
+/* Events that cross a hipGraph boundary: sei_event_record_external() issued on a capturing stream becomes an
+ * event-record node of the graph (hipEventRecordExternal), recorded anew at that point of every replay;
+ * sei_stream_wait_event() on another (non-captured) stream, issued after the replay was enqueued, waits for it.
+ * `stream` arguments are hipStream_t; `event` is an opaque handle from sei_event_create. */
+int sei_event_create(void **event);
+int sei_event_destroy(void *event);
+int sei_event_record_external(void *event, void *stream);
+int sei_stream_wait_event(void *stream, void *event);
+
 /* ---------------------------------------------------------------------------------------------
  * Physics: circular blur.
  * Replaces BlurV2.A, src/physics/blur/__init__.py:205-223 (rfft2 * OTF -> irfft2 == circular

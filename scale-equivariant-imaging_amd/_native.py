@@ -22,6 +22,10 @@ _P, _I, _F, _Z, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t, _c.c_longlo
 # tests/test_abi.py checks this table against the header and against the built library.
 SIGNATURES = {
     "sei_abi_version": [],
+    "sei_event_create": [_P],
+    "sei_event_destroy": [_P],
+    "sei_event_record_external": [_P, _P],
+    "sei_stream_wait_event": [_P, _P],
     "sei_build_target": [_c.c_char_p, _I],
     "sei_blur_sep_circ": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_blur_dense_circ": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -130,3 +134,35 @@ def call(name, *args):
         else:
             what = f"hipError_t {rc}"
         raise NativeLibraryError(f"{name} failed: {what}")
+
+
+class ExternalEvent:
+    """A HIP event that may be recorded inside a captured hipGraph and waited for from another stream
+    (what torch.cuda.Event(external=True) would be; PyTorch refuses that on ROCm)."""
+
+    def __init__(self):
+        handle = _c.c_void_p()
+        rc = lib().sei_event_create(_c.byref(handle))
+        if rc != 0:
+            raise NativeLibraryError(f"sei_event_create failed: {rc}")
+        self.handle = handle
+
+    def record(self, torch_stream=None):
+        s = (torch_stream or torch.cuda.current_stream()).cuda_stream
+        rc = lib().sei_event_record_external(self.handle, s)
+        if rc != 0:
+            raise NativeLibraryError(f"sei_event_record_external failed: hipError_t {rc}")
+
+    def wait(self, torch_stream=None):
+        """Make `torch_stream` (default: the current one) wait for the most recent record."""
+        s = (torch_stream or torch.cuda.current_stream()).cuda_stream
+        rc = lib().sei_stream_wait_event(s, self.handle)
+        if rc != 0:
+            raise NativeLibraryError(f"sei_stream_wait_event failed: hipError_t {rc}")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().sei_event_destroy(self.handle)
+        except Exception:
+            pass

@@ -21,7 +21,8 @@ import torch
 
 
 class GraphedLossStep:
-    def __init__(self, loss_module, model, optimizer, crop_shape, warmup=3, store_weight_grads=True):
+    def __init__(self, loss_module, model, optimizer, crop_shape, warmup=3, store_weight_grads=True,
+                 early_release=False):
         """loss_module: a `losses.Loss`; crop_shape: (B, 3, S, S) of the cropped measurement y."""
         self.loss_module = loss_module
         self.inner = loss_module.loss                # method-level loss working on cropped tensors
@@ -59,10 +60,37 @@ class GraphedLossStep:
         # The warm-up steps showed which gradients are written by the merged weight-gradient GEMMs; the
         # captured step stores those instead of accumulating and zeroes only the rest of the bucket.
         self.store_weight_grads = store_weight_grads and self.backbone.plan_weight_grad_store() is not None
+        # Early release of the largest gradients: an EXTERNAL event recorded inside the captured backward right
+        # after the two largest adjacent weight gradients (the bottleneck block: 83 % of the bucket at defaults)
+        # have been written; `early_grads` = (event, start, stop) in bucket elements, or None.
+        self.early_grads = None
+        if self.store_weight_grads and early_release:
+            self.early_grads = self._plan_early_release(_ops)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_loss = fwd_bwd()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.static_loss = fwd_bwd()
+        finally:
+            _ops.set_weight_grad_milestone(None, None)
         self.backbone.zero_grad_flat()
+
+    def _plan_early_release(self, _ops):
+        base, esz = self.backbone.flat_grads.data_ptr(), self.backbone.flat_grads.element_size()
+        total = self.backbone.flat_grads.numel()
+        views = sorted(((n, ptr) for ptr, n in _ops.weight_grad_views().items()
+                        if base <= ptr < base + total * esz), reverse=True)
+        if len(views) < 2:
+            return None
+        (n0, p0), (n1, p1) = views[0], views[1]
+        lo, hi = min(p0, p1), max(p0, p1)
+        lo_n = n0 if lo == p0 else n1
+        start, stop = (lo - base) // esz, (hi - base) // esz + (n0 if hi == p0 else n1)
+        if (hi - lo) // esz - lo_n >= 64 or (stop - start) < total // 4:       # not adjacent, or not worth it
+            return None
+        import _native
+        event = _native.ExternalEvent()
+        _ops.set_weight_grad_milestone({p0, p1}, event)
+        return (event, int(start), int(stop))
 
     def __call__(self, x, y):
         crop = self.loss_module.crop_fn

@@ -415,6 +415,7 @@ def begin_step(store=False):
     _DW["uses"] = 0
     _DW["arrivals"].clear()
     _DW["written"].clear()
+    _DW["milestone_done"] = False
     _DW["store"] = bool(store)
 
 
@@ -431,10 +432,30 @@ def weight_grad_views(reset=False):
     return seen
 
 
+def set_weight_grad_milestone(keys, event):
+    """Record `event` on the current stream right after the LAST of the gradients `keys` (data_ptrs) has been
+    launched in a step (GraphedLossStep: an external event inside the captured backward, after which the
+    bottleneck block's gradients -- most of the bucket -- are final and their all-reduce may start)."""
+    _DW["milestone"] = (frozenset(keys), event) if keys else None
+
+
 def _launch_weight_grad(grad2d, pairs):
     key = grad2d.data_ptr()
     store = _DW["store"] and key not in _DW["written"]
     _DW["written"].add(key)
+    try:
+        _launch_weight_grad_inner(grad2d, pairs, store)
+    finally:
+        ms = _DW.get("milestone")
+        if ms is not None and key in ms[0] and ms[0] <= _DW["written"] and not _DW.get("milestone_done"):
+            # every gradient of the milestone has had its (single, merged) launch of this step
+            if all(_DW["arrivals"].get(k, 0) >= max(_DW["uses"], 1) for k in ms[0]):
+                ms[1].record()
+                _DW["milestone_done"] = True
+
+
+def _launch_weight_grad_inner(grad2d, pairs, store):
+    key = grad2d.data_ptr()
     Np, Kp = grad2d.shape
     if len(pairs) == 2:
         (g1, x1), (g2, x2) = pairs

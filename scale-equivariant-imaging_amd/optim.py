@@ -43,7 +43,9 @@ class FlatAdam(torch.optim.Optimizer):
             grads_16 = grads.dtype == torch.bfloat16
         from models import _ops
         shadow = getattr(self.backbone, "flat_shadow", None) if _ops.get_compute_dtype() == "bf16" else None
-        for k, (s, e) in enumerate(bounds):
+        order = self.reducer.order if self.reducer is not None else range(len(bounds))
+        for k in order:                                   # chunks in the order their all-reduces complete
+            s, e = bounds[k]
             if self.reducer is not None:
                 self.reducer.wait(k)
             N.call("sei_adam_fused", flat[s:e].data_ptr(), grads[s:e].data_ptr(), int(grads_16),

@@ -54,37 +54,93 @@ class FlatGradientReducer:
     which lets the optimizer consume chunks in order while later ones are still on the wire.
     """
 
-    def __init__(self, flat_grads, chunk_mib=256, group=None, comm_dtype=torch.float32):
+    def __init__(self, flat_grads, chunk_mib=256, group=None, comm_dtype=torch.float32, early_range=None):
         """comm_dtype=torch.bfloat16 compresses the exchanged gradients (half the xGMI bytes): the f32
-        bucket is cast once into `self.comm`, which is what gets summed and what the optimizer reads."""
+        bucket is cast once into `self.comm`, which is what gets summed and what the optimizer reads.
+
+        early_range=(start, stop): a slice of the bucket whose gradients are final before the backward pass
+        ends (graphs.GraphedLossStep.early_grads); chunks never straddle its ends, and reduce_async(early=event)
+        exchanges it from a side stream as soon as `event` fires, under the rest of the backward."""
         self.flat = flat_grads
         self.group = group
         self.comm_dtype = comm_dtype
         self.comm = flat_grads if comm_dtype == flat_grads.dtype else torch.empty_like(flat_grads, dtype=comm_dtype)
-        self.bounds = chunk_bounds(flat_grads.numel(), max(1, (chunk_mib << 20) // self.comm.element_size()))
-        self._work = []
+        self._chunk = max(1, (chunk_mib << 20) // self.comm.element_size())
+        self._side = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
+        self.set_early_range(early_range)
 
-    def reduce_async(self):
-        self._work = []
-        if self.comm is not self.flat:
-            if self.flat.is_cuda:
-                import _native as N
-                N.call("sei_cast_bf16", self.flat.data_ptr(), self.comm.data_ptr(), self.flat.numel())
-            else:
-                self.comm.copy_(self.flat)
-        if world_size() == 1:
+    def set_early_range(self, early_range):
+        """(Re)plan the chunks; see __init__. Call before the first reduce_async of a step."""
+        n = self.flat.numel()
+        self.early_range = None
+        if early_range is not None and 0 <= early_range[0] < early_range[1] <= n:
+            lo, hi = int(early_range[0]), int(early_range[1])
+            self.early_range = (lo, hi)
+            parts = [(0, lo), (lo, hi), (hi, n)]
+        else:
+            parts = [(0, n)]
+        self.bounds, self._is_early = [], []
+        for a, b in parts:
+            for s, e in (chunk_bounds(b - a, self._chunk) if b > a else []):
+                self.bounds.append((a + s, a + e))
+                self._is_early.append(self.early_range is not None and (a, b) == self.early_range)
+        # the order in which chunks complete (and the optimizer should consume them): early ones first
+        self.order = [k for k, f in enumerate(self._is_early) if f] + [k for k, f in enumerate(self._is_early) if not f]
+        self._work = [None] * len(self.bounds)
+
+    def _cast(self, s, e):
+        if self.comm is self.flat:
             return
-        for s, e in self.bounds:
-            self._work.append(dist.all_reduce(self.comm[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.flat.is_cuda:
+            import _native as N
+            N.call("sei_cast_bf16", self.flat[s:e].data_ptr(), self.comm[s:e].data_ptr(), e - s)
+        else:
+            self.comm[s:e].copy_(self.flat[s:e])
+
+    def _exchange(self, k):
+        s, e = self.bounds[k]
+        self._work[k] = dist.all_reduce(self.comm[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def reduce_async(self, early=None):
+        """Cast (if compressed) and all-reduce every chunk asynchronously. early: an event with .wait(stream)
+        after which `early_range` is final -- that range is handled on a side stream waiting only for the event,
+        the rest on the current stream (i.e. after everything enqueued so far)."""
+        self._work = [None] * len(self.bounds)
+        single = world_size() == 1
+        if early is not None and self.early_range is not None and self._side is not None:
+            lo, hi = self.early_range
+            with torch.cuda.stream(self._side):
+                early.wait(self._side)
+                self._cast(lo, hi)
+                if not single:
+                    for k in self.order:
+                        if self._is_early[k]:
+                            self._exchange(k)
+            for a, b in ((0, lo), (hi, self.flat.numel())):
+                if b > a:
+                    self._cast(a, b)
+            if single:                                    # the consumer reads self.comm on the current stream
+                torch.cuda.current_stream().wait_stream(self._side)
+                return
+            for k in self.order:
+                if not self._is_early[k]:
+                    self._exchange(k)
+            return
+        self._cast(0, self.flat.numel())
+        if single:
+            return
+        for k in range(len(self.bounds)):
+            self._exchange(k)
 
     def wait(self, k):
-        if self._work:
+        if self._work[k] is not None:
             self._work[k].wait()
 
     def wait_all(self):
         for w in self._work:
-            w.wait()
-        self._work = []
+            if w is not None:
+                w.wait()
+        self._work = [None] * len(self.bounds)
 
 
 def broadcast_parameters(flat_params, src=0):

@@ -227,3 +227,25 @@ def test_flat_gradient_reducer_gloo_world2():
         assert grad_err < 1e-6                     # every rank holds the sum of both ranks' gradients
         assert param_max == 0                      # rank 0's weights everywhere
         assert loss == pytest.approx(1.5) and nchunks == 4
+
+
+def test_reducer_chunk_plan_with_an_early_range():
+    """Chunks never straddle the early range, cover the bucket exactly once, and the early ones come first in
+    the consumption order."""
+    import torch
+    import parallel
+    flat = torch.zeros(10_000)
+    red = parallel.FlatGradientReducer(flat, chunk_mib=1)
+    red._chunk = 1024                                   # small chunks for the test
+    red.set_early_range((3000, 8200))
+    assert red.bounds[0][0] == 0 and red.bounds[-1][1] == 10_000
+    assert all(a[1] == b[0] for a, b in zip(red.bounds, red.bounds[1:]))
+    assert all(not (s < 3000 < e or s < 8200 < e) for s, e in red.bounds)
+    early = [k for k in range(len(red.bounds)) if 3000 <= red.bounds[k][0] < 8200]
+    assert red.order[:len(early)] == early and sorted(red.order) == list(range(len(red.bounds)))
+    red.set_early_range(None)
+    assert red.order == list(range(len(red.bounds))) and red.bounds[0] == (0, 1024)
+    # single process: reduce_async is a cast / no-op and wait() never blocks
+    red.reduce_async()
+    red.wait(0)
+    red.wait_all()

@@ -406,3 +406,49 @@ def test_merged_and_stored_weight_grads_match_plain_accumulation():
         assert 0.5 < float(outs[0].norm() / grads["merged"].norm()) < 2.0
     finally:
         _ops.set_compute_dtype(prev)
+
+
+def test_early_gradient_release_from_inside_the_graph():
+    """The captured backward records an event right after the bottleneck block's weight gradients are written
+    (an event-record node inserted into the hipGraph); the reducer's side stream waits for it and casts that
+    range for the all-reduce while the rest of the backward is still running. Deterministic check on one GPU:
+    poison the range, replay, run the reducer's early path, and the bf16 exchange buffer must equal the cast of
+    the final gradients everywhere (a wait that did not wait would pick up the poison)."""
+    import bench
+    import physics
+    import models
+    import parallel
+    from graphs import GraphedLossStep
+    from losses import get_loss
+    from models import _ops
+    from optim import FlatAdam
+    prev = _ops.set_compute_dtype("bf16")
+    try:
+        args = bench.reference_args("cuda", 32, 4)
+        torch.manual_seed(0)
+        p = physics.get_physics(args, "cuda")
+        model = models.get_model(args, p, "cuda").to("cuda")
+        bb = model.get_backbone()
+        lf = get_loss(args, p)
+        opt = FlatAdam(model, lr=1e-4)
+        x = torch.rand(8, 3, 256, 256, device="cuda")
+        y = p(x)
+        g = GraphedLossStep(lf, model, opt, (8, 3, 48, 48), early_release=True)
+        assert g.early_grads is not None
+        event, lo, hi = g.early_grads
+        assert (hi - lo) > 0.5 * bb.flat_grads.numel()
+        red = parallel.FlatGradientReducer(bb.flat_grads, comm_dtype=torch.bfloat16, chunk_mib=16)
+        red.set_early_range((lo, hi))
+        assert all(not (s < lo < e or s < hi < e) for s, e in red.bounds)          # no chunk straddles the range
+        assert sorted(red.order) == list(range(len(red.bounds))) and red._is_early[red.order[0]]
+        for _ in range(3):
+            bb.flat_grads[lo:hi].fill_(float("nan"))
+            red.comm.fill_(float("nan"))
+            g(x, y)
+            red.reduce_async(early=event)
+            torch.cuda.synchronize()
+            assert torch.isfinite(red.comm.float()).all()
+            assert torch.equal(red.comm, bb.flat_grads.bfloat16())
+            opt.step()
+    finally:
+        _ops.set_compute_dtype(prev)

@@ -168,7 +168,7 @@ def main(argv=None):
         save_training_state(epoch=0, model=model, optimizer=optimizer, scheduler=scheduler,
                             state_path=checkpoint_name(0))
 
-    graphed = None
+    graphed, early_event = None, None
     for epoch in range(epochs):
         if sampler is not None:
             sampler.set_epoch(epoch)
@@ -176,20 +176,27 @@ def main(argv=None):
         steps = 0
         for x, y in dataloader:
             x, y = x.to(args.device), y.to(args.device)
+            used_graph = False
             can_graph = (args.hip_graph and isinstance(optimizer, FlatAdam) and loss.crop_fn is not None
                          and y.shape[0] == args.batch_size)
             if can_graph:
                 if graphed is None:                   # capture once; short last batches run eagerly
                     from graphs import GraphedLossStep
+                    early = reducer is not None and os.environ.get("SEI_NO_EARLY_RELEASE") != "1"
                     graphed = GraphedLossStep(loss, model, optimizer,
-                                              (args.batch_size, y.shape[1], args.Loss__crop_size, args.Loss__crop_size))
+                                              (args.batch_size, y.shape[1], args.Loss__crop_size, args.Loss__crop_size),
+                                              early_release=early)
+                    if early and graphed.early_grads is not None:
+                        early_event = graphed.early_grads[0]
+                        reducer.set_early_range(graphed.early_grads[1:])
                 training_loss = graphed(x, y)
+                used_graph = True
             else:
                 optimizer.zero_grad()
                 training_loss = loss(x=x, y=y, model=model)
                 training_loss.backward()
             if reducer is not None:
-                reducer.reduce_async()
+                reducer.reduce_async(early=early_event if used_graph else None)
                 if not isinstance(optimizer, FlatAdam):
                     reducer.wait_all()
                     backbone.flat_grads /= world
