@@ -137,7 +137,7 @@ __device__ __forceinline__ void wait_vmcnt() {          // counted wait: at most
 }
 
 template <int TM, int TN, int WM, int WN, bool ARM, bool BRM, int NSTAGE = 2>
-__global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
+__global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(NtArgs g) {
     static_assert(WM * WN == NWAVES, "8 waves per workgroup");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static_assert(!ARM || BM == 128, "a reduction-major A tile is 64 x 128");
@@ -278,7 +278,17 @@ __global__ __launch_bounds__(NT) void gemm_bf16nt_kernel(NtArgs g) {
         }
     };
 
-    if constexpr (NSTAGE == 2) {
+    if constexpr (NSTAGE == 1) {
+        // one stage, nothing overlapped inside the workgroup: 32 KB of LDS and <= 84 VGPRs let THREE workgroups
+        // share a CU and cover for one another (the guide's "step-3" structure)
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            stage(k0, smem);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(smem);
+            __syncthreads();
+        }
+    } else if constexpr (NSTAGE == 2) {
         // two stages, one workgroup's DMA in flight under its own MFMAs; relies on a second resident
         // workgroup per CU for overlap (128x128 tile)
         stage(k_begin, smem);
@@ -387,7 +397,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
     SEI_REQUIRE(tiles < ((size_t)1 << 27));
     {
         constexpr size_t STAGE_BYTES = NSTAGE * (size_t)(BM + BN) * ROW_BYTES;
-        const double conc = 32.0 * (STAGE_BYTES <= 80 * 1024 ? 2 : 1);        // tiles in flight per XCD
+        const double conc = 32.0 * (STAGE_BYTES <= 40 * 1024 ? 3 : (STAGE_BYTES <= 80 * 1024 ? 2 : 1));   // tiles in flight per XCD
         int band = g_force_band > 0 ? g_force_band : (int)(sqrt(conc * BM / BN) + 0.5);   // square patch in elements
         if (band < 1) band = 1;
         if (band > g.tiles_n) band = g.tiles_n;
@@ -402,7 +412,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         // Wave-quantisation-aware split: a launch takes ceil(tiles*sk / slots) rounds of workgroups, each
         // round costing (k-tiles per split + a fixed prologue/epilogue/atomics overhead); pick the cheapest sk.
         constexpr size_t STAGE_BYTES = NSTAGE * (size_t)(BM + BN) * ROW_BYTES;
-        const size_t slots = 256 * (STAGE_BYTES <= 80 * 1024 ? 2 : 1);       // workgroups resident on 256 CUs
+        const size_t slots = 256 * (STAGE_BYTES <= 40 * 1024 ? 3 : (STAGE_BYTES <= 80 * 1024 ? 2 : 1));   // resident workgroups
         const size_t ktiles = sei_ceil_div(g.K, BK);
         // up to 256 splits: a one-tile weight gradient of the shallow levels (128 x 32 outputs, K = 221,184 =
         // 3456 k-tiles) capped at 16 splits kept 16 CUs busy for 147 us; its atomics are contiguous and few
@@ -485,12 +495,17 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
             case 12: return launch_nt<4, 1, 2, 4, false, false, 3>(g, s);      // 256 x 128, 3 stages
             case 13: return launch_nt<2, 2, 2, 4, false, false, 3>(g, s);      // 128 x 256, 3 stages
             case 14: return launch_nt<2, 1, 2, 4, false, false, 3>(g, s);      // 128 x 128, 3 stages
+            case 15: return launch_nt<2, 1, 2, 4, false, false, 1>(g, s);      // 128 x 128, 1 stage, 3 blocks/CU
             default: break;
         }
     }
     // a reduction-major operand fixes the tile at 128 x 128 (its LDS rows are 256 bytes = 128 columns)
     if (a_rmajor && b_rmajor) return launch_nt<2, 1, 2, 4, true, true>(g, s);
     if (a_rmajor) return launch_nt<2, 1, 2, 4, true, false>(g, s);
+    if (g_force_tile == 15) {
+        if (a_rmajor && b_rmajor) return launch_nt<2, 1, 2, 4, true, true, 1>(g, s);
+        if (b_rmajor) return launch_nt<2, 1, 2, 4, false, true, 1>(g, s);
+    }
     if (b_rmajor) {
         // skinny data gradients (the bottleneck levels): 192 x 256 with two 128-column images of the weight
         if (g_force_tile != 1 && N >= 2048 && K >= 2048 && M <= 768)
@@ -512,6 +527,9 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     // N = 8192 / 32768) are weight-streaming: there 192x256 wins (M = 288: 221 vs 309 us), padding included,
     // and 96x256 never does. A 256x256 tile on this loop needs the rolled epilogue of gemm_bf16pp.h.
     if (N >= 2048 && K >= 2048 && M <= 768) return launch_nt<3, 2, 2, 4>(g, s);               // 192 x 256
+    // short reductions are all prologue and epilogue: one LDS stage (32 KB) and <= 84 VGPRs put three workgroups
+    // on a CU instead of two (36864 x 512 x 128: 34 -> 27 us; 9216 x 2048 x 512: 50 -> 44 us; loses from K ~ 2048)
+    if (K <= 1024 && g_force_tile != 1) return launch_nt<2, 1, 2, 4, false, false, 1>(g, s);
     return launch_nt<2, 1, 2, 4>(g, s);                                                  // 128 x 128
 }
 

@@ -1,0 +1,25 @@
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scale-equivariant-imaging_amd"))
+from models import _ops
+import _native
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+for (M, N, K) in [(147456, 128, 32), (147456, 32, 128), (36864, 512, 128), (36864, 128, 512), (9216, 2048, 512), (9216, 512, 2048), (2304, 8192, 2048)]:
+    A = torch.randn((M, K), device="cuda").bfloat16(); B = torch.randn((K, N), device="cuda").bfloat16()
+    ref = A.float() @ B.float(); R1 = torch.randn((M, N), device="cuda")
+    line = f"{M}x{N}x{K} kr:"
+    for tile in (0, 15, 0, 15):
+        _native.lib().sei_debug_set_nt_tile(tile)
+        out = torch.full((M, N), float("nan"), device="cuda")
+        _ops.gemm_nt16(A, B, M, N, K, _ops.EPI_NONE, out32=out, b_rmajor=True)
+        err = float((out - ref).abs().max() / ref.abs().max())
+        o16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        t = timeit(lambda: _ops.gemm_nt16(A, B, M, N, K, _ops.EPI_MUL_DGELU, out16=o16, R1=R1, b_rmajor=True))
+        line += f"  {'auto' if tile == 0 else 's1  '} {t:5.1f} us err {err:.0e} |"
+    print(line)
+_native.lib().sei_debug_set_nt_tile(0)

@@ -9,11 +9,11 @@ def timeit(fn, iters=8):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-names = {0: "auto", 1: "128x128 s2", 3: "192x256 s2", 11: "128x128 s4", 14: "128x128 s3", 12: "256x128 s3", 13: "128x256 s3"}
-for (M, N, K) in [(576, 32768, 8192), (576, 8192, 32768), (2304, 8192, 2048), (9216, 2048, 512), (4096, 4096, 4096)]:
+names = {0: "auto", 1: "128x128 s2", 15: "128x128 s1x3"}
+for (M, N, K) in [(2304, 8192, 2048), (2304, 2048, 8192), (9216, 2048, 512), (36864, 512, 128), (4096, 4096, 4096), (8192, 8192, 1024)]:
     A = torch.randn((M, K), device="cuda").bfloat16(); B = torch.randn((N, K), device="cuda").bfloat16()
     out = torch.zeros((M, N), device="cuda"); ref = None
-    for tile in (0, 1, 3, 11, 14, 12, 13):
+    for tile in (0, 1, 15, 1, 15):
         _native.lib().sei_debug_set_nt_tile(tile)
         t = timeit(lambda: _ops.gemm_nt16(A, B, M, N, K, _ops.EPI_NONE, out32=out))
         if ref is None: ref = out.clone()
