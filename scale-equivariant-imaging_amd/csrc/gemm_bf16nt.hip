@@ -499,13 +499,19 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
             default: break;
         }
     }
-    // a reduction-major operand fixes the tile at 128 x 128 (its LDS rows are 256 bytes = 128 columns)
-    if (a_rmajor && b_rmajor) return launch_nt<2, 1, 2, 4, true, true>(g, s);
-    if (a_rmajor) return launch_nt<2, 1, 2, 4, true, false>(g, s);
+    if (g_force_tile == 16 && a_rmajor && b_rmajor) return launch_nt<2, 2, 2, 4, true, true>(g, s);   // 128 x 256
     if (g_force_tile == 15) {
         if (a_rmajor && b_rmajor) return launch_nt<2, 1, 2, 4, true, true, 1>(g, s);
         if (b_rmajor) return launch_nt<2, 1, 2, 4, false, true, 1>(g, s);
     }
+    // a reduction-major operand fixes the tile at 128 x 128 (its LDS rows are 256 bytes = 128 columns)
+    if (a_rmajor && b_rmajor) {
+        // short reductions (the bottleneck weight gradient: K = 864 over 16,384 tiles) are prologue + epilogue
+        // bound: one LDS stage and three workgroups per CU (1030 -> 800 us); long ones want the double buffer
+        if (K <= 1024 && g_force_tile != 1) return launch_nt<2, 1, 2, 4, true, true, 1>(g, s);
+        return launch_nt<2, 1, 2, 4, true, true>(g, s);
+    }
+    if (a_rmajor) return launch_nt<2, 1, 2, 4, true, false>(g, s);
     if (b_rmajor) {
         // skinny data gradients (the bottleneck levels): 192 x 256 with two 128-column images of the weight
         if (g_force_tile != 1 && N >= 2048 && K >= 2048 && M <= 768)
@@ -545,5 +551,6 @@ extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int l
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
     g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
+    if (K1 + K2 <= 1024) return launch_nt<2, 1, 2, 4, true, true, 1>(g, (hipStream_t)stream);   // as sei_gemm_bf16nt
     return launch_nt<2, 1, 2, 4, true, true>(g, (hipStream_t)stream);
 }
