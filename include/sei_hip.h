@@ -112,6 +112,10 @@ int sei_sure_terms(const float *y, const float *y1, const float *y2, const float
                    float c_div, float *out2, float *g1, float *g2, float *work, void *stream);
 int sei_mse_terms(const float *a, const float *b, size_t n, float scale, float *out1, float *ga,
                   float *work, void *stream);
+/* Numerator of the luma PSNR of the evaluation step (reference src/metrics.py:10-13: kornia rgb_to_ycbcr's
+ * Y = 0.299 R + 0.587 G + 0.114 B, torchmetrics PSNR with data_range 1): out1[0] = sum over the npix pixels of
+ * (Y(a) - Y(b))^2 for planar RGB images a, b of shape (3, npix). `work` holds SEI_REDUCE_BLOCKS floats. */
+int sei_luma_sqerr(const float *a, const float *b, size_t npix, float *out1, float *work, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * U-Net (src/models/convolutional.py), NHWC activations ("rows" = B*H*W pixels of C channels).

@@ -80,6 +80,23 @@ __global__ __launch_bounds__(RED_THREADS) void mse_terms_kernel(const float *__r
     if (threadIdx.x == 0) work[blockIdx.x] = bs;
 }
 
+// sum over pixels of (Y(a) - Y(b))^2 for planar RGB images (3, npix): the numerator of the luma PSNR
+__global__ __launch_bounds__(RED_THREADS) void luma_sqerr_kernel(const float *__restrict__ a,
+                                                                 const float *__restrict__ b, size_t npix,
+                                                                 float *__restrict__ work) {
+    __shared__ float scratch[RED_THREADS / 64];
+    float s = 0.f;
+    const size_t stride = (size_t)gridDim.x * RED_THREADS;
+    for (size_t i = (size_t)blockIdx.x * RED_THREADS + threadIdx.x; i < npix; i += stride) {
+        const float ya = 0.299f * a[i] + 0.587f * a[npix + i] + 0.114f * a[2 * npix + i];
+        const float yb = 0.299f * b[i] + 0.587f * b[npix + i] + 0.114f * b[2 * npix + i];
+        const float d = ya - yb;
+        s = fmaf(d, d, s);
+    }
+    const float bs = sei_block_sum<RED_THREADS>(s, scratch);
+    if (threadIdx.x == 0) work[blockIdx.x] = bs;
+}
+
 // stage 2: one block sums `nparts` partials of each of `nout` quantities (stored SEI_REDUCE_BLOCKS apart)
 __global__ __launch_bounds__(RED_THREADS) void finish_sums_kernel(const float *__restrict__ work, int nparts,
                                                                   int nout, float *__restrict__ out) {
@@ -131,6 +148,16 @@ extern "C" int sei_mse_terms(const float *a, const float *b, size_t n, float sca
     const int grid = reduce_blocks(n);
     hipLaunchKernelGGL(mse_terms_kernel, dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, n, scale,
                        ga, work);
+    hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(RED_THREADS), 0, (hipStream_t)stream,
+                       (const float *)work, grid, 1, out1);
+    return sei_launch_status();
+}
+
+
+extern "C" int sei_luma_sqerr(const float *a, const float *b, size_t npix, float *out1, float *work, void *stream) {
+    SEI_REQUIRE(a && b && out1 && work && npix > 0);
+    const int grid = reduce_blocks(npix);
+    hipLaunchKernelGGL(luma_sqerr_kernel, dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, npix, work);
     hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(RED_THREADS), 0, (hipStream_t)stream,
                        (const float *)work, grid, 1, out1);
     return sei_launch_status();

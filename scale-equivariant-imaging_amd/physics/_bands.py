@@ -45,6 +45,23 @@ def aa_bicubic_matrix(n_in, scale_factor):
     return m
 
 
+def aa_bicubic_matrix_to_size(n_in, n_out):
+    """Dense (n_out, n_in) antialiased-bicubic matrix for F.interpolate(size=n_out, antialias=True): as
+    aa_bicubic_matrix with the scale ATen derives from the sizes, n_in / n_out (area_pixel_compute_scale with
+    align_corners=False and no scale_factor)."""
+    scale = float(n_in) / float(n_out)
+    support = 2.0 * scale if scale >= 1.0 else 2.0
+    inv = 1.0 / scale if scale >= 1.0 else 1.0
+    m = np.zeros((n_out, n_in))
+    for o in range(n_out):
+        centre = scale * (o + 0.5)
+        first = max(0, int(centre - support + 0.5))
+        last = min(n_in, int(centre + support + 0.5))
+        w = np.array([_cubic((j - centre + 0.5) * inv, -0.5) for j in range(first, last)])
+        m[o, first:last] = w / w.sum()
+    return m
+
+
 def plain_bicubic_matrix(n_in, scale_factor):
     """Dense (n_out, n_in) matrix of F.interpolate(scale_factor, mode='bicubic') without antialias."""
     n_out = resized_length(n_in, scale_factor)

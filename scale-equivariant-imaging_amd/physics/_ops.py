@@ -114,6 +114,29 @@ class SeparableResampleOp:
         return y
 
 
+_RESIZE_AXES = {}
+
+
+def resample_to_size(x, out_h, out_w):
+    """Antialiased bicubic resize of (.., H, W) float32 GPU images to (out_h, out_w) in one launch of the banded
+    separable resampler (the GroundTruthDataset resize, datasets/ground_truth.py). No autograd."""
+    planes, H, W = _as_planes(x)
+
+    def axis(n_in, n_out):
+        key = (n_in, n_out, str(x.device))
+        if key not in _RESIZE_AXES:
+            w, lo, nb, step = _bands.to_band(_bands.aa_bicubic_matrix_to_size(n_in, n_out))
+            _RESIZE_AXES[key] = (torch.from_numpy(w).to(x.device), torch.from_numpy(lo).to(x.device), nb, step)
+        return _RESIZE_AXES[key]
+
+    wv, lov, nbv, sv = axis(H, out_h)
+    wh, loh, nbh, sh = axis(W, out_w)
+    y = torch.empty(x.shape[:-2] + (out_h, out_w), dtype=x.dtype, device=x.device)
+    N.call("sei_resample_sepband", x.data_ptr(), y.data_ptr(), planes, H, W, out_h, out_w,
+           wv.data_ptr(), lov.data_ptr(), nbv, sv, wh.data_ptr(), loh.data_ptr(), nbh, sh)
+    return y
+
+
 class _Axpy(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, alpha):

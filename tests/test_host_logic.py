@@ -249,3 +249,89 @@ def test_reducer_chunk_plan_with_an_early_range():
     red.reduce_async()
     red.wait(0)
     red.wait_all()
+
+
+# ------------------------------------------------------------------ N1: file-based data path (host side)
+def _write_png(path, array):
+    from PIL import Image
+    Image.fromarray(array).save(path)
+
+
+def test_png_decode_matches_the_file(tmp_path):
+    """datasets._io.read_image restates torchvision.io.read_image (mode UNCHANGED): (C, H, W) uint8 with the
+    file's own channel count."""
+    import numpy as np
+    import torch
+    from datasets._io import read_image
+    rng = np.random.default_rng(0)
+    for name, shape in (("rgb", (37, 53, 3)), ("rgba", (20, 31, 4)), ("gray", (16, 9))):
+        a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        _write_png(tmp_path / f"{name}.png", a)
+        t = read_image(str(tmp_path / f"{name}.png"))
+        assert t.dtype == torch.uint8
+        expect = a[:, :, None] if a.ndim == 2 else a
+        assert t.shape == (expect.shape[2], expect.shape[0], expect.shape[1])
+        assert np.array_equal(t.numpy().transpose(1, 2, 0), expect)
+
+
+def test_resize_rule_and_filter_match_torch_antialiased_bicubic():
+    """GroundTruthDataset's TF.resize(size=256, BICUBIC, antialias=True): torchvision's shorter-edge rule, then
+    F.interpolate(size=...): the size-based band matrices reproduce torch's CPU result (float64) to 1e-12."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from datasets.ground_truth import resized_hw
+    from physics import _bands
+    assert resized_hw(1356, 2040, 256) == (256, 385) and resized_hw(2040, 1356, 256) == (385, 256)
+    assert resized_hw(256, 300, 256) == (256, 300) and resized_hw(100, 50, 256) == (512, 256)
+    g = torch.Generator().manual_seed(3)
+    for (h, w) in ((300, 421), (97, 64), (256, 513)):
+        oh, ow = resized_hw(h, w, 256) if min(h, w) != 256 else (256, 300)
+        x = torch.rand((1, 2, h, w), generator=g, dtype=torch.float64)
+        ref = F.interpolate(x, size=(oh, ow), mode="bicubic", antialias=True, align_corners=False)
+        Wv, Wh = _bands.aa_bicubic_matrix_to_size(h, oh), _bands.aa_bicubic_matrix_to_size(w, ow)
+        mine = Wv @ x.numpy() @ Wh.T                       # (oh,h) @ (1,2,h,w) @ (w,ow)
+        assert np.abs(mine - ref.numpy()).max() < 1e-12
+
+
+def test_dataset_wrappers_follow_the_reference(tmp_path):
+    """TestDataset crops x to a multiple of y; TrainingDataset crops pairs (css swaps in a re-degraded pair);
+    get_dataset refuses what this build does not carry."""
+    import types
+    import pytest
+    import torch
+    import datasets
+
+    class FakeSynthetic(torch.utils.data.Dataset):
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            return torch.arange(3 * 101 * 67, dtype=torch.float32).view(3, 101, 67), torch.ones(3, 50, 33)
+
+    sr = types.SimpleNamespace(task="sr", rate=2)
+    x, y = datasets.TestDataset(FakeSynthetic(), False, sr)[0]
+    assert x.shape == (3, 100, 66) and y.shape == (3, 50, 33)
+    torch.manual_seed(0)
+    xt, yt = datasets.TrainingDataset(FakeSynthetic(), sr, False, False, None, True)[0]      # _HOTFIX crops
+    assert xt.shape[-2:] == (96, 96) and yt.shape[-2:] == (48, 48)
+    prep = datasets.PrepareTrainingPairs(types.SimpleNamespace(task="deblurring"), 32, "center")
+    xc, yc = prep(torch.zeros(3, 64, 80), torch.zeros(3, 64, 80))
+    assert xc.shape == (3, 32, 32) and yc.shape == (3, 32, 32)
+    with pytest.raises(NotImplementedError):
+        datasets.TestDataset(FakeSynthetic(), True, sr)
+    args = types.SimpleNamespace(dataset="urban100", method="proposed", GroundTruthDataset__datasets_dir=str(tmp_path),
+                                 GroundTruthDataset__download=False, GroundTruthDataset__size=256,
+                                 GroundTruthDataset__split="train", memoize_gt=False,
+                                 PrepareTrainingPairs__crop_size=256, PrepareTrainingPairs__crop_location="random",
+                                 SingleImageDataset__image_path=None, SingleImageDataset__duplicates_count=4,
+                                 SyntheticDataset__unique_seeds=True, SyntheticDataset__deterministic_measurements=True)
+    phys = types.SimpleNamespace(task="deblurring")
+    setattr(phys, "__manager", types.SimpleNamespace(task="deblurring"))
+    with pytest.raises(NotImplementedError):
+        datasets.get_dataset(args, "train", phys, "cpu")
+    args.dataset = "div2k"
+    with pytest.raises(FileNotFoundError):
+        datasets.get_dataset(args, "train", phys, "cpu")
+    with pytest.raises(ValueError):
+        datasets.get_dataset(args, "validate", phys, "cpu")

@@ -251,6 +251,63 @@ def test_train_script_end_to_end(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_psnr_y_metric_and_registration():
+    """metrics.psnr_fn on the GPU (sei_luma_sqerr) against the oracle's luma PSNR; centre-crop registration."""
+    import metrics
+    gen = torch.Generator().manual_seed(9)
+    x = torch.rand((3, 97, 131), generator=gen)
+    x_hat = (x + 0.05 * torch.randn((3, 97, 131), generator=gen)).clamp(0, 1)
+    ref = float(tp.psnr_y(x_hat.double(), x.double()))
+    assert abs(float(metrics.psnr_fn(x_hat.cuda(), x.cuda())) - ref) < 1e-4
+    assert abs(float(metrics.psnr_fn(x_hat, x)) - ref) < 1e-4                  # host path (CPU tensors)
+    a, b = metrics.register_fn(torch.zeros(3, 100, 90), torch.zeros(3, 96, 95))
+    assert a.shape == b.shape == (3, 96, 90)
+    psnr, ssim, lpips = metrics.compute_metrics(x.cuda(), x_hat.cuda())
+    assert abs(psnr - ref) < 1e-4 and np.isnan(ssim) and np.isnan(lpips)
+
+
+def test_train_on_files_then_evaluate(tmp_path):
+    """N1 + N3 end to end: train.py on a single-image PNG dataset (decode, antialiased resize, seeded
+    measurements, random crops), then test.py on a small DIV2K validation tree with the saved weights."""
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    img = tmp_path / "one.png"
+    Image.fromarray(rng.integers(0, 256, size=(300, 340, 3), dtype=np.uint8)).save(img)
+    common = ["--device", "cuda", "--task", "deblurring", "--kernel", "Gaussian_R2", "--ProposedModel__architecture",
+              "Convolutional", "--ConvolutionalModel__hidden_channels", "8", "--ConvolutionalModel__scales", "3"]
+    out = tmp_path / "run"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), *common, "--method", "proposed", "--dataset",
+                        "single_image", "--SingleImageDataset__image_path", str(img),
+                        "--SingleImageDataset__duplicates_count", "8", "--batch_size", "4", "--epochs", "4",
+                        "--out_dir", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = open(out / "training.csv").read().strip().splitlines()
+    assert len(rows) == 5 and all(np.isfinite(float(r_.split(",")[1])) for r_ in rows[1:])
+    val = tmp_path / "data" / "DIV2K" / "DIV2K_valid_HR"
+    val.mkdir(parents=True)
+    for k, (h, w) in enumerate([(288, 300), (270, 256)]):
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(val / f"{801 + k:04d}.png")
+    res = tmp_path / "eval"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "test.py"), *common, "--dataset", "div2k",
+                        "--GroundTruthDataset__datasets_dir", str(tmp_path / "data"), "--weights",
+                        str(out / "weights.pt"), "--indices", "0,1", "--print_all_metrics", "--save_images",
+                        "--save_psf", "--out_dir", str(res)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert "N: 2" in lines
+    psnr = float([ln for ln in lines if ln.startswith("PSNR:")][0].split()[1])
+    per = [float(ln.split("PSNR:")[1].split(",")[0]) for ln in lines if ln.startswith("METRICS_")]
+    assert len(per) == 2 and np.isfinite(psnr) and abs(np.mean(per) - psnr) < 0.011 and 3.0 < psnr < 60.0
+    for folder in ("ground_truth", "predictors", "estimates"):
+        assert sorted(os.listdir(res / folder)) == ["0.png", "1.png"]
+    assert os.path.exists(res / "psf.png")
+    # the saved estimate reproduces the printed PSNR (8-bit images, luma PSNR of the oracle)
+    def load(p_):
+        return torch.from_numpy(np.asarray(Image.open(p_), dtype=np.float64).transpose(2, 0, 1) / 255.0)
+    again = float(tp.psnr_y(load(res / "estimates" / "0.png"), load(res / "ground_truth" / "0.png")))
+    assert abs(again - per[0]) < 0.011
+
+
 def test_graft_smoke():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g

@@ -6,6 +6,7 @@ by ~6e-7 relative, so 2e-6 relative (max-norm) is the bar; north_s
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import closed_form as cf
 from oracle import torch_path as tp
@@ -223,3 +224,77 @@ def test_scale_transform_module_and_variants(golden):
     assert set(r.tolist()) <= {0.75, 0.5} and c.abs().max() <= 1
     with pytest.raises(ValueError):
         transforms.ScalingTransform(kind="other", antialias=False)
+
+
+# ------------------------------------------------------------------ N1: file-based data path on the GPU
+def _div2k_tree(tmp_path, sizes):
+    import numpy as np
+    from PIL import Image
+    root = tmp_path / "DIV2K" / "DIV2K_train_HR"
+    root.mkdir(parents=True)
+    rng = np.random.default_rng(5)
+    for k, (h, w) in enumerate(sizes):
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(root / f"{k + 1:04d}.png")
+    return str(tmp_path)
+
+
+def _data_args(datasets_dir, **over):
+    import types
+    base = dict(dataset="div2k", method="proposed", task="deblurring", kernel="Gaussian_R2", sr_factor=None,
+                noise_level=5, physics_v2=True, physics_true_adjoint=False,
+                GroundTruthDataset__datasets_dir=datasets_dir, GroundTruthDataset__download=False,
+                GroundTruthDataset__size=256, GroundTruthDataset__split="train", memoize_gt=True,
+                PrepareTrainingPairs__crop_size=256, PrepareTrainingPairs__crop_location="random",
+                SingleImageDataset__image_path=None, SingleImageDataset__duplicates_count=4,
+                SyntheticDataset__unique_seeds=True, SyntheticDataset__deterministic_measurements=True)
+    base.update(over)
+    return types.SimpleNamespace(**base)
+
+
+def test_ground_truth_resize_on_files_matches_torch(tmp_path):
+    """PNG -> float -> antialiased bicubic resize to a 256 shorter edge on the HIP resampler, against
+    F.interpolate(size=..., antialias=True) on the CPU."""
+    import datasets
+    from datasets.ground_truth import GroundTruthDataset, resized_hw
+    sizes = [(300, 421), (512, 384), (256, 256)]
+    root = _div2k_tree(tmp_path, sizes)
+    gt = GroundTruthDataset(blueprint={}, datasets_dir=root, dataset_name="div2k", split="train", download=False,
+                            size=256, memoize_gt=False, device="cuda")
+    for k, (h, w) in enumerate(sizes):
+        raw = gt.dataset[k]
+        assert raw.shape == (3, h, w) and float(raw.max()) <= 1.0
+        out = gt[k]
+        oh, ow = resized_hw(h, w, 256)
+        assert out.shape == (3, oh, ow)
+        ref = raw if (oh, ow) == (h, w) else F.interpolate(raw[None].double(), size=(oh, ow), mode="bicubic",
+                                                           antialias=True, align_corners=False)[0]
+        assert relerr(out, ref) < 2e-6
+    assert gt.get_unique_id(2) == 2 and len(gt) == 800
+
+
+def test_div2k_training_and_test_items(tmp_path):
+    """get_dataset('div2k'): deterministic seeded measurements per image id, 256-crops for training, full pairs
+    for evaluation (deblurring and SR x2)."""
+    import physics
+    import datasets
+    root = _div2k_tree(tmp_path, [(300, 421), (280, 260)])
+    args = _data_args(root)
+    p = physics.get_physics(args, "cuda")
+    train = datasets.get_dataset(args, "train", p, "cuda")
+    torch.manual_seed(0)
+    x, y = train[0]
+    assert x.shape == (3, 256, 256) and y.shape == (3, 256, 256) and x.is_cuda
+    test = datasets.get_dataset(args, "test", p, "cuda")
+    xa, ya = test[0]
+    xb, yb = test[0]
+    assert xa.shape == (3, 256, 359) and torch.equal(ya, yb) and torch.equal(xa, xb)     # seeded by image id
+    assert relerr(ya, p.A(xa[None])[0]) < 0.2 and not torch.equal(ya, p.A(xa[None])[0])  # blur + noise
+    args2 = _data_args(root, task="sr", sr_factor=2, kernel=None)
+    p2 = physics.get_physics(args2, "cuda")
+    xs, ys = datasets.get_dataset(args2, "test", p2, "cuda")[1]
+    from datasets.ground_truth import resized_hw
+    rh, rw = resized_hw(280, 260, 256)                                # (275, 256)
+    assert ys.shape[-2:] == (rh // 2, rw // 2) and xs.shape[-2:] == (2 * (rh // 2), 2 * (rw // 2))
+    torch.manual_seed(1)
+    xh, yh = datasets.get_dataset(args2, "train", p2, "cuda", _HOTFIX=True)[1]
+    assert xh.shape[-2:] == (96, 96) and yh.shape[-2:] == (48, 48)
