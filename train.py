@@ -88,7 +88,8 @@ def main(argv=None):
 
     args = build_parser().parse_args(argv)
     if args.device == "cuda" and world > 1:
-        args.device = f"cuda:{local_rank}"
+        args.device = f"cuda:{local_rank % torch.cuda.device_count()}"     # (% only matters for shared-GPU rehearsals)
+        torch.cuda.set_device(args.device)
     if args.fine_tuning or args.fine_tuning_params or args.weights_distance_loss:
         raise NotImplementedError("fine-tuning options are outside the hot path of this build")
     crop.FIX_BATCHED_CROP = args.fix_batched_crop
