@@ -283,6 +283,15 @@ def test_train_on_files_then_evaluate(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     rows = open(out / "training.csv").read().strip().splitlines()
     assert len(rows) == 5 and all(np.isfinite(float(r_.split(",")[1])) for r_ in rows[1:])
+    # the same run fed from the GPU-resident pair cache
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), *common, "--method", "proposed", "--dataset",
+                        "single_image", "--SingleImageDataset__image_path", str(img),
+                        "--SingleImageDataset__duplicates_count", "8", "--batch_size", "4", "--epochs", "4",
+                        "--device_cache", "--out_dir", str(tmp_path / "run_cache")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Device cache: 8 pairs" in r.stdout, r.stdout + r.stderr
+    rows_c = open(tmp_path / "run_cache" / "training.csv").read().strip().splitlines()
+    assert len(rows_c) == 5 and all(np.isfinite(float(r_.split(",")[1])) for r_ in rows_c[1:])
     val = tmp_path / "data" / "DIV2K" / "DIV2K_valid_HR"
     val.mkdir(parents=True)
     for k, (h, w) in enumerate([(288, 300), (270, 256)]):

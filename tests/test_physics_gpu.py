@@ -298,3 +298,38 @@ def test_div2k_training_and_test_items(tmp_path):
     torch.manual_seed(1)
     xh, yh = datasets.get_dataset(args2, "train", p2, "cuda", _HOTFIX=True)[1]
     assert xh.shape[-2:] == (96, 96) and yh.shape[-2:] == (48, 48)
+
+
+def test_device_resident_pairs(tmp_path):
+    """The GPU-resident pair cache holds exactly the dataset path's (x, y) items (measurements are seeded by
+    image id), shards by rank, and an epoch of batches visits every pair once with paired crops."""
+    import physics
+    import datasets
+    from datasets.device_cache import DeviceResidentPairs
+    root = _div2k_tree(tmp_path, [(300, 421), (280, 260), (256, 256), (330, 257), (300, 300)])
+    args = _data_args(root, task="sr", sr_factor=2, kernel=None, memoize_gt=False)
+    p = physics.get_physics(args, "cuda")
+    ds = datasets.get_dataset(args, "train", p, "cuda", _HOTFIX=True)
+    syn = ds.dataset.synthetic_dataset
+    syn.ground_truth_dataset.dataset.split_size = 5            # the test tree holds five images
+    cache = DeviceResidentPairs(syn, p, crop_size=256, hotfix_sr_crop=True)
+    assert len(cache) == 5 and cache.nbytes() > 0
+    for k in range(5):
+        x, y = syn[k]
+        assert torch.equal(cache.pairs[k][0], x) and torch.equal(cache.pairs[k][1], y)
+    shard = DeviceResidentPairs(syn, p, crop_size=256, hotfix_sr_crop=True, rank=1, world=2)
+    assert len(shard) == 2 and torch.equal(shard.pairs[0][1], cache.pairs[1][1])
+    torch.manual_seed(3)
+    seen = 0
+    for xb, yb in cache.batches(batch_size=2):
+        assert xb.shape[1:] == (3, 96, 96) and yb.shape[1:] == (3, 48, 48) and xb.is_cuda
+        seen += xb.shape[0]
+    assert seen == 5
+    assert sum(xb.shape[0] for xb, _ in cache.batches(2, drop_last=True)) == 4
+    # a crop of the cache is a crop of the pair: the low-resolution crop is the measurement of ... the same pixels
+    torch.manual_seed(4)
+    xb, yb = next(cache.batches(batch_size=5, shuffle=False))
+    for k in range(5):
+        x, y = cache.pairs[k]
+        found = (y.unfold(1, 48, 1).unfold(2, 48, 1) == yb[k][:, None, None]).all(-1).all(-1).all(0)
+        assert bool(found.any())

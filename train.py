@@ -76,6 +76,9 @@ def build_parser():
     flag("--compute_dtype", choices=["f32", "bf16"], default="f32",
          help="1x1-conv GEMM arithmetic: f32 (reference precision) or bf16 MFMA with f32 accumulation")
     flag("--hip_graph", default=True, **onoff)
+    flag("--device_cache", default=False, **onoff,
+         help="keep every (x, y) training pair in HBM (deterministic measurements) and draw crops on the device "
+              "instead of the per-item DataLoader path (datasets/device_cache.py)")
     return parser
 
 
@@ -114,6 +117,21 @@ def main(argv=None):
         sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=True, seed=0)
     dataloader = torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=sampler is None,
                                              sampler=sampler)
+    device_cache = None
+    if args.device_cache:
+        if args.method == "css" or not args.SyntheticDataset__deterministic_measurements:
+            raise ValueError("--device_cache needs deterministic measurements (and no css re-degradation)")
+        from datasets import SyntheticPairs
+        from datasets.device_cache import DeviceResidentPairs
+        if isinstance(dataset, SyntheticPairs):
+            full = SyntheticPairs(physics, args.device, length=len(dataset))
+        else:
+            full = dataset.dataset.synthetic_dataset
+        device_cache = DeviceResidentPairs(full, physics, crop_size=args.PrepareTrainingPairs__crop_size,
+                                           crop_location=args.PrepareTrainingPairs__crop_location,
+                                           hotfix_sr_crop=(args.task == "sr"), rank=rank, world=world)
+        if rank == 0:
+            print(f"\nDevice cache: {len(device_cache)} pairs, {device_cache.nbytes() / 2**20:.0f} MiB\n")
 
     epochs = args.epochs if args.epochs is not None else {"urban100": 4000, "ct": 100}.get(args.dataset, 500)
     lr = args.lr if args.lr is not None else (2e-4 if args.task == "sr" else 1e-4)
@@ -175,7 +193,8 @@ def main(argv=None):
             sampler.set_epoch(epoch)
         loss_sum = torch.zeros((), device=args.device)
         steps = 0
-        for x, y in dataloader:
+        batches = dataloader if device_cache is None else device_cache.batches(args.batch_size)
+        for x, y in batches:
             x, y = x.to(args.device), y.to(args.device)
             used_graph = False
             can_graph = (args.hip_graph and isinstance(optimizer, FlatAdam) and loss.crop_fn is not None
