@@ -344,6 +344,24 @@ def ei_loss(x_net, A, model, transform, sigma, *, alpha=1.0, stop_gradient=True,
     return alpha * F.mse_loss(x3, x2), x2, x3
 
 
+def r2r_ei_loss(y, A, model, transform, sigma, *, unit_pert, n1, n2, stop_gradient=True):
+    """src/losses/r2r.py (in-tree): R2RLoss(eta=sigma, alpha=0.5) + the EI term with consistent input noise
+    (:9-57), with the three normal draws injected. Returns (loss, r2r_term, ei_term)."""
+    alpha = 0.5
+    pert = unit_pert * sigma
+    out = model(y + pert * alpha)
+    l_r2r = F.mse_loss(A(out), y - pert / alpha)
+    x1 = model(y + 0.5 * sigma * n1)
+    if stop_gradient:
+        with torch.no_grad():
+            x2 = transform(x1)
+    else:
+        x2 = transform(x1)
+    x3 = model(A(x2) + 1.5 * sigma * n2)
+    l_ei = F.mse_loss(x3, x2)
+    return l_r2r + l_ei, l_r2r, l_ei
+
+
 def proposed_loss(y, A, model, sigma, *, margin, rate, center, b=None, n=None, alpha=1.0,
                   stop_gradient=True, averaged_cst=None, cropped_div=True):
     """src/losses/__init__.py:133-142 (ProposedLoss.forward) with the default loss list

@@ -18,8 +18,9 @@ from torch.nn.functional import l1_loss
 
 from crop import CropPair
 from physics._ops import axpy
-from transforms import ScalingTransform
+from transforms import ScalingTransform, Shift
 from .ei import EILoss, SupLoss, mse
+from .r2r import R2REILoss
 from .sure import SureGaussianLoss, draw_probe
 
 
@@ -68,14 +69,21 @@ class ProposedLoss(Module):
         self.physics = physics
         if transforms == "Scaling_Transforms":
             ei_transform = ScalingTransform(**blueprint[ScalingTransform.__name__])
-        elif transforms in ("Rotations+Shifts", "Rotations", "Shifts"):
-            raise NotImplementedError(f"--ProposedLoss__transforms {transforms} (deepinv Rotate/Shift) is "
-                                      "outside the hot path of this build; use Scaling_Transforms")
+        elif transforms == "Shifts":
+            ei_transform = Shift()
+        elif transforms in ("Rotations+Shifts", "Rotations"):
+            raise NotImplementedError(f"--ProposedLoss__transforms {transforms}: deepinv's Rotate resamples through "
+                                      "kornia.geometry.rotate, which is neither in the reference tree nor "
+                                      "importable here (unpinned); Scaling_Transforms and Shifts are available")
         else:
             raise ValueError(f"Unknown transforms: {transforms}")
         assert sure_alternative in [None, "r2r"]
         if sure_alternative == "r2r":
-            raise NotImplementedError("--ProposedLoss__sure_alternative r2r is outside the hot path of this build")
+            self.loss_fns = [R2REILoss(transform=ei_transform, sigma=noise_level / 255, no_grad=stop_gradient,
+                                       metric=mse())]
+            self.compute_x_net = False
+            self.fuse_passes = False
+            return
         self.sure = SureGaussianLoss(sigma=noise_level / 255, cropped_div=sure_cropped_div,
                                      averaged_cst=sure_averaged_cst, margin=sure_margin)
         self.ei = EILoss(metric=mse(), transform=ei_transform, no_grad=stop_gradient, weight=alpha_tradeoff)
@@ -87,7 +95,7 @@ class ProposedLoss(Module):
 
     def forward(self, x, y, model):
         if not self.fuse_passes:
-            x_net = model(y)
+            x_net = model(y) if self.compute_x_net else None
             loss = 0
             for loss_fn in self.loss_fns:
                 loss = loss + loss_fn(x=x, x_net=x_net, y=y, physics=self.physics, model=model)

@@ -143,6 +143,25 @@ class ScalingTransform(Module):
         return self.transform(x)
 
 
+class Shift(Module):
+    """Random circular shift (deepinv.transform.Shift at v0.2.0, the `Shifts` option of
+    src/losses/__init__.py:92-94; restated from its documented behaviour -- deepinv is absent, unpinned): one
+    shift per axis, drawn without replacement from [-shift_max*size, shift_max*size) by a random permutation
+    (CPU generator: randperm over H first, then W), applied with torch.roll to the whole batch."""
+
+    def __init__(self, n_trans=1, shift_max=1.0):
+        super().__init__()
+        self.n_trans, self.shift_max = n_trans, shift_max
+
+    def forward(self, x):
+        H, W = x.shape[-2:]
+        assert self.n_trans <= H - 1 and self.n_trans <= W - 1
+        h_max, w_max = int(self.shift_max * H), int(self.shift_max * W)
+        sx = torch.arange(-h_max, h_max)[torch.randperm(2 * h_max)][: self.n_trans]
+        sy = torch.arange(-w_max, w_max)[torch.randperm(2 * w_max)][: self.n_trans]
+        return torch.cat([torch.roll(x, [int(a), int(b)], [-2, -1]) for a, b in zip(sx, sy)], dim=0)
+
+
 class CombinedTransform(Module):
     def __init__(self, transforms):
         super().__init__()

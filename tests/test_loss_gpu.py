@@ -251,6 +251,50 @@ def test_train_script_end_to_end(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_r2r_alternative_and_shift_transform_match_oracle():
+    """--ProposedLoss__sure_alternative r2r with --ProposedLoss__transforms Shifts: loss and weight gradients
+    against the oracle's restatement of src/losses/r2r.py on the same weights, shifts and injected noise."""
+    import physics
+    import models
+    import transforms
+    from losses import get_loss
+    args = ref_args(ProposedLoss__sure_alternative="r2r", ProposedLoss__transforms="Shifts",
+                    ConvolutionalModel__hidden_channels=8, ConvolutionalModel__scales=3)
+    p = physics.get_physics(args, "cuda")
+    torch.manual_seed(0)
+    model = models.get_model(args, p, "cuda").to("cuda")
+    lf = get_loss(args, p)
+    inner = lf.loss.loss_fns[0]
+    assert isinstance(inner.T, transforms.Shift) and lf.loss.compute_x_net is False
+    gen = torch.Generator().manual_seed(5)
+    y = torch.rand((2, 3, 48, 48), generator=gen)
+    n0, n1, n2 = (torch.randn((2, 3, 48, 48), generator=gen) for _ in range(3))
+    torch.manual_seed(77)                                   # the Shift transform's two randperm draws
+    val = inner(y=y.cuda(), physics=p, model=model, x=None, x_net=None, _noise=(n0.cuda(), n1.cuda(), n2.cuda()))
+    val.backward()
+    sd = {k: v.detach().double().cpu().requires_grad_(True) for k, v in model.get_weights().items()}
+    k2 = tp.blur_kernel("Gaussian_R2")
+    A = lambda v: tp.blur_fft(v, k2)
+    net = lambda v: tp.unet_forward(sd, v, scales=3)
+    torch.manual_seed(77)
+    ref, _, _ = tp.r2r_ei_loss(y.double(), A, net, transforms.Shift(), 5 / 255, unit_pert=n0.double(),
+                               n1=n1.double(), n2=n2.double())
+    ref.backward()
+    assert abs(float(val) - float(ref)) < 1e-4 * abs(float(ref))
+    params = dict(model.get_backbone().named_parameters())
+    worst = max(abs(float(params[k].grad.double().norm()) - float(v.grad.norm())) / float(v.grad.norm())
+                for k, v in sd.items())
+    assert worst < 1e-3, worst
+    # the Shift transform alone: a circular roll of the whole batch by one (dx, dy)
+    t = transforms.Shift()
+    x = torch.arange(2 * 3 * 6 * 5, dtype=torch.float32).view(2, 3, 6, 5)
+    torch.manual_seed(1)
+    out = t(x)
+    torch.manual_seed(1)
+    sx = int(torch.arange(-6, 6)[torch.randperm(12)][0]); sy = int(torch.arange(-5, 5)[torch.randperm(10)][0])
+    assert torch.equal(out, torch.roll(x, [sx, sy], [-2, -1]))
+
+
 def test_psnr_y_metric_and_registration():
     """metrics.psnr_fn on the GPU (sei_luma_sqerr) against the oracle's luma PSNR; centre-crop registration."""
     import metrics
