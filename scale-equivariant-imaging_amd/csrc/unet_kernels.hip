@@ -1015,10 +1015,7 @@ __global__ __launch_bounds__(256) void adam_vec_kernel(float *__restrict__ p, co
                                                        float step_size, float inv_bc2_sqrt, float gscale,
                                                        unsigned short *__restrict__ p16) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += stride) {
-        const float4 pq = reinterpret_cast<float4 *>(p)[q];
-        float4 mq = reinterpret_cast<float4 *>(m)[q], vq = reinterpret_cast<float4 *>(v)[q];
-        const float4 gq = grad_quad(g, q);
+    auto update = [&](size_t q, const float4 pq, float4 mq, float4 vq, const float4 gq) {
         float4 o;
         o.x = adam_element(pq.x, gq.x * gscale, mq.x, vq.x, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
         o.y = adam_element(pq.y, gq.y * gscale, mq.y, vq.y, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
@@ -1034,7 +1031,20 @@ __global__ __launch_bounds__(256) void adam_vec_kernel(float *__restrict__ p, co
             w.y = (unsigned)__builtin_bit_cast(unsigned short, b2) | ((unsigned)__builtin_bit_cast(unsigned short, b3) << 16);
             reinterpret_cast<uint2 *>(p16)[q] = w;
         }
+    };
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; q + stride < nquads; q += 2 * stride) {          // two quads per stream in flight
+        const size_t q2 = q + stride;
+        const float4 pa = reinterpret_cast<float4 *>(p)[q], pb = reinterpret_cast<float4 *>(p)[q2];
+        const float4 ma = reinterpret_cast<float4 *>(m)[q], mb = reinterpret_cast<float4 *>(m)[q2];
+        const float4 va = reinterpret_cast<float4 *>(v)[q], vb = reinterpret_cast<float4 *>(v)[q2];
+        const float4 ga = grad_quad(g, q), gb = grad_quad(g, q2);
+        update(q, pa, ma, va, ga);
+        update(q2, pb, mb, vb, gb);
     }
+    if (q < nquads)
+        update(q, reinterpret_cast<float4 *>(p)[q], reinterpret_cast<float4 *>(m)[q], reinterpret_cast<float4 *>(v)[q],
+               grad_quad(g, q));
 }
 
 inline unsigned capped_grid(size_t work_items, int per_block, unsigned cap) {
@@ -1351,7 +1361,9 @@ extern "C" int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, 
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     hipStream_t s = (hipStream_t)stream;
-    // 16-byte-aligned streams take the 4-wide kernel; a ragged tail (and unaligned views) the scalar one
+    // 16-byte-aligned streams take the 4-wide kernel; a ragged tail (and unaligned views) the scalar one.
+    // Grid: one two-quad iteration per thread (up to 2^20 workgroups) -- measured 3.17 ms for the 645 M-parameter
+    // bucket against 3.43 ms with 8192 looping workgroups (tools/exp_adam.py).
     const size_t gsz = grad_is_bf16 ? 2 : 4;
     const bool aligned = ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(exp_avg) |
                            reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0 &&
@@ -1359,7 +1371,7 @@ extern "C" int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, 
                          (!param_bf16 || (reinterpret_cast<uintptr_t>(param_bf16) & 7) == 0);
     const size_t nq = aligned ? n / 4 : 0, done = 4 * nq;
 #define SEI_ADAM(KERNEL, G, COUNT, OFF)                                                                              \
-    hipLaunchKernelGGL(KERNEL<G>, dim3(capped_grid(COUNT, 256 * 2, 8192)), dim3(256), 0, s, param + (OFF),          \
+    hipLaunchKernelGGL(KERNEL<G>, dim3(capped_grid(COUNT, 256 * 2, 1u << 20)), dim3(256), 0, s, param + (OFF),      \
                        reinterpret_cast<const G *>(grad) + (OFF), exp_avg + (OFF), exp_avg_sq + (OFF), COUNT, beta1, \
                        beta2, eps, weight_decay, step_size, inv_bc2_sqrt, grad_scale,                                \
                        param_bf16 ? param_bf16 + (OFF) : nullptr)

@@ -10,8 +10,9 @@ def timeit(fn, iters=6):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-for trial in range(3):
-    for stagger in (0, 64, 1024, 4096 + 64, 65536 + 1024):     # float32 elements between successive stream bases
+for trial in range(2):
+  for grid in ("library default",):
+    for stagger in (0, 1024):
         pad = 4 * max(stagger, 1) + 64
         bufs = [torch.zeros(n + pad, device="cuda") for _ in range(4)]
         p, g, m, v = (b[k * stagger:k * stagger + n] for k, b in enumerate(bufs))
@@ -19,5 +20,5 @@ for trial in range(3):
         g.normal_()
         t = timeit(lambda: N.call("sei_adam_fused", p.data_ptr(), g.data_ptr(), 0, m.data_ptr(), v.data_ptr(), n,
                                   1e-4, 0.9, 0.999, 1e-8, 0.0, 3, 1.0, sh.data_ptr()))
-        print(f"trial {trial} stagger {stagger:6d} floats: {t:6.3f} ms  {30.0 * n / t / 1e9:6.2f} TB/s", flush=True)
+        print(f"trial {trial} grid {grid} stagger {stagger:6d} floats: {t:6.3f} ms  {30.0 * n / t / 1e9:6.2f} TB/s", flush=True)
         del bufs, p, g, m, v, sh
