@@ -260,6 +260,11 @@ int sei_debug_set_dw_seg(int seg);
 int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
                 const float *L1, const float *R1, const float *L2, const float *R2, float *work,
                 size_t work_floats, void *stream);
+/* The same map with the four matrices packed for the kernel's scalar loads (what the build's host code uses):
+ * RW[j][j'][t] = R_t[j'][j] with j' padded to a multiple of 24 (zeros), LH[i][t][i'] = L_t[i'][i] with i' padded
+ * to a multiple of 24. Results are bit-identical to sei_sepmap2. */
+int sei_sepmap2_packed(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                       const float *RW, const float *LH, float *work, size_t work_floats, void *stream);
 
 int sei_colsum_f32(const float *X, float *out, size_t M, int N, void *stream);
 /* out[n] += sum_m row_weight[m] * X[m,n]: the bias gradient of a 1x1 convolution applied AFTER the ideal

@@ -57,6 +57,7 @@ SIGNATURES = {
     "sei_debug_set_nt_tile": [_I],
     "sei_debug_set_dw_seg": [_I],
     "sei_sepmap2": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P],
+    "sei_sepmap2_packed": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P],
     "sei_colsum_f32": [_P, _P, _Z, _I, _P],
     "sei_colsum_weighted_f32": [_P, _P, _P, _Z, _I, _P],
     "sei_adam_fused": [_P, _P, _I, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P, _P],

@@ -938,6 +938,112 @@ __global__ __launch_bounds__(SM_THREADS) void sepmap_h_kernel(const float *__res
         if (io0 + q < Ho) o[(size_t)q * row] = a[q];
 }
 
+// ---- the same two passes with the matrices packed for scalar loads ------------------------------------------
+// RW[j][j'][t] (t fastest, j' padded to SM_PAD) and LH[i][t][i'] (i' fastest, padded): the 2*OT (resp. OT) matrix
+// entries one activation value is multiplied with are CONTIGUOUS, so they arrive as two or three wide scalar
+// loads and feed packed FMAs directly. With separate (out, in) row-major matrices the same loop spent four scalar
+// moves / lane spills per packed FMA gathering them (112 s_mov + 164 v_readlane/v_writelane per 72 v_pk_fma_f32).
+// Accumulation order per output is unchanged.
+constexpr int SM_PAD = 24;
+
+template <int OT>
+__global__ __launch_bounds__(SM_THREADS) void sepmap_w_packed_kernel(const float *__restrict__ x, float *__restrict__ T,
+                                                                     const float *__restrict__ RW, size_t rows,
+                                                                     int Hi, int Wi, int Wo, int wo_pad, int C) {
+    const size_t idx = (size_t)blockIdx.x * SM_THREADS + threadIdx.x;      // (row = b*Hi + i, c)
+    if (idx >= rows * C) return;
+    const int jo0 = blockIdx.y * OT;
+    const size_t r = idx / C;
+    const int c = (int)(idx - r * C);
+    const float *xr = x + r * Wi * C + c;
+    const float *rw0 = RW + (size_t)jo0 * 2;
+    const size_t ldw = (size_t)wo_pad * 2;
+    float a1[OT], a2[OT];
+#pragma unroll
+    for (int q = 0; q < OT; ++q) a1[q] = a2[q] = 0.f;
+    int j = 0;
+    for (; j + SM_LOADS <= Wi; j += SM_LOADS) {
+        float v[SM_LOADS];
+#pragma unroll
+        for (int u = 0; u < SM_LOADS; ++u) v[u] = xr[(size_t)(j + u) * C];
+#pragma unroll
+        for (int u = 0; u < SM_LOADS; ++u) {
+            const float *rw = rw0 + (size_t)(j + u) * ldw;
+#pragma unroll
+            for (int q = 0; q < OT; ++q) {
+                a1[q] = fmaf(rw[2 * q], v[u], a1[q]);
+                a2[q] = fmaf(rw[2 * q + 1], v[u], a2[q]);
+            }
+        }
+    }
+    for (; j < Wi; ++j) {
+        const float v = xr[(size_t)j * C];
+        const float *rw = rw0 + (size_t)j * ldw;
+#pragma unroll
+        for (int q = 0; q < OT; ++q) {
+            a1[q] = fmaf(rw[2 * q], v, a1[q]);
+            a2[q] = fmaf(rw[2 * q + 1], v, a2[q]);
+        }
+    }
+    const size_t b = r / Hi;
+    const int i = (int)(r - b * Hi);
+    const size_t plane = (size_t)Hi * Wo * C;
+    float *o = T + (b * 2) * plane + ((size_t)i * Wo + jo0) * C + c;
+#pragma unroll
+    for (int q = 0; q < OT; ++q)
+        if (jo0 + q < Wo) {
+            o[(size_t)q * C] = a1[q];
+            o[(size_t)q * C + plane] = a2[q];
+        }
+}
+
+template <int OT>
+__global__ __launch_bounds__(SM_THREADS) void sepmap_h_packed_kernel(const float *__restrict__ T, float *__restrict__ y,
+                                                                     const float *__restrict__ LH, int B, int Hi,
+                                                                     int Ho, int ho_pad, size_t row) {
+    const size_t idx = (size_t)blockIdx.x * SM_THREADS + threadIdx.x;      // (b, jc = j'*C + c)
+    if (idx >= (size_t)B * row) return;
+    const int io0 = blockIdx.y * OT;
+    const size_t b = idx / row, jc = idx - b * row;
+    const size_t plane = (size_t)Hi * row;
+    const float *t1 = T + (b * 2) * plane + jc, *t2 = t1 + plane;
+    const float *lh0 = LH + io0;
+    float a[OT];
+#pragma unroll
+    for (int q = 0; q < OT; ++q) a[q] = 0.f;
+    int i = 0;
+    for (; i + SM_LOADS <= Hi; i += SM_LOADS) {
+        float v1[SM_LOADS], v2[SM_LOADS];
+#pragma unroll
+        for (int u = 0; u < SM_LOADS; ++u) {
+            v1[u] = t1[(size_t)(i + u) * row];
+            v2[u] = t2[(size_t)(i + u) * row];
+        }
+#pragma unroll
+        for (int u = 0; u < SM_LOADS; ++u) {
+            const float *l1 = lh0 + (size_t)(i + u) * 2 * ho_pad, *l2 = l1 + ho_pad;
+#pragma unroll
+            for (int q = 0; q < OT; ++q) {
+                a[q] = fmaf(l1[q], v1[u], a[q]);
+                a[q] = fmaf(l2[q], v2[u], a[q]);
+            }
+        }
+    }
+    for (; i < Hi; ++i) {
+        const float v1 = t1[(size_t)i * row], v2 = t2[(size_t)i * row];
+        const float *l1 = lh0 + (size_t)i * 2 * ho_pad, *l2 = l1 + ho_pad;
+#pragma unroll
+        for (int q = 0; q < OT; ++q) {
+            a[q] = fmaf(l1[q], v1, a[q]);
+            a[q] = fmaf(l2[q], v2, a[q]);
+        }
+    }
+    float *o = y + (b * Ho + io0) * row + jc;
+#pragma unroll
+    for (int q = 0; q < OT; ++q)
+        if (io0 + q < Ho) o[(size_t)q * row] = a[q];
+}
+
 // =================================================================================================
 // column sums and Adam
 // =================================================================================================
@@ -1324,6 +1430,32 @@ extern "C" int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int 
     else
         hipLaunchKernelGGL(sepmap_h_kernel<8>, dim3(gh.x, (unsigned)sei_ceil_div(Ho, 8)), dim3(SM_THREADS), 0, s,
                            (const float *)work, y, L1, L2, B, Hi, Ho, (size_t)Wo * C);
+    return sei_launch_status();
+}
+
+extern "C" int sei_sepmap2_packed(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                  const float *RW, const float *LH, float *work, size_t work_floats, void *stream) {
+    SEI_REQUIRE(x && y && RW && LH && work && x != y);
+    SEI_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0);
+    const size_t need = (size_t)2 * B * Hi * Wo * C;
+    SEI_REQUIRE(work_floats >= need);
+    hipStream_t s = (hipStream_t)stream;
+    const int wo_pad = (int)sei_ceil_div(Wo, SM_PAD) * SM_PAD, ho_pad = (int)sei_ceil_div(Ho, SM_PAD) * SM_PAD;
+    const size_t rows = (size_t)B * Hi, nw = rows * C, nh = (size_t)B * Wo * C;
+    SEI_REQUIRE(sei_ceil_div(nw, SM_THREADS) < (1u << 31) && sei_ceil_div(nh, SM_THREADS) < (1u << 31));
+    const dim3 gw((unsigned)sei_ceil_div(nw, SM_THREADS)), gh((unsigned)sei_ceil_div(nh, SM_THREADS));
+    if (Wo % 12 == 0)
+        hipLaunchKernelGGL(sepmap_w_packed_kernel<12>, dim3(gw.x, Wo / 12), dim3(SM_THREADS), 0, s, x, work, RW, rows, Hi,
+                           Wi, Wo, wo_pad, C);
+    else
+        hipLaunchKernelGGL(sepmap_w_packed_kernel<8>, dim3(gw.x, (unsigned)sei_ceil_div(Wo, 8)), dim3(SM_THREADS), 0, s, x,
+                           work, RW, rows, Hi, Wi, Wo, wo_pad, C);
+    if (Ho % 12 == 0)
+        hipLaunchKernelGGL(sepmap_h_packed_kernel<12>, dim3(gh.x, Ho / 12), dim3(SM_THREADS), 0, s, (const float *)work, y,
+                           LH, B, Hi, Ho, ho_pad, (size_t)Wo * C);
+    else
+        hipLaunchKernelGGL(sepmap_h_packed_kernel<8>, dim3(gh.x, (unsigned)sei_ceil_div(Ho, 8)), dim3(SM_THREADS), 0, s,
+                           (const float *)work, y, LH, B, Hi, Ho, ho_pad, (size_t)Wo * C);
     return sei_launch_status();
 }
 

@@ -89,10 +89,29 @@ def resample_matrices(kind, H, W, rate, device):
     key = (kind, H, W, rate, str(device))
     if key not in _DEVICE_CACHE:
         host = _host_matrices(kind, H, W, rate)
-        fwd = tuple(torch.from_numpy(m).to(device) for m in host)
-        bwd = tuple(torch.from_numpy(np.ascontiguousarray(m.T)).to(device) for m in host)
+        host_t = tuple(np.ascontiguousarray(m.T) for m in host)
+        fwd = tuple(torch.from_numpy(m).to(device) for m in host) + pack_for_kernel(host, device)
+        bwd = tuple(torch.from_numpy(m).to(device) for m in host_t) + pack_for_kernel(host_t, device)
         _DEVICE_CACHE[key] = (fwd, bwd)
     return _DEVICE_CACHE[key]
+
+
+SM_PAD = 24          # padding of the output axis in the packed layouts (csrc/unet_kernels.hip)
+
+
+def pack_for_kernel(mats, device):
+    """(L1, R1, L2, R2), each (out, in) -> (RW, LH) for sei_sepmap2_packed:
+    RW[j][j'][t] = R_t[j'][j] (j' padded to SM_PAD), LH[i][t][i'] = L_t[i'][i] (i' padded)."""
+    L1, R1, L2, R2 = (np.asarray(m.detach().cpu() if isinstance(m, torch.Tensor) else m, dtype=np.float32)
+                      for m in mats)
+    Wo, Wi = R1.shape
+    Ho, Hi = L1.shape
+    wo_pad, ho_pad = -(-Wo // SM_PAD) * SM_PAD, -(-Ho // SM_PAD) * SM_PAD
+    RW = np.zeros((Wi, wo_pad, 2), dtype=np.float32)
+    RW[:, :Wo, 0], RW[:, :Wo, 1] = R1.T, R2.T
+    LH = np.zeros((Hi, 2, ho_pad), dtype=np.float32)
+    LH[:, 0, :Ho], LH[:, 1, :Ho] = L1.T, L2.T
+    return torch.from_numpy(RW).to(device), torch.from_numpy(LH).to(device)
 
 
 def constant_response(kind, H, W, rate, device, batch):

@@ -133,12 +133,14 @@ def dwconv7_weight_grad(x, gy, gw, gb):
 
 
 def sepmap2(x, mats, Ho, Wo):
+    """mats: (L1, R1, L2, R2[, RW, LH]) -- the packed pair comes with `_mats.resample_matrices`; a bare 4-tuple
+    (tests, experiments) is packed here."""
     B, Hi, Wi, C = x.shape
     y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
     work = torch.empty(2 * B * Hi * Wo * C, dtype=torch.float32, device=x.device)
-    L1, R1, L2, R2 = mats
-    N.call("sei_sepmap2", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, L1.data_ptr(), R1.data_ptr(),
-           L2.data_ptr(), R2.data_ptr(), work.data_ptr(), work.numel())
+    RW, LH = (mats[4], mats[5]) if len(mats) >= 6 else _mats.pack_for_kernel(mats[:4], x.device)
+    N.call("sei_sepmap2_packed", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, RW.data_ptr(), LH.data_ptr(),
+           work.data_ptr(), work.numel())
     return y
 
 

@@ -19,6 +19,7 @@ for lvl in range(4):
             Hi, Ho, Cc = H // 2, H, 2 * C
         x = torch.randn((B, Hi, Hi, Cc), device="cuda")
         mats = [torch.randn((Ho, Hi), device="cuda") for _ in range(4)]
+        mats = tuple(mats) + _mats.pack_for_kernel(mats, "cuda")
         t = timeit(lambda: _ops.sepmap2(x, mats, Ho, Ho))
         mac = B * Cc * (Hi * Ho * 2 * Hi + Ho * Ho * 2 * Hi)
         mb = (x.numel() + B * Ho * Ho * Cc) * 4 / 1e6
