@@ -208,6 +208,11 @@ def main():
             e1.synchronize()
             total_ms += e0.elapsed_time(e1) / reps
             flops += fl
+            if os.environ.get("SEI_GEMM_TABLE"):            # per-launch table for kernel work (tools/, not the bench line)
+                with open(os.environ["SEI_GEMM_TABLE"], "a") as f:
+                    ints = [a for a in cargs if isinstance(a, int) and 0 <= a < (1 << 24)]
+                    us = 1e3 * e0.elapsed_time(e1) / reps
+                    f.write(f"{entry} {ints} {us:.1f} us {fl / us / 1e6:.1f} TF\n")
         del keep
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:

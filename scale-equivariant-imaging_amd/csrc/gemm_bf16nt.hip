@@ -387,6 +387,7 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, s
 int g_force_band = 0;     // tuning aid (sei_debug_set_nt_tile codes 100 + band); 0 = automatic
 
 #include "gemm_bf16pp.h"  // 256 x 256 ping-pong schedule on the same LDS images
+#include "gemm_bf16pq.h"
 
 template <int TM, int TN, int WM, int WN, bool ARM = false, bool BRM = false, int NSTAGE = 2>
 int launch_nt(NtArgs &g, hipStream_t s) {
@@ -459,6 +460,29 @@ extern "C" int sei_debug_set_nt_tile(int code) {
     return SEI_OK;
 }
 
+// Quadrant schedule (gemm_bf16pq.h) or not, and which tile: returns 0, or 10 * RF + NF.
+//   * launches that do not split K (bf16 / GELU / GELU' outputs: the expanding 1x1 convolutions and their data
+//     gradients) take it when 288- or 256-row tiles fill the chip (tools/exp_pq.py: 2304 x 8192 x 2048
+//     124 -> 83 us, 576 x 32768 x 8192 495 -> 246 us, 288 x 32768 x 8192 249 -> 170 us);
+//   * split-K launches (f32 outputs of the contracting convolutions) only with a long reduction and a wide
+//     output (576 x 8192 x 32768: 441 -> 288 us; 2304 x 2048 x 8192: 130 -> 104 us); shorter ones lose to the
+//     128 x 128 loop (9216 x 512 x 2048: 44 vs 55 us), whose three workgroups per CU hide the atomics.
+int pq_choose(const NtArgs &g, bool would_split) {
+    const int M = g.M, N = g.N, K = g.K;
+    const int rf = M % 288 == 0 ? 9 : ((M % 256 == 0 || M >= 4096) ? 8 : 0);
+    if (g_force_tile != 0 || !rf || K < 512 || N < 512 || !pq_eligible(g)) return 0;
+    const size_t tm = sei_ceil_div(M, 32 * rf);
+    const size_t t4 = tm * sei_ceil_div(N, 256), t2 = tm * sei_ceil_div(N, 128);
+    auto fills = [](size_t t) { return (double)t / (double)(sei_ceil_div(t, 256) * 256) >= 0.8; };
+    if (would_split && t4 < 1024) {
+        if (K < 8192 || N < 2048 || (M < 2304 && N < 8192)) return 0;
+        return 10 * rf + ((t4 >= 64 && N >= 8192) ? 4 : 2);
+    }
+    if (t4 >= 192 && fills(t4)) return 10 * rf + 4;
+    if (t2 >= 128 && t4 < 192 && fills(t2)) return 10 * rf + 2;
+    return 0;
+}
+
 extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
                                float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
                                const float *R1, const float *R2, uint16_t *D2_16, void *stream) {
@@ -483,6 +507,29 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
     g.A2 = A; g.B2 = B; g.k_seg = K;                       // one reduction segment
     hipStream_t s = (hipStream_t)stream;
+    const bool would_split = (epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_RES ||
+                              epilogue == SEI_EPI_ACCUM) && D32 && !D16;
+    if (g_force_tile >= 30 && g_force_tile < 40 && !a_rmajor && pq_eligible(g)) {   // quadrant schedule
+        if (b_rmajor) {
+            switch (g_force_tile) {
+                case 30: return launch_pq<8, 4, true>(g, s);
+                case 31: return launch_pq<9, 4, true>(g, s);
+                case 32: return launch_pq<9, 2, true>(g, s);
+                case 33: return launch_pq<8, 2, true>(g, s);
+                default: break;
+            }
+        } else {
+            switch (g_force_tile) {
+                case 30: return launch_pq<8, 4>(g, s);
+                case 31: return launch_pq<9, 4>(g, s);
+                case 32: return launch_pq<9, 2>(g, s);
+                case 33: return launch_pq<8, 2>(g, s);
+                case 34: return launch_pq<8, 4, false, 2>(g, s);      // ablations: timing only, wrong results
+                case 35: return launch_pq<8, 4, false, 7>(g, s);
+                default: break;
+            }
+        }
+    }
     if (g_force_tile == 20) {                            // 256 x 256 ping-pong schedule (tuning aid)
         if (a_rmajor && b_rmajor) return launch_pp<true, true>(g, s);
         if (a_rmajor) return launch_pp<true, false>(g, s);
@@ -513,6 +560,13 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     }
     if (a_rmajor) return launch_nt<2, 1, 2, 4, true, false>(g, s);
     if (b_rmajor) {
+        switch (pq_choose(g, would_split)) {
+            case 94: return launch_pq<9, 4, true>(g, s);
+            case 92: return launch_pq<9, 2, true>(g, s);
+            case 84: return launch_pq<8, 4, true>(g, s);
+            case 82: return launch_pq<8, 2, true>(g, s);
+            default: break;
+        }
         // skinny data gradients (the bottleneck levels): 192 x 256 with two 128-column images of the weight
         if (g_force_tile != 1 && N >= 2048 && K >= 2048 && M <= 768)
             return launch_nt<3, 2, 2, 4, false, true>(g, s);
@@ -532,6 +586,13 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     // 110 vs 144 us for 192x256). Skinny outputs (the 8192-channel bottleneck: M = 288 or 576 rows against
     // N = 8192 / 32768) are weight-streaming: there 192x256 wins (M = 288: 221 vs 309 us), padding included,
     // and 96x256 never does. A 256x256 tile on this loop needs the rolled epilogue of gemm_bf16pp.h.
+    switch (pq_choose(g, would_split)) {
+        case 94: return launch_pq<9, 4>(g, s);
+        case 92: return launch_pq<9, 2>(g, s);
+        case 84: return launch_pq<8, 4>(g, s);
+        case 82: return launch_pq<8, 2>(g, s);
+        default: break;
+    }
     if (N >= 2048 && K >= 2048 && M <= 768) return launch_nt<3, 2, 2, 4>(g, s);               // 192 x 256
     // short reductions are all prologue and epilogue: one LDS stage (32 KB) and <= 84 VGPRs put three workgroups
     // on a CU instead of two (36864 x 512 x 128: 34 -> 27 us; 9216 x 2048 x 512: 50 -> 44 us; loses from K ~ 2048)

@@ -43,7 +43,8 @@ constexpr int PP_BM = 256, PP_BN = 256;
 constexpr int PP_HALF = 128 * ROW_BYTES;              // 16 KB
 constexpr int PP_LDS = 2 * 4 * PP_HALF;               // 128 KB
 
-template <bool ARM, bool BRM>
+// ABL (tuning aid, wrong results): 1 = no fragment reads in the loop, 2 = no DMA in the loop, 4 = no barriers.
+template <bool ARM, bool BRM, int ABL = 0>
 __global__ __launch_bounds__(NT) void gemm_bf16pp_kernel(NtArgs g) {
     __shared__ __attribute__((aligned(1024))) char smem[PP_LDS];
     const int lane = threadIdx.x & 63;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pp_kernel(NtArgs g) {
 
     // ---- DMA: half-tile h (0,1 = A row halves; 2,3 = B column halves) of k-tile u, 2 pieces per wave ----------
     auto issue_half = [&](int u, int h) {
+        if constexpr (ABL & 2) { if (u > 1) return; }
         char *dst = smem + ((u & 1) * 4 + h) * PP_HALF;
         const int k0 = k_begin + u * BK;
 #pragma unroll
@@ -102,7 +104,9 @@ __global__ __launch_bounds__(NT) void gemm_bf16pp_kernel(NtArgs g) {
     // ---- fragments ---------------------------------------------------------------------------------------------
     const int sw = (li >> 1) & 7;
     bf16x8 fa[2][4], fb0[4], fb1[4];                  // A: 2 row fragments x 4 k-steps; B: column fragment 0 / 1
+    bool abl_first = true;
     auto read_a = [&](const char *buf, int qm) {      // rows 64*qm .. +64 of this wave group's A half
+        if constexpr (ABL & 1) { if (!abl_first) return; }
         const char *t = buf + wr * PP_HALF;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pp_kernel(NtArgs g) {
             }
     };
     auto read_b = [&](const char *buf, int qn, bf16x8 (&fb)[4]) {   // cols 64*(wc&1) + 32*qn .. +32 of B half wc>>1
+        if constexpr (ABL & 1) { if (!abl_first) return; }
         const char *t = buf + (2 + (wc >> 1)) * PP_HALF;
         const int c0 = 64 * (wc & 1) + 32 * qn;
 #pragma unroll
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pp_kernel(NtArgs g) {
                 acc[2 * qm + i][qn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][s], fb[s], acc[2 * qm + i][qn], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    auto bar = [&]() { __builtin_amdgcn_s_barrier(); };
+    auto bar = [&]() { if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier(); };
     auto lds_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
     // ---- prologue: k-tile 0 complete, Bh0 of k-tile 1 in flight ---------------------------------------------
@@ -151,6 +156,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pp_kernel(NtArgs g) {
     for (int t = 0; t < nt; ++t) {
         const char *buf = smem + (t & 1) * 4 * PP_HALF;
         const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+        if constexpr (ABL & 1) abl_first = t == 0;
         // phase 1
         read_a(buf, 0);
         read_b(buf, 0, fb0);
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pp_kernel(NtArgs g) {
     }
 }
 
-template <bool ARM, bool BRM>
+template <bool ARM, bool BRM, int ABL = 0>
 int launch_pp(NtArgs &g, hipStream_t s) {
     g.tiles_m = (int)sei_ceil_div(g.M, PP_BM);
     g.tiles_n = (int)sei_ceil_div(g.N, PP_BN);
@@ -356,7 +362,7 @@ int launch_pp(NtArgs &g, hipStream_t s) {
         if ((reinterpret_cast<uintptr_t>(g.D32) & 15) != 0) return SEI_ERR_BAD_ARG;
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
-    hipLaunchKernelGGL((gemm_bf16pp_kernel<ARM, BRM>), dim3((unsigned)(8 * (size_t)g.tiles_per_xcd * g.splitk)),
+    hipLaunchKernelGGL((gemm_bf16pp_kernel<ARM, BRM, ABL>), dim3((unsigned)(8 * (size_t)g.tiles_per_xcd * g.splitk)),
                        dim3(NT), 0, s, g);
     return sei_launch_status();
 }

@@ -1,0 +1,511 @@
+// gemm_bf16pq_kernel: the "quadrant" schedule of the bf16 GEMM for the deep U-Net levels (included by
+// gemm_bf16nt.hip). One workgroup per CU, 8 waves = 2 (rows) x 4 (columns), 16x16x32 MFMAs, tile
+// (32 RF) x (64 NF) x 64:  RF = 9 -> 288 rows: every row count of this model is 288 * 2^j (9 * 2^j pixels x 32
+// images), so 2304-, 576- and 288-row GEMMs cut into whole tiles and a 2304 x 8192 output is exactly 256 tiles;
+// RF = 8 -> 256 rows for everything else. NF = 4 -> 256 columns, NF = 2 -> 128 (twice the tiles for short M).
+//
+// What differs from the 128 x 128 loop and from gemm_bf16pp_kernel (measured on 4096^3: removing the LDS-DMA
+// issue from the ping-pong loop gave +22 %, removing the fragment reads +1 %, removing the barriers nothing):
+//   * DMA issue costs instructions, not bandwidth. A piece is one global_load_lds whose per-lane byte offset is
+//     fixed for the whole launch (row clamped to the matrix, chunk pre-swizzled) and whose base is a uniform
+//     pointer that advances 128 B per k-tile: no 64-bit lane arithmetic and no bounds selects in the loop.
+//     (K ranges are multiples of 64 here; the host falls back to the 128 x 128 kernel otherwise.)
+//   * Half-tiles are cut by QUADRANT, not by wave group: A(q) holds the rows every wave needs for its row
+//     quadrant q, B(q) the columns for column quadrant q. A half-tile is therefore read in ONE phase and free
+//     again right after it, which lets the DMA run 5-6 phases (1.5 k-tiles) ahead inside two stages of LDS:
+//         phase 1: read B(0), A(0)   MFMA (0,0)   issue A(1) of tile t+1
+//         phase 2: read B(1)         MFMA (0,1)   issue B(0) of tile t+2
+//         phase 3: read A(1)         MFMA (1,1)   issue A(0) of tile t+2
+//         phase 4: --                MFMA (1,0)   issue B(1) of tile t+2;  counted vmcnt: tile t+1 landed
+//     each phase = [reads + DMA issue] s_barrier [lgkmcnt(0); MFMAs] s_barrier; the wr = 1 waves run one barrier
+//     behind, so their read segment coincides with the other group's MFMA segment.
+//   * The epilogue goes through a wave-private LDS patch (16 rows x 64 NF/4 columns): accumulators in, whole
+//     rows out, so every auxiliary load, store and atomic is 16 B per lane on full 128/256-B row segments
+//     (a 16x16 accumulator stored as it stands is 32-B bf16 segments).
+//
+// Hazards, by count (segments: group 0 reads in segment 2p and computes in 2p+1, group 1 reads in 2p+1 and
+// computes in 2p+2; a barrier event separates consecutive segments):
+//   WAR  B(0) is re-staged one phase after its reads: those reads are retired BEFORE the first barrier of
+//        phase 1 (lgkmcnt counted down to the A reads issued after them). Everything else is re-staged two
+//        phases after its reads were retired by lgkmcnt(0).
+//   RAW  the vmcnt of phase 4 leaves only the pieces issued in phases 2-4 in flight (a wave with a third A(0)
+//        piece counts one more) and sits before the barrier event that ends segment 2*4+1; tile t+1 is first
+//        read in the segment after it.
+#pragma once
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int N>
+__device__ __forceinline__ void pq_wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else static_assert(N < 0, "add the immediate");
+}
+template <int N>
+__device__ __forceinline__ void pq_wait_lgkmcnt() {
+    if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+    else static_assert(N < 0, "add the immediate");
+}
+
+template <int RF, int NF>
+struct PqGeom {
+    static constexpr int QA0 = (RF + 1) / 2, QA1 = RF / 2, QB = NF / 2;     // fragments per quadrant
+    static constexpr int BM = 32 * RF, BN = 64 * NF;
+    static constexpr int A0_ROWS = 32 * QA0, A1_ROWS = 32 * QA1, B_ROWS = 64 * QB;
+    static constexpr int OFF_A0 = 0, OFF_A1 = A0_ROWS * ROW_BYTES, OFF_B0 = OFF_A1 + A1_ROWS * ROW_BYTES,
+                         OFF_B1 = OFF_B0 + B_ROWS * ROW_BYTES, STAGE = OFF_B1 + B_ROWS * ROW_BYTES;
+    static constexpr int PA0 = A0_ROWS / 8, PA1 = A1_ROWS / 8, PB = B_ROWS / 8;     // 1-KiB pieces per half-tile
+    static constexpr int NA0 = (PA0 + 7) / 8, NA1 = PA1 / 8, NB = PB / 8;            // pieces per wave (NA0: max)
+    static_assert(PA1 % 8 == 0 && PB % 8 == 0, "uniform piece counts except A(0)");
+    static constexpr int EPI_LDW = 16 * NF + 4;                                      // floats per patch row
+    static_assert(8 * 16 * EPI_LDW * 4 <= 2 * STAGE, "epilogue patches fit the stages");
+};
+
+// 16-B chunk swizzle of a reduction-major half-tile ([64 k-rows][128 or 64 columns]): the fragment reads of 32
+// lanes (ds_read_b64_tr_b16: k-rows 8 lg + q, two neighbouring chunks each) fall on 16 different chunk slots of
+// the 256-B bank row. 256-B rows: swz_rmajor (gemm_bf16nt.hip); 128-B rows (two per bank row): below.
+__device__ __forceinline__ int pq_swz_rm128(int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }
+
+// BRM: B stored reduction-major (element (n, k) at B[k * ldb + n]: the weight as the forward pass stores it, used
+// by the data gradient). Its half-tiles are [64 k-rows][columns of the quadrant] images read with
+// ds_read_b64_tr_b16; the DMA base then advances 64 rows per k-tile.
+template <int RF, int NF, bool BRM = false, int ABL = 0>
+__global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
+    using G = PqGeom<RF, NF>;
+    constexpr int QA0 = G::QA0, QA1 = G::QA1, QB = G::QB;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * G::STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l16 = lane & 15, lg = lane >> 4;
+
+    // ---- tile / split assignment (band-major order per XCD, as gemm_bf16nt_kernel) -------------------------
+    int bid = blockIdx.x;
+    const int per_split = 8 * g.tiles_per_xcd;
+    const int zs = bid / per_split;
+    bid -= zs * per_split;
+    const int ord = (bid & 7) * g.tiles_per_xcd + (bid >> 3);
+    if ((bid >> 3) >= g.tiles_per_xcd || ord >= g.tiles_m * g.tiles_n) return;
+    int tm_i, tn_i;
+    {
+        const int band_tiles = g.tiles_m * g.band;
+        const int b = ord / band_tiles, r = ord - b * band_tiles;
+        const int width = min(g.band, g.tiles_n - b * g.band);
+        tm_i = r / width;
+        tn_i = b * g.band + (r - tm_i * width);
+    }
+    const int m0 = tm_i * G::BM, n0 = tn_i * G::BN;
+    const int M = g.M, N = g.N;
+    const int k_begin = zs * g.k_per_split;
+    const int k_end = min(g.K, k_begin + g.k_per_split);
+    const int nt = (k_end - k_begin) / BK;                    // whole k-tiles only (host-checked)
+
+    f32x4 acc[RF][NF];
+#pragma unroll
+    for (int i = 0; i < RF; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- DMA pieces: fixed per-lane byte offsets from the tile's row origin ---------------------------------
+    // LDS row r of a half-tile -> (group = r / rows-per-group, rr) -> matrix row; chunk swizzle (r >> 1) & 7.
+    const char *a_ptr = reinterpret_cast<const char *>(g.A + (size_t)m0 * g.lda + k_begin);
+    const char *b_ptr = reinterpret_cast<const char *>(BRM ? g.B + (size_t)k_begin * g.ldb + n0
+                                                           : g.B + (size_t)n0 * g.ldb + k_begin);
+    const size_t b_step = BRM ? (size_t)BK * g.ldb * 2 : (size_t)BK * 2;       // bytes per k-tile
+    constexpr int BRP = G::B_ROWS * 2;                         // row pitch of a reduction-major B half (256 / 128 B)
+    auto a_off = [&](int p, int q) -> unsigned {              // piece p of A(q)
+        const int r = 8 * p + (lane >> 3);
+        const int per = 16 * (q ? QA1 : QA0);
+        const int grp = r / per, rr = r - grp * per;
+        int row = grp * 16 * RF + (q ? 16 * QA0 : 0) + rr;
+        row = min(row, M - 1 - m0);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        return (unsigned)row * (unsigned)g.lda * 2u + 16u * c;
+    };
+    auto b_off = [&](int p, int q) -> unsigned {              // piece p of B(q)
+        if constexpr (BRM) {
+            constexpr int CPR = BRP / 16;                     // chunks per k-row (16 or 8)
+            const int krow = (64 / CPR) * p + lane / CPR;
+            const int ch = (lane % CPR) ^ (BRP == 256 ? swz_rmajor(krow) : pq_swz_rm128(krow));
+            const int c = 8 * ch;                             // column inside the half: group of 16 QB columns
+            const int grp = c / (16 * QB), rr = c - grp * 16 * QB;
+            int col = grp * 16 * NF + q * 16 * QB + rr;
+            col = min(col, N - 8 - n0);                       // N % 8 == 0 (host-checked)
+            return (unsigned)krow * (unsigned)g.ldb * 2u + 2u * col;
+        }
+        const int r = 8 * p + (lane >> 3);
+        const int grp = r / (16 * QB), rr = r - grp * 16 * QB;
+        int col = grp * 16 * NF + q * 16 * QB + rr;
+        col = min(col, N - 1 - n0);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        return (unsigned)col * (unsigned)g.ldb * 2u + 16u * c;
+    };
+    unsigned oa0[G::NA0], oa1[G::NA1], ob0[G::NB], ob1[G::NB];
+#pragma unroll
+    for (int e = 0; e < G::NA0; ++e) oa0[e] = a_off(min(wave + 8 * e, G::PA0 - 1), 0);
+#pragma unroll
+    for (int e = 0; e < G::NA1; ++e) oa1[e] = a_off(wave + 8 * e, 1);
+#pragma unroll
+    for (int e = 0; e < G::NB; ++e) {
+        ob0[e] = b_off(wave + 8 * e, 0);
+        ob1[e] = b_off(wave + 8 * e, 1);
+    }
+    const bool third = G::PA0 % 8 != 0 && wave < G::PA0 % 8;   // this wave issues NA0 pieces of A(0), else NA0 - 1
+    auto issue = [&](int u, int which) {                      // which: 0 = A(0), 1 = A(1), 2 = B(0), 3 = B(1)
+        if constexpr (ABL & 2) { if (u > 1) return; }
+        char *stage = smem + (u & 1) * G::STAGE;
+        const char *ap = a_ptr + (size_t)u * (BK * 2);
+        const char *bp = b_ptr + (size_t)u * b_step;
+        if (which == 0) {
+#pragma unroll
+            for (int e = 0; e < G::NA0; ++e) {
+                if (G::PA0 % 8 != 0 && e == G::NA0 - 1 && !third) break;
+                __builtin_amdgcn_global_load_lds((glb_void *)(ap + oa0[e]),
+                                                 (lds_void *)(stage + G::OFF_A0 + (wave + 8 * e) * 1024), 16, 0, 0);
+            }
+        } else if (which == 1) {
+#pragma unroll
+            for (int e = 0; e < G::NA1; ++e)
+                __builtin_amdgcn_global_load_lds((glb_void *)(ap + oa1[e]),
+                                                 (lds_void *)(stage + G::OFF_A1 + (wave + 8 * e) * 1024), 16, 0, 0);
+        } else if (which == 2) {
+#pragma unroll
+            for (int e = 0; e < G::NB; ++e)
+                __builtin_amdgcn_global_load_lds((glb_void *)(bp + ob0[e]),
+                                                 (lds_void *)(stage + G::OFF_B0 + (wave + 8 * e) * 1024), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < G::NB; ++e)
+                __builtin_amdgcn_global_load_lds((glb_void *)(bp + ob1[e]),
+                                                 (lds_void *)(stage + G::OFF_B1 + (wave + 8 * e) * 1024), 16, 0, 0);
+        }
+    };
+    // at most the pieces of B(0), A(0), B(1) of the tile after next stay in flight
+    auto wait_tile = [&](bool full) {
+        if (!full) { pq_wait_vmcnt<0>(); return; }
+        if constexpr (G::PA0 % 8 != 0) {
+            if (third) pq_wait_vmcnt<2 * G::NB + G::NA0>();
+            else pq_wait_vmcnt<2 * G::NB + G::NA0 - 1>();
+        } else {
+            pq_wait_vmcnt<2 * G::NB + G::NA0>();
+        }
+    };
+
+    // ---- fragments: lane (row l16, 16-B chunk 4 ks + lg) of a 16-row block; the swizzle depends on l16 only ----
+    const int frag_x0 = l16 * ROW_BYTES + (((0 + lg) ^ (l16 >> 1)) * 16);
+    const int frag_x1 = l16 * ROW_BYTES + (((4 + lg) ^ (l16 >> 1)) * 16);
+    bf16x8 fa[QA0][2], fb0[QB][2], fb1[QB][2];
+    bool abl_first = true;
+    auto read_a = [&](const char *stage, int q) {
+        if constexpr (ABL & 1) { if (!abl_first) return; }
+        const char *t = stage + (q ? G::OFF_A1 + wr * 16 * QA1 * ROW_BYTES : G::OFF_A0 + wr * 16 * QA0 * ROW_BYTES);
+#pragma unroll
+        for (int i = 0; i < QA0; ++i) {
+            if (q && i >= QA1) break;
+            fa[i][0] = *reinterpret_cast<const bf16x8 *>(t + i * 16 * ROW_BYTES + frag_x0);
+            fa[i][1] = *reinterpret_cast<const bf16x8 *>(t + i * 16 * ROW_BYTES + frag_x1);
+        }
+    };
+    auto read_b = [&](const char *stage, int q, bf16x8 (&fb)[QB][2]) {
+        if constexpr (ABL & 1) { if (!abl_first) return; }
+        if constexpr (BRM) {
+            const char *t = stage + (q ? G::OFF_B1 : G::OFF_B0);
+            const int tq = l16 >> 2, tp = l16 & 3;
+#pragma unroll
+            for (int f = 0; f < QB; ++f)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int chunk = 2 * (wc * QB + f) + (tp >> 1);
+                    const int row = 32 * ks + 8 * lg + tq;
+                    auto addr = [&](int r) {
+                        const int sw = BRP == 256 ? swz_rmajor(r) : pq_swz_rm128(r);
+                        return (__attribute__((address_space(3))) v4s *)(t + BRP * r + 16 * (chunk ^ sw) + 8 * (tp & 1));
+                    };
+                    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(addr(row));
+                    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(addr(row + 4));
+                    fb[f][ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            return;
+        }
+        const char *t = stage + (q ? G::OFF_B1 : G::OFF_B0) + wc * 16 * QB * ROW_BYTES;
+#pragma unroll
+        for (int f = 0; f < QB; ++f) {
+            fb[f][0] = *reinterpret_cast<const bf16x8 *>(t + f * 16 * ROW_BYTES + frag_x0);
+            fb[f][1] = *reinterpret_cast<const bf16x8 *>(t + f * 16 * ROW_BYTES + frag_x1);
+        }
+    };
+    auto mfma_quadrant = [&](int qm, int qn, const bf16x8 (&fb)[QB][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < QA0; ++i) {
+                if (qm && i >= QA1) break;
+#pragma unroll
+                for (int f = 0; f < QB; ++f) {
+                    f32x4 &c = acc[qm ? QA0 + i : i][qn * QB + f];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s], fb[f][s], c, 0, 0, 0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() { if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier(); };
+    auto lds_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
+    // ---- prologue: k-tile 0 complete; B(0), A(0), B(1) of k-tile 1 in flight -------------------------------
+    issue(0, 0);
+    issue(0, 2);
+    issue(0, 3);
+    issue(0, 1);
+    if (nt > 1) {
+        issue(1, 2);
+        issue(1, 0);
+        issue(1, 3);
+    }
+    wait_tile(nt > 1);
+    bar();
+    if (wr == 1) bar();                               // group 1 runs one barrier behind from here on
+
+    for (int t = 0; t < nt; ++t) {
+        const char *stage = smem + (t & 1) * G::STAGE;
+        const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+        if constexpr (ABL & 1) abl_first = t == 0;
+        // phase 1 (the B reads are issued first and retired before the barrier: B(0) is re-staged in phase 2)
+        read_b(stage, 0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(stage, 0);
+        if (more1) issue(t + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(ABL & 1)) pq_wait_lgkmcnt<2 * QA0>();
+        bar();
+        lds_done();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quadrant(0, 0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+        // phase 2
+        read_b(stage, 1, fb1);
+        if (more2) issue(t + 2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+        lds_done();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quadrant(0, 1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+        // phase 3
+        read_a(stage, 1);
+        if (more2) issue(t + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+        lds_done();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quadrant(1, 1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+        // phase 4
+        if (more2) issue(t + 2, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wr == 1) wait_tile(more2);
+        bar();
+        mfma_quadrant(1, 0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wr == 0) wait_tile(more2);
+        bar();
+    }
+    if (wr == 0) bar();                               // rebalance the barrier count of the two groups
+
+    // ---- epilogue through a wave-private LDS patch: 16 rows x 16 NF columns at a time ------------------------
+    const int epi = g.epilogue;
+    const bool lead = zs == 0;
+    const bool split = g.splitk > 1;
+    constexpr int LDW = G::EPI_LDW;
+    float *patch = reinterpret_cast<float *>(smem) + wave * 16 * LDW;
+    constexpr int LPR = 4 * NF;                        // lanes per patch row (one float4 each)
+    constexpr int RPP = 64 / LPR;                      // rows per pass; NF passes cover the 16 rows
+    const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
+    const int col = n0 + wc * 16 * NF + pc4;
+    const bool col_ok = col < N;                       // N % 4 == 0 (host-checked): the whole float4 or nothing
+    const bool with_bias = (!split || lead) && (epi == SEI_EPI_BIAS || epi == SEI_EPI_BIAS_GELU ||
+                                                epi == SEI_EPI_BIAS_RES || epi == SEI_EPI_BIAS_ROWSCALE);
+    f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (with_bias && col_ok) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
+    const float *aux1 = nullptr, *aux2 = nullptr;
+    if (!split) {
+        if (epi == SEI_EPI_ACCUM) aux1 = g.D32;
+        else if (epi == SEI_EPI_MUL_DGELU || epi == SEI_EPI_BIAS_RES) aux1 = g.R1;
+        if (epi == SEI_EPI_BIAS_RES) aux2 = g.R2;
+    } else if (lead && epi == SEI_EPI_BIAS_RES) {
+        aux1 = g.R1;
+        aux2 = g.R2;
+    }
+#pragma unroll 1
+    for (int i = 0; i < RF; ++i) {
+        f32x4 c[NF];
+        // static copies picked by a switch: a runtime-indexed acc[] would be demoted to scratch
+#define PQ_PICK(I) case I: if constexpr (I < RF) { _Pragma("unroll") for (int f = 0; f < NF; ++f) c[f] = acc[I < RF ? I : 0][f]; } break;
+        switch (i) {
+            PQ_PICK(0) PQ_PICK(1) PQ_PICK(2) PQ_PICK(3) PQ_PICK(4) PQ_PICK(5) PQ_PICK(6) PQ_PICK(7)
+            default: if constexpr (RF > 8) { _Pragma("unroll") for (int f = 0; f < NF; ++f) c[f] = acc[RF - 1][f]; } break;
+        }
+#undef PQ_PICK
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) patch[(4 * lg + j) * LDW + 16 * f + l16] = c[f][j];
+        __builtin_amdgcn_sched_barrier(0);
+        if (split) {
+            // float atomics: one dword per lane on whole row segments (a float4-strided lane layout would make
+            // every atomic instruction 16 quarter-filled 64-B requests: measured 2.4x the launch time)
+            constexpr int CW = 16 * NF, RPI = 64 / CW;         // columns per row; rows per instruction
+            const int sc = lane % CW, sr = lane / CW;
+            const int scol = n0 + wc * CW + sc;
+            const bool sok = scol < N;
+            const float sbias = (with_bias && sok) ? g.bias[scol] : 0.f;
+            float x[16 / RPI];
+#pragma unroll
+            for (int p = 0; p < 16 / RPI; ++p) x[p] = patch[(p * RPI + sr) * LDW + sc] + sbias;
+            if (aux1) {                                        // lead split of BIAS_RES: residuals, loads batched
+#pragma unroll
+                for (int p = 0; p < 16 / RPI; ++p) {
+                    const int row = m0 + wr * 16 * RF + 16 * i + p * RPI + sr;
+                    const bool ok = sok && row < M;
+                    const size_t o = ok ? (size_t)row * N + scol : 0;
+                    const float r1 = aux1[o], r2 = aux2 ? aux2[o] : 0.f;
+                    x[p] += ok ? r1 + r2 : 0.f;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 16 / RPI; ++p) {
+                const int row = m0 + wr * 16 * RF + 16 * i + p * RPI + sr;
+                if (sok && row < M) atomicAdd(g.D32 + (size_t)row * N + scol, x[p]);
+            }
+            continue;
+        }
+        const int row_base = m0 + wr * 16 * RF + 16 * i + prow;
+        f32x4 v[NF], a1[NF], a2[NF];
+#pragma unroll
+        for (int p = 0; p < NF; ++p) {
+            v[p] = *reinterpret_cast<const f32x4 *>(patch + (p * RPP + prow) * LDW + pc4);
+            a1[p] = a2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (aux1) {
+#pragma unroll
+            for (int p = 0; p < NF; ++p) {
+                const int row = row_base + p * RPP;
+                const bool ok = col_ok && row < M;
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(aux1 + (ok ? (size_t)row * N + col : 0));
+                a1[p] = ok ? x : a1[p];
+            }
+        }
+        if (aux2) {
+#pragma unroll
+            for (int p = 0; p < NF; ++p) {
+                const int row = row_base + p * RPP;
+                const bool ok = col_ok && row < M;
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(aux2 + (ok ? (size_t)row * N + col : 0));
+                a2[p] = ok ? x : a2[p];
+            }
+        }
+        if (epi == SEI_EPI_BIAS_ROWSCALE) {              // D = acc + bias[n] * R1[m]
+#pragma unroll
+            for (int p = 0; p < NF; ++p) {
+                const int row = row_base + p * RPP;
+                const float s = g.R1[row < M ? row : 0];
+                v[p] += bias4 * s;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NF; ++p) v[p] += bias4;
+        }
+        if (epi == SEI_EPI_MUL_DGELU) {
+#pragma unroll
+            for (int p = 0; p < NF; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[p][j] *= sei_dgelu(a1[p][j]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < NF; ++p) v[p] += a1[p] + a2[p];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < NF; ++p) {
+            const int row = row_base + p * RPP;
+            if (!col_ok || row >= M) continue;
+            const size_t o = (size_t)row * N + col;
+            if (epi == SEI_EPI_BIAS_GELU) {
+                ushort4 h;
+                h.x = f2bf(sei_gelu(v[p][0])); h.y = f2bf(sei_gelu(v[p][1]));
+                h.z = f2bf(sei_gelu(v[p][2])); h.w = f2bf(sei_gelu(v[p][3]));
+                *reinterpret_cast<ushort4 *>(g.D2_16 + o) = h;
+            }
+            if (g.D32) *reinterpret_cast<f32x4 *>(g.D32 + o) = v[p];
+            if (g.D16) {
+                ushort4 h;
+                h.x = f2bf(v[p][0]); h.y = f2bf(v[p][1]); h.z = f2bf(v[p][2]); h.w = f2bf(v[p][3]);
+                *reinterpret_cast<ushort4 *>(g.D16 + o) = h;
+            }
+        }
+    }
+}
+
+// Shapes the quadrant kernel takes: K-contiguous operands, whole k-tiles, float4-able rows.
+inline bool pq_eligible(const NtArgs &g) {
+    return g.K % BK == 0 && g.N % 4 == 0 && g.K >= 4 * BK &&
+           (!g.D32 || (reinterpret_cast<uintptr_t>(g.D32) & 15) == 0) &&
+           (!g.D16 || (reinterpret_cast<uintptr_t>(g.D16) & 7) == 0) &&
+           (!g.D2_16 || (reinterpret_cast<uintptr_t>(g.D2_16) & 7) == 0) &&
+           (!g.bias || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) &&
+           (!g.R1 || g.epilogue == SEI_EPI_BIAS_ROWSCALE || (reinterpret_cast<uintptr_t>(g.R1) & 15) == 0) &&
+           (!g.R2 || (reinterpret_cast<uintptr_t>(g.R2) & 15) == 0);
+}
+
+template <int RF, int NF, bool BRM = false, int ABL = 0>
+int launch_pq(NtArgs &g, hipStream_t s) {
+    using G = PqGeom<RF, NF>;
+    g.tiles_m = (int)sei_ceil_div(g.M, G::BM);
+    g.tiles_n = (int)sei_ceil_div(g.N, G::BN);
+    const size_t tiles = (size_t)g.tiles_m * g.tiles_n;
+    SEI_REQUIRE(tiles < ((size_t)1 << 27));
+    int band = g_force_band > 0 ? g_force_band : 6;       // ~sqrt(32 tiles in flight per XCD)
+    if (band > g.tiles_n) band = g.tiles_n;
+    g.band = band;
+    g.tiles_per_xcd = (int)sei_ceil_div(tiles, 8);
+    g.splitk = 1;
+    g.k_per_split = g.K;
+    const bool splittable = g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
+                            g.epilogue == SEI_EPI_BIAS_RES || g.epilogue == SEI_EPI_ACCUM;
+    if (splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
+        const size_t slots = 256, ktiles = g.K / BK;
+        const size_t max_sk = ktiles / 4 < 16 ? ktiles / 4 : 16;
+        const double overhead = 8.0 + (g.epilogue == SEI_EPI_ACCUM ? 0.0 : 2.0);
+        double best = 1e30;
+        size_t best_sk = 1;
+        for (size_t sk = 1; sk <= max_sk; ++sk) {
+            const double rounds = (double)sei_ceil_div(tiles * sk, slots);
+            const double cost = rounds * ((double)sei_ceil_div(ktiles, sk) + overhead + (sk > 1 ? 2.0 : 0.0));
+            if (cost < best * 0.97) {
+                best = cost;
+                best_sk = sk;
+            }
+        }
+        if (best_sk > 1) {
+            g.k_per_split = (int)(sei_ceil_div(ktiles, best_sk) * BK);
+            g.splitk = (int)sei_ceil_div(g.K, g.k_per_split);
+        }
+    }
+    if (g.splitk > 1 && g.epilogue != SEI_EPI_ACCUM) {
+        const size_t n = (size_t)g.M * g.N;
+        size_t zg = sei_ceil_div(n / 4 + 1, 256);
+        if (zg > 2048) zg = 2048;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
+    }
+    hipLaunchKernelGGL((gemm_bf16pq_kernel<RF, NF, BRM, ABL>), dim3((unsigned)(8 * (size_t)g.tiles_per_xcd * g.splitk)),
+                       dim3(NT), 0, s, g);
+    return sei_launch_status();
+}

@@ -575,6 +575,56 @@ def test_gemm_bf16_pingpong_schedule(ops, M, N, K, ar, br):
         lib().sei_debug_set_nt_tile(0)
 
 
+@pytest.mark.parametrize("br", [0, 1])
+@pytest.mark.parametrize("code", [30, 31, 32, 33])
+@pytest.mark.parametrize("M,N,K", [(576, 512, 256), (300, 520, 320), (2304, 2048, 2048), (288, 1024, 4096)])
+def test_gemm_bf16_quadrant_schedule(ops, M, N, K, code, br):
+    """The quadrant schedule (gemm_bf16pq.h; tile codes 30-33 = 256/288 rows x 256/128 columns): ragged row and
+    column edges, split K, every fused epilogue, against float64; launches that do not split K must agree bit
+    for bit run to run (the schedule orders its LDS-DMA by counted waits and raw barriers only)."""
+    from _native import lib
+    gen = torch.Generator().manual_seed(M + N + K + code + br)
+    kw = dict(b_rmajor=bool(br))
+    A = torch.randn((M, K), generator=gen).bfloat16().cuda()
+    B = torch.randn((K, N) if br else (N, K), generator=gen).bfloat16().cuda()
+    bias, R1 = torch.randn(N, generator=gen).cuda(), torch.randn((M, N), generator=gen).cuda()
+    R2, rs = torch.randn((M, N), generator=gen).cuda(), torch.randn(M, generator=gen).cuda()
+    ref = (A.double() @ (B.double() if br else B.double().t())).cpu()
+    try:
+        assert lib().sei_debug_set_nt_tile(code) == 0
+        outs = []
+        for _ in range(3):
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out16=out, **kw)            # bf16 output: never split
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert relerr(outs[0].float(), ref) < 1e-2
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        out = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out32=out, **kw)                 # f32 output: may split K
+        assert relerr(out, ref) < 2e-5
+        out = torch.empty((M, N), device="cuda")
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_RES, out32=out, bias=bias, R1=R1, R2=R2, **kw)
+        assert relerr(out, ref + bias.double().cpu() + R1.double().cpu() + R2.double().cpu()) < 2e-5
+        h3, h4 = torch.empty((M, N), device="cuda"), torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_GELU, out32=h3, bias=bias, D2_16=h4, **kw)
+        pre = ref + bias.double().cpu()
+        assert relerr(h3, pre) < 2e-5 and relerr(h4.float(), F.gelu(pre)) < 1e-2
+        g16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_MUL_DGELU, out16=g16, R1=R1, **kw)
+        x = R1.double().cpu().requires_grad_(True)
+        dg, = torch.autograd.grad(F.gelu(x).sum(), x)
+        assert relerr(g16.float(), ref * dg) < 1e-2
+        acc = R1.clone()
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_ACCUM, out32=acc, **kw)
+        assert relerr(acc, ref + R1.double().cpu()) < 2e-5
+        out = torch.empty((M, N), device="cuda")
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_ROWSCALE, out32=out, bias=bias, R1=rs, **kw)
+        assert relerr(out, ref + rs.double().cpu()[:, None] * bias.double().cpu()[None, :]) < 2e-5
+    finally:
+        lib().sei_debug_set_nt_tile(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(2304, 8192, 2048), (300, 520, 72)])
 def test_gemm_bf16nt_bias_rowscale_and_weighted_colsum(ops, M, N, K):
     """D = A B^T + bias[n] * s[m] (the bias of a 1x1 convolution that was moved behind the ideal downsampler)
