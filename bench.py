@@ -192,7 +192,12 @@ def main():
     if opt.profile_gemms:
         import _native
         _ops.profile_gemms(True)
-        optimizer.zero_grad()
+        backbone = model.get_backbone() if hasattr(model, "get_backbone") else model
+        if opt.graph and graphed.store_weight_grads:
+            # the launches of the timed (graphed) step: merged weight gradients STORE instead of accumulating
+            backbone.zero_grad_flat(store_weight_grads=True)
+        else:
+            optimizer.zero_grad()
         keep = loss_fn(x=x, y=y, model=model)
         keep.backward(retain_graph=True)       # keeps the saved activations (GEMM operands) alive for the replay
         records = _ops.profile_gemms(False)

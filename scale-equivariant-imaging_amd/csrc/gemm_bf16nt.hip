@@ -236,10 +236,66 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
         }
     }
 
-    auto stage = [&](int k0, char *dst) {
-        if constexpr (ARM) stage_tile_rmajor(g.A, g.A2, g.k_seg, g.lda, m0, M, k0, k_end, dst, wave, lane);
-        else stage_tile<BM>(g.A, g.lda, m0, M, k0, k_end, dst, wave, lane);
+    // Staging. A k-tile that lies inside [k_begin, k_end) -- and, for a reduction-major operand, inside one of
+    // its two K segments -- is issued from per-lane byte offsets fixed for the whole launch and a uniform base
+    // pointer (rows / columns past the edge are clamped to the last valid one: they only feed outputs that are
+    // never stored). Measured on the 256x256 schedule: the per-piece 64-bit lane arithmetic and bounds selects of
+    // the general path cost 20 % of the loop. Everything else (K tails, the tile that straddles k_seg) takes the
+    // general path below.
+    constexpr int NPA = ARM ? 2 : (BM + 63) / 64, NPB = BN / 64;               // pieces per wave (1 KiB each)
+    static_assert(BN % 64 == 0, "whole pieces per wave");
+    unsigned off_a[NPA], off_b[NPB];
+#pragma unroll
+    for (int e = 0; e < NPA; ++e) {
+        const int q = wave + NWAVES * e;
+        if constexpr (ARM) {
+            const int row = 4 * q + (lane >> 4), ch = (lane & 15) ^ swz_rmajor(row);
+            off_a[e] = (unsigned)row * (unsigned)g.lda * 2u + 2u * (unsigned)min(8 * ch, M - 8 - m0);
+        } else {
+            const int row = 8 * q + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            off_a[e] = (unsigned)min(row, M - 1 - m0) * (unsigned)g.lda * 2u + 16u * c;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NPB; ++e) {
+        const int q = wave + NWAVES * e;
         if constexpr (BRM) {
+            const int im = q >> 4, qq = q & 15;                // 16 pieces per 128-column image
+            const int row = 4 * qq + (lane >> 4), ch = (lane & 15) ^ swz_rmajor(row);
+            off_b[e] = (unsigned)row * (unsigned)g.ldb * 2u +
+                       2u * (unsigned)max(min(128 * im + 8 * ch, N - 8 - n0), 0);
+        } else {
+            const int row = 8 * q + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            off_b[e] = (unsigned)min(row, N - 1 - n0) * (unsigned)g.ldb * 2u + 16u * c;
+        }
+    }
+    auto rm_base = [&](const unsigned short *X1, const unsigned short *X2, int ld, int o0, int k0) -> const char * {
+        if (k0 + BK <= g.k_seg && k0 + BK <= k_end) return reinterpret_cast<const char *>(X1 + (size_t)k0 * ld + o0);
+        if (k0 >= g.k_seg && k0 + BK <= k_end) return reinterpret_cast<const char *>(X2 + (size_t)(k0 - g.k_seg) * ld + o0);
+        return nullptr;
+    };
+    auto stage = [&](int k0, char *dst) {
+        const char *ab, *bb;
+        if constexpr (ARM) ab = rm_base(g.A, g.A2, g.lda, m0, k0);
+        else ab = k0 + BK <= k_end ? reinterpret_cast<const char *>(g.A + (size_t)m0 * g.lda + k0) : nullptr;
+        if (ab) {
+#pragma unroll
+            for (int e = 0; e < NPA; ++e)
+                if (ARM || wave + NWAVES * e < BM / 8)         // wave-uniform (a 96-row tile has 12 pieces)
+                    __builtin_amdgcn_global_load_lds((glb_void *)(ab + off_a[e]),
+                                                     (lds_void *)(dst + (wave + NWAVES * e) * 1024), 16, 0, 0);
+        } else {
+            if constexpr (ARM) stage_tile_rmajor(g.A, g.A2, g.k_seg, g.lda, m0, M, k0, k_end, dst, wave, lane);
+            else stage_tile<BM>(g.A, g.lda, m0, M, k0, k_end, dst, wave, lane);
+        }
+        if constexpr (BRM) bb = rm_base(g.B, g.B2, g.ldb, n0, k0);
+        else bb = k0 + BK <= k_end ? reinterpret_cast<const char *>(g.B + (size_t)n0 * g.ldb + k0) : nullptr;
+        if (bb) {
+#pragma unroll
+            for (int e = 0; e < NPB; ++e)
+                __builtin_amdgcn_global_load_lds((glb_void *)(bb + off_b[e]),
+                                                 (lds_void *)(dst + BM * ROW_BYTES + (wave + NWAVES * e) * 1024), 16, 0, 0);
+        } else if constexpr (BRM) {
 #pragma unroll
             for (int im = 0; im < BN / 128; ++im)           // 16 KB image per 128 columns
                 stage_tile_rmajor(g.B, g.B2, g.k_seg, g.ldb, n0 + 128 * im, N, k0, k_end,
@@ -483,6 +539,12 @@ int pq_choose(const NtArgs &g, bool would_split) {
     return 0;
 }
 
+// Weight gradients (both operands reduction-major) do NOT take the quadrant schedule by default: measured on the
+// two deepest levels it ties the 128 x 128 loop at K = 3456 (160 vs 155 us) and loses at K = 864 (912 vs 720 us:
+// 13 k-tiles per tile do not amortise one workgroup's unoverlapped 256-KB epilogue, and every fragment is two
+// transposing LDS reads). The kernel supports the layout (tile codes 30 / 33; tests) for later work on it.
+int pq_choose_rr(const NtArgs &) { return 0; }
+
 extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
                                float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
                                const float *R1, const float *R2, uint16_t *D2_16, void *stream) {
@@ -509,13 +571,17 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     hipStream_t s = (hipStream_t)stream;
     const bool would_split = (epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_RES ||
                               epilogue == SEI_EPI_ACCUM) && D32 && !D16;
+    if (g_force_tile >= 30 && g_force_tile < 40 && a_rmajor && b_rmajor && pq_eligible(g, true)) {
+        if (g_force_tile == 30) return launch_pq<8, 4, true, true>(g, s);
+        if (g_force_tile == 33) return launch_pq<8, 2, true, true>(g, s);
+    }
     if (g_force_tile >= 30 && g_force_tile < 40 && !a_rmajor && pq_eligible(g)) {   // quadrant schedule
         if (b_rmajor) {
             switch (g_force_tile) {
-                case 30: return launch_pq<8, 4, true>(g, s);
-                case 31: return launch_pq<9, 4, true>(g, s);
-                case 32: return launch_pq<9, 2, true>(g, s);
-                case 33: return launch_pq<8, 2, true>(g, s);
+                case 30: return launch_pq<8, 4, false, true>(g, s);
+                case 31: return launch_pq<9, 4, false, true>(g, s);
+                case 32: return launch_pq<9, 2, false, true>(g, s);
+                case 33: return launch_pq<8, 2, false, true>(g, s);
                 default: break;
             }
         } else {
@@ -524,8 +590,8 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
                 case 31: return launch_pq<9, 4>(g, s);
                 case 32: return launch_pq<9, 2>(g, s);
                 case 33: return launch_pq<8, 2>(g, s);
-                case 34: return launch_pq<8, 4, false, 2>(g, s);      // ablations: timing only, wrong results
-                case 35: return launch_pq<8, 4, false, 7>(g, s);
+                case 34: return launch_pq<8, 4, false, false, 2>(g, s);      // ablations: timing only, wrong results
+                case 35: return launch_pq<8, 4, false, false, 7>(g, s);
                 default: break;
             }
         }
@@ -553,6 +619,11 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     }
     // a reduction-major operand fixes the tile at 128 x 128 (its LDS rows are 256 bytes = 128 columns)
     if (a_rmajor && b_rmajor) {
+        switch (pq_choose_rr(g)) {
+            case 84: return launch_pq<8, 4, true, true>(g, s);
+            case 82: return launch_pq<8, 2, true, true>(g, s);
+            default: break;
+        }
         // short reductions (the bottleneck weight gradient: K = 864 over 16,384 tiles) are prologue + epilogue
         // bound: one LDS stage and three workgroups per CU (1030 -> 800 us); long ones want the double buffer
         if (K <= 1024 && g_force_tile != 1) return launch_nt<2, 1, 2, 4, true, true, 1>(g, s);
@@ -561,10 +632,10 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     if (a_rmajor) return launch_nt<2, 1, 2, 4, true, false>(g, s);
     if (b_rmajor) {
         switch (pq_choose(g, would_split)) {
-            case 94: return launch_pq<9, 4, true>(g, s);
-            case 92: return launch_pq<9, 2, true>(g, s);
-            case 84: return launch_pq<8, 4, true>(g, s);
-            case 82: return launch_pq<8, 2, true>(g, s);
+            case 94: return launch_pq<9, 4, false, true>(g, s);
+            case 92: return launch_pq<9, 2, false, true>(g, s);
+            case 84: return launch_pq<8, 4, false, true>(g, s);
+            case 82: return launch_pq<8, 2, false, true>(g, s);
             default: break;
         }
         // skinny data gradients (the bottleneck levels): 192 x 256 with two 128-column images of the weight
@@ -612,6 +683,11 @@ extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int l
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
     g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
+    switch (pq_choose_rr(g)) {
+        case 84: return launch_pq<8, 4, true, true>(g, (hipStream_t)stream);
+        case 82: return launch_pq<8, 2, true, true>(g, (hipStream_t)stream);
+        default: break;
+    }
     if (K1 + K2 <= 1024) return launch_nt<2, 1, 2, 4, true, true, 1>(g, (hipStream_t)stream);   // as sei_gemm_bf16nt
     return launch_nt<2, 1, 2, 4, true, true>(g, (hipStream_t)stream);
 }

@@ -46,8 +46,9 @@ __device__ __forceinline__ void pq_wait_vmcnt() {
 }
 template <int N>
 __device__ __forceinline__ void pq_wait_lgkmcnt() {
-    if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     else static_assert(N < 0, "add the immediate");
 }
 
@@ -73,7 +74,9 @@ __device__ __forceinline__ int pq_swz_rm128(int row) { return (((row >> 1) & 1) 
 // BRM: B stored reduction-major (element (n, k) at B[k * ldb + n]: the weight as the forward pass stores it, used
 // by the data gradient). Its half-tiles are [64 k-rows][columns of the quadrant] images read with
 // ds_read_b64_tr_b16; the DMA base then advances 64 rows per k-tile.
-template <int RF, int NF, bool BRM = false, int ABL = 0>
+// ARM: A stored reduction-major as well (element (m, k) at A[k * lda + m]): the weight gradient dW = dY^T X, both
+// operands pixel-major; RF = 8 only. Both reduction-major: any K (zero rows past k_end), two K segments.
+template <int RF, int NF, bool ARM = false, bool BRM = false, int ABL = 0>
 __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     using G = PqGeom<RF, NF>;
     constexpr int QA0 = G::QA0, QA1 = G::QA1, QB = G::QB;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     const int M = g.M, N = g.N;
     const int k_begin = zs * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
-    const int nt = (k_end - k_begin) / BK;                    // whole k-tiles only (host-checked)
+    const int nt = (k_end - k_begin + BK - 1) / BK;           // a partial last k-tile only with ARM && BRM (host-checked)
 
     f32x4 acc[RF][NF];
 #pragma unroll
@@ -110,14 +113,38 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- DMA pieces: fixed per-lane byte offsets from the tile's row origin ---------------------------------
-    // LDS row r of a half-tile -> (group = r / rows-per-group, rr) -> matrix row; chunk swizzle (r >> 1) & 7.
-    const char *a_ptr = reinterpret_cast<const char *>(g.A + (size_t)m0 * g.lda + k_begin);
-    const char *b_ptr = reinterpret_cast<const char *>(BRM ? g.B + (size_t)k_begin * g.ldb + n0
-                                                           : g.B + (size_t)n0 * g.ldb + k_begin);
-    const size_t b_step = BRM ? (size_t)BK * g.ldb * 2 : (size_t)BK * 2;       // bytes per k-tile
-    constexpr int BRP = G::B_ROWS * 2;                         // row pitch of a reduction-major B half (256 / 128 B)
+    // ---- DMA pieces: fixed per-lane byte offsets, uniform base per k-tile ---------------------------------------
+    // K-contiguous operand: LDS row r of a half-tile -> (group = r / rows-per-group, rr) -> matrix row; chunk
+    //   swizzle (r >> 1) & 7; offset = row * ld * 2 + 16 * chunk; the base advances 128 B per k-tile.
+    // Reduction-major operand: a piece is 4 (256-B rows) or 8 (128-B rows) k-rows of the [64][columns] image;
+    //   offset = k-row * ld * 2 + 2 * column; the base advances 64 rows per k-tile and moves to the second
+    //   segment (A2 / B2: the other forward pass of a merged weight gradient) at k_seg. A k-tile that straddles
+    //   k_seg or runs past k_end is issued by the slow path (per-lane row select, zero chunk past the end).
+    constexpr int ARP = 256, BRP = G::B_ROWS * 2;             // row pitch of a reduction-major half
+    static_assert(!ARM || RF == 8, "a reduction-major A half is 64 k-rows x 128 columns");
+    auto rm_piece = [&](int p, int pitch, int &krow, int &ch) {
+        const int cpr = pitch / 16;
+        krow = (64 / cpr) * p + lane / cpr;
+        ch = (lane % cpr) ^ (pitch == 256 ? swz_rmajor(krow) : pq_swz_rm128(krow));
+    };
+    auto a_col = [&](int p, int q, int &krow) -> int {        // ARM: first of this lane's 8 rows of D, from m0
+        int ch;
+        rm_piece(p, ARP, krow, ch);
+        const int c = 8 * ch, grp = c / (16 * QA0), rr = c - grp * 16 * QA0;
+        return min(grp * 16 * RF + q * 16 * QA0 + rr, M - 8 - m0);           // M % 8 == 0 (host-checked)
+    };
+    auto b_col = [&](int p, int q, int &krow) -> int {        // BRM: first of this lane's 8 columns of D, from n0
+        int ch;
+        rm_piece(p, BRP, krow, ch);
+        const int c = 8 * ch, grp = c / (16 * QB), rr = c - grp * 16 * QB;
+        return min(grp * 16 * NF + q * 16 * QB + rr, N - 8 - n0);            // N % 8 == 0 (host-checked)
+    };
     auto a_off = [&](int p, int q) -> unsigned {              // piece p of A(q)
+        if constexpr (ARM) {
+            int krow;
+            const int col = a_col(p, q, krow);
+            return (unsigned)krow * (unsigned)g.lda * 2u + 2u * col;
+        }
         const int r = 8 * p + (lane >> 3);
         const int per = 16 * (q ? QA1 : QA0);
         const int grp = r / per, rr = r - grp * per;
@@ -128,13 +155,8 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     };
     auto b_off = [&](int p, int q) -> unsigned {              // piece p of B(q)
         if constexpr (BRM) {
-            constexpr int CPR = BRP / 16;                     // chunks per k-row (16 or 8)
-            const int krow = (64 / CPR) * p + lane / CPR;
-            const int ch = (lane % CPR) ^ (BRP == 256 ? swz_rmajor(krow) : pq_swz_rm128(krow));
-            const int c = 8 * ch;                             // column inside the half: group of 16 QB columns
-            const int grp = c / (16 * QB), rr = c - grp * 16 * QB;
-            int col = grp * 16 * NF + q * 16 * QB + rr;
-            col = min(col, N - 8 - n0);                       // N % 8 == 0 (host-checked)
+            int krow;
+            const int col = b_col(p, q, krow);
             return (unsigned)krow * (unsigned)g.ldb * 2u + 2u * col;
         }
         const int r = 8 * p + (lane >> 3);
@@ -155,33 +177,67 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         ob1[e] = b_off(wave + 8 * e, 1);
     }
     const bool third = G::PA0 % 8 != 0 && wave < G::PA0 % 8;   // this wave issues NA0 pieces of A(0), else NA0 - 1
+    // uniform base of k-tile u for a reduction-major operand; nullptr = slow path
+    auto rm_base = [&](const unsigned short *X1, const unsigned short *X2, int ld, int o0, int k0) -> const char * {
+        if (k0 + BK <= g.k_seg && k0 + BK <= k_end) return reinterpret_cast<const char *>(X1 + (size_t)k0 * ld + o0);
+        if (k0 >= g.k_seg && k0 + BK <= k_end) return reinterpret_cast<const char *>(X2 + (size_t)(k0 - g.k_seg) * ld + o0);
+        return nullptr;
+    };
+    auto rm_slow = [&](const unsigned short *X1, const unsigned short *X2, int ld, int o0, int k0, int krow, int col)
+        -> const unsigned short * {
+        const int k = k0 + krow;
+        if (k >= k_end) return g_zero_chunk;
+        return k < g.k_seg ? X1 + (size_t)k * ld + o0 + col : X2 + (size_t)(k - g.k_seg) * ld + o0 + col;
+    };
     auto issue = [&](int u, int which) {                      // which: 0 = A(0), 1 = A(1), 2 = B(0), 3 = B(1)
         if constexpr (ABL & 2) { if (u > 1) return; }
         char *stage = smem + (u & 1) * G::STAGE;
-        const char *ap = a_ptr + (size_t)u * (BK * 2);
-        const char *bp = b_ptr + (size_t)u * b_step;
-        if (which == 0) {
+        const int k0 = k_begin + u * BK;
+        if (which < 2) {
+            const char *ap;
+            if constexpr (ARM) ap = rm_base(g.A, g.A2, g.lda, m0, k0);
+            else ap = reinterpret_cast<const char *>(g.A + (size_t)m0 * g.lda + k0);
+            char *dst = stage + (which ? G::OFF_A1 : G::OFF_A0);
+            if (ARM && ap == nullptr) {
 #pragma unroll
-            for (int e = 0; e < G::NA0; ++e) {
-                if (G::PA0 % 8 != 0 && e == G::NA0 - 1 && !third) break;
-                __builtin_amdgcn_global_load_lds((glb_void *)(ap + oa0[e]),
-                                                 (lds_void *)(stage + G::OFF_A0 + (wave + 8 * e) * 1024), 16, 0, 0);
+                for (int e = 0; e < G::NA1; ++e) {            // ARM: NA0 == NA1, uniform
+                    int krow;
+                    const int col = a_col(wave + 8 * e, which, krow);
+                    __builtin_amdgcn_global_load_lds((glb_void *)rm_slow(g.A, g.A2, g.lda, m0, k0, krow, col),
+                                                     (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
+                }
+            } else if (which == 0) {
+#pragma unroll
+                for (int e = 0; e < G::NA0; ++e) {
+                    if (G::PA0 % 8 != 0 && e == G::NA0 - 1 && !third) break;
+                    __builtin_amdgcn_global_load_lds((glb_void *)(ap + oa0[e]), (lds_void *)(dst + (wave + 8 * e) * 1024),
+                                                     16, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < G::NA1; ++e)
+                    __builtin_amdgcn_global_load_lds((glb_void *)(ap + oa1[e]), (lds_void *)(dst + (wave + 8 * e) * 1024),
+                                                     16, 0, 0);
             }
-        } else if (which == 1) {
-#pragma unroll
-            for (int e = 0; e < G::NA1; ++e)
-                __builtin_amdgcn_global_load_lds((glb_void *)(ap + oa1[e]),
-                                                 (lds_void *)(stage + G::OFF_A1 + (wave + 8 * e) * 1024), 16, 0, 0);
-        } else if (which == 2) {
-#pragma unroll
-            for (int e = 0; e < G::NB; ++e)
-                __builtin_amdgcn_global_load_lds((glb_void *)(bp + ob0[e]),
-                                                 (lds_void *)(stage + G::OFF_B0 + (wave + 8 * e) * 1024), 16, 0, 0);
         } else {
+            const char *bp;
+            if constexpr (BRM) bp = rm_base(g.B, g.B2, g.ldb, n0, k0);
+            else bp = reinterpret_cast<const char *>(g.B + (size_t)n0 * g.ldb + k0);
+            char *dst = stage + (which == 3 ? G::OFF_B1 : G::OFF_B0);
+            if (BRM && bp == nullptr) {
 #pragma unroll
-            for (int e = 0; e < G::NB; ++e)
-                __builtin_amdgcn_global_load_lds((glb_void *)(bp + ob1[e]),
-                                                 (lds_void *)(stage + G::OFF_B1 + (wave + 8 * e) * 1024), 16, 0, 0);
+                for (int e = 0; e < G::NB; ++e) {
+                    int krow;
+                    const int col = b_col(wave + 8 * e, which - 2, krow);
+                    __builtin_amdgcn_global_load_lds((glb_void *)rm_slow(g.B, g.B2, g.ldb, n0, k0, krow, col),
+                                                     (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < G::NB; ++e)
+                    __builtin_amdgcn_global_load_lds((glb_void *)(bp + (which == 3 ? ob1[e] : ob0[e])),
+                                                     (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
+            }
         }
     };
     // at most the pieces of B(0), A(0), B(1) of the tile after next stay in flight
@@ -195,40 +251,49 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         }
     };
 
-    // ---- fragments: lane (row l16, 16-B chunk 4 ks + lg) of a 16-row block; the swizzle depends on l16 only ----
+    // ---- fragments ---------------------------------------------------------------------------------------------
+    // K-contiguous: lane (row l16, 16-B chunk 4 ks + lg) of a 16-row block, one ds_read_b128; the swizzle depends
+    // on l16 only. Reduction-major: 8 k-values (32 ks + 8 lg + j) of column l16, two ds_read_b64_tr_b16.
     const int frag_x0 = l16 * ROW_BYTES + (((0 + lg) ^ (l16 >> 1)) * 16);
     const int frag_x1 = l16 * ROW_BYTES + (((4 + lg) ^ (l16 >> 1)) * 16);
+    const int tq = l16 >> 2, tp = l16 & 3;
+    auto frag_rm = [&](const char *t, int pitch, int blk, int ks) -> bf16x8 {   // 16-column block blk of the half
+        const int chunk = 2 * blk + (tp >> 1);
+        const int row = 32 * ks + 8 * lg + tq;
+        auto addr = [&](int r) {
+            const int sw = pitch == 256 ? swz_rmajor(r) : pq_swz_rm128(r);
+            return (__attribute__((address_space(3))) v4s *)(t + pitch * r + 16 * (chunk ^ sw) + 8 * (tp & 1));
+        };
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(addr(row));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(addr(row + 4));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
     bf16x8 fa[QA0][2], fb0[QB][2], fb1[QB][2];
     bool abl_first = true;
-    auto read_a = [&](const char *stage, int q) {
+    auto read_a = [&](const char *stage, int q, int ks) {
         if constexpr (ABL & 1) { if (!abl_first) return; }
+        if constexpr (ARM) {
+            const char *t = stage + (q ? G::OFF_A1 : G::OFF_A0);
+#pragma unroll
+            for (int i = 0; i < QA0; ++i) fa[i][ks] = frag_rm(t, ARP, wr * QA0 + i, ks);
+            return;
+        }
         const char *t = stage + (q ? G::OFF_A1 + wr * 16 * QA1 * ROW_BYTES : G::OFF_A0 + wr * 16 * QA0 * ROW_BYTES);
 #pragma unroll
         for (int i = 0; i < QA0; ++i) {
             if (q && i >= QA1) break;
-            fa[i][0] = *reinterpret_cast<const bf16x8 *>(t + i * 16 * ROW_BYTES + frag_x0);
-            fa[i][1] = *reinterpret_cast<const bf16x8 *>(t + i * 16 * ROW_BYTES + frag_x1);
+            fa[i][ks] = *reinterpret_cast<const bf16x8 *>(t + i * 16 * ROW_BYTES + (ks ? frag_x1 : frag_x0));
         }
     };
     auto read_b = [&](const char *stage, int q, bf16x8 (&fb)[QB][2]) {
         if constexpr (ABL & 1) { if (!abl_first) return; }
         if constexpr (BRM) {
             const char *t = stage + (q ? G::OFF_B1 : G::OFF_B0);
-            const int tq = l16 >> 2, tp = l16 & 3;
 #pragma unroll
-            for (int f = 0; f < QB; ++f)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int chunk = 2 * (wc * QB + f) + (tp >> 1);
-                    const int row = 32 * ks + 8 * lg + tq;
-                    auto addr = [&](int r) {
-                        const int sw = BRP == 256 ? swz_rmajor(r) : pq_swz_rm128(r);
-                        return (__attribute__((address_space(3))) v4s *)(t + BRP * r + 16 * (chunk ^ sw) + 8 * (tp & 1));
-                    };
-                    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(addr(row));
-                    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(addr(row + 4));
-                    fb[f][ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
+            for (int f = 0; f < QB; ++f) {
+                fb[f][0] = frag_rm(t, BRP, wc * QB + f, 0);
+                fb[f][1] = frag_rm(t, BRP, wc * QB + f, 1);
+            }
             return;
         }
         const char *t = stage + (q ? G::OFF_B1 : G::OFF_B0) + wc * 16 * QB * ROW_BYTES;
@@ -277,10 +342,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         // phase 1 (the B reads are issued first and retired before the barrier: B(0) is re-staged in phase 2)
         read_b(stage, 0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        read_a(stage, 0);
+        read_a(stage, 0, 0);
         if (more1) issue(t + 1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(ABL & 1)) pq_wait_lgkmcnt<2 * QA0>();
+        if constexpr (!(ABL & 1)) pq_wait_lgkmcnt<(ARM ? 2 : 1) * QA0>();      // the B reads have returned
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(stage, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
         bar();
         lds_done();
         __builtin_amdgcn_sched_barrier(0);
@@ -298,7 +366,8 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         bar();
         // phase 3
-        read_a(stage, 1);
+        read_a(stage, 1, 0);
+        read_a(stage, 1, 1);
         if (more2) issue(t + 2, 0);
         __builtin_amdgcn_sched_barrier(0);
         bar();
@@ -454,9 +523,9 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     }
 }
 
-// Shapes the quadrant kernel takes: K-contiguous operands, whole k-tiles, float4-able rows.
-inline bool pq_eligible(const NtArgs &g) {
-    return g.K % BK == 0 && g.N % 4 == 0 && g.K >= 4 * BK &&
+// Shapes the quadrant kernel takes: whole k-tiles unless both operands are reduction-major, float4-able rows.
+inline bool pq_eligible(const NtArgs &g, bool both_rmajor = false) {
+    return (g.K % BK == 0 || both_rmajor) && g.N % 4 == 0 && g.K >= 4 * BK &&
            (!g.D32 || (reinterpret_cast<uintptr_t>(g.D32) & 15) == 0) &&
            (!g.D16 || (reinterpret_cast<uintptr_t>(g.D16) & 7) == 0) &&
            (!g.D2_16 || (reinterpret_cast<uintptr_t>(g.D2_16) & 7) == 0) &&
@@ -465,7 +534,7 @@ inline bool pq_eligible(const NtArgs &g) {
            (!g.R2 || (reinterpret_cast<uintptr_t>(g.R2) & 15) == 0);
 }
 
-template <int RF, int NF, bool BRM = false, int ABL = 0>
+template <int RF, int NF, bool ARM = false, bool BRM = false, int ABL = 0>
 int launch_pq(NtArgs &g, hipStream_t s) {
     using G = PqGeom<RF, NF>;
     g.tiles_m = (int)sei_ceil_div(g.M, G::BM);
@@ -481,7 +550,7 @@ int launch_pq(NtArgs &g, hipStream_t s) {
     const bool splittable = g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
                             g.epilogue == SEI_EPI_BIAS_RES || g.epilogue == SEI_EPI_ACCUM;
     if (splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
-        const size_t slots = 256, ktiles = g.K / BK;
+        const size_t slots = 256, ktiles = sei_ceil_div(g.K, BK);
         const size_t max_sk = ktiles / 4 < 16 ? ktiles / 4 : 16;
         const double overhead = 8.0 + (g.epilogue == SEI_EPI_ACCUM ? 0.0 : 2.0);
         double best = 1e30;
@@ -505,7 +574,7 @@ int launch_pq(NtArgs &g, hipStream_t s) {
         if (zg > 2048) zg = 2048;
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
-    hipLaunchKernelGGL((gemm_bf16pq_kernel<RF, NF, BRM, ABL>), dim3((unsigned)(8 * (size_t)g.tiles_per_xcd * g.splitk)),
+    hipLaunchKernelGGL((gemm_bf16pq_kernel<RF, NF, ARM, BRM, ABL>), dim3((unsigned)(8 * (size_t)g.tiles_per_xcd * g.splitk)),
                        dim3(NT), 0, s, g);
     return sei_launch_status();
 }

@@ -513,7 +513,8 @@ def test_gemm_bf16nt_reduction_major_operands(ops, M, N, K, arm, brm):
 
 
 @pytest.mark.parametrize("M,N,K1,K2", [(128, 32, 147456, 73728), (512, 2048, 576, 288), (2048, 512, 2304, 1152),
-                                       (96, 160, 1000, 24), (32, 128, 40, 8)])
+                                       (96, 160, 1000, 24), (32, 128, 40, 8),
+                                       (2048, 8192, 288, 576), (8192, 2048, 1152, 2304), (6144, 2560, 24, 296)])
 def test_gemm_bf16nt_two_segment_weight_gradient(ops, M, N, K1, K2):
     """sei_gemm_bf16nt_dw2: D (+)= A1^T B1 + A2^T B2 on reduction-major operands, store and accumulate."""
     from _native import call
@@ -621,6 +622,37 @@ def test_gemm_bf16_quadrant_schedule(ops, M, N, K, code, br):
         out = torch.empty((M, N), device="cuda")
         ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_ROWSCALE, out32=out, bias=bias, R1=rs, **kw)
         assert relerr(out, ref + rs.double().cpu()[:, None] * bias.double().cpu()[None, :]) < 2e-5
+    finally:
+        lib().sei_debug_set_nt_tile(0)
+
+
+@pytest.mark.parametrize("code", [30, 33])
+@pytest.mark.parametrize("M,N,K", [(512, 768, 256), (304, 520, 328), (2048, 2048, 864), (256, 1024, 4104)])
+def test_gemm_bf16_quadrant_schedule_weight_gradient(ops, M, N, K, code):
+    """Quadrant schedule with both operands reduction-major (the weight gradient): ragged edges, a K that is not
+    a multiple of the k-tile (zero rows past the end), store and accumulate, bit-stable without split K."""
+    from _native import lib
+    gen = torch.Generator().manual_seed(M + N + K + code)
+    A = torch.randn((K, M), generator=gen).bfloat16().cuda()
+    B = torch.randn((K, N), generator=gen).bfloat16().cuda()
+    R1 = torch.randn((M, N), generator=gen).cuda()
+    ref = (A.double().t() @ B.double()).cpu()
+    try:
+        assert lib().sei_debug_set_nt_tile(code) == 0
+        outs = []
+        for _ in range(3):
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out16=out, a_rmajor=True, b_rmajor=True)
+            torch.cuda.synchronize()
+            outs.append(out)
+        assert relerr(outs[0].float(), ref) < 1e-2
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        out = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out32=out, a_rmajor=True, b_rmajor=True)
+        assert relerr(out, ref) < 2e-5
+        acc = R1.clone()
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_ACCUM, out32=acc, a_rmajor=True, b_rmajor=True)
+        assert relerr(acc, ref + R1.double().cpu()) < 2e-5
     finally:
         lib().sei_debug_set_nt_tile(0)
 
