@@ -228,15 +228,16 @@ def main():
     if records:
         achieved = flops / (total_ms * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[opt.dtype]
-        kernels = ("gemm_bf16nt_kernel<*> (direct-to-LDS NT, all large GEMMs) + gemm_bf16_kernel<*> (K<64 layers)"
+        kernels = ("gemm_bf16pq_kernel<*> (quadrant schedule, deep levels) + gemm_bf16nt_kernel<*> (128x128 loop, "
+                   "everything else) + gemm_bf16_kernel<*> (K<64 layers)"
                    if opt.dtype == "bf16" else "gemm_f32_kernel<*>")
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_e_pmc_gemm.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01_g_pmc_gemm.json")
         if opt.dtype == "bf16" and not sr and not opt.full256 and opt.hidden == 32 and opt.scales == 5 and opt.batch == 32 and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))                 # PMC counters cannot be read live; see the file
             traffic = round(pmc["traffic_bytes_per_launch"])
             traffic_src = ("bytes beyond L2 per GEMM launch from committed rocprofv3 --pmc passes of this command "
-                           "(profiles/r01_e_pmc_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections)")
+                           "(profiles/r01_g_pmc_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections)")
         roofline = {"bound": "mfma", "kernel": kernels, "achieved": round(achieved, 2), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
