@@ -530,12 +530,14 @@ int pq_choose(const NtArgs &g, bool would_split) {
     const size_t tm = sei_ceil_div(M, 32 * rf);
     const size_t t4 = tm * sei_ceil_div(N, 256), t2 = tm * sei_ceil_div(N, 128);
     auto fills = [](size_t t) { return (double)t / (double)(sei_ceil_div(t, 256) * 256) >= 0.8; };
-    if (would_split && t4 < 1024) {
+    // enough whole tiles to fill the chip: the launch does not split K whatever its epilogue allows
+    if (t4 >= 192 && fills(t4)) return 10 * rf + 4;
+    if (t2 >= 192 && t4 < 192 && fills(t2)) return 10 * rf + 2;
+    if (would_split) {
         if (K < 8192 || N < 2048 || (M < 2304 && N < 8192)) return 0;
         return 10 * rf + ((t4 >= 64 && N >= 8192) ? 4 : 2);
     }
-    if (t4 >= 192 && fills(t4)) return 10 * rf + 4;
-    if (t2 >= 128 && t4 < 192 && fills(t2)) return 10 * rf + 2;
+    if (t2 >= 128 && t4 < 192) return 10 * rf + 2;             // half the chip on 288-row tiles beats 96 tiles of 192x256
     return 0;
 }
 
