@@ -420,9 +420,10 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
                     atomicAdd(g.D32 + o, v + a1[i][j][r] + a2[i][j][r]);
                     continue;
                 }
-                if (epi == SEI_EPI_MUL_DGELU) v *= sei_dgelu(a1[i][j][r]);
+                if (epi == SEI_EPI_MUL_DGELU)
+                    v *= (g.D16 && !g.D32) ? sei_dgelu_bf16out(a1[i][j][r]) : sei_dgelu(a1[i][j][r]);
                 else v += a1[i][j][r] + a2[i][j][r];
-                if (epi == SEI_EPI_BIAS_GELU) g.D2_16[o] = f2bf(sei_gelu(v));
+                if (epi == SEI_EPI_BIAS_GELU) g.D2_16[o] = f2bf(sei_gelu_bf16out(v));
                 if (g.D32) g.D32[o] = v;
                 if (g.D16) g.D16[o] = f2bf(v);
             }

@@ -403,6 +403,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
                                                 epi == SEI_EPI_BIAS_RES || epi == SEI_EPI_BIAS_ROWSCALE);
     f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
     if (with_bias && col_ok) bias4 = *reinterpret_cast<const f32x4 *>(g.bias + col);
+    const bool dgelu_to_bf16 = g.D16 != nullptr && g.D32 == nullptr;     // the product is rounded to bf16 only
     const float *aux1 = nullptr, *aux2 = nullptr;
     if (!split) {
         if (epi == SEI_EPI_ACCUM) aux1 = g.D32;
@@ -496,7 +497,8 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
 #pragma unroll
             for (int p = 0; p < NF; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[p][j] *= sei_dgelu(a1[p][j]);
+                for (int j = 0; j < 4; ++j)
+                    v[p][j] *= dgelu_to_bf16 ? sei_dgelu_bf16out(a1[p][j]) : sei_dgelu(a1[p][j]);
         } else {
 #pragma unroll
             for (int p = 0; p < NF; ++p) v[p] += a1[p] + a2[p];
@@ -509,8 +511,8 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
             const size_t o = (size_t)row * N + col;
             if (epi == SEI_EPI_BIAS_GELU) {
                 ushort4 h;
-                h.x = f2bf(sei_gelu(v[p][0])); h.y = f2bf(sei_gelu(v[p][1]));
-                h.z = f2bf(sei_gelu(v[p][2])); h.w = f2bf(sei_gelu(v[p][3]));
+                h.x = f2bf(sei_gelu_bf16out(v[p][0])); h.y = f2bf(sei_gelu_bf16out(v[p][1]));
+                h.z = f2bf(sei_gelu_bf16out(v[p][2])); h.w = f2bf(sei_gelu_bf16out(v[p][3]));
                 *reinterpret_cast<ushort4 *>(g.D2_16 + o) = h;
             }
             if (g.D32) *reinterpret_cast<f32x4 *>(g.D32 + o) = v[p];
