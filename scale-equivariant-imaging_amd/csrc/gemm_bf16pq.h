@@ -256,16 +256,21 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     // on l16 only. Reduction-major: 8 k-values (32 ks + 8 lg + j) of column l16, two ds_read_b64_tr_b16.
     const int frag_x0 = l16 * ROW_BYTES + (((0 + lg) ^ (l16 >> 1)) * 16);
     const int frag_x1 = l16 * ROW_BYTES + (((4 + lg) ^ (l16 >> 1)) * 16);
+    // Transposing reads: lane (tq = l16 >> 2, tp = l16 & 3) of lane group lg addresses k-row 32 ks + 8 lg + tq (+4
+    // for the second read) and the 8 bytes tp & 1 of chunk (2 blk + (tp >> 1)) ^ swizzle(row). Both swizzles depend
+    // on tq and lg only (256-B rows: the second read's key is the first's ^ 1; 128-B rows: the same key), and
+    // 2 blk only touches chunk bits 1-3, so one per-lane offset serves every block, k-step and read of a
+    // half-tile: address = tile + (lane_off ^ 32 blk [^ 16]) + pitch * (32 ks [+ 4]), the last term an immediate.
     const int tq = l16 >> 2, tp = l16 & 3;
+    const int rm_lane256 = 256 * (8 * lg + tq) + 16 * ((tp >> 1) ^ ((tq << 2) | ((2 * lg) & 3))) + 8 * (tp & 1);
+    const int rm_lane128 = 128 * (8 * lg + tq) + 16 * ((tp >> 1) ^ pq_swz_rm128(8 * lg + tq)) + 8 * (tp & 1);
     auto frag_rm = [&](const char *t, int pitch, int blk, int ks) -> bf16x8 {   // 16-column block blk of the half
-        const int chunk = 2 * blk + (tp >> 1);
-        const int row = 32 * ks + 8 * lg + tq;
-        auto addr = [&](int r) {
-            const int sw = pitch == 256 ? swz_rmajor(r) : pq_swz_rm128(r);
-            return (__attribute__((address_space(3))) v4s *)(t + pitch * r + 16 * (chunk ^ sw) + 8 * (tp & 1));
-        };
-        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(addr(row));
-        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(addr(row + 4));
+        const int base = (pitch == 256 ? rm_lane256 : rm_lane128) ^ (32 * blk);
+        const int base_hi = pitch == 256 ? base ^ 16 : base;
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s *)(t + base + pitch * 32 * ks));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s *)(t + base_hi + pitch * (32 * ks + 4)));
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     bf16x8 fa[QA0][2], fb0[QB][2], fb1[QB][2];
