@@ -527,7 +527,9 @@ extern "C" int sei_debug_set_nt_tile(int code) {
 int pq_choose(const NtArgs &g, bool would_split) {
     const int M = g.M, N = g.N, K = g.K;
     const int rf = M % 288 == 0 ? 9 : ((M % 256 == 0 || M >= 4096) ? 8 : 0);
-    if (g_force_tile != 0 || !rf || K < 512 || N < 512 || !pq_eligible(g)) return 0;
+    // K >= 128: even two k-tiles per tile pay, because the epilogue moves whole rows (36864 x 512 x 128 with
+    // GELU 36 -> 28 us, its data gradient 49 -> 32 us); the 128 x 128 loop stores element by element
+    if (g_force_tile != 0 || !rf || K < 128 || N < 512 || !pq_eligible(g)) return 0;
     const size_t tm = sei_ceil_div(M, 32 * rf);
     const size_t t4 = tm * sei_ceil_div(N, 256), t2 = tm * sei_ceil_div(N, 128);
     auto fills = [](size_t t) { return (double)t / (double)(sei_ceil_div(t, 256) * 256) >= 0.8; };

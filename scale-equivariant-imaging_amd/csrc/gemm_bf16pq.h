@@ -532,7 +532,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
 
 // Shapes the quadrant kernel takes: whole k-tiles unless both operands are reduction-major, float4-able rows.
 inline bool pq_eligible(const NtArgs &g, bool both_rmajor = false) {
-    return (g.K % BK == 0 || both_rmajor) && g.N % 4 == 0 && g.K >= 4 * BK &&
+    return (g.K % BK == 0 || both_rmajor) && g.N % 4 == 0 && g.K >= 2 * BK &&
            (!g.D32 || (reinterpret_cast<uintptr_t>(g.D32) & 15) == 0) &&
            (!g.D16 || (reinterpret_cast<uintptr_t>(g.D16) & 7) == 0) &&
            (!g.D2_16 || (reinterpret_cast<uintptr_t>(g.D2_16) & 7) == 0) &&
