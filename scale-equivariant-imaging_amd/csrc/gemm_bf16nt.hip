@@ -529,10 +529,12 @@ int pq_choose(const NtArgs &g, bool would_split) {
     const int rf = M % 288 == 0 ? 9 : ((M % 256 == 0 || M >= 4096) ? 8 : 0);
     // K >= 128: even two k-tiles per tile pay, because the epilogue moves whole rows (36864 x 512 x 128 with
     // GELU 36 -> 28 us, its data gradient 49 -> 32 us); the 128 x 128 loop stores element by element
-    if (g_force_tile != 0 || !rf || K < 128 || N < 512 || !pq_eligible(g)) return 0;
+    if (g_force_tile != 0 || !rf || K < 32 || N < 128 || !pq_eligible(g)) return 0;
     const size_t tm = sei_ceil_div(M, 32 * rf);
-    const size_t t4 = tm * sei_ceil_div(N, 256), t2 = tm * sei_ceil_div(N, 128);
+    const size_t t4 = N >= 256 ? tm * sei_ceil_div(N, 256) : 0, t2 = tm * sei_ceil_div(N, 128);
     auto fills = [](size_t t) { return (double)t / (double)(sei_ceil_div(t, 256) * 256) >= 0.8; };
+    if (K < 128 && (would_split || N > 128)) return 0;          // one-k-tile launches: only the C = 32 expanding convolutions
+    if (N < 512 && would_split) return 0;                       // narrow f32 outputs: no gain measured (36864 x 128 x 512)
     // enough whole tiles to fill the chip: the launch does not split K whatever its epilogue allows
     if (t4 >= 192 && fills(t4)) return 10 * rf + 4;
     if (t2 >= 192 && t4 < 192 && fills(t2)) return 10 * rf + 2;

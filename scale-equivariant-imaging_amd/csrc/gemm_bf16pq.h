@@ -105,7 +105,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     const int M = g.M, N = g.N;
     const int k_begin = zs * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
-    const int nt = (k_end - k_begin + BK - 1) / BK;           // a partial last k-tile only with ARM && BRM (host-checked)
+    const int nt = (k_end - k_begin + BK - 1) / BK;           // the last k-tile may be partial (zero-filled)
 
     f32x4 acc[RF][NF];
 #pragma unroll
@@ -189,10 +189,16 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         if (k >= k_end) return g_zero_chunk;
         return k < g.k_seg ? X1 + (size_t)k * ld + o0 + col : X2 + (size_t)(k - g.k_seg) * ld + o0 + col;
     };
+    // K-contiguous operand, last k-tile of a K that is not a multiple of 64: chunks past k_end come from the zero chunk
+    auto kc_src = [&](const char *base, unsigned off, int p, int k0) -> const void * {
+        const int c = (lane & 7) ^ ((4 * (p & 1) + (lane >> 4)) & 7);         // logical chunk of this lane in piece p
+        return k0 + 8 * c < k_end ? (const void *)(base + off) : (const void *)g_zero_chunk;
+    };
     auto issue = [&](int u, int which) {                      // which: 0 = A(0), 1 = A(1), 2 = B(0), 3 = B(1)
         if constexpr (ABL & 2) { if (u > 1) return; }
         char *stage = smem + (u & 1) * G::STAGE;
         const int k0 = k_begin + u * BK;
+        const bool tail = k0 + BK > k_end;                    // wave-uniform
         if (which < 2) {
             const char *ap;
             if constexpr (ARM) ap = rm_base(g.A, g.A2, g.lda, m0, k0);
@@ -204,6 +210,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
                     int krow;
                     const int col = a_col(wave + 8 * e, which, krow);
                     __builtin_amdgcn_global_load_lds((glb_void *)rm_slow(g.A, g.A2, g.lda, m0, k0, krow, col),
+                                                     (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
+                }
+            } else if (!ARM && tail) {
+#pragma unroll
+                for (int e = 0; e < G::NA0; ++e) {
+                    if (which ? e >= G::NA1 : (G::PA0 % 8 != 0 && e == G::NA0 - 1 && !third)) break;
+                    __builtin_amdgcn_global_load_lds((glb_void *)kc_src(ap, which ? oa1[e < G::NA1 ? e : 0] : oa0[e], wave + 8 * e, k0),
                                                      (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
                 }
             } else if (which == 0) {
@@ -232,6 +245,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
                     __builtin_amdgcn_global_load_lds((glb_void *)rm_slow(g.B, g.B2, g.ldb, n0, k0, krow, col),
                                                      (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
                 }
+            } else if (!BRM && tail) {
+#pragma unroll
+                for (int e = 0; e < G::NB; ++e)
+                    __builtin_amdgcn_global_load_lds((glb_void *)kc_src(bp, which == 3 ? ob1[e] : ob0[e], wave + 8 * e, k0),
+                                                     (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
             } else {
 #pragma unroll
                 for (int e = 0; e < G::NB; ++e)
@@ -530,9 +548,9 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     }
 }
 
-// Shapes the quadrant kernel takes: whole k-tiles unless both operands are reduction-major, float4-able rows.
-inline bool pq_eligible(const NtArgs &g, bool both_rmajor = false) {
-    return (g.K % BK == 0 || both_rmajor) && g.N % 4 == 0 && g.K >= 2 * BK &&
+// Shapes the quadrant kernel takes: float4-able rows (K % 8 == 0 is checked by the entry points).
+inline bool pq_eligible(const NtArgs &g, bool = false) {
+    return g.N % 4 == 0 && g.K >= 32 &&
            (!g.D32 || (reinterpret_cast<uintptr_t>(g.D32) & 15) == 0) &&
            (!g.D16 || (reinterpret_cast<uintptr_t>(g.D16) & 7) == 0) &&
            (!g.D2_16 || (reinterpret_cast<uintptr_t>(g.D2_16) & 7) == 0) &&

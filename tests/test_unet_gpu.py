@@ -578,10 +578,10 @@ def test_gemm_bf16_pingpong_schedule(ops, M, N, K, ar, br):
 
 @pytest.mark.parametrize("br", [0, 1])
 @pytest.mark.parametrize("code", [30, 31, 32, 33])
-@pytest.mark.parametrize("M,N,K", [(576, 512, 256), (300, 520, 320), (2304, 2048, 2048), (288, 1024, 4096)])
+@pytest.mark.parametrize("M,N,K", [(576, 512, 256), (300, 520, 328), (2304, 2048, 2048), (288, 1024, 4096), (1000, 128, 32)])
 def test_gemm_bf16_quadrant_schedule(ops, M, N, K, code, br):
     """The quadrant schedule (gemm_bf16pq.h; tile codes 30-33 = 256/288 rows x 256/128 columns): ragged row and
-    column edges, split K, every fused epilogue, against float64; launches that do not split K must agree bit
+    column edges, a K that is not a multiple of the k-tile (also a single partial k-tile), split K, every fused epilogue, against float64; launches that do not split K must agree bit
     for bit run to run (the schedule orders its LDS-DMA by counted waits and raw barriers only)."""
     from _native import lib
     gen = torch.Generator().manual_seed(M + N + K + code + br)
