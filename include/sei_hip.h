@@ -250,7 +250,7 @@ int sei_debug_tr_probe(const uint16_t *in, uint16_t *out, int r0, int c0, void *
 /* Tuning aid: force the tile / schedule of sei_gemm_bf16nt (0 = automatic; 1, 2, 3, 5 = 128x128, 128x256,
  * 192x256, 96x256; 11-16 = LDS-ring / single-stage variants; 20 = the 256x256 ping-pong schedule of
  * gemm_bf16pp.h; 30-33 = the quadrant schedule of gemm_bf16pq.h with 256x256, 288x256, 288x128, 256x128 tiles
- * (34, 35: timing-only ablations); 100 + b = band width b of the tile order, 100 = automatic).
+ * (34-37: timing-only ablations of that kernel: no DMA / MFMAs only, K-contiguous and reduction-major); 100 + b = band width b of the tile order, 100 = automatic).
  * Process-global; not for production use. */
 int sei_debug_set_nt_tile(int code);
 

@@ -690,6 +690,8 @@ extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int l
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
     g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
+    if (g_force_tile == 36) return launch_pq<8, 4, true, true, 2>(g, (hipStream_t)stream);   // ablations: timing only
+    if (g_force_tile == 37) return launch_pq<8, 4, true, true, 7>(g, (hipStream_t)stream);
     if (g_force_tile == 30 && pq_eligible(g, true)) return launch_pq<8, 4, true, true>(g, (hipStream_t)stream);   // tuning aid
     if (g_force_tile == 33 && pq_eligible(g, true)) return launch_pq<8, 2, true, true>(g, (hipStream_t)stream);
     switch (pq_choose_rr(g)) {
