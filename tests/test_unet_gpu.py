@@ -626,6 +626,55 @@ def test_gemm_bf16_quadrant_schedule(ops, M, N, K, code, br):
         lib().sei_debug_set_nt_tile(0)
 
 
+@pytest.mark.parametrize("M,N,K,kind", [
+    (2304, 8192, 2048, "gelu"), (576, 32768, 8192, "gelu"), (288, 32768, 8192, "gelu"), (36864, 512, 128, "gelu"),
+    (147456, 128, 32, "gelu"), (2304, 8192, 2048, "dgelu_kr"), (576, 32768, 8192, "dgelu_kr"),
+    (147456, 128, 32, "dgelu_kr"), (2304, 2048, 8192, "res"), (576, 8192, 32768, "res"), (576, 8192, 32768, "none_kr"),
+    (2304, 8192, 2048, "none_kr")])
+def test_gemm_bf16_full_size_layers_on_the_automatic_dispatch(ops, M, N, K, kind):
+    """The 1x1-convolution GEMMs of BASELINE configs[1] at their full sizes (batch 32), as the library dispatches
+    them (quadrant schedule for most, split K where it splits): f32 results against a float32 matmul of the same
+    bf16 operands, bf16 results to bf16 resolution; no run-to-run difference where K is not split."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    kr = kind.endswith("_kr")
+    A = (torch.randn((M, K), generator=gen) * 0.5).bfloat16().cuda()
+    B = (torch.randn((K, N) if kr else (N, K), generator=gen) * (K ** -0.5)).bfloat16().cuda()
+    bias = torch.randn(N, generator=gen).cuda()
+    ref = A.float() @ (B.float() if kr else B.float().t())
+    scale = float(ref.abs().max())
+    if kind == "gelu":
+        outs = []
+        for _ in range(2):
+            h3 = torch.empty((M, N), device="cuda")
+            h4 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+            ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_GELU, out32=h3, bias=bias, D2_16=h4)
+            outs.append((h3, h4))
+        pre = ref + bias
+        assert float((outs[0][0] - pre).abs().max()) < 2e-5 * max(scale, 1.0) * (K ** 0.5)
+        assert float((outs[0][1].float() - F.gelu(pre)).abs().max()) < 1e-2 * max(scale, 1.0)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    elif kind == "dgelu_kr":
+        R1 = torch.randn((M, N), generator=gen).cuda()
+        x = R1.clone().requires_grad_(True)
+        dg, = torch.autograd.grad(F.gelu(x).sum(), x)
+        outs = []
+        for _ in range(2):
+            g16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+            ops.gemm_nt16(A, B, M, N, K, ops.EPI_MUL_DGELU, out16=g16, R1=R1, b_rmajor=True)
+            outs.append(g16)
+        assert float((outs[0].float() - ref * dg).abs().max()) < 1e-2 * max(scale, 1.0)
+        assert torch.equal(outs[0], outs[1])
+    elif kind == "res":
+        R1 = torch.randn((M, N), generator=gen).cuda()
+        out = torch.empty((M, N), device="cuda")
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_RES, out32=out, bias=bias, R1=R1)
+        assert float((out - (ref + bias + R1)).abs().max()) < 2e-5 * max(scale, 1.0) * (K ** 0.5)
+    else:
+        out = torch.full((M, N), float("nan"), device="cuda")
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out32=out, b_rmajor=True)
+        assert float((out - ref).abs().max()) < 2e-5 * max(scale, 1.0) * (K ** 0.5)
+
+
 @pytest.mark.parametrize("code", [30, 33])
 @pytest.mark.parametrize("M,N,K", [(512, 768, 256), (304, 520, 328), (2048, 2048, 864), (256, 1024, 4104)])
 def test_gemm_bf16_quadrant_schedule_weight_gradient(ops, M, N, K, code):
