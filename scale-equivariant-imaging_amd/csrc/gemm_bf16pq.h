@@ -516,12 +516,16 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
 #pragma unroll
             for (int p = 0; p < NF; ++p) v[p] += bias4;
         }
-        if (epi == SEI_EPI_MUL_DGELU) {
+        if (epi == SEI_EPI_MUL_DGELU && dgelu_to_bf16) {      // one uniform branch per 16-row chunk, not per value
 #pragma unroll
             for (int p = 0; p < NF; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    v[p][j] *= dgelu_to_bf16 ? sei_dgelu_bf16out(a1[p][j]) : sei_dgelu(a1[p][j]);
+                for (int j = 0; j < 4; ++j) v[p][j] *= sei_dgelu_bf16out(a1[p][j]);
+        } else if (epi == SEI_EPI_MUL_DGELU) {
+#pragma unroll
+            for (int p = 0; p < NF; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[p][j] *= sei_dgelu(a1[p][j]);
         } else {
 #pragma unroll
             for (int p = 0; p < NF; ++p) v[p] += a1[p] + a2[p];
