@@ -12,9 +12,13 @@ Workload: config[1] of BASELINE.json -- deblurring, Gaussian_R2, noise 5, propos
 default ConvolutionalModel (hidden 32, 5 scales, 645,063,043 parameters), per-GPU batch 32 (config[3]'s
 256 / 8), synthetic inputs resident in HBM, random-init weights (torch.manual_seed(0)).
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
-  roofline     -- the dominant kernel (sei_gemm_f32: all 1x1 convolutions and their gradients), timed
-                  live with HIP events on the launch stream during the timed steps.
+Prints ONE JSON line on rank 0 (contract in the task statement), with these extra objects:
+  roofline     -- the dominant kernel family (the bf16 MFMA GEMMs: all 1x1 convolutions and their gradients),
+                  every launch of one step re-issued between HIP events on the launch stream.
+  roofline_hbm -- the streaming kernel families of the same step (Adam, depthwise 7x7, LayerNorm, ideal resamplers,
+                  casts + column sums, 3x3 convolutions, physics + loss terms): algorithmic bytes per step / the
+                  event-timed ms of their re-issued launches / 8 TB/s.
+  secondary    -- the same step in the reference's own arithmetic (float32 GEMMs; --secondary, N=1 only).
   cpu_baseline -- the oracle's torch-CPU restatement of the same step on the host cores (N=1 only).
 """
 import argparse
@@ -48,8 +52,9 @@ def reference_args(device, hidden=32, scales=5, task="deblurring", sr_factor=Non
         ScalingTransform__kind="padded", ScalingTransform__antialias=False)
 
 
-def cpu_baseline(batch, hidden, scales):
-    """The oracle's restatement of the same training step on the host CPU (kind "port")."""
+def cpu_baseline(batch, hidden, scales, timed_steps=2):
+    """The oracle's restatement of the same training step on the host CPU (kind "port"), by the protocol of
+    BASELINE.md section 3 / SURVEY 8(d): batch 4, float32, all host cores, 1 warm-up step + >= 2 timed steps."""
     from oracle import torch_path as tp
     torch.manual_seed(0)
     threads = torch.get_num_threads()
@@ -61,18 +66,246 @@ def cpu_baseline(batch, hidden, scales):
     x = torch.rand((batch, 3, 256, 256), generator=g)
     y = tp.add_noise(A(x), NOISE / 255)
     model = lambda v: tp.unet_forward(sd, v, scales=scales)
+
+    def step():
+        opt.zero_grad()
+        _, yc = tp.crop_pair(x, y, CROP, 1)
+        rate, center = tp.sample_scale_params(batch)
+        loss, _ = tp.proposed_loss(yc.contiguous(), A, model, NOISE / 255, margin=6, rate=rate, center=center)
+        loss.backward()
+        opt.step()
+
     t0 = time.perf_counter()
-    opt.zero_grad()
-    _, yc = tp.crop_pair(x, y, CROP, 1)
-    rate, center = tp.sample_scale_params(batch)
-    loss, _ = tp.proposed_loss(yc.contiguous(), A, model, NOISE / 255, margin=6, rate=rate, center=center)
-    loss.backward()
-    opt.step()
-    dt = time.perf_counter() - t0
-    return {"value": batch / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"1 un-warmed proposed-loss step (crop {CROP}, 3 fwd + 3 bwd + Adam) of the same U-Net at "
-                      f"batch {batch}, float32, torch CPU ops in the reference's order (oracle/torch_path.py), "
-                      f"{dt:.1f} s"}
+    step()                                                 # warm-up (first-call overheads, allocator, Adam state)
+    t1 = time.perf_counter()
+    for _ in range(timed_steps):
+        step()
+    dt = (time.perf_counter() - t1) / timed_steps
+    return {"value": round(batch / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{timed_steps} timed proposed-loss steps after 1 warm-up ({t1 - t0:.1f} s) of the same U-Net at "
+                      f"batch {batch} (crop {CROP}, 3 fwd + 3 bwd + Adam), float32, torch CPU ops in the reference's "
+                      f"order (oracle/torch_path.py), {dt:.1f} s per step"}
+
+
+# Algorithmic HBM bytes of one launch of the streaming entry points, from the call's own arguments (DESIGN.md
+# section 4: every operand read once, every result written once; f32 = 4 B, bf16 = 2 B).
+def _stream_bytes(name, a):
+    if name in ("sei_dwconv7_fwd", "sei_dwconv7_fwd_ex"):
+        B, H, W, C = a[6:10]
+        return (8 + (4 if a[3] else 0)) * B * H * W * C
+    if name in ("sei_dwconv7_bwd_weight", "sei_dwconv7_bwd_weight_ex"):
+        B, H, W, C = a[4:8]
+        return 8 * B * H * W * C
+    if name == "sei_ln_fwd":
+        return 8 * a[6] * a[7]
+    if name == "sei_ln_fwd_bf16":
+        return 6 * a[6] * a[7]
+    if name == "sei_ln_bwd":
+        return 12 * a[8] * a[9]
+    if name == "sei_sepmap2_packed":
+        B, Hi, Wi, Ho, Wo, C = a[2:8]
+        return 4 * B * C * (Hi * Wi + Ho * Wo)
+    if name == "sei_cast_transpose_bf16":
+        return 6 * a[4] * a[5]
+    if name == "sei_cast_bf16":
+        return 6 * a[2]
+    if name == "sei_colsum_bf16":
+        return 2 * a[2] * a[3]
+    if name == "sei_colsum_f32":
+        return 4 * a[2] * a[3]
+    if name == "sei_colsum_weighted_f32":
+        return 4 * a[3] * a[4]
+    if name == "sei_conv3x3_fwd":
+        B, H, W, Ci, Co = a[5:10]
+        return 4 * B * H * W * (Ci + Co + (Co if a[3] else 0))
+    if name == "sei_conv3x3_bwd_weight":
+        B, H, W, Ci, Co = a[4:9]
+        return 4 * B * H * W * (Ci + Co)
+    if name == "sei_adam_fused":
+        return a[5] * (24 + (2 if a[2] else 4) + (2 if a[-1] else 0))
+    if name == "sei_blur_sep_circ":
+        return 8 * a[6] * a[7] * a[8]
+    if name in ("sei_scale_resample_fwd", "sei_scale_resample_bwd"):
+        B, C, Hi, Wi, H, W = a[4:10]
+        return 4 * B * C * (Hi * Wi + H * W)
+    if name == "sei_resample_sepband":
+        return 4 * a[2] * (a[3] * a[4] + a[5] * a[6])
+    if name == "sei_axpy":
+        return 12 * a[4]
+    if name == "sei_sure_terms":
+        return 24 * a[4] * a[5] * a[6]
+    if name == "sei_mse_terms":
+        return 12 * a[2]
+    return None
+
+
+_STREAM_FAMILIES = [
+    ("adam_vec_kernel (fused Adam over the flat bucket)", ("sei_adam_fused",)),
+    ("dwconv7_* (depthwise 7x7: forward, data and weight gradients)", ("sei_dwconv7_",)),
+    ("ln_* (channel LayerNorm forward / backward)", ("sei_ln_",)),
+    ("sepmap_* (ideal resamplers)", ("sei_sepmap2",)),
+    ("cast / colsum kernels (bf16 copies, bias gradients)", ("sei_cast_", "sei_colsum_")),
+    ("conv3x3_* (in / out convolutions)", ("sei_conv3x3_",)),
+    ("blur / scale_resample / axpy / sure / mse kernels (physics + loss terms)",
+     ("sei_blur_", "sei_scale_resample_", "sei_axpy", "sei_sure_terms", "sei_mse_terms", "sei_resample_")),
+]
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def stream_roofline(log, reps=3):
+    """Re-issue the logged streaming launches of one step, family by family, between HIP events."""
+    import _native
+    out = []
+    for label, prefixes in _STREAM_FAMILIES:
+        calls = [(n, a) for n, a in log if n.startswith(prefixes) and _stream_bytes(n, a) is not None]
+        if not calls:
+            continue
+        nbytes = float(sum(_stream_bytes(n, a) for n, a in calls))
+        for n, a in calls:
+            _native.call(n, *a)                           # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            for n, a in calls:
+                _native.call(n, *a)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out.append({"kernel": label, "launches_per_step": len(calls), "bytes_per_step": round(nbytes),
+                    "ms_per_step": round(ms, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4)})
+    return out
+
+
+class Leg:
+    """One configured training job on this rank: model, loss, optimizer, resident synthetic pairs, step()."""
+
+    def __init__(self, opt, dtype, device, rank, world):
+        import parallel
+        from losses import get_loss
+        from models import _ops, get_model
+        from optim import FlatAdam
+        from physics import get_physics
+        self.opt, self.dtype, self.world = opt, dtype, world
+        sr = opt.task == "sr"
+        args = reference_args(device, opt.hidden, opt.scales, opt.task, opt.sr_factor if sr else None)
+        if opt.full256:
+            args.Loss__crop_training_pairs = False
+        _ops.set_compute_dtype(dtype)
+        torch.manual_seed(0)
+        physics = get_physics(args, device)
+        self.model = model = get_model(args, physics, device)
+        model.to(device)
+        model.train()
+        self.backbone = backbone = model.get_backbone()
+        self.nparams = sum(p.numel() for p in backbone.parameters())
+        if world > 1:
+            parallel.broadcast_parameters(backbone.flat_params)
+        self.loss_fn = loss_fn = get_loss(args, physics)
+        self.comm_dtype = torch.bfloat16 if (dtype == "bf16" and opt.grad_comm == "auto") or opt.grad_comm == "bf16" \
+            else torch.float32
+        self.reducer = reducer = parallel.FlatGradientReducer(backbone.flat_grads, comm_dtype=self.comm_dtype,
+                                                              mode=opt.grad_comm_mode) if world > 1 else None
+        self.optimizer = optimizer = FlatAdam(model, lr=1e-4, betas=(0.9, 0.999), reducer=reducer)
+
+        # synthetic 256x256 pairs, resident in HBM before the timed region (SURVEY 8d)
+        g = torch.Generator().manual_seed(1234 + rank)
+        self.side = side = CROP * opt.sr_factor if sr else 256   # SR: the dataset's _HOTFIX crop (datasets/__init__.py:84-85)
+        self.x = x = torch.rand((opt.batch, 3, side, side), generator=g).to(device)
+        torch.manual_seed(4321 + rank)
+        torch.cuda.manual_seed(4321 + rank)
+        self.y = y = physics(x)
+
+        def eager_step():
+            optimizer.zero_grad()
+            loss = loss_fn(x=x, y=y, model=model)
+            loss.backward()
+            if reducer is not None:
+                reducer.reduce_async()
+            optimizer.step()
+            return loss
+
+        self.step, self.graphed, self.early_event = eager_step, None, None
+        if opt.graph:
+            from graphs import GraphedLossStep
+            ys = 256 if opt.full256 else CROP
+            early = reducer is not None and os.environ.get("SEI_NO_EARLY_RELEASE") != "1"
+            self.graphed = graphed = GraphedLossStep(loss_fn, model, optimizer, (opt.batch, 3, ys, ys),
+                                                     early_release=early)
+            if early and graphed.early_grads is not None:        # the bottleneck block's gradients leave early
+                self.early_event = graphed.early_grads[0]
+                reducer.set_early_range(graphed.early_grads[1:])
+
+            def step():
+                loss = graphed(x, y)
+                if reducer is not None:
+                    reducer.reduce_async(early=self.early_event)
+                optimizer.step()
+                return loss
+
+            self.step = step
+
+    def timed(self, warmup, steps, fence):
+        for _ in range(warmup):
+            self.step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = self.step()
+        fence()
+        return time.perf_counter() - t0, float(last.detach())
+
+    def record_one_step(self):
+        """One eager step with every native call logged (streaming families) and every GEMM launch recorded with its
+        FLOPs, issued exactly as the timed (graphed) step issues them: merged weight gradients STORE."""
+        import _native
+        from models import _ops
+        _ops.profile_gemms(True)
+        _native.record_calls(True)
+        if self.graphed is not None and self.graphed.store_weight_grads:
+            self.backbone.zero_grad_flat(store_weight_grads=True)
+        else:
+            self.optimizer.zero_grad()
+        keep = self.loss_fn(x=self.x, y=self.y, model=self.model)
+        keep.backward(retain_graph=True)       # keeps the saved activations (GEMM operands) alive for the replay
+        if self.reducer is not None:
+            self.reducer.reduce_async()
+        self.optimizer.step()
+        log = _native.record_calls(False)
+        records = _ops.profile_gemms(False)
+        torch.cuda.synchronize()
+        return keep, records, log
+
+
+def gemm_roofline(records, dtype, reps=3):
+    import _native
+    total_ms, flops = 0.0, 0.0
+    for fl, entry, cargs in records:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _native.call(entry, *cargs)                 # warm
+        e0.record()
+        for _ in range(reps):
+            _native.call(entry, *cargs)
+        e1.record()
+        e1.synchronize()
+        total_ms += e0.elapsed_time(e1) / reps
+        flops += fl
+        if os.environ.get("SEI_GEMM_TABLE"):            # per-launch table for kernel work (tools/, not the bench line)
+            with open(os.environ["SEI_GEMM_TABLE"], "a") as f:
+                ints = [a for a in cargs if isinstance(a, int) and 0 <= a < (1 << 24)]
+                us = 1e3 * e0.elapsed_time(e1) / reps
+                f.write(f"{entry} {ints} {us:.1f} us {fl / us / 1e6:.1f} TF\n")
+    achieved = flops / (total_ms * 1e-3) / 1e12
+    peak = MFMA_PEAK_TFLOPS[dtype]
+    kernels = ("gemm_bf16pq_kernel<*> (quadrant schedule, deep levels) + gemm_bf16nt_kernel<*> (128x128 loop, "
+               "everything else) + gemm_bf16_kernel<*> (K<64 layers)" if dtype == "bf16" else "gemm_f32_kernel<*>")
+    return {"bound": "mfma", "kernel": kernels, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None, "traffic_source": None,
+            "launches_per_step": len(records), "avg_launch_us": round(1e3 * total_ms / len(records), 2),
+            "gemm_ms_per_step": round(total_ms, 2), "algorithmic_gflop_per_step": round(flops / 1e9, 1),
+            "timed_with": "HIP events on the launch stream around back-to-back re-issues of every GEMM launch of one "
+                          "step (recorded arguments), right after the timed region"}
 
 
 def main():
@@ -84,10 +317,15 @@ def main():
     ap.add_argument("--hidden", type=int, default=32)
     ap.add_argument("--scales", type=int, default=5)
     ap.add_argument("--cpu-baseline", action=argparse.BooleanOptionalAction, default=True)
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--profile-gemms", action=argparse.BooleanOptionalAction, default=True)
+    ap.add_argument("--cpu-batch", type=int, default=4, help="batch of the CPU baseline (BASELINE.md section 3: 4)")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU steps after one warm-up step")
+    ap.add_argument("--profile-gemms", action=argparse.BooleanOptionalAction, default=True,
+                    help="the roofline legs (GEMM family + streaming families) after the timed region")
+    ap.add_argument("--secondary", action=argparse.BooleanOptionalAction, default=True,
+                    help="N=1: also time a short run in the reference's own arithmetic (float32 GEMMs)")
     ap.add_argument("--grad-comm", choices=["auto", "f32", "bf16"], default="auto",
                     help="dtype of the all-reduced gradient bucket (auto: bf16 in bf16 mode, f32 in f32 mode)")
+    ap.add_argument("--grad-comm-mode", choices=["all_reduce", "rs_ag"], default="all_reduce")
     ap.add_argument("--graph", action=argparse.BooleanOptionalAction, default=True,
                     help="replay forward+backward as one hipGraph (the eager launch path otherwise)")
     ap.add_argument("--task", choices=["deblurring", "sr"], default="deblurring",
@@ -107,145 +345,61 @@ def main():
         raise SystemExit(f"--gpus {opt.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     device = f"cuda:{local_rank % torch.cuda.device_count()}"     # (% only matters for shared-GPU rehearsals)
     torch.cuda.set_device(device)
-
     import torch.distributed as dist
-    from losses import get_loss
-    from models import _ops, get_model
-    from optim import FlatAdam
-    from physics import get_physics
-
-    sr = opt.task == "sr"
-    args = reference_args(device, opt.hidden, opt.scales, opt.task, opt.sr_factor if sr else None)
-    if opt.full256:
-        args.Loss__crop_training_pairs = False
-    _ops.set_compute_dtype(opt.dtype)
-    torch.manual_seed(0)
-    physics = get_physics(args, device)
-    model = get_model(args, physics, device)
-    model.to(device)
-    model.train()
-    backbone = model.get_backbone()
-    nparams = sum(p.numel() for p in backbone.parameters())
-    if world > 1:
-        parallel.broadcast_parameters(backbone.flat_params)
-    loss_fn = get_loss(args, physics)
-    comm_dtype = torch.bfloat16 if (opt.dtype == "bf16" and opt.grad_comm == "auto") or opt.grad_comm == "bf16" \
-        else torch.float32
-    reducer = parallel.FlatGradientReducer(backbone.flat_grads, comm_dtype=comm_dtype) if world > 1 else None
-    optimizer = FlatAdam(model, lr=1e-4, betas=(0.9, 0.999), reducer=reducer)
-
-    # synthetic 256x256 pairs, resident in HBM before the timed region
-    g = torch.Generator().manual_seed(1234 + rank)
-    side = CROP * opt.sr_factor if sr else 256              # SR: the dataset's _HOTFIX crop (datasets/__init__.py:84-85)
-    x = torch.rand((opt.batch, 3, side, side), generator=g).to(device)
-    torch.manual_seed(4321 + rank)
-    torch.cuda.manual_seed(4321 + rank)
-    y = physics(x)
-
-    def eager_step():
-        optimizer.zero_grad()
-        loss = loss_fn(x=x, y=y, model=model)
-        loss.backward()
-        if reducer is not None:
-            reducer.reduce_async()
-        optimizer.step()
-        return loss
-
-    step = eager_step
-    if opt.graph:
-        from graphs import GraphedLossStep
-        ys = 256 if opt.full256 else CROP
-        early = reducer is not None and os.environ.get("SEI_NO_EARLY_RELEASE") != "1"
-        graphed = GraphedLossStep(loss_fn, model, optimizer, (opt.batch, 3, ys, ys), early_release=early)
-        early_event = None
-        if early and graphed.early_grads is not None:        # the bottleneck block's gradients leave early
-            early_event = graphed.early_grads[0]
-            reducer.set_early_range(graphed.early_grads[1:])
-
-        def step():
-            loss = graphed(x, y)
-            if reducer is not None:
-                reducer.reduce_async(early=early_event)
-            optimizer.step()
-            return loss
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(opt.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(opt.steps):
-        last = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    loss_value = float(last.detach())
-
-    # Roofline leg: the dominant kernel family (all GEMM launches of one step). One eager step records each
-    # launch's entry point and arguments (the tensors stay alive in the autograd graph / local scope), then
-    # every recorded launch is re-issued back to back between HIP events on the launch stream: device time
-    # per launch with a full queue, free of host-side gaps, same shapes and data as the timed steps.
-    records = None
-    if opt.profile_gemms:
-        import _native
-        _ops.profile_gemms(True)
-        backbone = model.get_backbone() if hasattr(model, "get_backbone") else model
-        if opt.graph and graphed.store_weight_grads:
-            # the launches of the timed (graphed) step: merged weight gradients STORE instead of accumulating
-            backbone.zero_grad_flat(store_weight_grads=True)
-        else:
-            optimizer.zero_grad()
-        keep = loss_fn(x=x, y=y, model=model)
-        keep.backward(retain_graph=True)       # keeps the saved activations (GEMM operands) alive for the replay
-        records = _ops.profile_gemms(False)
-        torch.cuda.synchronize()
-        reps, total_ms, flops = 3, 0.0, 0.0
-        for fl, entry, cargs in records:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            _native.call(entry, *cargs)                 # warm
-            e0.record()
-            for _ in range(reps):
-                _native.call(entry, *cargs)
-            e1.record()
-            e1.synchronize()
-            total_ms += e0.elapsed_time(e1) / reps
-            flops += fl
-            if os.environ.get("SEI_GEMM_TABLE"):            # per-launch table for kernel work (tools/, not the bench line)
-                with open(os.environ["SEI_GEMM_TABLE"], "a") as f:
-                    ints = [a for a in cargs if isinstance(a, int) and 0 <= a < (1 << 24)]
-                    us = 1e3 * e0.elapsed_time(e1) / reps
-                    f.write(f"{entry} {ints} {us:.1f} us {fl / us / 1e6:.1f} TF\n")
-        del keep
+    sr = opt.task == "sr"
+    leg = Leg(opt, opt.dtype, device, rank, world)
+    elapsed, loss_value = leg.timed(opt.warmup, opt.steps, fence)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    ms_step = 1e3 * elapsed / opt.steps
 
-    roofline = None
-    if records:
-        achieved = flops / (total_ms * 1e-3) / 1e12
-        peak = MFMA_PEAK_TFLOPS[opt.dtype]
-        kernels = ("gemm_bf16pq_kernel<*> (quadrant schedule, deep levels) + gemm_bf16nt_kernel<*> (128x128 loop, "
-                   "everything else) + gemm_bf16_kernel<*> (K<64 layers)"
-                   if opt.dtype == "bf16" else "gemm_f32_kernel<*>")
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_g_pmc_gemm.json")
-        if opt.dtype == "bf16" and not sr and not opt.full256 and opt.hidden == 32 and opt.scales == 5 and opt.batch == 32 and os.path.exists(pmc_file):
+    # Roofline legs, after the timed region: one eager step records every launch's entry point and arguments (the
+    # tensors stay alive in the autograd graph / the allocator's pool), then each family is re-issued back to back
+    # between HIP events on the launch stream: device time with a full queue, free of host-side gaps, same shapes
+    # and data as the timed steps.
+    roofline, roofline_hbm = None, None
+    if opt.profile_gemms:
+        keep, records, log = leg.record_one_step()
+        roofline = gemm_roofline(records, opt.dtype)
+        roofline_hbm = stream_roofline(log)
+        del keep
+        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_gemm.json")
+        default_cfg = (opt.dtype == "bf16" and not sr and not opt.full256 and opt.hidden == 32 and opt.scales == 5
+                       and opt.batch == 32)
+        if default_cfg and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))                 # PMC counters cannot be read live; see the file
-            traffic = round(pmc["traffic_bytes_per_launch"])
-            traffic_src = ("bytes beyond L2 per GEMM launch from committed rocprofv3 --pmc passes of this command "
-                           "(profiles/r01_g_pmc_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections)")
-        roofline = {"bound": "mfma", "kernel": kernels, "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_source": traffic_src,
-                    "launches_per_step": len(records), "avg_launch_us": round(1e3 * total_ms / len(records), 2),
-                    "gemm_ms_per_step": round(total_ms, 2),
-                    "algorithmic_gflop_per_step": round(flops / 1e9, 1),
-                    "timed_with": "HIP events on the launch stream around back-to-back re-issues of every GEMM "
-                                  "launch of one step (recorded arguments), right after the timed region"}
+            roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
+            roofline["traffic_source"] = ("bytes beyond L2 per GEMM launch from committed rocprofv3 --pmc passes of "
+                                          "this command (profiles/r02_pmc_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, "
+                                          "gfx950 corrections)")
+        accounted = roofline["gemm_ms_per_step"] + sum(f["ms_per_step"] for f in roofline_hbm)
+        roofline_hbm.append({"kernel": "not attributed (torch fills / adds / copies / RNG, zero fills inside GEMM "
+                                       "entry points are counted with the GEMMs, launch gaps)",
+                             "ms_per_step": round(ms_step - accounted, 3)})
+
+    secondary = None
+    if opt.secondary and world == 1 and opt.dtype == "bf16" and not opt.full256:
+        del leg                                             # frees the bf16 job's buckets before the f32 one
+        torch.cuda.empty_cache()
+        leg32 = Leg(opt, "f32", device, rank, world)
+        el32, loss32 = leg32.timed(2, 5, fence)
+        secondary = {"f32": {"value": round(opt.batch * 5 / el32, 2), "unit": "images/s", "steps": 5, "warmup": 2,
+                             "ms_per_step": round(1e3 * el32 / 5, 2), "dtype": "f32",
+                             "note": "same workload and launch path with exact-f32 MFMA GEMMs: the reference's own "
+                                     "arithmetic, the mode every parity claim is made in", "final_loss": loss32}}
+        nparams, side, comm_dtype, graphed_early = leg32.nparams, leg32.side, leg32.comm_dtype, False
+        del leg32
+    else:
+        nparams, side, comm_dtype = leg.nparams, leg.side, leg.comm_dtype
+        graphed_early = leg.early_event is not None
 
     if rank == 0:
         images = opt.batch * world * opt.steps
@@ -253,7 +407,7 @@ def main():
             "metric": ("training images/sec, proposed-loss super-resolution" if sr else
                        "training images/sec (256x256 crops), proposed-loss deblur"),
             "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": opt.steps,
-            "warmup": opt.warmup, "ms_per_step": round(1e3 * elapsed / opt.steps, 2), "higher_is_better": True,
+            "warmup": opt.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": opt.dtype, "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[2]: super-resolution x{opt.sr_factor} noise=5, proposed loss "
                                     f"(SURE + scale-EI), pairs {side}x{side} / 48x48, ConvolutionalModel "
@@ -264,13 +418,18 @@ def main():
                                     f", ConvolutionalModel hidden={opt.hidden} scales={opt.scales}"),
                        "parameters": nparams, "batch_per_gpu": opt.batch, "global_batch": opt.batch * world,
                        "parallelism": f"dp{world}", "optimizer": "Adam (fused, flat bucket)",
-                       "grad_allreduce": None if world == 1 else str(comm_dtype).replace("torch.", ""),
-                       "launch": ("hipGraph replay of forward+backward" + (", early gradient release" if opt.graph and world > 1 and early_event is not None else "")) if opt.graph else "eager",
+                       "grad_allreduce": None if world == 1 else
+                       f"{str(comm_dtype).replace('torch.', '')}, {opt.grad_comm_mode}",
+                       "launch": ("hipGraph replay of forward+backward (random draws made eagerly into static buffers)"
+                                  + (", early gradient release" if graphed_early else "")) if opt.graph else "eager",
                        "final_loss": loss_value},
             "roofline": roofline,
+            "roofline_hbm": roofline_hbm,
         }
+        if secondary is not None:
+            out["secondary"] = secondary
         if opt.cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(opt.cpu_batch, opt.hidden, opt.scales)
+            out["cpu_baseline"] = cpu_baseline(opt.cpu_batch, opt.hidden, opt.scales, opt.cpu_steps)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -32,7 +32,7 @@ extern "C" {
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
-#define SEI_ABI_VERSION 2
+#define SEI_ABI_VERSION 3
 int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
@@ -163,6 +163,14 @@ int sei_dwconv7_fwd(const float *x, const float *w, const float *bias, const flo
 size_t sei_dwconv7_bwd_weight_workspace(int B, int H, int W, int C);
 int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
                            int W, int C, float *work, size_t work_floats, void *stream);
+/* The same three with the caller's explicit kernel choice: seg = 0 chooses by shape (LDS-tiled, whole-image or
+ * generic; what the plain entry points pass), seg = 1..64 takes the generic sliding-window kernels with that many
+ * output columns per worker segment (tests compare the paths bit for bit). Per call, no library state. */
+int sei_dwconv7_fwd_ex(const float *x, const float *w, const float *bias, const float *res,
+                       float res_scale, float *y, int B, int H, int W, int C, int flip, int seg, void *stream);
+size_t sei_dwconv7_bwd_weight_workspace_ex(int B, int H, int W, int C, int seg);
+int sei_dwconv7_bwd_weight_ex(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
+                              int W, int C, float *work, size_t work_floats, int seg, void *stream);
 
 int sei_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
                float *rstd, size_t rows, int C, float eps, void *stream);
@@ -244,20 +252,28 @@ int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
 int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1, const uint16_t *B2,
                         int ldb, float *D32, int M, int N, int K1, int K2, int accumulate, void *stream);
 
-/* Development probe (tools/probe_tr_read.py): what ds_read_b64_tr_b16 delivers for a 64x128 LDS image. */
+/* The two entry points above with the caller's explicit schedule choice (tests of every tile variant, tools/):
+ * tile = 0 lets the dispatcher decide (what the plain entry points pass); 1, 2, 3, 5 = 128x128, 128x256, 192x256,
+ * 96x256 tiles of the 128x128-style loop; 15 / 16 = its single-stage / 128x256 reduction-major variants;
+ * 30-33 = the quadrant schedule of gemm_bf16pq.h with 256x256, 288x256, 288x128, 256x128 tiles. band > 0 fixes
+ * the band width of the XCD-aware tile order (0 = automatic). A choice the operands do not allow falls back to
+ * the automatic one. Per call: the library keeps no mutable state. */
+int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                       float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
+                       const float *R1, const float *R2, uint16_t *D2_16, int tile, int band, void *stream);
+int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
+                           const uint16_t *B2, int ldb, float *D32, int M, int N, int K1, int K2, int accumulate,
+                           int tile, void *stream);
+
+#ifdef SEI_TUNING
+/* Tools-only build (make tuning -> libsei_hip_tuning.so; not part of libsei_hip.so).
+ * sei_debug_tr_probe: what ds_read_b64_tr_b16 delivers for a 64x128 LDS image (tools/probe_tr_read.py).
+ * sei_debug_set_nt_tile: process-wide default for the tile / band arguments above (100 + b = band b), so the
+ * experiment scripts can steer GEMMs launched by the model code; adds tile codes 4, 11-14 (LDS-ring variants),
+ * 20 (the 256x256 ping-pong schedule of gemm_bf16pp.h) and 34-37 (timing-only ablations, wrong results). */
 int sei_debug_tr_probe(const uint16_t *in, uint16_t *out, int r0, int c0, void *stream);
-
-/* Tuning aid: force the tile / schedule of sei_gemm_bf16nt (0 = automatic; 1, 2, 3, 5 = 128x128, 128x256,
- * 192x256, 96x256; 11-16 = LDS-ring / single-stage variants; 20 = the 256x256 ping-pong schedule of
- * gemm_bf16pp.h; 30-33 = the quadrant schedule of gemm_bf16pq.h with 256x256, 288x256, 288x128, 256x128 tiles
- * (34-37: timing-only ablations of that kernel: no DMA / MFMAs only, K-contiguous and reduction-major); 100 + b = band width b of the tile order, 100 = automatic).
- * Process-global; not for production use. */
 int sei_debug_set_nt_tile(int code);
-
-/* Tuning aid / test hook for the depthwise kernels (process-global): 1..64 = output columns per worker
- * segment of the generic kernel (default 16); 0 = route every shape through the generic kernels; -1 = back
- * to the automatic choice (LDS-tiled, whole-image or generic by shape). */
-int sei_debug_set_dw_seg(int seg);
+#endif
 
 int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
                 const float *L1, const float *R1, const float *L2, const float *R2, float *work,

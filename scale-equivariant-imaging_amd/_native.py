@@ -40,6 +40,8 @@ SIGNATURES = {
     "sei_conv3x3_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "sei_dwconv7_fwd": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
     "sei_dwconv7_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P],
+    "sei_dwconv7_fwd_ex": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sei_dwconv7_bwd_weight_ex": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _I, _P],
     "sei_ln_fwd": [_P, _P, _P, _P, _P, _P, _Z, _I, _F, _P],
     "sei_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P, _Z, _P],
     "sei_gemm_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -52,10 +54,9 @@ SIGNATURES = {
     "sei_colsum_bf16": [_P, _P, _Z, _I, _P],
     "sei_cast_transpose_bf16": [_P, _I, _P, _P, _I, _I, _I, _P, _P],
     "sei_gemm_bf16nt": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
-    "sei_debug_tr_probe": [_P, _P, _I, _I, _P],
     "sei_gemm_bf16nt_dw2": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    "sei_debug_set_nt_tile": [_I],
-    "sei_debug_set_dw_seg": [_I],
+    "sei_gemm_bf16nt_ex": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],
+    "sei_gemm_bf16nt_dw2_ex": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_sepmap2": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P],
     "sei_sepmap2_packed": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P],
     "sei_colsum_f32": [_P, _P, _Z, _I, _P],
@@ -69,9 +70,10 @@ _lib = None
 # size queries: return size_t, take no stream
 SIZE_QUERIES = {
     "sei_dwconv7_bwd_weight_workspace": [_I, _I, _I, _I],
+    "sei_dwconv7_bwd_weight_workspace_ex": [_I, _I, _I, _I, _I],
     "sei_ln_bwd_workspace": [_Z, _I],
 }
-ABI_VERSION = 2       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
+ABI_VERSION = 3       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 
 
 class NativeLibraryError(RuntimeError):
@@ -125,8 +127,22 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_CALL_LOG = None
+
+
+def record_calls(enable):
+    """Measurement aid (bench.py): while enabled, every entry-point call is logged as (name, args) so that the
+    launches of one step can be re-issued back to back between HIP events, family by family. Returns the log
+    collected so far."""
+    global _CALL_LOG
+    log, _CALL_LOG = _CALL_LOG, ([] if enable else None)
+    return log
+
+
 def call(name, *args):
     """Invoke an entry point with the current stream appended; raise on a non-zero status."""
+    if _CALL_LOG is not None:
+        _CALL_LOG.append((name, args))
     rc = getattr(lib(), name)(*args, stream())
     if rc != 0:
         if rc == 10001:

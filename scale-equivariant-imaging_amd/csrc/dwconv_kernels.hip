@@ -19,8 +19,7 @@
 namespace {
 
 constexpr int DW_THREADS = 256;
-int g_dw_seg = 16;                   // generic kernel: output columns per worker segment (sei_debug_set_dw_seg)
-int g_dw_force_generic = 0;          // tuning aid / test hook: 1 = always take the generic kernels
+constexpr int DW_SEG = 16;           // generic kernel: output columns per worker segment unless the caller says
 
 inline unsigned capped_grid(size_t work_items, int per_block, unsigned cap) {
     size_t g = sei_ceil_div(work_items, (size_t)per_block);
@@ -407,8 +406,10 @@ __global__ __launch_bounds__(FIN_E * FIN_S) void dwconv7_wgrad_finish_kernel(con
 }
 
 enum DwPath { DW_GENERIC, DW_TILED, DW_WHOLE3, DW_WHOLE6 };
-inline DwPath dw_path(int H, int W, int C) {
-    if (g_dw_force_generic) return DW_GENERIC;
+// seg: the `seg` argument of the _ex entry points: 0 = choose by shape, 1..64 = the generic kernels with that many
+// output columns per worker segment (tests compare the paths; tools/exp_dwseg.py times them)
+inline DwPath dw_path(int H, int W, int C, int seg) {
+    if (seg > 0) return DW_GENERIC;
     if (H == 3 && W == 3) return DW_WHOLE3;
     if (H == 6 && W == 6) return DW_WHOLE6;
     if (H >= 8 && W >= 8 && C % 4 == 0) return DW_TILED;
@@ -423,14 +424,15 @@ inline int generic_cc(int C) {
 struct DwWgradPlan {
     DwPath path;
     DwTiling tiling;
-    int tiles_per_block, imgs_per_thread, Cc, nseg;
+    int tiles_per_block, imgs_per_thread, Cc, nseg, seg;
     size_t total;
     unsigned gx, gy;
     size_t nparts;
 };
-inline DwWgradPlan dw_wgrad_plan(int B, int H, int W, int C) {
+inline DwWgradPlan dw_wgrad_plan(int B, int H, int W, int C, int seg) {
     DwWgradPlan p{};
-    p.path = dw_path(H, W, C);
+    p.path = dw_path(H, W, C, seg);
+    p.seg = seg > 0 ? seg : DW_SEG;
     if (p.path == DW_TILED) {
         p.tiling = dw_tiling(B, H, W);
         p.gy = (unsigned)sei_ceil_div(C, DT_CC);
@@ -450,7 +452,7 @@ inline DwWgradPlan dw_wgrad_plan(int B, int H, int W, int C) {
     } else {
         p.Cc = generic_cc(C);
         const int workers = DW_THREADS / p.Cc;
-        p.nseg = (int)sei_ceil_div(W, g_dw_seg);
+        p.nseg = (int)sei_ceil_div(W, p.seg);
         p.total = (size_t)B * H * p.nseg;
         p.gy = (unsigned)sei_ceil_div(C, p.Cc);
         p.gx = capped_grid(p.total, workers * 2, 65535);
@@ -464,27 +466,15 @@ inline DwWgradPlan dw_wgrad_plan(int B, int H, int W, int C) {
 }  // namespace
 
 // -------------------------------------------------------------------------------------------------
-extern "C" int sei_debug_set_dw_seg(int seg) {
-    if (seg == 0) {                       // 0 / -1: route everything through / back from the generic kernels
-        g_dw_force_generic = 1;
-        return SEI_OK;
-    }
-    if (seg == -1) {
-        g_dw_force_generic = 0;
-        return SEI_OK;
-    }
-    if (seg < 1 || seg > 64) return SEI_ERR_BAD_ARG;
-    g_dw_seg = seg;
-    return SEI_OK;
-}
-
-extern "C" int sei_dwconv7_fwd(const float *x, const float *w, const float *bias, const float *res,
-                               float res_scale, float *y, int B, int H, int W, int C, int flip, void *stream) {
-    SEI_REQUIRE(x && w && y && x != y && B > 0 && H > 0 && W > 0 && C > 0);
+extern "C" int sei_dwconv7_fwd_ex(const float *x, const float *w, const float *bias, const float *res,
+                                  float res_scale, float *y, int B, int H, int W, int C, int flip, int seg,
+                                  void *stream) {
+    SEI_REQUIRE(x && w && y && x != y && B > 0 && H > 0 && W > 0 && C > 0 && seg >= 0 && seg <= 64);
+    const int gseg = seg > 0 ? seg : DW_SEG;
     hipStream_t s = (hipStream_t)stream;
     const float *nof = nullptr;
     float *nom = nullptr;
-    switch (dw_path(H, W, C)) {
+    switch (dw_path(H, W, C, seg)) {
         case DW_TILED: {
             const DwTiling t = dw_tiling(B, H, W);
             SEI_REQUIRE(t.ntiles < (size_t)1 << 31);
@@ -511,26 +501,35 @@ extern "C" int sei_dwconv7_fwd(const float *x, const float *w, const float *bias
         default: {
             const int Cc = generic_cc(C);
             const int workers = DW_THREADS / Cc;
-            const int nseg = (int)sei_ceil_div(W, g_dw_seg);
+            const int nseg = (int)sei_ceil_div(W, gseg);
             const size_t total = (size_t)B * H * nseg;
             SEI_REQUIRE(total < (size_t)1 << 31);
             dim3 grid(capped_grid(total, workers, 65535), (unsigned)sei_ceil_div(C, Cc));
             hipLaunchKernelGGL(dwconv7_kernel<false>, grid, dim3(DW_THREADS), 0, s, x, w, bias, res, res_scale, y, nof,
-                               nom, B, H, W, C, flip ? 1 : 0, Cc, nseg, (int)total, g_dw_seg);
+                               nom, B, H, W, C, flip ? 1 : 0, Cc, nseg, (int)total, gseg);
         }
     }
     return sei_launch_status();
 }
 
-extern "C" size_t sei_dwconv7_bwd_weight_workspace(int B, int H, int W, int C) {
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-    return dw_wgrad_plan(B, H, W, C).nparts * 50 * (size_t)C;
+extern "C" int sei_dwconv7_fwd(const float *x, const float *w, const float *bias, const float *res,
+                               float res_scale, float *y, int B, int H, int W, int C, int flip, void *stream) {
+    return sei_dwconv7_fwd_ex(x, w, bias, res, res_scale, y, B, H, W, C, flip, 0, stream);
 }
 
-extern "C" int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
-                                      int W, int C, float *work, size_t work_floats, void *stream) {
-    SEI_REQUIRE(x && gy && gw && work && B > 0 && H > 0 && W > 0 && C > 0);
-    const DwWgradPlan p = dw_wgrad_plan(B, H, W, C);
+extern "C" size_t sei_dwconv7_bwd_weight_workspace_ex(int B, int H, int W, int C, int seg) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || seg < 0 || seg > 64) return 0;
+    return dw_wgrad_plan(B, H, W, C, seg).nparts * 50 * (size_t)C;
+}
+
+extern "C" size_t sei_dwconv7_bwd_weight_workspace(int B, int H, int W, int C) {
+    return sei_dwconv7_bwd_weight_workspace_ex(B, H, W, C, 0);
+}
+
+extern "C" int sei_dwconv7_bwd_weight_ex(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
+                                         int W, int C, float *work, size_t work_floats, int seg, void *stream) {
+    SEI_REQUIRE(x && gy && gw && work && B > 0 && H > 0 && W > 0 && C > 0 && seg >= 0 && seg <= 64);
+    const DwWgradPlan p = dw_wgrad_plan(B, H, W, C, seg);
     SEI_REQUIRE(work_floats >= p.nparts * 50 * (size_t)C);
     hipStream_t s = (hipStream_t)stream;
     const float *nof = nullptr;
@@ -551,11 +550,16 @@ extern "C" int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw
         SEI_REQUIRE(p.total < (size_t)1 << 31);
         const size_t lds = sizeof(float) * (size_t)(DW_THREADS / p.Cc) * 50 * p.Cc;
         hipLaunchKernelGGL(dwconv7_kernel<true>, dim3(p.gx, p.gy), dim3(DW_THREADS), lds, s, x, nof, nof, nof, 0.f, nom,
-                           gy, work, B, H, W, C, 0, p.Cc, p.nseg, (int)p.total, g_dw_seg);
+                           gy, work, B, H, W, C, 0, p.Cc, p.nseg, (int)p.total, p.seg);
     }
     // stage 2: fold the partials into the running gradient
     hipLaunchKernelGGL(dwconv7_wgrad_finish_kernel, dim3((unsigned)sei_ceil_div((size_t)50 * C, FIN_E)),
                        dim3(FIN_E * FIN_S), 0, s,
                        (const float *)work, (int)p.nparts, C, gw, gbias);
     return sei_launch_status();
+}
+
+extern "C" int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
+                                      int W, int C, float *work, size_t work_floats, void *stream) {
+    return sei_dwconv7_bwd_weight_ex(x, gy, gw, gbias, B, H, W, C, work, work_floats, 0, stream);
 }

@@ -56,6 +56,9 @@ struct NtArgs {
     // second reduction segment of reduction-major operands: rows k >= k_seg come from A2 / B2 (row k - k_seg)
     const unsigned short *A2, *B2;
     int k_seg;
+    // host-side only (the kernels never read them): the caller's explicit tile / band choice of the _ex entry
+    // points; 0 = the dispatcher decides. Per call, so the library holds no mutable state.
+    int force_tile, force_band;
 };
 
 __device__ __forceinline__ unsigned short f2bf(float v) {
@@ -441,9 +444,9 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, s
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.f;
 }
 
-int g_force_band = 0;     // tuning aid (sei_debug_set_nt_tile codes 100 + band); 0 = automatic
-
-#include "gemm_bf16pp.h"  // 256 x 256 ping-pong schedule on the same LDS images
+#ifdef SEI_TUNING
+#include "gemm_bf16pp.h"  // 256 x 256 ping-pong schedule on the same LDS images (tools-only build)
+#endif
 #include "gemm_bf16pq.h"
 
 template <int TM, int TN, int WM, int WN, bool ARM = false, bool BRM = false, int NSTAGE = 2>
@@ -456,7 +459,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
     {
         constexpr size_t STAGE_BYTES = NSTAGE * (size_t)(BM + BN) * ROW_BYTES;
         const double conc = 32.0 * (STAGE_BYTES <= 40 * 1024 ? 3 : (STAGE_BYTES <= 80 * 1024 ? 2 : 1));   // tiles in flight per XCD
-        int band = g_force_band > 0 ? g_force_band : (int)(sqrt(conc * BM / BN) + 0.5);   // square patch in elements
+        int band = g.force_band > 0 ? g.force_band : (int)(sqrt(conc * BM / BN) + 0.5);   // square patch in elements
         if (band < 1) band = 1;
         if (band > g.tiles_n) band = g.tiles_n;
         g.band = band;
@@ -504,18 +507,24 @@ int launch_nt(NtArgs &g, hipStream_t s) {
     return sei_launch_status();
 }
 
-int g_force_tile = 0;     // tuning aid only (sei_debug_set_nt_tile); 0 = automatic choice
+#ifdef SEI_TUNING
+// Tools-only build (make tuning -> libsei_hip_tuning.so): a process-wide default for the tile / band arguments,
+// so that the experiment scripts under tools/ can steer launches issued by the model code. Not in libsei_hip.so.
+int g_tuning_tile = 0, g_tuning_band = 0;
+#endif
 
 }  // namespace
 
+#ifdef SEI_TUNING
 extern "C" int sei_debug_set_nt_tile(int code) {
     if (code >= 100) {                 // 100 + band: force the band width of the tile order (100 = automatic)
-        g_force_band = code - 100;
+        g_tuning_band = code - 100;
         return SEI_OK;
     }
-    g_force_tile = code;
+    g_tuning_tile = code;
     return SEI_OK;
 }
+#endif
 
 // Quadrant schedule (gemm_bf16pq.h) or not, and which tile: returns 0, or 10 * RF + NF.
 //   * launches that do not split K (bf16 / GELU / GELU' outputs: the expanding 1x1 convolutions and their data
@@ -529,7 +538,7 @@ int pq_choose(const NtArgs &g, bool would_split) {
     const int rf = M % 288 == 0 ? 9 : ((M % 256 == 0 || M >= 4096) ? 8 : 0);
     // K >= 128: even two k-tiles per tile pay, because the epilogue moves whole rows (36864 x 512 x 128 with
     // GELU 36 -> 28 us, its data gradient 49 -> 32 us); the 128 x 128 loop stores element by element
-    if (g_force_tile != 0 || !rf || K < 32 || N < 128 || !pq_eligible(g)) return 0;
+    if (g.force_tile != 0 || !rf || K < 32 || N < 128 || !pq_eligible(g)) return 0;
     const size_t tm = sei_ceil_div(M, 32 * rf);
     const size_t t4 = N >= 256 ? tm * sei_ceil_div(N, 256) : 0, t2 = tm * sei_ceil_div(N, 128);
     auto fills = [](size_t t) { return (double)t / (double)(sei_ceil_div(t, 256) * 256) >= 0.8; };
@@ -552,9 +561,10 @@ int pq_choose(const NtArgs &g, bool would_split) {
 // transposing LDS reads). The kernel supports the layout (tile codes 30 / 33; tests) for later work on it.
 int pq_choose_rr(const NtArgs &) { return 0; }
 
-extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
-                               float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
-                               const float *R1, const float *R2, uint16_t *D2_16, void *stream) {
+extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                                  float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
+                                  const float *R1, const float *R2, uint16_t *D2_16, int tile, int band,
+                                  void *stream) {
     SEI_REQUIRE(A && B && (D32 || D16) && M > 0 && N > 0 && K > 0);
     SEI_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0);
     SEI_REQUIRE(lda >= (a_rmajor ? M : K) && ldb >= (b_rmajor ? N : K));
@@ -575,16 +585,23 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     g.A = A; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
     g.A2 = A; g.B2 = B; g.k_seg = K;                       // one reduction segment
+    SEI_REQUIRE(tile >= 0 && band >= 0);
+#ifdef SEI_TUNING
+    if (tile == 0) tile = g_tuning_tile;
+    if (band == 0) band = g_tuning_band;
+#endif
+    g.force_tile = tile;
+    g.force_band = band;
     hipStream_t s = (hipStream_t)stream;
     const bool would_split = (epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_RES ||
                               epilogue == SEI_EPI_ACCUM) && D32 && !D16;
-    if (g_force_tile >= 30 && g_force_tile < 40 && a_rmajor && b_rmajor && pq_eligible(g, true)) {
-        if (g_force_tile == 30) return launch_pq<8, 4, true, true>(g, s);
-        if (g_force_tile == 33) return launch_pq<8, 2, true, true>(g, s);
+    if (tile >= 30 && tile < 40 && a_rmajor && b_rmajor && pq_eligible(g, true)) {
+        if (tile == 30) return launch_pq<8, 4, true, true>(g, s);
+        if (tile == 33) return launch_pq<8, 2, true, true>(g, s);
     }
-    if (g_force_tile >= 30 && g_force_tile < 40 && !a_rmajor && pq_eligible(g)) {   // quadrant schedule
+    if (tile >= 30 && tile < 40 && !a_rmajor && pq_eligible(g)) {   // quadrant schedule
         if (b_rmajor) {
-            switch (g_force_tile) {
+            switch (tile) {
                 case 30: return launch_pq<8, 4, false, true>(g, s);
                 case 31: return launch_pq<9, 4, false, true>(g, s);
                 case 32: return launch_pq<9, 2, false, true>(g, s);
@@ -592,35 +609,39 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
                 default: break;
             }
         } else {
-            switch (g_force_tile) {
+            switch (tile) {
                 case 30: return launch_pq<8, 4>(g, s);
                 case 31: return launch_pq<9, 4>(g, s);
                 case 32: return launch_pq<9, 2>(g, s);
                 case 33: return launch_pq<8, 2>(g, s);
+#ifdef SEI_TUNING
                 case 34: return launch_pq<8, 4, false, false, 2>(g, s);      // ablations: timing only, wrong results
                 case 35: return launch_pq<8, 4, false, false, 7>(g, s);
+#endif
                 default: break;
             }
         }
     }
-    if (g_force_tile == 20) {                            // 256 x 256 ping-pong schedule (tuning aid)
+#ifdef SEI_TUNING
+    if (tile == 20) {                            // 256 x 256 ping-pong schedule (tuning aid)
         if (a_rmajor && b_rmajor) return launch_pp<true, true>(g, s);
         if (a_rmajor) return launch_pp<true, false>(g, s);
         if (b_rmajor) return launch_pp<false, true>(g, s);
         return launch_pp<false, false>(g, s);
     }
     if (!a_rmajor && !b_rmajor) {
-        switch (g_force_tile) {                          // ring-pipelined candidates (tuning aid)
+        switch (tile) {                          // ring-pipelined candidates (tuning aid)
             case 11: return launch_nt<2, 1, 2, 4, false, false, 4>(g, s);      // 128 x 128, 4 stages
             case 12: return launch_nt<4, 1, 2, 4, false, false, 3>(g, s);      // 256 x 128, 3 stages
             case 13: return launch_nt<2, 2, 2, 4, false, false, 3>(g, s);      // 128 x 256, 3 stages
             case 14: return launch_nt<2, 1, 2, 4, false, false, 3>(g, s);      // 128 x 128, 3 stages
-            case 15: return launch_nt<2, 1, 2, 4, false, false, 1>(g, s);      // 128 x 128, 1 stage, 3 blocks/CU
             default: break;
         }
     }
-    if (g_force_tile == 16 && a_rmajor && b_rmajor) return launch_nt<2, 2, 2, 4, true, true>(g, s);   // 128 x 256
-    if (g_force_tile == 15) {
+#endif
+    if (tile == 15 && !a_rmajor && !b_rmajor) return launch_nt<2, 1, 2, 4, false, false, 1>(g, s);   // 1 stage
+    if (tile == 16 && a_rmajor && b_rmajor) return launch_nt<2, 2, 2, 4, true, true>(g, s);   // 128 x 256
+    if (tile == 15) {
         if (a_rmajor && b_rmajor) return launch_nt<2, 1, 2, 4, true, true, 1>(g, s);
         if (b_rmajor) return launch_nt<2, 1, 2, 4, false, true, 1>(g, s);
     }
@@ -633,7 +654,7 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
         }
         // short reductions (the bottleneck weight gradient: K = 864 over 16,384 tiles) are prologue + epilogue
         // bound: one LDS stage and three workgroups per CU (1030 -> 800 us); long ones want the double buffer
-        if (K <= 1024 && g_force_tile != 1) return launch_nt<2, 1, 2, 4, true, true, 1>(g, s);
+        if (K <= 1024 && tile != 1) return launch_nt<2, 1, 2, 4, true, true, 1>(g, s);
         return launch_nt<2, 1, 2, 4, true, true>(g, s);
     }
     if (a_rmajor) return launch_nt<2, 1, 2, 4, true, false>(g, s);
@@ -646,16 +667,18 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
             default: break;
         }
         // skinny data gradients (the bottleneck levels): 192 x 256 with two 128-column images of the weight
-        if (g_force_tile != 1 && N >= 2048 && K >= 2048 && M <= 768)
+        if (tile != 1 && N >= 2048 && K >= 2048 && M <= 768)
             return launch_nt<3, 2, 2, 4, false, true>(g, s);
         return launch_nt<2, 1, 2, 4, false, true>(g, s);
     }
-    switch (g_force_tile) {
+    switch (tile) {
         case 1: return launch_nt<2, 1, 2, 4>(g, s);      // 128 x 128
         case 2: return launch_nt<2, 2, 2, 4>(g, s);      // 128 x 256
         case 3: return launch_nt<3, 2, 2, 4>(g, s);      // 192 x 256
         case 5: return launch_nt<3, 1, 1, 8>(g, s);      //  96 x 256
+#ifdef SEI_TUNING
         case 4: return launch_nt<4, 2, 2, 4>(g, s);      // 256 x 256 (tuning aid)
+#endif
         default: break;
     }
     // Tile choice (measured on MI355X with the band-major tile order, tools/exp_tiles576.py): 128x128 runs two
@@ -674,13 +697,20 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
     if (N >= 2048 && K >= 2048 && M <= 768) return launch_nt<3, 2, 2, 4>(g, s);               // 192 x 256
     // short reductions are all prologue and epilogue: one LDS stage (32 KB) and <= 84 VGPRs put three workgroups
     // on a CU instead of two (36864 x 512 x 128: 34 -> 27 us; 9216 x 2048 x 512: 50 -> 44 us; loses from K ~ 2048)
-    if (K <= 1024 && g_force_tile != 1) return launch_nt<2, 1, 2, 4, false, false, 1>(g, s);
+    if (K <= 1024 && tile != 1) return launch_nt<2, 1, 2, 4, false, false, 1>(g, s);
     return launch_nt<2, 1, 2, 4>(g, s);                                                  // 128 x 128
 }
 
-extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
-                                   const uint16_t *B2, int ldb, float *D32, int M, int N, int K1, int K2,
-                                   int accumulate, void *stream) {
+extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                               float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
+                               const float *R1, const float *R2, uint16_t *D2_16, void *stream) {
+    return sei_gemm_bf16nt_ex(A, lda, a_rmajor, B, ldb, b_rmajor, D32, D16, M, N, K, epilogue, bias, R1, R2, D2_16, 0,
+                              0, stream);
+}
+
+extern "C" int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
+                                      const uint16_t *B2, int ldb, float *D32, int M, int N, int K1, int K2,
+                                      int accumulate, int tile, void *stream) {
     SEI_REQUIRE(A1 && A2 && B1 && B2 && D32 && M > 0 && N > 0 && K1 > 0 && K2 > 0);
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
@@ -690,10 +720,19 @@ extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int l
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
     g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
-    if (g_force_tile == 36) return launch_pq<8, 4, true, true, 2>(g, (hipStream_t)stream);   // ablations: timing only
-    if (g_force_tile == 37) return launch_pq<8, 4, true, true, 7>(g, (hipStream_t)stream);
-    if (g_force_tile == 30 && pq_eligible(g, true)) return launch_pq<8, 4, true, true>(g, (hipStream_t)stream);   // tuning aid
-    if (g_force_tile == 33 && pq_eligible(g, true)) return launch_pq<8, 2, true, true>(g, (hipStream_t)stream);
+    SEI_REQUIRE(tile >= 0);
+    g.force_band = 0;
+#ifdef SEI_TUNING
+    if (tile == 0) tile = g_tuning_tile;
+    g.force_band = g_tuning_band;
+#endif
+    g.force_tile = tile;
+#ifdef SEI_TUNING
+    if (tile == 36) return launch_pq<8, 4, true, true, 2>(g, (hipStream_t)stream);   // ablations: timing only
+    if (tile == 37) return launch_pq<8, 4, true, true, 7>(g, (hipStream_t)stream);
+#endif
+    if (tile == 30 && pq_eligible(g, true)) return launch_pq<8, 4, true, true>(g, (hipStream_t)stream);   // tuning aid
+    if (tile == 33 && pq_eligible(g, true)) return launch_pq<8, 2, true, true>(g, (hipStream_t)stream);
     switch (pq_choose_rr(g)) {
         case 84: return launch_pq<8, 4, true, true>(g, (hipStream_t)stream);
         case 82: return launch_pq<8, 2, true, true>(g, (hipStream_t)stream);
@@ -701,4 +740,10 @@ extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int l
     }
     if (K1 + K2 <= 1024) return launch_nt<2, 1, 2, 4, true, true, 1>(g, (hipStream_t)stream);   // as sei_gemm_bf16nt
     return launch_nt<2, 1, 2, 4, true, true>(g, (hipStream_t)stream);
+}
+
+extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
+                                   const uint16_t *B2, int ldb, float *D32, int M, int N, int K1, int K2,
+                                   int accumulate, void *stream) {
+    return sei_gemm_bf16nt_dw2_ex(A1, A2, lda, B1, B2, ldb, D32, M, N, K1, K2, accumulate, 0, stream);
 }

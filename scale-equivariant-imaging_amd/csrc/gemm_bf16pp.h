@@ -328,7 +328,7 @@ int launch_pp(NtArgs &g, hipStream_t s) {
     g.tiles_n = (int)sei_ceil_div(g.N, PP_BN);
     const size_t tiles = (size_t)g.tiles_m * g.tiles_n;
     SEI_REQUIRE(tiles < ((size_t)1 << 27));
-    int band = g_force_band > 0 ? g_force_band : 6;       // ~sqrt(32 tiles in flight per XCD)
+    int band = g.force_band > 0 ? g.force_band : 6;       // ~sqrt(32 tiles in flight per XCD)
     if (band > g.tiles_n) band = g.tiles_n;
     g.band = band;
     g.tiles_per_xcd = (int)sei_ceil_div(tiles, 8);

@@ -23,10 +23,11 @@ class SyntheticPairs(BaseDataset):
     """File-less pairs: x = seeded uniform noise in [0,1], y = the physics manager's seeded measurement of it,
     deterministic per index exactly like SyntheticDataset.__getitem__ (synthetic_dataset.py:26-55)."""
 
-    def __init__(self, physics, device, length=800, size=256, seed=1234, hotfix_sr_crop=False):
+    def __init__(self, physics, device, length=800, size=256, seed=1234, hotfix_sr_crop=False, css=False):
         self.physics, self.device, self.length, self.size = physics, device, length, size
         self.seed = seed
         self.hotfix = hotfix_sr_crop
+        self.css = css
 
     def __len__(self):
         return self.length
@@ -36,6 +37,8 @@ class SyntheticPairs(BaseDataset):
         x = torch.rand((3, self.size, self.size), generator=g).to(self.device)
         manager = getattr(self.physics, "__manager")
         y = manager.randomly_degrade(x[None], seed=index)[0]
+        if self.css:                                        # as TrainingDataset below (reference :70-76)
+            x, y = y, manager.randomly_degrade(y[None].contiguous(), seed=None)[0]
         if self.hotfix:
             return CropPair(location="random", size=48)(x, y, xy_size_ratio=self.physics.rate)
         return x, y
@@ -131,7 +134,7 @@ def get_dataset(args, purpose, physics, device, _HOTFIX=False):
     else:
         raise ValueError(f"Unknown purpose: {purpose}")
     if args.dataset == "synthetic":                         # this build's file-less stand-in
-        return SyntheticPairs(physics, device, hotfix_sr_crop=_HOTFIX and purpose == "train")
+        return SyntheticPairs(physics, device, hotfix_sr_crop=_HOTFIX and purpose == "train", css=css)
     blueprint = {
         GroundTruthDataset.__name__: {
             "dataset_name": args.dataset,

@@ -17,7 +17,10 @@ class DeviceResidentPairs:
     def __init__(self, synthetic_dataset, physics, crop_size, crop_location="random", hotfix_sr_crop=False,
                  rank=0, world=1):
         """synthetic_dataset: map-style dataset of full-size (x, y) device tensors (datasets.SyntheticDataset or
-        SyntheticPairs); rank/world: this process keeps items rank, rank + world, ... (one shard per GPU)."""
+        SyntheticPairs); rank/world: this process keeps items rank, rank + world, ... of the index list padded by
+        wrapping around to a multiple of `world` (torch's DistributedSampler rule), so every rank holds the SAME
+        number of pairs, runs the same number of steps and takes the same launch path on the last, short batch --
+        ranks that disagree on either would hang in, or corrupt, the gradient all-reduce."""
         if getattr(synthetic_dataset, "deterministic_measurements", True) is not True:
             raise ValueError("the device cache needs deterministic measurements")
         self.ratio = physics.rate if physics.task == "sr" else 1
@@ -25,7 +28,9 @@ class DeviceResidentPairs:
             CropPair(location=crop_location, size=crop_size)
         self.pairs = []
         with torch.no_grad():
-            for index in range(rank, len(synthetic_dataset), world):
+            n = len(synthetic_dataset)
+            padded = [i % n for i in range(-(-n // world) * world)]
+            for index in padded[rank::world]:
                 x, y = synthetic_dataset[index]
                 self.pairs.append((x.contiguous(), y.contiguous()))
 

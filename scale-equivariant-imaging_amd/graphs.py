@@ -13,11 +13,22 @@ GEMM each that STORES its result (models/_ops.py), so only the small remainder o
 zeroed per step.
 
 What stays outside the graph: the random 48-crop of Loss.forward (two CPU randint draws + a strided
-copy into the static input), the gradient all-reduce and the fused Adam launch. Random draws on the
-device (probe b, measurement noise, scale rates/centres) are captured with torch's graph-safe
-generator, so every replay sees fresh numbers.
+copy into the static input), the step's device-side random draws, the gradient all-reduce and the fused
+Adam launch. The draws (probe b, scale rates/centres, measurement noise) are made eagerly before every
+replay, by the same calls in the same order as an eager step (`loss.draw`), into static buffers the
+captured kernels read: with equal seeds a replayed step and an eager step see the same numbers, so
+replay == eager is an equality the tests assert, and no torch RNG kernel sits inside the graph.
+
+Only steps without host-side randomness or host syncs can be captured (`graph_safe` of the method-level
+loss: proposed with the padded scaling transform and no antialias, sure, supervised, css); `can_capture`
+is the allow-list train.py consults, everything else runs eagerly.
 """
 import torch
+
+
+def can_capture(loss_module):
+    """True when `loss_module` (a losses.Loss) cropping + method can be replayed from a hipGraph."""
+    return loss_module.crop_fn is not None and bool(getattr(loss_module.loss, "graph_safe", False))
 
 
 class GraphedLossStep:
@@ -32,15 +43,26 @@ class GraphedLossStep:
         if getattr(backbone, "flat_grads", None) is None:
             raise ValueError("GraphedLossStep needs a flattened model")
         self.backbone = backbone
+        if not getattr(self.inner, "graph_safe", False):
+            raise ValueError(f"{type(self.inner).__name__} in this configuration draws random numbers on the host or "
+                             "synchronises with it inside the step: it cannot be captured (graphs.can_capture)")
         device = backbone.flat_params.device
         self.static_y = torch.zeros(crop_shape, dtype=torch.float32, device=device)
         self.static_x = None
+        if getattr(self.inner, "needs_x", False):
+            r = loss_module.xy_size_ratio if loss_module.crop_fn is not None else 1
+            self.static_x = torch.zeros(tuple(crop_shape[:2]) + (crop_shape[2] * r, crop_shape[3] * r),
+                                        dtype=torch.float32, device=device)
+        # static homes of the step's random numbers, refreshed by `_draw` before every replay
+        state = torch.cuda.get_rng_state(device)
+        self.static_draws = self.inner.draw(self.static_y)
+        torch.cuda.set_rng_state(state, device)        # sizing the buffers must not advance the generator
 
         self.store_weight_grads = False
 
         def fwd_bwd():
             self.backbone.zero_grad_flat(store_weight_grads=self.store_weight_grads)
-            value = self.inner(x=self.static_x, y=self.static_y, model=self.model)
+            value = self.inner(x=self.static_x, y=self.static_y, model=self.model, draws=self.static_draws)
             value.backward()
             return value.detach()
 
@@ -92,13 +114,26 @@ class GraphedLossStep:
         _ops.set_weight_grad_milestone({p0, p1}, event)
         return (event, int(start), int(stop))
 
-    def __call__(self, x, y):
+    def _draw(self, given=None):
+        """Fresh random numbers for the next replay: the eager step's own draw calls (or `given`, a dict of the
+        same tensors), copied into the buffers the graph reads."""
+        if self.static_draws is None:
+            return
+        fresh = given if given is not None else self.inner.draw(self.static_y)
+        for name, buf in self.static_draws.items():
+            buf.copy_(fresh[name].reshape(buf.shape))
+
+    def __call__(self, x, y, draws=None):
+        """One replay on the crop of (x, y); draws: inject the step's random numbers (tests) instead of drawing."""
         crop = self.loss_module.crop_fn
         if crop is not None:
             x, y = crop(x, y, xy_size_ratio=self.loss_module.xy_size_ratio)
         if tuple(y.shape) != tuple(self.static_y.shape):
             raise ValueError(f"graphed step was captured for {tuple(self.static_y.shape)}, got {tuple(y.shape)}")
         self.static_y.copy_(y)
+        if self.static_x is not None:
+            self.static_x.copy_(x)
+        self._draw(draws)
         if not self._ops.plain_shadow_is_current(self.backbone):   # weights changed by something other than FlatAdam
             self._ops.refresh_plain_shadow(self.backbone)
         self.graph.replay()

@@ -25,19 +25,30 @@ from .sure import SureGaussianLoss, draw_probe
 
 
 class _ModelPlusOneLoss(Module):
-    """x_net = model(y); one deepinv-style loss term (reference :13-64)."""
+    """x_net = model(y); one deepinv-style loss term (reference :13-64).
+
+    `graph_safe`: the step consumes no host-side randomness and issues no host sync, so graphs.GraphedLossStep
+    may capture it; `needs_x`: the ground truth enters the loss (the graph then needs a static x as well)."""
+    graph_safe = True
+    needs_x = False
 
     def __init__(self, physics, loss):
         super().__init__()
         self.physics = physics
         self.loss = loss
 
-    def forward(self, x, y, model):
+    def draw(self, y):
+        """The step's device-side random numbers, in the order the step consumes them (none here)."""
+        return None
+
+    def forward(self, x, y, model, draws=None):
         x_net = model(y)
         return self.loss(x=x, x_net=x_net, y=y, physics=self.physics, model=model)
 
 
 class SupervisedLoss(_ModelPlusOneLoss):
+    needs_x = True
+
     def __init__(self, physics):
         metric = mse()
         if "SUPERVISED_L1" in environ:
@@ -47,11 +58,15 @@ class SupervisedLoss(_ModelPlusOneLoss):
 
 
 class CSSLoss(_ModelPlusOneLoss):
+    needs_x = True
+
     def __init__(self, physics):
         super().__init__(physics, SupLoss(metric=mse()))
 
 
 class Noise2InverseLoss(_ModelPlusOneLoss):
+    needs_x = True
+
     def __init__(self, physics):
         super().__init__(physics, SupLoss(metric=mse()))
 
@@ -61,12 +76,24 @@ class SURELoss(_ModelPlusOneLoss):
         super().__init__(physics, SureGaussianLoss(sigma=noise_level / 255, cropped_div=cropped_div,
                                                    averaged_cst=averaged_cst, margin=margin))
 
+    def draw(self, y):
+        return {"b": draw_probe(y, self.loss.div_margin)}
+
+    def forward(self, x, y, model, draws=None):
+        y = y.contiguous()
+        b = (draws if draws is not None else self.draw(y))["b"]
+        return self.loss(x=x, x_net=model(y), y=y, physics=self.physics, model=model, b=b)
+
 
 class ProposedLoss(Module):
+    needs_x = False             # the ground truth never enters the proposed loss
+    keep_outputs = False        # diagnostics: keep the restored images of the (fused) first pass in `self.kept`
+
     def __init__(self, blueprint, sure_alternative, noise_level, stop_gradient, sure_cropped_div,
                  sure_averaged_cst, sure_margin, alpha_tradeoff, transforms, physics, fuse_passes=None):
         super().__init__()
         self.physics = physics
+        self.graph_safe = False
         if transforms == "Scaling_Transforms":
             ei_transform = ScalingTransform(**blueprint[ScalingTransform.__name__])
         elif transforms == "Shifts":
@@ -92,24 +119,49 @@ class ProposedLoss(Module):
         if fuse_passes is None:
             fuse_passes = "SEI_NO_FUSED_PASSES" not in environ
         self.fuse_passes = fuse_passes
+        # Every random number of the default step is a device-side draw whose shape is known from y alone
+        # (probe b, then the per-image rate and centre, then the measurement noise of the EI branch): `draw`
+        # can hoist them in front of the step, which is what lets graphs.GraphedLossStep replay the step with
+        # the numbers an eager step would have drawn. The `normal` kind and the antialiased variant read
+        # their rates on the host (.item() / .tolist()), the Shift transform draws on the host.
+        padded = isinstance(ei_transform, ScalingTransform) and ei_transform.kind == "padded"
+        self.graph_safe = padded and not ei_transform.antialias
 
-    def forward(self, x, y, model):
+    def draw(self, y):
+        """{"b", "rate", "center", "noise"} in the reference's draw order (src/losses/sure.py:13-22, then
+        src/transforms.py:15-24 inside EILoss, then GaussianNoise on A(T x_net), which has y's shape), or None
+        when this configuration draws on the host or in data-dependent shapes."""
+        if not self.graph_safe:
+            return None
+        b = draw_probe(y, self.sure.div_margin)
+        rate, center = self.ei.T.sample(y.shape[0], y.device, y.dtype)
+        return {"b": b, "rate": rate, "center": center, "noise": torch.randn_like(y)}
+
+    def forward(self, x, y, model, draws=None):
+        y = y.contiguous()
+        if draws is None:
+            draws = self.draw(y) if self.compute_x_net else None
+        ei_kw = {} if draws is None else {"transform_params": (draws["rate"], draws["center"]),
+                                          "noise": draws["noise"]}
         if not self.fuse_passes:
             x_net = model(y) if self.compute_x_net else None
             loss = 0
             for loss_fn in self.loss_fns:
-                loss = loss + loss_fn(x=x, x_net=x_net, y=y, physics=self.physics, model=model)
+                kw = ei_kw if loss_fn is getattr(self, "ei", None) else \
+                    ({"b": draws["b"]} if draws is not None and loss_fn is getattr(self, "sure", None) else {})
+                loss = loss + loss_fn(x=x, x_net=x_net, y=y, physics=self.physics, model=model, **kw)
             return loss
         # Same arithmetic and the same RNG draw order (probe b first: the network consumes no random
         # numbers), but model(y) and model(y + tau b) share one pass of 2B images.
-        y = y.contiguous()
         B = y.shape[0]
-        b = draw_probe(y, self.sure.div_margin)
+        b = draws["b"] if draws is not None else draw_probe(y, self.sure.div_margin)
         both = model(torch.cat([y, axpy(y, b, self.sure.tau)], dim=0))
         y12 = self.physics.A(both)
         x_net = both[:B]
         loss = self.sure(y=y, x_net=x_net, physics=self.physics, model=model, b=b, y1=y12[:B], y2=y12[B:])
-        return loss + self.ei(x=x, x_net=x_net, y=y, physics=self.physics, model=model)
+        if self.keep_outputs:
+            self.kept = {"x_net": x_net.detach()}
+        return loss + self.ei(x=x, x_net=x_net, y=y, physics=self.physics, model=model, **ei_kw)
 
 
 class Loss(Module):
@@ -140,10 +192,14 @@ class Loss(Module):
         if "HOMOGENEOUS_SWINIR" in environ:
             self.crop_fn = None
 
-    def forward(self, x, y, model):
+    def forward(self, x, y, model, draws=None):
+        """draws: the step's device-side random numbers (`self.loss.draw(y_cropped)`), injected by tests and by
+        graphs.GraphedLossStep; drawn here, in the reference's order, when absent."""
         if self.crop_fn is not None:
             x, y = self.crop_fn(x, y, xy_size_ratio=self.xy_size_ratio)
-        return self.loss(x=x, y=y, model=model)
+        if draws is None:
+            return self.loss(x=x, y=y, model=model)
+        return self.loss(x=x, y=y, model=model, draws=draws)
 
 
 def get_loss(args, physics):

@@ -61,13 +61,21 @@ class EILoss(Module):
         self.noise = apply_noise
         self.no_grad = no_grad
 
-    def forward(self, x_net, physics, model, **kwargs):
+    def forward(self, x_net, physics, model, transform_params=None, noise=None, **kwargs):
+        """transform_params / noise: the transform's draws and the unit measurement noise, when the caller has
+        drawn them already (losses.ProposedLoss.draw); drawn here otherwise, as deepinv does."""
+        T = self.T if transform_params is None else (lambda v: self.T(v, params=transform_params))
         if self.no_grad:
             with torch.no_grad():
-                x2 = self.T(x_net)
+                x2 = T(x_net)
         else:
-            x2 = self.T(x_net)
-        y2 = physics(x2) if self.noise else physics.A(x2)
+            x2 = T(x_net)
+        if not self.noise:
+            y2 = physics.A(x2)
+        elif noise is None:
+            y2 = physics(x2)
+        else:
+            y2 = physics.noise_model(physics.A(x2), noise=noise)
         x3 = model(y2, physics)
         if isinstance(self.metric, mse):
             return self.metric(x3, x2, weight=self.weight)

@@ -58,9 +58,16 @@ class Model(Module):
         else:
             raise ValueError(f"Unknown model kind: {kind}")
         if data_parallel_devices is not None:
+            # reference :142-145,178-182: nn.DataParallel over these device ids, re-replicating the weights on
+            # every forward. Here one process per GPU owns a replica; the same devices are used by:
+            n = len(data_parallel_devices)
+            ids = ",".join(data_parallel_devices)
             raise NotImplementedError(
-                "--data_parallel_devices (single-process nn.DataParallel) is replaced by one process per GPU: "
-                "launch train.py with torch.distributed.run (see parallel.py)")
+                f"--data_parallel_devices {ids}: single-process nn.DataParallel is replaced by one process per "
+                f"GPU with an RCCL gradient all-reduce (parallel.py). Equivalent launch on the same devices:\n"
+                f"  HIP_VISIBLE_DEVICES={ids} python -m torch.distributed.run --nnodes=1 --nproc-per-node {n} "
+                f"--master-addr 127.0.0.1 train.py <the same flags without --data_parallel_devices> "
+                f"--batch_size <batch_size / {n}>")
 
     def forward(self, x, *args):
         return self.model(x)

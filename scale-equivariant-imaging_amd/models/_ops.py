@@ -75,16 +75,20 @@ def gemm(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2
 
 
 def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=None, R2=None, D2_16=None,
-              lda=None, ldb=None, a_rmajor=False, b_rmajor=False):
+              lda=None, ldb=None, a_rmajor=False, b_rmajor=False, tile=0, band=0):
     """D[M,N] = op(A16) op(B16) on the direct-to-LDS bf16 kernel. A16 is (M,K) [or (K,M) when a_rmajor],
-    B16 is (N,K) [or (K,N) when b_rmajor]; K % 8 == 0. Outputs as given."""
+    B16 is (N,K) [or (K,N) when b_rmajor]; K % 8 == 0. Outputs as given. tile / band: an explicit schedule
+    choice (sei_gemm_bf16nt_ex; tests and tools), 0 = the library's dispatch."""
     if lda is None:
         lda = M if a_rmajor else K
     if ldb is None:
         ldb = Nn if b_rmajor else K
-    _gemm_call(2.0 * M * Nn * K, "sei_gemm_bf16nt", A16.data_ptr(), lda, int(a_rmajor), B16.data_ptr(), ldb,
-               int(b_rmajor), N.ptr(out32), N.ptr(out16), M, Nn, K, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2),
-               N.ptr(D2_16))
+    args = (A16.data_ptr(), lda, int(a_rmajor), B16.data_ptr(), ldb, int(b_rmajor), N.ptr(out32), N.ptr(out16), M, Nn,
+            K, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2_16))
+    if tile or band:
+        _gemm_call(2.0 * M * Nn * K, "sei_gemm_bf16nt_ex", *args, int(tile), int(band))
+    else:
+        _gemm_call(2.0 * M * Nn * K, "sei_gemm_bf16nt", *args)
 
 
 def layer_norm(x2d, gamma, beta):
@@ -116,20 +120,24 @@ def colsum_into(acc, x2d, row_weight=None):
         N.call("sei_colsum_weighted_f32", x2d.data_ptr(), row_weight.data_ptr(), acc.data_ptr(), M, Nn)
 
 
-def dwconv7(x, w, bias, flip=False, res=None, res_scale=1.0):
+def dwconv7(x, w, bias, flip=False, res=None, res_scale=1.0, seg=0):
+    """seg > 0: the generic kernels with that segment width (sei_dwconv7_fwd_ex; tests), 0 = chosen by shape."""
     B, H, W, C = x.shape
     y = torch.empty_like(x)
-    N.call("sei_dwconv7_fwd", x.data_ptr(), w.data_ptr(), N.ptr(bias), N.ptr(res), float(res_scale),
-           y.data_ptr(), B, H, W, C, int(flip))
+    args = (x.data_ptr(), w.data_ptr(), N.ptr(bias), N.ptr(res), float(res_scale), y.data_ptr(), B, H, W, C, int(flip))
+    if seg:
+        N.call("sei_dwconv7_fwd_ex", *args, int(seg))
+    else:
+        N.call("sei_dwconv7_fwd", *args)
     return y
 
 
-def dwconv7_weight_grad(x, gy, gw, gb):
+def dwconv7_weight_grad(x, gy, gw, gb, seg=0):
     B, H, W, C = x.shape
-    need = N.lib().sei_dwconv7_bwd_weight_workspace(B, H, W, C)
+    need = N.lib().sei_dwconv7_bwd_weight_workspace_ex(B, H, W, C, int(seg))
     work = torch.empty(need, dtype=torch.float32, device=x.device)
-    N.call("sei_dwconv7_bwd_weight", x.data_ptr(), gy.data_ptr(), gw.data_ptr(), N.ptr(gb), B, H, W, C,
-           work.data_ptr(), need)
+    N.call("sei_dwconv7_bwd_weight_ex", x.data_ptr(), gy.data_ptr(), gw.data_ptr(), N.ptr(gb), B, H, W, C,
+           work.data_ptr(), need, int(seg))
 
 
 def sepmap2(x, mats, Ho, Wo):

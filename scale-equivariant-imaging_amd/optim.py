@@ -2,7 +2,11 @@
 for the U-Net; same update rule, one kernel launch per chunk instead of a foreach sweep per tensor).
 
 Keeps a torch.optim.Optimizer-compatible surface (param_groups with "lr", state_dict / load_state_dict,
-zero_grad, step) so the reference's schedulers and checkpoint code drive it unchanged.
+zero_grad, step) so the reference's schedulers and checkpoint code drive it unchanged. `state_dict()` is
+written, and `load_state_dict()` read, in torch.optim.Adam's own per-parameter layout over
+`model.parameters()` (what the reference saves under "optimizer", src/training.py:23-31), so `--RESUME`
+interchanges checkpoints with the reference and with `--no-fused_optimizer` runs; the flat moment buckets
+are an internal layout that never reaches a file.
 """
 import torch
 
@@ -16,6 +20,7 @@ class FlatAdam(torch.optim.Optimizer):
             raise ValueError("FlatAdam needs a model whose parameters live in one flat bucket")
         self.backbone = backbone
         self.reducer = reducer
+        self._named = list(model.parameters())        # the order torch.optim.Adam(model.parameters()) indexes by
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__([backbone.flat_params], defaults)
         flat = backbone.flat_params
@@ -23,6 +28,64 @@ class FlatAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         self.backbone.zero_grad_flat()
+
+    # -- checkpoint interchange ----------------------------------------------------------------
+    _TORCH_ADAM_GROUP = {"amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                         "differentiable": False, "fused": None, "decoupled_weight_decay": False}
+
+    def _slices(self):
+        flat = self.backbone.flat_params
+        base, esz = flat.data_ptr(), flat.element_size()
+        for p in self._named:
+            off = (p.data_ptr() - base) // esz
+            if not (0 <= off and off + p.numel() <= flat.numel()):
+                raise RuntimeError("a model parameter lives outside the flat bucket (flatten_parameters not run?)")
+            yield p, off
+
+    def state_dict(self):
+        """torch.optim.Adam's layout: state[i] = {step, exp_avg, exp_avg_sq} for parameter i of
+        model.parameters(); empty before the first step, as torch's."""
+        st = self.state[self.backbone.flat_params]
+        state = {}
+        if st["step"] > 0:
+            for i, (p, off) in enumerate(self._slices()):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(st["step"])),
+                            "exp_avg": st["exp_avg"][off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": st["exp_avg_sq"][off:off + n].view(p.shape).clone()}
+        group = dict(self._TORCH_ADAM_GROUP)
+        group.update({k: v for k, v in self.param_groups[0].items() if k != "params"})
+        group["params"] = list(range(len(self._named)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        count = sum(len(g["params"]) for g in groups)
+        if len(groups) != 1 or count != len(self._named):
+            raise ValueError(f"optimizer state has {len(groups)} group(s) over {count} parameters; this model has "
+                             f"{len(self._named)} parameters in one group (a torch.optim.Adam(model.parameters()) "
+                             "state of the same architecture is expected)")
+        if any(groups[0].get(k) for k in ("amsgrad", "maximize")):
+            raise ValueError("amsgrad / maximize Adam states are not supported by the fused optimizer")
+        st = self.state[self.backbone.flat_params]
+        saved = state_dict["state"]
+        steps = {int(float(e["step"])) for e in saved.values()}
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ: not a state the fused optimizer can continue")
+        st["step"] = steps.pop() if steps else 0
+        st["exp_avg"].zero_()
+        st["exp_avg_sq"].zero_()
+        for i, (p, off) in enumerate(self._slices()):
+            e = saved.get(i, saved.get(str(i)))
+            if e is None:
+                continue
+            n = p.numel()
+            if tuple(e["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state {i}: shape {tuple(e['exp_avg'].shape)} != parameter {tuple(p.shape)}")
+            st["exp_avg"][off:off + n].copy_(e["exp_avg"].reshape(-1))
+            st["exp_avg_sq"][off:off + n].copy_(e["exp_avg_sq"].reshape(-1))
+        self.param_groups[0].update({k: v for k, v in groups[0].items()
+                                     if k != "params" and k not in self._TORCH_ADAM_GROUP})
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -54,15 +54,26 @@ class FlatGradientReducer:
     which lets the optimizer consume chunks in order while later ones are still on the wire.
     """
 
-    def __init__(self, flat_grads, chunk_mib=256, group=None, comm_dtype=torch.float32, early_range=None):
-        """comm_dtype=torch.bfloat16 compresses the exchanged gradients (half the xGMI bytes): the f32
+    def __init__(self, flat_grads, chunk_mib=256, group=None, comm_dtype=torch.float32, early_range=None,
+                 mode="all_reduce"):
+        """mode: "all_reduce" (one dist.all_reduce per chunk) or "rs_ag" (a reduce-scatter of the chunk into this
+        rank's 1/world share, then an all-gather of the shares: the two halves of an all-reduce as separate
+        collectives, each of which moves 1/world of the chunk per peer -- on a fully connected xGMI node all 7
+        links carry one share each; chunks whose length is not a multiple of world_size fall
+        back to all_reduce).
+
+        comm_dtype=torch.bfloat16 compresses the exchanged gradients (half the xGMI bytes): the f32
         bucket is cast once into `self.comm`, which is what gets summed and what the optimizer reads.
 
         early_range=(start, stop): a slice of the bucket whose gradients are final before the backward pass
         ends (graphs.GraphedLossStep.early_grads); chunks never straddle its ends, and reduce_async(early=event)
         exchanges it from a side stream as soon as `event` fires, under the rest of the backward."""
+        if mode not in ("all_reduce", "rs_ag"):
+            raise ValueError(f"unknown gradient exchange mode {mode!r}")
         self.flat = flat_grads
         self.group = group
+        self.mode = mode
+        self._shards = {}
         self.comm_dtype = comm_dtype
         self.comm = flat_grads if comm_dtype == flat_grads.dtype else torch.empty_like(flat_grads, dtype=comm_dtype)
         self._chunk = max(1, (chunk_mib << 20) // self.comm.element_size())
@@ -99,7 +110,19 @@ class FlatGradientReducer:
 
     def _exchange(self, k):
         s, e = self.bounds[k]
-        self._work[k] = dist.all_reduce(self.comm[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        chunk = self.comm[s:e]
+        world = dist.get_world_size(self.group)
+        if self.mode == "rs_ag" and (e - s) % world == 0:
+            share = self._shards.get(k)
+            if share is None or share.numel() != (e - s) // world:
+                share = self._shards[k] = torch.empty((e - s) // world, dtype=chunk.dtype, device=chunk.device)
+            rs = dist.reduce_scatter_tensor(share, chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if not chunk.is_cuda:
+                rs.wait()             # gloo runs async work on a thread pool: order the two halves by hand
+            # (RCCL: both collectives are enqueued on the process group's stream, in this order)
+            self._work[k] = dist.all_gather_into_tensor(chunk, share, group=self.group, async_op=True)
+            return
+        self._work[k] = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def reduce_async(self, early=None):
         """Cast (if compressed) and all-reduce every chunk asynchronously. early: an event with .wait(stream)
@@ -129,7 +152,7 @@ class FlatGradientReducer:
         self._cast(0, self.flat.numel())
         if single:
             return
-        for k in range(len(self.bounds)):
+        for k in self.order:          # the same collective sequence on every rank, whichever path a rank's step took
             self._exchange(k)
 
     def wait(self, k):

@@ -103,9 +103,13 @@ class PaddedDownsamplingTransform(Module):
         self.antialias = antialias
         self.downsampling_rates = downsampling_rates
 
-    def forward(self, x):
-        rate, center = sample_downsampling_parameters(
-            image_count=x.shape[0], device=x.device, dtype=x.dtype, rates=self.downsampling_rates)
+    def sample(self, image_count, device, dtype):
+        return sample_downsampling_parameters(image_count=image_count, device=device, dtype=dtype,
+                                              rates=self.downsampling_rates)
+
+    def forward(self, x, params=None):
+        """params: (rate (B,), centre (B,1,1,2)) drawn by the caller with `sample`; drawn here otherwise."""
+        rate, center = params if params is not None else self.sample(x.shape[0], x.device, x.dtype)
         return padded_downsampling_transform(x, downsampling_rate=rate, center=center,
                                              antialiased=self.antialias, mode="bicubic",
                                              padding_mode="reflection")
@@ -137,10 +141,15 @@ class ScalingTransform(Module):
         kinds = {"padded": PaddedDownsamplingTransform, "normal": NormalDownsamplingTransform}
         if kind not in kinds:
             raise ValueError(f"Unknown kind: {kind}")
+        self.kind, self.antialias = kind, antialias
         self.transform = kinds[kind](antialias=antialias, downsampling_rates=rates)
 
-    def forward(self, x):
-        return self.transform(x)
+    def sample(self, image_count, device, dtype):
+        """The padded kind's per-image draws (rate, centre), in the reference's order (:15-24)."""
+        return self.transform.sample(image_count, device, dtype)
+
+    def forward(self, x, params=None):
+        return self.transform(x) if params is None else self.transform(x, params=params)
 
 
 class Shift(Module):

@@ -12,6 +12,7 @@ HEADER = os.path.join(ROOT, "include", "sei_hip.h")
 def declared():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef SEI_TUNING.*?#endif", "", text, flags=re.S)     # tools-only build, not the product
     decls = {}
     for m in re.finditer(r"\b(?:int|size_t)\s+(sei_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = [a.strip() for a in m.group(2).split(",")]
@@ -30,9 +31,27 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_native.LIB_PATH)       # loads on a GPU-less host: no HIP call at load time
     missing = [name for name in declared() if not hasattr(handle, name)]
     assert not missing, f"declared in sei_hip.h but not exported: {missing}"
-    assert handle.sei_abi_version() == _native.ABI_VERSION == 2
+    assert handle.sei_abi_version() == _native.ABI_VERSION == 3
     buf = ctypes.create_string_buffer(16)
     assert handle.sei_build_target(buf, 16) == 0 and buf.value == b"gfx950"
+
+
+def test_product_library_has_no_debug_state():
+    """re-entrant, no mutable globals. Schedule overrides are per-call arguments of the _ex entry
+    points; the process-wide tuning switches and hardware probes exist only in the tools build (-DSEI_TUNING)."""
+    import subprocess
+    import _native
+    handle = ctypes.CDLL(_native.LIB_PATH)
+    for name in ("sei_debug_set_nt_tile", "sei_debug_set_dw_seg", "sei_debug_tr_probe"):
+        assert not hasattr(handle, name), name
+    syms = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in syms.splitlines() if ln.strip()}
+    assert "sei_gemm_bf16nt_ex" in exported
+    assert not [s_ for s_ in exported if "debug" in s_ or "gemm_bf16pp" in s_], exported
+    # no writable override variable of any visibility survives in the product library
+    allsyms = subprocess.run(["nm", _native.LIB_PATH], capture_output=True, text=True).stdout
+    writable = [ln.split()[-1] for ln in allsyms.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "bBdD"]
+    assert not [w for w in writable if "force" in w or "tuning" in w or "g_dw" in w], writable
 
 
 def test_python_binding_table_matches_header():

@@ -1,0 +1,53 @@
+"""Multi-GPU readiness on one GPU: two freshly spawned ranks share the card and exchange gradients over gloo
+(RCCL refuses two ranks on one device); same code path as the 8-GPU run except for the backend."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "ddp_worker.py")
+
+
+def _run(out, world, extra):
+    env = dict(os.environ, SEI_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if world == 1:
+        cmd = [sys.executable, WORKER, "--out", out] + extra
+    else:
+        port = 29600 + os.getpid() % 300
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, "--out", out] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return [torch.load(os.path.join(out, f"rank{k}.pt")) for k in range(world)]
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+@pytest.mark.parametrize("extra,tol", [
+    (["--dtype", "f32", "--graph", "1", "--mode", "all_reduce"], 2e-5),
+    (["--dtype", "f32", "--graph", "0", "--mode", "rs_ag"], 2e-5),
+    (["--dtype", "bf16", "--graph", "1", "--mode", "rs_ag", "--comm", "bf16"], 2e-2)])
+def test_two_ranks_on_one_gpu_match_the_single_process_run(tmp_path, extra, tol):
+    """Two ranks x half the batch == one process x the whole batch: the summed, world-averaged gradient of the first
+    step equals the single-process gradient (to split-K / atomic-order noise; to bf16 rounding when the exchange
+    is compressed), the replicas stay bit-identical through the optimizer steps, and the per-step losses agree."""
+    two = _run(str(tmp_path / "w2"), 2, extra)
+    one = _run(str(tmp_path / "w1"), 1, extra)                             # (exchange flags are inert at world 1)
+    assert torch.equal(two[0]["params"], two[1]["params"])                  # replicas never diverge
+    assert torch.equal(two[0]["grads_step0"], two[1]["grads_step0"])
+    assert relerr(two[0]["grads_step0"], one[0]["grads_step0"]) < tol
+    # mean of the rank means == the global mean, up to the SURE constant sigma^2 / local batch
+    sigma2 = (5 / 255) ** 2
+    for l2, l1 in zip(two[0]["losses"], one[0]["losses"]):
+        assert abs((l2 + sigma2 / 4) - (l1 + sigma2 / 8)) < max(tol, 1e-4) * abs(l1), (two[0]["losses"], one[0]["losses"])
+    assert relerr(two[0]["params"], one[0]["params"]) < 2e-3               # Adam's first steps are sign-like
+    assert np.isfinite(two[0]["losses"]).all()

@@ -170,6 +170,66 @@ def test_checkpoint_format(tmp_path):
     assert torch.equal(training.get_weights(path, "cpu")["seq.0.in_conv.weight"], torch.ones(2))
 
 
+def test_fused_adam_state_interchanges_with_torch_adam():
+    """FlatAdam.state_dict() / load_state_dict() speak torch.optim.Adam's per-parameter layout over
+    model.parameters() (what the reference checkpoints under "optimizer", src/training.py:23-31), so --RESUME
+    works across the reference, --no-fused_optimizer and --fused_optimizer runs."""
+    from models.convolutional import ConvolutionalModel
+    from optim import FlatAdam
+    torch.manual_seed(0)
+    m = ConvolutionalModel(in_channels=3, upsampling_rate=2, residual=True, inner_residual=True, num_conv_blocks=1,
+                           hidden_channels=8, inout_convs=True, scales=3)
+    m.flatten_parameters()
+    ref = torch.optim.Adam(m.parameters(), lr=3e-4, betas=(0.9, 0.99))
+    sch = torch.optim.lr_scheduler.LinearLR(ref)                   # adds "initial_lr" to the group, as training does
+    for p in m.parameters():
+        p.grad = torch.randn_like(p)
+    ref.step()
+    ref.step()
+    fused = FlatAdam(m, lr=1e-4)
+    assert fused.state_dict()["state"] == {}                       # torch's Adam has no state before a step either
+    fused.load_state_dict(ref.state_dict())
+    st = fused.state[m.flat_params]
+    assert st["step"] == 2 and fused.param_groups[0]["lr"] == ref.param_groups[0]["lr"]
+    assert fused.param_groups[0]["betas"] == (0.9, 0.99) and "initial_lr" in fused.param_groups[0]
+    p0 = next(iter(m.parameters()))
+    off = (p0.data_ptr() - m.flat_params.data_ptr()) // 4
+    assert torch.equal(st["exp_avg"][off:off + p0.numel()].view(p0.shape), ref.state[p0]["exp_avg"])
+    back = torch.optim.Adam(m.parameters(), lr=1.0)
+    back.load_state_dict(fused.state_dict())                       # and the way back, into a plain torch Adam
+    a, b = ref.state_dict(), back.state_dict()
+    assert a["param_groups"][0].keys() == b["param_groups"][0].keys()
+    assert all(torch.equal(a["state"][i][k], b["state"][i][k]) for i in a["state"] for k in a["state"][i])
+    bad = ref.state_dict()
+    bad["param_groups"][0]["params"] = bad["param_groups"][0]["params"][:-1]
+    with pytest.raises(ValueError, match="parameters"):
+        fused.load_state_dict(bad)
+
+
+def test_device_cache_shards_have_equal_length():
+    """Every rank of a multi-GPU run holds the same number of cached pairs (wrap-around padding, as torch's
+    DistributedSampler): ranks that run different numbers of steps would hang in the all-reduce."""
+    from datasets.device_cache import DeviceResidentPairs
+
+    class Items:
+        deterministic_measurements = True
+
+        def __len__(self):
+            return 7
+
+        def __getitem__(self, i):
+            return torch.full((3, 8, 8), float(i)), torch.full((3, 8, 8), float(i))
+
+    class P:
+        task = "deblurring"
+
+    shards = [DeviceResidentPairs(Items(), P(), crop_size=8, rank=r, world=3) for r in range(3)]
+    assert [len(s) for s in shards] == [3, 3, 3]
+    seen = sorted(int(x[0, 0, 0]) for s in shards for x, _ in s.pairs)
+    assert seen == [0, 0, 1, 1, 2, 3, 4, 5, 6]
+    assert len(list(shards[0].batches(2))) == len(list(shards[2].batches(2))) == 2
+
+
 def test_psnr_metric():
     import metrics
     a, b = torch.rand(3, 20, 20), torch.rand(3, 20, 20)
@@ -200,6 +260,13 @@ def _reducer_worker(rank, world, port, numel, chunk_mib, q):
     red16.wait_all()
     want16 = sum(torch.randn(numel, generator=torch.Generator().manual_seed(200 + k)).bfloat16().float() for k in range(w))
     assert red16.comm.dtype == torch.bfloat16 and (red16.comm.float() - want16).abs().max() < 0.05
+    # reduce-scatter + all-gather mode: same sums; the ragged last chunk falls back to all_reduce
+    g3 = torch.randn(numel, generator=torch.Generator().manual_seed(300 + r))
+    red_rs = parallel.FlatGradientReducer(g3, chunk_mib=chunk_mib, mode="rs_ag")
+    red_rs.reduce_async()
+    red_rs.wait_all()
+    want3 = sum(torch.randn(numel, generator=torch.Generator().manual_seed(300 + k)) for k in range(w))
+    assert (g3 - want3).abs().max() < 1e-6 and len(red_rs._shards) == len(red_rs.bounds) - 1
     loss = parallel.all_reduce_mean_scalar(torch.tensor(float(r + 1)))
     want = sum(torch.randn(numel, generator=torch.Generator().manual_seed(100 + k)) for k in range(w))
     # plain floats only: tensors sent through the queue would outlive this process's shared memory

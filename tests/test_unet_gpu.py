@@ -122,23 +122,19 @@ DW_SHAPES = [(2, 48, 48, 32), (3, 6, 6, 2048), (2, 3, 3, 8192), (1, 5, 7, 8), (2
 def test_dwconv7_paths_agree(ops, B, H, W, C):
     """LDS-tiled / whole-image kernels against the generic kernel: same accumulation order, so the forward
     and the data gradient (flip + residual) are bit-identical; the weight gradient sums in another order."""
-    from _native import lib
     gen = torch.Generator().manual_seed(7 * B + H + C)
     x, r = torch.randn((B, H, W, C), generator=gen).cuda(), torch.randn((B, H, W, C), generator=gen).cuda()
     w, b = (torch.randn((C, 1, 7, 7), generator=gen) * 0.1).cuda(), torch.randn(C, generator=gen).cuda()
     out = {}
-    try:
-        for mode in (0, -1):                     # 0: generic kernels, -1: automatic choice
-            assert lib().sei_debug_set_dw_seg(mode) == 0
-            gw, gb = torch.zeros_like(w), torch.zeros(C, device="cuda")
-            ops.dwconv7_weight_grad(x, r, gw, gb)
-            ops.dwconv7_weight_grad(x, r, gw, gb)                   # accumulates: twice the gradient
-            out[mode] = (ops.dwconv7(x, w, b), ops.dwconv7(x, w, None, flip=True, res=r, res_scale=2.0), gw, gb)
-            torch.cuda.synchronize()
-    finally:
-        lib().sei_debug_set_dw_seg(-1)
-    assert torch.equal(out[0][0], out[-1][0]) and torch.equal(out[0][1], out[-1][1])
-    assert relerr(out[-1][2], out[0][2]) < 2e-6 and relerr(out[-1][3], out[0][3]) < 2e-6
+    for seg in (16, 0):                          # 16: generic kernels (explicit per-call choice), 0: chosen by shape
+        gw, gb = torch.zeros_like(w), torch.zeros(C, device="cuda")
+        ops.dwconv7_weight_grad(x, r, gw, gb, seg=seg)
+        ops.dwconv7_weight_grad(x, r, gw, gb, seg=seg)              # accumulates: twice the gradient
+        out[seg] = (ops.dwconv7(x, w, b, seg=seg), ops.dwconv7(x, w, None, flip=True, res=r, res_scale=2.0, seg=seg),
+                    gw, gb)
+        torch.cuda.synchronize()
+    assert torch.equal(out[16][0], out[0][0]) and torch.equal(out[16][1], out[0][1])
+    assert relerr(out[0][2], out[16][2]) < 2e-6 and relerr(out[0][3], out[16][3]) < 2e-6
 
 
 @pytest.mark.parametrize("B,H,W,C", DW_SHAPES[:6])
@@ -531,51 +527,6 @@ def test_gemm_bf16nt_two_segment_weight_gradient(ops, M, N, K1, K2):
     assert relerr(D, 2 * ref) < 2e-5
 
 
-@pytest.mark.parametrize("ar,br", [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(512, 768, 1024), (264, 776, 200), (2304, 2048, 448), (4096, 4096, 1024)])
-def test_gemm_bf16_pingpong_schedule(ops, M, N, K, ar, br):
-    """The opt-in 256x256 ping-pong schedule (gemm_bf16pp.h, tile code 20): every operand layout, ragged edges,
-    a K tail, and the fused epilogues, against float64; repeated launches must agree bit for bit (the schedule
-    synchronises its LDS-DMA by counted waits and raw barriers: a race would show as run-to-run differences)."""
-    from _native import lib
-    gen = torch.Generator().manual_seed(M + N + K + ar + 2 * br)
-    A = torch.randn((K, M) if ar else (M, K), generator=gen).bfloat16().cuda()
-    B = torch.randn((K, N) if br else (N, K), generator=gen).bfloat16().cuda()
-    bias, R1 = torch.randn(N, generator=gen).cuda(), torch.randn((M, N), generator=gen).cuda()
-    Ad = (A.double().t() if ar else A.double())
-    Bd = (B.double() if br else B.double().t())
-    ref = (Ad @ Bd).cpu()
-    try:
-        assert lib().sei_debug_set_nt_tile(20) == 0
-        outs = []
-        for _ in range(3):
-            out = torch.full((M, N), float("nan"), device="cuda")
-            ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out32=out, a_rmajor=bool(ar), b_rmajor=bool(br))
-            torch.cuda.synchronize()
-            outs.append(out)
-        assert relerr(outs[0], ref) < 2e-5
-        if K < 512 or M * N >= 256 * 256 * 256:      # launches that do not split K (no float atomics)
-            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-        # bias + residual, GELU pair (f32 + bf16), GELU' product with a bf16 output, accumulate
-        out = torch.empty((M, N), device="cuda")
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_RES, out32=out, bias=bias, R1=R1, a_rmajor=bool(ar), b_rmajor=bool(br))
-        assert relerr(out, ref + bias.double().cpu() + R1.double().cpu()) < 2e-5
-        h3, h4 = torch.empty((M, N), device="cuda"), torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_GELU, out32=h3, bias=bias, D2_16=h4, a_rmajor=bool(ar), b_rmajor=bool(br))
-        pre = ref + bias.double().cpu()
-        assert relerr(h3, pre) < 2e-5 and relerr(h4.float(), F.gelu(pre)) < 1e-2
-        g16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_MUL_DGELU, out16=g16, R1=R1, a_rmajor=bool(ar), b_rmajor=bool(br))
-        x = R1.double().cpu().requires_grad_(True)
-        dg, = torch.autograd.grad(F.gelu(x).sum(), x)
-        assert relerr(g16.float(), ref * dg) < 1e-2
-        acc = R1.clone()
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_ACCUM, out32=acc, a_rmajor=bool(ar), b_rmajor=bool(br))
-        assert relerr(acc, ref + R1.double().cpu()) < 2e-5
-    finally:
-        lib().sei_debug_set_nt_tile(0)
-
-
 @pytest.mark.parametrize("br", [0, 1])
 @pytest.mark.parametrize("code", [30, 31, 32, 33])
 @pytest.mark.parametrize("M,N,K", [(576, 512, 256), (300, 520, 328), (2304, 2048, 2048), (288, 1024, 4096), (1000, 128, 32)])
@@ -583,47 +534,42 @@ def test_gemm_bf16_quadrant_schedule(ops, M, N, K, code, br):
     """The quadrant schedule (gemm_bf16pq.h; tile codes 30-33 = 256/288 rows x 256/128 columns): ragged row and
     column edges, a K that is not a multiple of the k-tile (also a single partial k-tile), split K, every fused epilogue, against float64; launches that do not split K must agree bit
     for bit run to run (the schedule orders its LDS-DMA by counted waits and raw barriers only)."""
-    from _native import lib
     gen = torch.Generator().manual_seed(M + N + K + code + br)
-    kw = dict(b_rmajor=bool(br))
+    kw = dict(b_rmajor=bool(br), tile=code)
     A = torch.randn((M, K), generator=gen).bfloat16().cuda()
     B = torch.randn((K, N) if br else (N, K), generator=gen).bfloat16().cuda()
     bias, R1 = torch.randn(N, generator=gen).cuda(), torch.randn((M, N), generator=gen).cuda()
     R2, rs = torch.randn((M, N), generator=gen).cuda(), torch.randn(M, generator=gen).cuda()
     ref = (A.double() @ (B.double() if br else B.double().t())).cpu()
-    try:
-        assert lib().sei_debug_set_nt_tile(code) == 0
-        outs = []
-        for _ in range(3):
-            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
-            ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out16=out, **kw)            # bf16 output: never split
-            torch.cuda.synchronize()
-            outs.append(out)
-        assert relerr(outs[0].float(), ref) < 1e-2
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-        out = torch.full((M, N), float("nan"), device="cuda")
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out32=out, **kw)                 # f32 output: may split K
-        assert relerr(out, ref) < 2e-5
-        out = torch.empty((M, N), device="cuda")
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_RES, out32=out, bias=bias, R1=R1, R2=R2, **kw)
-        assert relerr(out, ref + bias.double().cpu() + R1.double().cpu() + R2.double().cpu()) < 2e-5
-        h3, h4 = torch.empty((M, N), device="cuda"), torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_GELU, out32=h3, bias=bias, D2_16=h4, **kw)
-        pre = ref + bias.double().cpu()
-        assert relerr(h3, pre) < 2e-5 and relerr(h4.float(), F.gelu(pre)) < 1e-2
-        g16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_MUL_DGELU, out16=g16, R1=R1, **kw)
-        x = R1.double().cpu().requires_grad_(True)
-        dg, = torch.autograd.grad(F.gelu(x).sum(), x)
-        assert relerr(g16.float(), ref * dg) < 1e-2
-        acc = R1.clone()
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_ACCUM, out32=acc, **kw)
-        assert relerr(acc, ref + R1.double().cpu()) < 2e-5
-        out = torch.empty((M, N), device="cuda")
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_ROWSCALE, out32=out, bias=bias, R1=rs, **kw)
-        assert relerr(out, ref + rs.double().cpu()[:, None] * bias.double().cpu()[None, :]) < 2e-5
-    finally:
-        lib().sei_debug_set_nt_tile(0)
+    outs = []
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out16=out, **kw)            # bf16 output: never split
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert relerr(outs[0].float(), ref) < 1e-2
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out32=out, **kw)                 # f32 output: may split K
+    assert relerr(out, ref) < 2e-5
+    out = torch.empty((M, N), device="cuda")
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_RES, out32=out, bias=bias, R1=R1, R2=R2, **kw)
+    assert relerr(out, ref + bias.double().cpu() + R1.double().cpu() + R2.double().cpu()) < 2e-5
+    h3, h4 = torch.empty((M, N), device="cuda"), torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_GELU, out32=h3, bias=bias, D2_16=h4, **kw)
+    pre = ref + bias.double().cpu()
+    assert relerr(h3, pre) < 2e-5 and relerr(h4.float(), F.gelu(pre)) < 1e-2
+    g16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_MUL_DGELU, out16=g16, R1=R1, **kw)
+    x = R1.double().cpu().requires_grad_(True)
+    dg, = torch.autograd.grad(F.gelu(x).sum(), x)
+    assert relerr(g16.float(), ref * dg) < 1e-2
+    acc = R1.clone()
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_ACCUM, out32=acc, **kw)
+    assert relerr(acc, ref + R1.double().cpu()) < 2e-5
+    out = torch.empty((M, N), device="cuda")
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_ROWSCALE, out32=out, bias=bias, R1=rs, **kw)
+    assert relerr(out, ref + rs.double().cpu()[:, None] * bias.double().cpu()[None, :]) < 2e-5
 
 
 @pytest.mark.parametrize("M,N,K,kind", [
@@ -680,30 +626,25 @@ def test_gemm_bf16_full_size_layers_on_the_automatic_dispatch(ops, M, N, K, kind
 def test_gemm_bf16_quadrant_schedule_weight_gradient(ops, M, N, K, code):
     """Quadrant schedule with both operands reduction-major (the weight gradient): ragged edges, a K that is not
     a multiple of the k-tile (zero rows past the end), store and accumulate, bit-stable without split K."""
-    from _native import lib
     gen = torch.Generator().manual_seed(M + N + K + code)
     A = torch.randn((K, M), generator=gen).bfloat16().cuda()
     B = torch.randn((K, N), generator=gen).bfloat16().cuda()
     R1 = torch.randn((M, N), generator=gen).cuda()
     ref = (A.double().t() @ B.double()).cpu()
-    try:
-        assert lib().sei_debug_set_nt_tile(code) == 0
-        outs = []
-        for _ in range(3):
-            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
-            ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out16=out, a_rmajor=True, b_rmajor=True)
-            torch.cuda.synchronize()
-            outs.append(out)
-        assert relerr(outs[0].float(), ref) < 1e-2
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-        out = torch.full((M, N), float("nan"), device="cuda")
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out32=out, a_rmajor=True, b_rmajor=True)
-        assert relerr(out, ref) < 2e-5
-        acc = R1.clone()
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_ACCUM, out32=acc, a_rmajor=True, b_rmajor=True)
-        assert relerr(acc, ref + R1.double().cpu()) < 2e-5
-    finally:
-        lib().sei_debug_set_nt_tile(0)
+    outs = []
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out16=out, a_rmajor=True, b_rmajor=True, tile=code)
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert relerr(outs[0].float(), ref) < 1e-2
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out32=out, a_rmajor=True, b_rmajor=True, tile=code)
+    assert relerr(out, ref) < 2e-5
+    acc = R1.clone()
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_ACCUM, out32=acc, a_rmajor=True, b_rmajor=True, tile=code)
+    assert relerr(acc, ref + R1.double().cpu()) < 2e-5
 
 
 @pytest.mark.parametrize("M,N,K", [(2304, 8192, 2048), (300, 520, 72)])

@@ -1,6 +1,8 @@
 """Ablations of the 256x256 ping-pong kernel (timing only): which of fragment reads / DMA / barriers costs what."""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scale-equivariant-imaging_amd"))
+sys.path.insert(1, os.path.dirname(os.path.abspath(__file__)))
+import _tuning; _tuning.use()    # process-wide tile switches live in the tools-only build
 from models import _ops
 import _native
 NAMES = {0: "auto", 20: "pp", 21: "-reads", 22: "-dma", 23: "-reads-dma", 24: "-bar", 25: "-reads-bar", 26: "-dma-bar", 27: "mfma only"}

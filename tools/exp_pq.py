@@ -2,6 +2,8 @@
 with the epilogues the model uses: interleaved rounds in one process, median times."""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scale-equivariant-imaging_amd"))
+sys.path.insert(1, os.path.dirname(os.path.abspath(__file__)))
+import _tuning; _tuning.use()    # process-wide tile switches live in the tools-only build
 from models import _ops
 import _native
 NAMES = {0: "auto", 30: "256x256", 31: "288x256", 32: "288x128", 33: "256x128", 34: "256^2-dma", 35: "256^2 mfma"}

@@ -1,5 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scale-equivariant-imaging_amd"))
+sys.path.insert(1, os.path.dirname(os.path.abspath(__file__)))
+import _tuning; _tuning.use()    # process-wide tile switches live in the tools-only build
 from models import _ops
 import _native
 def timeit(fn, iters=8):

@@ -2,6 +2,8 @@
 the rows padded by 64 / 256 elements (lda / ldb arguments), quadrant schedule (30) and 128x128 loop (0)."""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scale-equivariant-imaging_amd"))
+sys.path.insert(1, os.path.dirname(os.path.abspath(__file__)))
+import _tuning; _tuning.use()    # process-wide tile switches live in the tools-only build
 import _native
 from _native import call
 def once(fn, iters=4):

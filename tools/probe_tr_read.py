@@ -1,6 +1,8 @@
 """Print what ds_read_b64_tr_b16 returns (lane -> 4 elements) for a known LDS image."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scale-equivariant-imaging_amd"))
+sys.path.insert(1, os.path.dirname(os.path.abspath(__file__)))
+import _tuning; _tuning.use()    # process-wide tile switches live in the tools-only build
 import _native as N
 img = (torch.arange(64).view(64, 1) * 128 + torch.arange(128).view(1, 128)).to(torch.int16).cuda()
 out = torch.zeros(64 * 4, dtype=torch.int16, device="cuda")

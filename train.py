@@ -7,7 +7,12 @@
 Same flags, defaults, epoch loop, csv log and checkpoint files as the reference; the arithmetic of the
 step runs in libsei_hip.so. Differences, all build-side and documented in DESIGN.md:
   * multi-GPU = one process per GPU (`python -m torch.distributed.run --nproc-per-node N train.py ...`),
-    gradients summed over RCCL; `--data_parallel_devices` is refused.
+    gradients summed over RCCL; `--data_parallel_devices 0,1,..` (the reference's single-process
+    nn.DataParallel) stops with the equivalent launch command. `--batch_size` is PER PROCESS: the reference's
+    DataParallel splits one batch over the devices, here every rank draws its own batch, so the global batch
+    is world x batch_size (pass batch_size / world to keep the reference's global batch and learning rate).
+  * `--grad_comm_dtype bf16` halves the bytes of the gradient exchange (summed in bf16 across ranks; the
+    default f32 keeps the exchange exact whatever the compute dtype).
   * `--fused_optimizer` (default on for Adam): one fused Adam kernel over the flat parameter bucket.
   * `--fix_batched_crop`: opt out of the reference's batched-crop padding quirk (crop.py).
   * the per-step `.item()` host sync of the reference is replaced by a device-side running mean.
@@ -25,6 +30,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scale-equivariant-imaging_amd"))
 
 import crop  # noqa: E402
+import graphs  # noqa: E402
 import parallel  # noqa: E402
 from datasets import get_dataset  # noqa: E402
 from losses import get_loss  # noqa: E402
@@ -76,6 +82,12 @@ def build_parser():
     flag("--compute_dtype", choices=["f32", "bf16"], default="f32",
          help="1x1-conv GEMM arithmetic: f32 (reference precision) or bf16 MFMA with f32 accumulation")
     flag("--hip_graph", default=True, **onoff)
+    flag("--grad_comm_dtype", choices=["f32", "bf16"], default="f32",
+         help="dtype of the all-reduced gradient bucket under torch.distributed.run: f32 (exact sum, default) or "
+              "bf16 (half the xGMI bytes; the sum runs in bf16, its rounding grows with the number of ranks; "
+              "needs --fused_optimizer)")
+    flag("--grad_comm_mode", choices=["all_reduce", "rs_ag"], default="all_reduce",
+         help="gradient exchange: chunked all-reduce, or reduce-scatter + all-gather of each chunk (parallel.py)")
     flag("--device_cache", default=False, **onoff,
          help="keep every (x, y) training pair in HBM (deterministic measurements) and draw crops on the device "
               "instead of the per-item DataLoader path (datasets/device_cache.py)")
@@ -143,8 +155,11 @@ def main(argv=None):
     from models import _ops as model_ops
     model_ops.set_compute_dtype(args.compute_dtype)
     fused_adam = optimizer_kind == "Adam" and args.fused_optimizer
-    comm_dtype = torch.bfloat16 if (args.compute_dtype == "bf16" and fused_adam) else torch.float32
-    reducer = parallel.FlatGradientReducer(backbone.flat_grads, comm_dtype=comm_dtype) if world > 1 else None
+    if args.grad_comm_dtype == "bf16" and not fused_adam:
+        raise ValueError("--grad_comm_dtype bf16 needs the fused Adam (it reads the bf16 bucket directly)")
+    comm_dtype = torch.bfloat16 if args.grad_comm_dtype == "bf16" else torch.float32
+    reducer = parallel.FlatGradientReducer(backbone.flat_grads, comm_dtype=comm_dtype,
+                                           mode=args.grad_comm_mode) if world > 1 else None
     if optimizer_kind == "Adam" and args.fused_optimizer:
         optimizer = FlatAdam(model, lr=lr, betas=(0.9, args.optimizer_beta2), reducer=reducer)
     elif optimizer_kind == "Adam":
@@ -188,6 +203,7 @@ def main(argv=None):
                             state_path=checkpoint_name(0))
 
     graphed, early_event = None, None
+    trace_step_kind = rank == 0 and os.environ.get("SEI_TRACE_STEP_KIND") == "1"
     for epoch in range(epochs):
         if sampler is not None:
             sampler.set_epoch(epoch)
@@ -197,7 +213,7 @@ def main(argv=None):
         for x, y in batches:
             x, y = x.to(args.device), y.to(args.device)
             used_graph = False
-            can_graph = (args.hip_graph and isinstance(optimizer, FlatAdam) and loss.crop_fn is not None
+            can_graph = (args.hip_graph and isinstance(optimizer, FlatAdam) and graphs.can_capture(loss)
                          and y.shape[0] == args.batch_size)
             if can_graph:
                 if graphed is None:                   # capture once; short last batches run eagerly
@@ -215,6 +231,9 @@ def main(argv=None):
                 optimizer.zero_grad()
                 training_loss = loss(x=x, y=y, model=model)
                 training_loss.backward()
+            if trace_step_kind:                       # tests: which launch path the first step took
+                print("step kind: hipGraph replay" if used_graph else "step kind: eager")
+                trace_step_kind = False
             if reducer is not None:
                 reducer.reduce_async(early=early_event if used_graph else None)
                 if not isinstance(optimizer, FlatAdam):
