@@ -475,8 +475,12 @@ def _launch_weight_grad_inner(grad2d, pairs, store):
                        x1.data_ptr(), x2.data_ptr(), Kp, grad2d.data_ptr(), Np, Kp, K1, K2, 0 if store else 1)
             return
     for gy16, x16 in pairs:
-        gemm_nt16(gy16, x16, Np, Kp, gy16.shape[0], EPI_NONE if store else EPI_ACCUM, out32=grad2d, a_rmajor=True,
-                  b_rmajor=True)
+        rows = gy16.shape[0]
+        if rows % 8 == 0:
+            gemm_nt16(gy16, x16, Np, Kp, rows, EPI_NONE if store else EPI_ACCUM, out32=grad2d, a_rmajor=True,
+                      b_rmajor=True)
+        else:       # a pixel count the LDS-DMA kernel cannot chunk (e.g. 9 bottleneck pixels x batch 2): staged kernel
+            gemm_mixed(gy16, x16, Np, Kp, rows, 1, 0, EPI_NONE if store else EPI_ACCUM, out=grad2d)
         store = False
 
 

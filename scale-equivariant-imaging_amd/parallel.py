@@ -117,7 +117,7 @@ class FlatGradientReducer:
             if share is None or share.numel() != (e - s) // world:
                 share = self._shards[k] = torch.empty((e - s) // world, dtype=chunk.dtype, device=chunk.device)
             rs = dist.reduce_scatter_tensor(share, chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            if not chunk.is_cuda:
+            if dist.get_backend(self.group) != "nccl":
                 rs.wait()             # gloo runs async work on a thread pool: order the two halves by hand
             # (RCCL: both collectives are enqueued on the process group's stream, in this order)
             self._work[k] = dist.all_gather_into_tensor(chunk, share, group=self.group, async_op=True)

@@ -404,13 +404,13 @@ def test_train_script_methods_and_transforms(tmp_path, flags, graphed):
     out = tmp_path / "run"
     cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--device", "cuda", "--task", "deblurring", "--kernel",
            "Gaussian_R2", "--ProposedModel__architecture", "Convolutional", "--ConvolutionalModel__hidden_channels",
-           "8", "--ConvolutionalModel__scales", "3", "--dataset", "synthetic", "--batch_size", "2", "--epochs", "2",
-           "--max_steps", "3", "--out_dir", str(out)] + flags
+           "8", "--ConvolutionalModel__scales", "3", "--dataset", "synthetic", "--batch_size", "2", "--epochs", "4",
+           "--max_steps", "2", "--out_dir", str(out)] + flags
     env = dict(os.environ, SEI_TRACE_STEP_KIND="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     rows = open(out / "training.csv").read().strip().splitlines()
-    assert len(rows) == 3 and all(np.isfinite(float(r_.split(",")[1])) for r_ in rows[1:])
+    assert len(rows) == 5 and all(np.isfinite(float(r_.split(",")[1])) for r_ in rows[1:])
     assert ("step kind: hipGraph replay" in r.stdout) == graphed, r.stdout
     assert ("step kind: eager" in r.stdout) == (not graphed), r.stdout
 
