@@ -190,6 +190,8 @@ int sei_ln_bwd(const float *x, const float *gamma, const float *mean, const floa
 #define SEI_EPI_MUL_DGELU 4       /* D = acc * gelu'(R1)                                      */
 #define SEI_EPI_ACCUM 5           /* D += acc   (gradient accumulation)                       */
 #define SEI_EPI_BIAS_ROWSCALE 6   /* D = acc + bias[n]*R1[m]                                  */
+#define SEI_EPI_BIAS_SCALE_RES 7  /* D = R2 + R1[m]*(acc + bias[n])  (stochastic depth: one factor per row; sei_gemm_f32[_ex],
+                                     sei_gemm_bf16_ex / _mixed only)                          */
 int sei_gemm_f32(const float *A, const float *B, float *D, int M, int N, int K, int transA,
                  int transB, int epilogue, const float *bias, const float *R1, const float *R2,
                  float *D2, void *stream);
@@ -289,6 +291,33 @@ int sei_colsum_f32(const float *X, float *out, size_t M, int N, void *stream);
  * downsampler (models/_ops.py, DownsampleFn: the bias enters as bias[n] * s[m], s = the resampler's response
  * to a constant image). */
 int sei_colsum_weighted_f32(const float *X, const float *row_weight, float *out, size_t M, int N, void *stream);
+
+/* ---- SwinIR building blocks (csrc/swin_kernels.hip; reference: deepinv.models.SwinIR as configured at
+ * src/models/__init__.py:51-74 = the official SwinIR network_swinir.py; parity unpinned, see oracle/swinir_path.py).
+ *
+ * sei_swin_attn_fwd: WindowAttention.forward for every 8x8 window and head of a batch of B images of HxW tokens
+ * (H, W multiples of 8). qkv (B*H*W, 3*heads*head_dim) = the qkv projection of the tokens in natural (b, y, x)
+ * order; out (B*H*W, heads*head_dim) in the same order. The cyclic shift by `shift` (torch.roll of
+ * SwinTransformerBlock.forward), window_partition / window_reverse, the relative-position bias
+ * (table ((2*8-1)^2, heads), index computed in-kernel) and the -100 mask of shifted windows are index arithmetic
+ * inside the kernel. scale = head_dim^-0.5 (applied to q first, as the reference). head_dim 30 (SwinIR), 32, 16, 8.
+ * sei_swin_attn_bwd: dqkv (every element written) and dtable (+=, float atomics) from dout; the probabilities are
+ * recomputed from qkv. */
+int sei_swin_attn_fwd(const float *qkv, const float *table, float *out, int B, int H, int W, int heads,
+                      int head_dim, int shift, float scale, void *stream);
+int sei_swin_attn_bwd(const float *qkv, const float *table, const float *dout, float *dqkv, float *dtable,
+                      int B, int H, int W, int heads, int head_dim, int shift, float scale, void *stream);
+/* Padded-grid form of an NHWC batch for the 3x3 convolutions with many channels (RSTB.conv, conv_after_body,
+ * conv_before_upsample, upsample.*): xp = guard_rows zero rows of C floats, then (B, H+2, W+2, C) with a zero
+ * border, then guard_rows zero rows. On that grid the convolution is nine row-shifted GEMMs over the same flat
+ * array (row offset dy*(W+2)+dx), with no im2col buffer. sei_unpad_nhwc takes the interior of a (B, H+2, W+2, C)
+ * result back to (B, H, W, C), applies LeakyReLU(0.01) when act = 1, then adds `res` when non-NULL. C % 4 == 0. */
+int sei_pad_nhwc(const float *x, float *xp, int B, int H, int W, int C, int guard_rows, void *stream);
+int sei_unpad_nhwc(const float *xp, const float *res, float *y, int B, int H, int W, int C, int act, void *stream);
+/* y[m, n] = row_scale[m] * x[m, n] (row_scale may be NULL = 1), times 1 or 0.01 by the sign of leaky_gate[m, n]
+ * when leaky_gate is non-NULL: the backward of stochastic depth (timm DropPath) and of LeakyReLU. N % 4 == 0. */
+int sei_rowscale(const float *x, const float *row_scale, const float *leaky_gate, float *y, size_t M, int N,
+                 void *stream);
 
 int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, float *exp_avg, float *exp_avg_sq,
                    size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

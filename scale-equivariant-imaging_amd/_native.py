@@ -61,6 +61,11 @@ SIGNATURES = {
     "sei_sepmap2_packed": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P],
     "sei_colsum_f32": [_P, _P, _Z, _I, _P],
     "sei_colsum_weighted_f32": [_P, _P, _P, _Z, _I, _P],
+    "sei_swin_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "sei_swin_attn_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "sei_pad_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "sei_unpad_nhwc": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sei_rowscale": [_P, _P, _P, _P, _Z, _I, _P],
     "sei_adam_fused": [_P, _P, _I, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P, _P],
 }
 

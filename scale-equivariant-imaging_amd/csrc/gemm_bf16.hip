@@ -244,7 +244,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_kernel(GemmArgs g) {
             const int col = n0 + wn * (32 * TN) + 32 * j + li;
             if (col >= N) continue;
             const float bias = (epi == SEI_EPI_BIAS || epi == SEI_EPI_BIAS_GELU || epi == SEI_EPI_BIAS_RES ||
-                                epi == SEI_EPI_BIAS_ROWSCALE) ? g.bias[col] : 0.f;
+                                epi == SEI_EPI_BIAS_ROWSCALE || epi == SEI_EPI_BIAS_SCALE_RES) ? g.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -269,6 +269,7 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_bf16_kernel(GemmArgs g) {
                     case SEI_EPI_MUL_DGELU: v *= sei_dgelu(g.R1[o]); break;
                     case SEI_EPI_ACCUM: v += D[o]; break;
                     case SEI_EPI_BIAS_ROWSCALE: v += bias * g.R1[row]; break;
+                    case SEI_EPI_BIAS_SCALE_RES: v = g.R2[o] + g.R1[row] * (v + bias); break;
                     default: break;
                 }
                 D[o] = v;
@@ -312,13 +313,15 @@ extern "C" int sei_gemm_bf16_mixed(const void *A, int a_is_bf16, const void *B, 
                                    const float *R1, const float *R2, float *D2, int batch, long long strideA,
                                    long long strideB, long long strideD, int allow_splitk, void *stream) {
     SEI_REQUIRE(A && B && D && M > 0 && N > 0 && K > 0 && batch > 0);
-    SEI_REQUIRE(epilogue >= SEI_EPI_NONE && epilogue <= SEI_EPI_BIAS_ROWSCALE);
+    SEI_REQUIRE(epilogue >= SEI_EPI_NONE && epilogue <= SEI_EPI_BIAS_SCALE_RES);
     if (epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU || epilogue == SEI_EPI_BIAS_RES ||
-        epilogue == SEI_EPI_BIAS_ROWSCALE)
+        epilogue == SEI_EPI_BIAS_ROWSCALE || epilogue == SEI_EPI_BIAS_SCALE_RES)
         SEI_REQUIRE(bias);
     if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D2);
-    if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_BIAS_ROWSCALE)
+    if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_BIAS_ROWSCALE ||
+        epilogue == SEI_EPI_BIAS_SCALE_RES)
         SEI_REQUIRE(R1);
+    if (epilogue == SEI_EPI_BIAS_SCALE_RES) SEI_REQUIRE(R2);
     GemmArgs g;
     g.A = A; g.B = B; g.D = D; g.M = M; g.N = N; g.K = K; g.epilogue = epilogue;
     g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2 = D2;

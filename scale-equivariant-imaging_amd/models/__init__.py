@@ -4,14 +4,19 @@
 with `get_backbone() / get_weights() / load_weights()` working on the backbone's state_dict exactly as
 the reference's (same keys), so checkpoints interchange.
 
-In scope this round: kind "Proposed" with architecture "Convolutional" (the in-tree U-Net) and the
-trivial "Identity". The reference's default architecture "Transformer" is deepinv's SwinIR, which is
-not part of the reference tree; it and the test-time baselines (DIP, PnP, BM3D, DiffPIR, DPS, TV, ...)
+In scope: kind "Proposed" with architecture "Convolutional" (the in-tree U-Net) or "Transformer" (the
+reference's default: deepinv's SwinIR with the arguments at src/models/__init__.py:51-74, rebuilt in
+models/swinir.py from the published architecture -- deepinv is not part of the reference tree, parity
+unpinned), and the trivial "Identity". The test-time baselines (DIP, PnP, BM3D, DiffPIR, DPS, TV, ...)
 raise a clear error instead of silently running something else.
 """
+from os import environ
+
+from torch import nn
 from torch.nn import Module
 
 from .convolutional import ConvolutionalModel
+from .swinir import SwinIR
 
 _OUT_OF_SCOPE = ("DeepImagePrior", "PlugAndPlay", "BM3D", "DiffPIR_DRUNet", "DiffPIR_DiffUNet", "DPS", "TV",
                  "InverseFilter", "Upsample")
@@ -29,15 +34,23 @@ class ProposedModel(Module):
             self.model = ConvolutionalModel(in_channels=3, upsampling_rate=sampling_rate,
                                             **blueprint[ConvolutionalModel.__name__])
         elif architecture == "Transformer":
-            raise NotImplementedError(
-                "--ProposedModel__architecture Transformer is deepinv's SwinIR (not vendored by the "
-                "reference); this build implements the in-tree U-Net: pass "
-                "--ProposedModel__architecture Convolutional")
+            if sampling_rate > 1:
+                upsampling_rate, upsampler = sampling_rate, "pixelshuffle"
+                if "HOMOGENEOUS_SWINIR" in environ:                 # reference :43-47
+                    print("\nUsing homogeneous SwinIR\n")
+                    upsampling_rate, upsampler = 1, None
+            else:
+                upsampling_rate, upsampler = 1, None
+            self.model = SwinIR(upscale=upsampling_rate, upsampler=upsampler, img_size=48, patch_size=1, in_chans=3,
+                                embed_dim=180, depths=[6, 6, 6, 6, 6, 6], num_heads=[6, 6, 6, 6, 6, 6], window_size=8,
+                                mlp_ratio=2, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                                drop_path_rate=0.1, norm_layer=nn.LayerNorm, ape=False, patch_norm=True,
+                                use_checkpoint=False, img_range=1.0, resi_connection="1conv", pretrained=None)
         else:
             raise ValueError(f"Unknown model kind: {architecture}")
 
-    def forward(self, y):
-        return self.model(y)
+    def forward(self, y, **kwargs):
+        return self.model(y, **kwargs)
 
     def get_backbone(self):
         return self.model
@@ -69,8 +82,10 @@ class Model(Module):
                 f"--master-addr 127.0.0.1 train.py <the same flags without --data_parallel_devices> "
                 f"--batch_size <batch_size / {n}>")
 
-    def forward(self, x, *args):
-        return self.model(x)
+    def forward(self, x, *args, **kwargs):
+        """Extra positional arguments are ignored, as upstream (:148-149); keyword arguments (the SwinIR backbone's
+        injected stochastic-depth masks) go to the backbone."""
+        return self.model(x, **kwargs)
 
     def get_backbone(self):
         model = self.model

@@ -402,3 +402,35 @@ def test_dataset_wrappers_follow_the_reference(tmp_path):
         datasets.get_dataset(args, "train", phys, "cpu")
     with pytest.raises(ValueError):
         datasets.get_dataset(args, "validate", phys, "cpu")
+
+
+# ------------------------------------------------------------------ SwinIR (host side; parity unpinned, see the oracle)
+def test_swinir_module_tree_matches_the_published_layout():
+    """Parameter / buffer names, shapes and counts of the official SwinIR for the reference's constructor arguments
+    (src/models/__init__.py:51-74): 11,504,163 parameters (deblurring), 11,752,487 (x2), 11,900,199 (x4); the oracle's
+    functional state_dict has the same parameter keys; the mask buffer equals the oracle's shift mask."""
+    from models.swinir import SwinIR
+    from oracle import swinir_path as sp
+    for up, count in ((1, 11_504_163), (2, 11_752_487), (4, 11_900_199)):
+        torch.manual_seed(0)
+        m = SwinIR(upscale=up, upsampler="pixelshuffle" if up > 1 else None)
+        assert sum(p.numel() for p in m.parameters()) == count
+        names = {k for k, _ in m.named_parameters()}
+        ref = sp.swinir_init_state_dict(up)
+        assert names == set(ref) and all(tuple(ref[k].shape) == tuple(m.state_dict()[k].shape) for k in ref)
+    sd = m.state_dict()
+    assert "layers.0.residual_group.blocks.0.attn_mask" not in sd
+    assert torch.equal(sd["layers.0.residual_group.blocks.1.attn_mask"], sp.shift_mask(48, 48))
+    assert torch.equal(sd["layers.5.residual_group.blocks.5.attn.relative_position_index"], sp.relative_position_index())
+    rates = [b.drop_path_rate for b in m.blocks()]
+    assert rates[0] == 0.0 and abs(rates[-1] - 0.1) < 1e-7 and np.allclose(rates, sp.drop_path_rates(), atol=1e-7)
+    # Linear weights are re-initialised by trunc_normal(std 0.02), LayerNorm to (1, 0), as upstream's _init_weights
+    w = sd["layers.2.residual_group.blocks.3.mlp.fc1.weight"]
+    assert 0.015 < float(w.std()) < 0.025 and float(w.abs().max()) <= 2.0
+    assert float(sd["norm.weight"].min()) == 1.0 and float(sd["layers.0.residual_group.blocks.0.attn.qkv.bias"].abs().max()) == 0.0
+    m.eval()
+    assert m.draw_drop_masks(4, "cpu") is None
+    m.train()
+    masks = m.draw_drop_masks(4, "cpu")
+    assert masks[0] is None and len(masks) == 36
+    assert all(abs(v) < 1e-6 or abs(v - 1 / 0.9) < 1e-5 for v in masks[-1][0].tolist())

@@ -1,0 +1,155 @@
+"""SwinIR backbone (BASELINE configs[4]) on the GPU against oracle/swinir_path.py.
+
+PARITY UNPINNED: deepinv / timm are absent and the reference holds no SwinIR fixtures, so the oracle is a
+restatement of the published architecture (see its header); these tests pin the HIP path to that restatement:
+float32 forward <= 1e-4, gradients <= 1e-3 (the bar VERDICT r1 set)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import swinir_path as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double().numpy()
+    b = b.detach().cpu().double().numpy()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _attention_reference(qkv, table, B, H, W, heads, shift):
+    """WindowAttention on natural-order tokens by the reference's own steps: roll, window_partition, bias lookup,
+    mask, softmax, window_reverse, roll back (float64)."""
+    C = qkv.shape[1] // 3
+    x = qkv.view(B, H, W, 3 * C)
+    if shift:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    xw = sp.window_partition(x, 8).view(-1, 64, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = xw[0] * (C // heads) ** -0.5, xw[1], xw[2]
+    attn = q @ k.transpose(-2, -1)
+    idx = sp.relative_position_index(8)
+    attn = attn + table[idx.view(-1)].view(64, 64, -1).permute(2, 0, 1).unsqueeze(0)
+    if shift:
+        mask = sp.shift_mask(H, W, 8, shift).to(attn.dtype)
+        nW = mask.shape[0]
+        attn = (attn.view(-1, nW, heads, 64, 64) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, 64, 64)
+    out = (attn.softmax(-1) @ v).transpose(1, 2).reshape(-1, 8, 8, C)
+    out = sp.window_reverse(out, 8, H, W)
+    if shift:
+        out = torch.roll(out, shifts=(shift, shift), dims=(1, 2))
+    return out.reshape(B * H * W, C)
+
+
+@pytest.mark.parametrize("shift", [0, 4])
+@pytest.mark.parametrize("B,H,W,heads,hd", [(2, 16, 16, 6, 30), (1, 24, 16, 3, 32), (3, 48, 48, 6, 30)])
+def test_window_attention_fwd_bwd(B, H, W, heads, hd, shift):
+    from models import _swin_ops as S
+    gen = torch.Generator().manual_seed(B + H + shift)
+    C = heads * hd
+    qkv = torch.randn((B * H * W, 3 * C), generator=gen)
+    table = torch.randn((225, heads), generator=gen) * 0.5
+    go = torch.randn((B * H * W, C), generator=gen)
+    qd, td = qkv.double().requires_grad_(True), table.double().requires_grad_(True)
+    ref = _attention_reference(qd, td, B, H, W, heads, shift)
+    rq, rt = torch.autograd.grad(ref, [qd, td], go.double())
+    out = S.window_attention(qkv.cuda(), table.cuda(), B, H, W, heads, shift)
+    assert relerr(out, ref) < 5e-6
+    dtable = torch.zeros_like(table).cuda()
+    dqkv = S.window_attention_bwd(qkv.cuda(), table.cuda(), go.cuda(), dtable, B, H, W, heads, shift)
+    assert relerr(dqkv, rq) < 2e-5 and relerr(dtable, rt) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,res", [(2, 16, 16, 180, 180, 0, True), (1, 8, 24, 180, 64, 1, False),
+                                                    (2, 12, 12, 64, 256, 0, False)])
+def test_conv3x3_on_the_padded_grid(B, H, W, Cin, Cout, act, res):
+    from models import _swin_ops as S
+    gen = torch.Generator().manual_seed(Cin + Cout + H)
+    x = torch.randn((B, H, W, Cin), generator=gen)
+    w = torch.randn((Cout, Cin, 3, 3), generator=gen) * (Cin * 9) ** -0.5
+    b = torch.randn(Cout, generator=gen)
+    r = torch.randn((B, H, W, Cout), generator=gen) if res else None
+    go = torch.randn((B, H, W, Cout), generator=gen)
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(xd.permute(0, 3, 1, 2), wd, bd, padding=1).permute(0, 2, 3, 1)
+    if act:
+        ref = F.leaky_relu(ref, 0.01)
+    if res:
+        ref = ref + r.double()
+    rx, rw, rb = torch.autograd.grad(ref, [xd, wd, bd], go.double())
+    xc = x.cuda().requires_grad_(True)
+    wc, bc = torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda())
+    rc = r.cuda().requires_grad_(True) if res else None
+    y = S.Conv3x3GemmFn.apply(xc, wc, bc, rc, act)
+    assert relerr(y, ref) < 5e-6
+    y.backward(go.cuda())
+    assert relerr(xc.grad, rx) < 1e-5 and relerr(wc.grad, rw) < 1e-5 and relerr(bc.grad, rb) < 1e-5
+    if res:
+        assert torch.equal(rc.grad.cpu(), go)
+
+
+def _load(model, sd):
+    own = model.state_dict()
+    model.load_state_dict({k: sd.get(k, own[k]) for k in own})        # buffers (index, mask) keep their own values
+
+
+@pytest.mark.parametrize("cfg", ["deblur_d22_train", "deblur_full_eval", "sr2_d2_train_ragged", "sr4_d2_eval"])
+def test_swinir_model_vs_oracle(cfg):
+    from models.swinir import SwinIR
+    depths = {"deblur_d22_train": (2, 2), "deblur_full_eval": (6,) * 6, "sr2_d2_train_ragged": (2,), "sr4_d2_eval": (2,)}[cfg]
+    up = {"deblur_d22_train": 1, "deblur_full_eval": 1, "sr2_d2_train_ragged": 2, "sr4_d2_eval": 4}[cfg]
+    train = "train" in cfg
+    shape = (2, 3, 20, 27) if "ragged" in cfg else ((2, 3, 48, 48) if "full" in cfg else (2, 3, 24, 32))
+    torch.manual_seed(3)
+    model = SwinIR(upscale=up, upsampler="pixelshuffle" if up > 1 else None, depths=depths, num_heads=(6,) * len(depths))
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items() if v.dtype.is_floating_point
+          and "attn_mask" not in k}
+    # make every parameter matter (LayerNorm / bias defaults are 1 / 0)
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for k, v in sd.items():
+            if k.endswith("bias") or "norm" in k:
+                v.add_(0.1 * torch.randn(v.shape, generator=gen))
+    _load(model, {k: v.detach() for k, v in sd.items()})
+    model = model.cuda()
+    model.train(train)
+    x = torch.rand(shape, generator=gen)
+    go = torch.randn((shape[0], 3, shape[2] * up, shape[3] * up), generator=gen)
+    masks = None
+    if train:
+        masks = sp.draw_drop_masks(shape[0], depths=depths, generator=gen)
+        assert masks[0] is None and masks[-1] is not None
+    ref = sp.swinir_forward(sd, x, upscale=up, drop_masks=masks, depths=depths)
+    ref.backward(go)
+    dev_masks = None if masks is None else [None if m is None else tuple(v.cuda() for v in m) for m in masks]
+    model.zero_grad_flat()
+    out = model(x.cuda(), drop_masks=dev_masks)
+    assert out.shape == ref.shape
+    assert relerr(out, ref) < 1e-4, relerr(out, ref)
+    out.backward(go.cuda())
+    worst = max((relerr(p.grad, sd[k].grad), k) for k, p in model.named_parameters())
+    assert worst[0] < 1e-3, worst
+
+
+def test_swinir_factory_and_training_mode_draws():
+    """get_model with the reference's default architecture builds the 11.5 M-parameter SwinIR; training-mode
+    forwards draw stochastic-depth masks (two calls differ), eval-mode forwards are deterministic."""
+    import bench
+    import models
+    import physics
+    args = bench.reference_args("cuda")
+    args.ProposedModel__architecture = "Transformer"
+    p = physics.get_physics(args, "cuda")
+    torch.manual_seed(0)
+    model = models.get_model(args, p, "cuda").to("cuda")
+    bb = model.get_backbone()
+    assert sum(q.numel() for q in bb.parameters()) == 11_504_163 and bb.flat_params is not None
+    assert model.get_parameter("model.model.conv_last.weight").shape == (3, 180, 3, 3)     # demo/train.py:180-184
+    y = torch.rand(2, 3, 48, 48, device="cuda")
+    model.train()
+    torch.cuda.manual_seed(1)
+    a, b = model(y), model(y)
+    assert not torch.equal(a, b)
+    model.eval()
+    assert torch.equal(model(y), model(y))
