@@ -38,10 +38,10 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 CROP, NOISE, KERNEL = 48, 5, "Gaussian_R2"
 
 
-def reference_args(device, hidden=32, scales=5, task="deblurring", sr_factor=None):
+def reference_args(device, hidden=32, scales=5, task="deblurring", sr_factor=None, arch="Convolutional"):
     return argparse.Namespace(
         device=device, task=task, kernel=KERNEL, sr_factor=sr_factor, noise_level=NOISE, physics_v2=True,
-        physics_true_adjoint=False, model_kind="Proposed", ProposedModel__architecture="Convolutional",
+        physics_true_adjoint=False, model_kind="Proposed", ProposedModel__architecture=arch,
         ConvolutionalModel__residual=True, ConvolutionalModel__inner_residual=True,
         ConvolutionalModel__num_conv_blocks=1, ConvolutionalModel__inout_convs=True,
         ConvolutionalModel__hidden_channels=hidden, ConvolutionalModel__scales=scales,
@@ -189,7 +189,8 @@ class Leg:
         from physics import get_physics
         self.opt, self.dtype, self.world = opt, dtype, world
         sr = opt.task == "sr"
-        args = reference_args(device, opt.hidden, opt.scales, opt.task, opt.sr_factor if sr else None)
+        args = reference_args(device, opt.hidden, opt.scales, opt.task, opt.sr_factor if sr else None,
+                              "Transformer" if opt.arch == "swinir" else "Convolutional")
         if opt.full256:
             args.Loss__crop_training_pairs = False
         _ops.set_compute_dtype(dtype)
@@ -298,8 +299,14 @@ def gemm_roofline(records, dtype, reps=3):
                 f.write(f"{entry} {ints} {us:.1f} us {fl / us / 1e6:.1f} TF\n")
     achieved = flops / (total_ms * 1e-3) / 1e12
     peak = MFMA_PEAK_TFLOPS[dtype]
-    kernels = ("gemm_bf16pq_kernel<*> (quadrant schedule, deep levels) + gemm_bf16nt_kernel<*> (128x128 loop, "
-               "everything else) + gemm_bf16_kernel<*> (K<64 layers)" if dtype == "bf16" else "gemm_f32_kernel<*>")
+    names = sorted({entry for _, entry, _ in records})
+    if names == ["sei_gemm_bf16_ex"]:
+        kernels = "gemm_bf16_kernel<*> (register-staged bf16 MFMA, f32 operands in HBM)"
+    elif dtype == "bf16":
+        kernels = ("gemm_bf16pq_kernel<*> (quadrant schedule, deep levels) + gemm_bf16nt_kernel<*> (128x128 loop, "
+                   "everything else) + gemm_bf16_kernel<*> (K<64 layers)")
+    else:
+        kernels = "gemm_f32_kernel<*>"
     return {"bound": "mfma", "kernel": kernels, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": None, "traffic_source": None,
             "launches_per_step": len(records), "avg_launch_us": round(1e3 * total_ms / len(records), 2),
@@ -332,6 +339,9 @@ def main():
                     help="deblurring = BASELINE configs[1] (the headline); sr = configs[2] (x4 by default), a "
                          "secondary series: pairs (48r x 48r, 48 x 48) as the reference's dataset hands them over")
     ap.add_argument("--sr-factor", type=int, default=4)
+    ap.add_argument("--arch", choices=["unet", "swinir"], default="unet",
+                    help="unet = ConvolutionalModel (configs[1..3], the headline); swinir = the reference's default "
+                         "backbone (configs[4]: --arch swinir --task sr --sr-factor 2)")
     ap.add_argument("--full256", action="store_true",
                     help="secondary series of SURVEY 8d: --no-Loss__crop_training_pairs, the network sees the whole "
                          "256x256 pair (28x the pixels of the default 48-crop); use a small --batch")
@@ -373,7 +383,7 @@ def main():
         del keep
         pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_gemm.json")
         default_cfg = (opt.dtype == "bf16" and not sr and not opt.full256 and opt.hidden == 32 and opt.scales == 5
-                       and opt.batch == 32)
+                       and opt.batch == 32 and opt.arch == "unet")
         if default_cfg and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))                 # PMC counters cannot be read live; see the file
             roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
@@ -386,7 +396,7 @@ def main():
                              "ms_per_step": round(ms_step - accounted, 3)})
 
     secondary = None
-    if opt.secondary and world == 1 and opt.dtype == "bf16" and not opt.full256:
+    if opt.secondary and world == 1 and opt.dtype == "bf16" and not opt.full256 and opt.arch == "unet":
         del leg                                             # frees the bf16 job's buckets before the f32 one
         torch.cuda.empty_cache()
         leg32 = Leg(opt, "f32", device, rank, world)
@@ -405,13 +415,18 @@ def main():
         images = opt.batch * world * opt.steps
         out = {
             "metric": ("training images/sec, proposed-loss super-resolution" if sr else
-                       "training images/sec (256x256 crops), proposed-loss deblur"),
+                       "training images/sec (256x256 crops), proposed-loss deblur") +
+                      (", SwinIR backbone" if opt.arch == "swinir" else ""),
             "value": round(images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": opt.steps,
             "warmup": opt.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": opt.dtype, "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[2]: super-resolution x{opt.sr_factor} noise=5, proposed loss "
-                                    f"(SURE + scale-EI), pairs {side}x{side} / 48x48, ConvolutionalModel "
-                                    f"hidden={opt.hidden} scales={opt.scales}") if sr else
+            "config": {"workload": (f"BASELINE configs[4]: SwinIR backbone (embed 180, 6 x 6 blocks, window 8; "
+                                    f"deepinv.models.SwinIR as src/models/__init__.py:51-74), {opt.task}"
+                                    + (f" x{opt.sr_factor}" if sr else "") + ", proposed loss (SURE + scale-EI), "
+                                    f"pairs {side}x{side} / " + ("48x48" if sr else "cropped to 48")) if opt.arch == "swinir"
+                                   else (f"BASELINE configs[2]: super-resolution x{opt.sr_factor} noise=5, proposed loss "
+                                         f"(SURE + scale-EI), pairs {side}x{side} / 48x48, ConvolutionalModel "
+                                         f"hidden={opt.hidden} scales={opt.scales}") if sr else
                                    ("BASELINE configs[1]: deblurring Gaussian_R2 noise=5, proposed loss (SURE + "
                                     "scale-EI), 256x256 pairs " +
                                     ("NOT cropped (full-256 series)" if opt.full256 else "cropped to 48 in Loss.forward") +

@@ -31,6 +31,22 @@ def can_capture(loss_module):
     return loss_module.crop_fn is not None and bool(getattr(loss_module.loss, "graph_safe", False))
 
 
+def _copy_nested(dst, src):
+    """dst <- src over matching dicts / sequences of tensors (None entries must match)."""
+    if isinstance(dst, torch.Tensor):
+        dst.copy_(src.reshape(dst.shape))
+    elif isinstance(dst, dict):
+        for key, value in dst.items():
+            _copy_nested(value, src[key])
+    elif isinstance(dst, (list, tuple)):
+        if len(dst) != len(src):
+            raise ValueError("random draws changed structure between capture and replay")
+        for d, s_ in zip(dst, src):
+            _copy_nested(d, s_)
+    elif dst is not None or src is not None:
+        raise ValueError("random draws changed structure between capture and replay")
+
+
 class GraphedLossStep:
     def __init__(self, loss_module, model, optimizer, crop_shape, warmup=3, store_weight_grads=True,
                  early_release=False):
@@ -55,7 +71,7 @@ class GraphedLossStep:
                                         dtype=torch.float32, device=device)
         # static homes of the step's random numbers, refreshed by `_draw` before every replay
         state = torch.cuda.get_rng_state(device)
-        self.static_draws = self.inner.draw(self.static_y)
+        self.static_draws = self.inner.draw(self.static_y, self.model)
         torch.cuda.set_rng_state(state, device)        # sizing the buffers must not advance the generator
 
         self.store_weight_grads = False
@@ -119,9 +135,8 @@ class GraphedLossStep:
         same tensors), copied into the buffers the graph reads."""
         if self.static_draws is None:
             return
-        fresh = given if given is not None else self.inner.draw(self.static_y)
-        for name, buf in self.static_draws.items():
-            buf.copy_(fresh[name].reshape(buf.shape))
+        fresh = given if given is not None else self.inner.draw(self.static_y, self.model)
+        _copy_nested(self.static_draws, fresh)
 
     def __call__(self, x, y, draws=None):
         """One replay on the crop of (x, y); draws: inject the step's random numbers (tests) instead of drawing."""

@@ -24,6 +24,22 @@ from .r2r import R2REILoss
 from .sure import SureGaussianLoss, draw_probe
 
 
+def _stochastic_depth_masks(model, batch):
+    """The per-sample stochastic-depth masks of one model call (SwinIR in training mode), else None."""
+    if model is None:
+        return None
+    backbone = model.get_backbone() if hasattr(model, "get_backbone") else model
+    draw = getattr(backbone, "draw_drop_masks", None)
+    return draw(batch) if draw is not None else None
+
+
+def _with_masks(model, masks):
+    """`model` as a callable that hands `masks` to the backbone (extra positional arguments ignored, as Model)."""
+    if masks is None:
+        return model
+    return lambda v, *ignored: model(v, drop_masks=masks)
+
+
 class _ModelPlusOneLoss(Module):
     """x_net = model(y); one deepinv-style loss term (reference :13-64).
 
@@ -37,13 +53,16 @@ class _ModelPlusOneLoss(Module):
         self.physics = physics
         self.loss = loss
 
-    def draw(self, y):
-        """The step's device-side random numbers, in the order the step consumes them (none here)."""
-        return None
+    def draw(self, y, model=None):
+        """The step's device-side random numbers, in the order the step consumes them."""
+        masks = _stochastic_depth_masks(model, y.shape[0])
+        return None if masks is None else {"drop": [masks]}
 
     def forward(self, x, y, model, draws=None):
-        x_net = model(y)
-        return self.loss(x=x, x_net=x_net, y=y, physics=self.physics, model=model)
+        if draws is None:
+            draws = self.draw(y, model)
+        call = model if draws is None else _with_masks(model, draws["drop"][0])
+        return self.loss(x=x, x_net=call(y), y=y, physics=self.physics, model=model)
 
 
 class SupervisedLoss(_ModelPlusOneLoss):
@@ -76,13 +95,21 @@ class SURELoss(_ModelPlusOneLoss):
         super().__init__(physics, SureGaussianLoss(sigma=noise_level / 255, cropped_div=cropped_div,
                                                    averaged_cst=averaged_cst, margin=margin))
 
-    def draw(self, y):
-        return {"b": draw_probe(y, self.loss.div_margin)}
+    def draw(self, y, model=None):
+        first = _stochastic_depth_masks(model, y.shape[0])                       # model(y)
+        draws = {"b": draw_probe(y, self.loss.div_margin)}
+        second = _stochastic_depth_masks(model, y.shape[0])                      # model(y + tau b)
+        if first is not None:
+            draws["drop"] = [first, second]
+        return draws
 
     def forward(self, x, y, model, draws=None):
         y = y.contiguous()
-        b = (draws if draws is not None else self.draw(y))["b"]
-        return self.loss(x=x, x_net=model(y), y=y, physics=self.physics, model=model, b=b)
+        if draws is None:
+            draws = self.draw(y, model)
+        drop = draws.get("drop", [None, None])
+        return self.loss(x=x, x_net=_with_masks(model, drop[0])(y), y=y, physics=self.physics,
+                         model=_with_masks(model, drop[1]), b=draws["b"])
 
 
 class ProposedLoss(Module):
@@ -127,41 +154,58 @@ class ProposedLoss(Module):
         padded = isinstance(ei_transform, ScalingTransform) and ei_transform.kind == "padded"
         self.graph_safe = padded and not ei_transform.antialias
 
-    def draw(self, y):
-        """{"b", "rate", "center", "noise"} in the reference's draw order (src/losses/sure.py:13-22, then
-        src/transforms.py:15-24 inside EILoss, then GaussianNoise on A(T x_net), which has y's shape), or None
-        when this configuration draws on the host or in data-dependent shapes."""
+    def draw(self, y, model=None):
+        """{"b", "rate", "center", "noise"[, "drop"]} in the order an eager step consumes them: the probe
+        (src/losses/sure.py:13-22), the transform's rates and centres (src/transforms.py:15-24, inside EILoss), the
+        measurement noise of A(T x_net) (y's shape); with a backbone that uses stochastic depth (SwinIR in training
+        mode) also one set of per-sample masks per model call, drawn where that call happens. None when this
+        configuration draws on the host or in data-dependent shapes."""
         if not self.graph_safe:
             return None
-        b = draw_probe(y, self.sure.div_margin)
-        rate, center = self.ei.T.sample(y.shape[0], y.device, y.dtype)
-        return {"b": b, "rate": rate, "center": center, "noise": torch.randn_like(y)}
+        B = y.shape[0]
+        drop = []
+        if not self.fuse_passes:
+            drop.append(_stochastic_depth_masks(model, B))                      # model(y)
+        draws = {"b": draw_probe(y, self.sure.div_margin)}
+        drop.append(_stochastic_depth_masks(model, B if not self.fuse_passes else 2 * B))   # model(y + tau b) / both
+        draws["rate"], draws["center"] = self.ei.T.sample(B, y.device, y.dtype)
+        draws["noise"] = torch.randn_like(y)
+        drop.append(_stochastic_depth_masks(model, B))                          # model(y2) of the EI branch
+        if any(d is not None for d in drop):
+            draws["drop"] = drop
+        return draws
 
     def forward(self, x, y, model, draws=None):
         y = y.contiguous()
         if draws is None:
-            draws = self.draw(y) if self.compute_x_net else None
+            draws = self.draw(y, model) if self.compute_x_net else None
         ei_kw = {} if draws is None else {"transform_params": (draws["rate"], draws["center"]),
                                           "noise": draws["noise"]}
+        drop = draws.get("drop") if draws is not None else None
+        calls = [model] * 3 if drop is None else [_with_masks(model, m) for m in drop]
         if not self.fuse_passes:
-            x_net = model(y) if self.compute_x_net else None
+            x_net = calls[0](y) if self.compute_x_net else None
             loss = 0
             for loss_fn in self.loss_fns:
-                kw = ei_kw if loss_fn is getattr(self, "ei", None) else \
-                    ({"b": draws["b"]} if draws is not None and loss_fn is getattr(self, "sure", None) else {})
-                loss = loss + loss_fn(x=x, x_net=x_net, y=y, physics=self.physics, model=model, **kw)
+                if loss_fn is getattr(self, "ei", None):
+                    loss = loss + loss_fn(x=x, x_net=x_net, y=y, physics=self.physics, model=calls[2], **ei_kw)
+                elif loss_fn is getattr(self, "sure", None):
+                    kw = {"b": draws["b"]} if draws is not None else {}
+                    loss = loss + loss_fn(x=x, x_net=x_net, y=y, physics=self.physics, model=calls[1], **kw)
+                else:
+                    loss = loss + loss_fn(x=x, x_net=x_net, y=y, physics=self.physics, model=model)
             return loss
         # Same arithmetic and the same RNG draw order (probe b first: the network consumes no random
         # numbers), but model(y) and model(y + tau b) share one pass of 2B images.
         B = y.shape[0]
         b = draws["b"] if draws is not None else draw_probe(y, self.sure.div_margin)
-        both = model(torch.cat([y, axpy(y, b, self.sure.tau)], dim=0))
+        both = calls[0](torch.cat([y, axpy(y, b, self.sure.tau)], dim=0))
         y12 = self.physics.A(both)
         x_net = both[:B]
         loss = self.sure(y=y, x_net=x_net, physics=self.physics, model=model, b=b, y1=y12[:B], y2=y12[B:])
         if self.keep_outputs:
             self.kept = {"x_net": x_net.detach()}
-        return loss + self.ei(x=x, x_net=x_net, y=y, physics=self.physics, model=model, **ei_kw)
+        return loss + self.ei(x=x, x_net=x_net, y=y, physics=self.physics, model=calls[-1], **ei_kw)
 
 
 class Loss(Module):

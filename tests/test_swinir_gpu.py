@@ -153,3 +153,75 @@ def test_swinir_factory_and_training_mode_draws():
     assert not torch.equal(a, b)
     model.eval()
     assert torch.equal(model(y), model(y))
+
+
+@pytest.mark.parametrize("task", ["deblurring", "sr"])
+def test_proposed_loss_step_with_swinir_vs_oracle(task):
+    """One proposed-loss step (SURE + scale-EI) around the SwinIR backbone in training mode -- three model calls,
+    each with its own stochastic-depth masks, the first two fused into one pass of 2B images -- against the oracle
+    with the same masks, probe, rates, centres and noise injected; then the same step replayed from a hipGraph."""
+    import bench
+    import physics
+    from graphs import GraphedLossStep
+    from losses import get_loss
+    from losses.sure import embed_probe
+    from models.swinir import SwinIR
+    from optim import FlatAdam
+    from oracle import torch_path as tp
+    sr = task == "sr"
+    up, margin, depths = (2, 0, (2,)) if sr else (1, 6, (2, 2))
+    args = bench.reference_args("cuda", task=task, sr_factor=2 if sr else None)
+    p = physics.get_physics(args, "cuda")
+    lf = get_loss(args, p)
+    torch.manual_seed(4)
+    model = SwinIR(upscale=up, upsampler="pixelshuffle" if sr else None, depths=depths, num_heads=(6,) * len(depths))
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()
+          if v.dtype.is_floating_point and "attn_mask" not in k}
+    model = model.cuda().train()
+    gen = torch.Generator().manual_seed(8)
+    B = 2
+    y = torch.rand((B, 3, 48, 48), generator=gen)
+    b_int = torch.randn((B, 3, 48 - 2 * margin, 48 - 2 * margin), generator=gen)
+    noise = torch.randn((B, 3, 48, 48), generator=gen)
+    rate, center = torch.tensor([0.5, 0.75]), torch.tensor([[0.2, -0.3], [-0.6, 0.4]])
+    masks = [sp.draw_drop_masks(B, depths=depths, rate=0.5, generator=gen) for _ in range(3)]   # (rates of the draw are
+    # irrelevant to the arithmetic: any per-sample factors exercise the same path; 0.5 makes zeros likely)
+    if sr:
+        A = lambda v: tp.downsample_aa(v, 2)
+    else:
+        k = tp.blur_kernel("Gaussian_R2")
+        A = lambda v: tp.blur_fft(v, k)
+    calls = iter(masks)
+    ref_model = lambda v: sp.swinir_forward(sd, v, upscale=up, drop_masks=next(calls), depths=depths)
+    ref, aux = tp.proposed_loss(y, A, ref_model, 5 / 255, margin=margin, rate=rate, center=center.view(B, 1, 1, 2),
+                                b=b_int, n=noise)
+    ref.backward()
+
+    def dev(m):
+        return None if m is None else tuple(v.cuda() for v in m)
+
+    both = [None if a is None else tuple(torch.cat([u, v]).cuda() for u, v in zip(a, b_)) for a, b_ in zip(masks[0], masks[1])]
+    yd = y.cuda()
+    draws = {"b": embed_probe(yd, b_int.cuda(), margin), "rate": rate.cuda(), "center": center.cuda().view(B, 1, 1, 2),
+             "noise": noise.cuda(), "drop": [both, [dev(m) for m in masks[2]]]}
+    model.zero_grad_flat()
+    val = lf.loss(x=None, y=yd, model=model, draws=draws)
+    val.backward()
+    assert abs(float(val) - float(ref)) < 1e-4 * abs(float(ref)), (float(val), float(ref))
+    worst = max((relerr(q.grad, sd[k_].grad), k_) for k_, q in model.named_parameters())
+    assert worst[0] < 2e-3, worst
+    eager_grads = model.flat_grads.clone()
+    # hipGraph replay of the same step: static masks / draws refreshed outside the graph
+    lf.crop_fn = lf.crop_fn                                 # (Loss.forward crops; feed 48x48 pairs through a no-op crop)
+    opt = FlatAdam(model, lr=1e-4)
+    graphed = GraphedLossStep(lf, model, opt, (B, 3, 48, 48))
+    assert graphed.static_draws is not None and "drop" in graphed.static_draws
+    model.flat_grads.fill_(float("nan"))
+    x_dummy = torch.zeros((B, 3, 48 * up, 48 * up), device="cuda")
+    val_g = graphed(x_dummy, yd, draws=draws)
+    assert abs(float(val_g) - float(val)) <= 1e-6 * abs(float(val))
+    assert relerr(model.flat_grads, eager_grads) < 1e-5
+    torch.cuda.manual_seed(3)
+    a = float(graphed(x_dummy, yd))
+    b2 = float(graphed(x_dummy, yd))                        # fresh masks / draws reach the replay
+    assert np.isfinite(a) and a != b2
