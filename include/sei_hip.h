@@ -307,6 +307,13 @@ int sei_swin_attn_fwd(const float *qkv, const float *table, float *out, int B, i
                       int head_dim, int shift, float scale, void *stream);
 int sei_swin_attn_bwd(const float *qkv, const float *table, const float *dout, float *dqkv, float *dtable,
                       int B, int H, int W, int heads, int head_dim, int shift, float scale, void *stream);
+/* The same two on the bf16 MFMA (csrc/swin_attn_mfma.hip, throughput mode): qkv (B*H*W, 3*heads*32) and out / dout
+ * (B*H*W, heads*32) in bf16, every head padded from 30 to 32 dims (the pad dims must be zero in qkv; they come out
+ * zero). dqkv is bf16, dtable float (+=). */
+int sei_swin_attn_fwd_bf16(const uint16_t *qkv, const float *table, uint16_t *out, int B, int H, int W,
+                           int heads, int shift, float scale, void *stream);
+int sei_swin_attn_bwd_bf16(const uint16_t *qkv, const float *table, const uint16_t *dout, uint16_t *dqkv,
+                           float *dtable, int B, int H, int W, int heads, int shift, float scale, void *stream);
 /* Padded-grid form of an NHWC batch for the 3x3 convolutions with many channels (RSTB.conv, conv_after_body,
  * conv_before_upsample, upsample.*): xp = guard_rows zero rows of C floats, then (B, H+2, W+2, C) with a zero
  * border, then guard_rows zero rows. On that grid the convolution is nine row-shifted GEMMs over the same flat

@@ -63,6 +63,8 @@ SIGNATURES = {
     "sei_colsum_weighted_f32": [_P, _P, _P, _Z, _I, _P],
     "sei_swin_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "sei_swin_attn_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "sei_swin_attn_fwd_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "sei_swin_attn_bwd_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "sei_pad_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "sei_unpad_nhwc": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "sei_rowscale": [_P, _P, _P, _P, _Z, _I, _P],

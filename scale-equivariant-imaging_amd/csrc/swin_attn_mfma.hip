@@ -1,0 +1,383 @@
+// 8x8-window multi-head self-attention of SwinIR on the bf16 MFMA (v_mfma_f32_32x32x16_bf16), gfx950.
+// (reference: WindowAttention.forward of the official SwinIR / deepinv.models.SwinIR, src/models/__init__.py:51-74.)
+//
+// Throughput-mode twin of swin_kernels.hip's exact-f32 kernels. Layout: the qkv projection of ALL tokens in natural
+// (b, y, x) order, bf16, heads padded from 30 to HP = 32 dims (the two pad dims are exactly zero because the packed
+// qkv weights have zero rows there): qkv16 (B*H*W, 3*heads*32), out16 / dout16 (B*H*W, heads*32). The cyclic shift,
+// window partition / reverse, relative-position bias and shift mask are index arithmetic, as in the f32 kernels.
+//
+// One wave per (window, head); a workgroup of 4 waves walks a strided list of windows of ONE head, so that the
+// bias-table gradient is summed in LDS across all of them and leaves as 225 float atomics per workgroup.
+//
+//   forward   S^T = K Q^T as 2x2 tiles of 32x32 (keys on the accumulator rows, the query on the lane: the softmax
+//             over keys is lane-local plus one exchange with lane^32), scale + bias + mask + softmax in registers,
+//             then O = P V with the P^T accumulators re-used directly as the A operand (cdna_hip_programming.md
+//             section 3, "an accumulator tile as the next MFMA's operand": the k order inside a step is permuted, and
+//             V is read from LDS with ds_read_b64_tr_b16 in that same order).
+//   backward  recomputes P^T; dP^T = V dO^T; dS^T = P^T (dP^T - delta) -> dQ = scale dS K (reduction over keys =
+//             accumulator rows of dS^T); then the same products in the other orientation (S = Q K^T, queries on the
+//             rows) -> dV = P^T dO and dK = scale dS^T Q (reduction over queries = accumulator rows of P, dS).
+//             56 MFMAs per (window, head), no transposes through LDS.
+#include "sei_common.h"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+
+constexpr int WS = 8, NTOK = 64, HP = 32, NB = (2 * WS - 1) * (2 * WS - 1), WAVES = 4;
+constexpr int TILE_BYTES = NTOK * HP * 2;                  // one [token][32] bf16 matrix: 4 KiB, 64-byte rows
+
+struct MGeom {
+    int H, W, nwy, nwx, shift, heads, nwin;               // nwin = B * nwy * nwx
+};
+
+__device__ __forceinline__ void win_token(const MGeom &g, int win, int i, int &tok, int &region) {
+    const int per = g.nwy * g.nwx;
+    const int b = win / per, w = win - b * per;
+    const int wy = w / g.nwx, wx = w - wy * g.nwx;
+    const int sy = wy * WS + (i >> 3), sx = wx * WS + (i & 7);
+    int oy = sy + g.shift, ox = sx + g.shift;
+    if (oy >= g.H) oy -= g.H;
+    if (ox >= g.W) ox -= g.W;
+    tok = (b * g.H + oy) * g.W + ox;
+    region = 0;
+    if (g.shift > 0) {
+        const int ry = sy < g.H - WS ? 0 : (sy < g.H - g.shift ? 1 : 2);
+        const int rx = sx < g.W - WS ? 0 : (sx < g.W - g.shift ? 1 : 2);
+        region = 3 * ry + rx;
+    }
+}
+
+__device__ __forceinline__ int bias_bin(int i, int j) {
+    return ((i >> 3) - (j >> 3) + WS - 1) * (2 * WS - 1) + ((i & 7) - (j & 7) + WS - 1);
+}
+
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// rows r0 .. r0+31 of a [token][32] tile as the A operand (row = lane & 31) or, equally, as the B operand of the
+// TRANSPOSED matrix (column = lane & 31): k = 16 s + 8 (lane >> 5) + 0..7 -> 16 contiguous bytes of the row.
+__device__ __forceinline__ bf16x8 row_frag(const char *tile, int r0, int s, int lane) {
+    return *reinterpret_cast<const bf16x8 *>(tile + (r0 + (lane & 31)) * (HP * 2) + (16 * s + 8 * (lane >> 5)) * 2);
+}
+
+// B operand [k = token][col = d] of a [token][32] tile for a k-step whose A operand is an ACCUMULATOR tile converted
+// in place: element e of lane half h is token t0 + 8 (e >> 2) + 4 h + (e & 3). Two transposing reads.
+__device__ __forceinline__ bf16x8 tr_frag_perm(const char *tile, int t0, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const char *a = tile + (t0 + 4 * (g >> 1) + q) * (HP * 2) + (16 * (g & 1) + 4 * p) * 2;
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s *)a);
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s *)(a + 8 * HP * 2));
+    const v8s both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+
+// registers 8 s .. 8 s + 7 of an accumulator tile as the A operand of k-step s (rows of the tile = reduction index)
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16 &x, int s) {
+    bf16x8 a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = (__bf16)x[8 * s + e];
+    return a;
+}
+
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// per-wave LDS: four [token][32] tiles + bias column of this head + token / region tables
+struct __attribute__((aligned(16))) WaveLds {
+    char q[TILE_BYTES], k[TILE_BYTES], v[TILE_BYTES], g[TILE_BYTES];
+    float rowstat[3][NTOK];                               // per query: delta, max, 1 / sum (backward)
+    int tok[NTOK], region[NTOK];
+};
+
+// load the three (or four) tiles of one (window, head): lane = token; 4 x 16 bytes per matrix row
+__device__ __forceinline__ void load_tiles(WaveLds &L, const unsigned short *qkv, const unsigned short *dout,
+                                           const MGeom &g, int win, int h, int lane) {
+    int tok, region;
+    win_token(g, win, lane, tok, region);
+    L.tok[lane] = tok;
+    L.region[lane] = region;
+    const int C = g.heads * HP;
+    const uint4 *src = reinterpret_cast<const uint4 *>(qkv + (size_t)tok * 3 * C + h * HP);
+    uint4 *dq = reinterpret_cast<uint4 *>(L.q + lane * HP * 2);
+    uint4 *dk = reinterpret_cast<uint4 *>(L.k + lane * HP * 2);
+    uint4 *dv = reinterpret_cast<uint4 *>(L.v + lane * HP * 2);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dq[c] = src[c];
+        dk[c] = src[C / 8 + c];
+        dv[c] = src[2 * C / 8 + c];
+    }
+    if (dout) {
+        const uint4 *gs = reinterpret_cast<const uint4 *>(dout + (size_t)tok * C + h * HP);
+        uint4 *dg = reinterpret_cast<uint4 *>(L.g + lane * HP * 2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dg[c] = gs[c];
+    }
+}
+
+// S^T tiles [jt][it] (rows = keys of tile jt, column = query 32 it + (lane & 31)): scale, bias, mask, softmax over
+// the keys. On return p[jt][it] holds the probabilities; mx / inv_sum per query are returned for the backward.
+template <bool KEEP_STATS>
+__device__ __forceinline__ void scores_T(WaveLds &L, const float *bias_col, float scale, int lane,
+                                         f32x16 (&p)[2][2]) {
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            f32x16 acc = {0};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc = mfma(row_frag(L.k, 32 * jt, s, lane), row_frag(L.q, 32 * it, s, lane), acc);
+            p[jt][it] = acc;
+        }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = 32 * it + (lane & 31);
+        const int ri = L.region[i];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * jt + acc_row(r, lane);
+                float v = p[jt][it][r] * scale + bias_col[bias_bin(i, j)];
+                if (L.region[j] != ri) v += -100.0f;
+                p[jt][it][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(p[jt][it][r] - mx);
+                p[jt][it][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        if (KEEP_STATS && lane < 32) {
+            L.rowstat[1][i] = mx;
+            L.rowstat[2][i] = inv;
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[jt][it][r] *= inv;
+    }
+}
+
+__global__ __launch_bounds__(64 * WAVES) void swin_attn_fwd_mfma_kernel(const unsigned short *__restrict__ qkv,
+                                                                          const float *__restrict__ table,
+                                                                          unsigned short *__restrict__ out, MGeom g,
+                                                                          float scale, int groups) {
+    __shared__ WaveLds lds[WAVES];
+    __shared__ float bias_col[NB];
+    const int h = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = threadIdx.x; b < NB; b += 64 * WAVES) bias_col[b] = table[b * g.heads + h];
+    WaveLds &L = lds[wave];
+    const int C = g.heads * HP;
+    const int stride = groups * WAVES;
+    const int rounds = (g.nwin + stride - 1) / stride;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int win_raw = (rd * groups + blockIdx.x) * WAVES + wave;
+        const bool live = win_raw < g.nwin;
+        const int win = live ? win_raw : g.nwin - 1;
+        __syncthreads();                                   // previous round's LDS reads are done
+        load_tiles(L, qkv, nullptr, g, win, h, lane);
+        __syncthreads();
+        f32x16 p[2][2];
+        scores_T<false>(L, bias_col, scale, lane, p);
+        // O[it] = sum over keys P[query][key] V[key][d]  =  (P^T tile)^T V
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            f32x16 o = {0};
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) o = mfma(acc_frag(p[jt][it], s), tr_frag_perm(L.v, 32 * jt + 16 * s, lane), o);
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = 32 * it + acc_row(r, lane);
+                    const __bf16 v = (__bf16)o[r];
+                    out[(size_t)L.tok[i] * C + h * HP + (lane & 31)] = __builtin_bit_cast(unsigned short, v);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * WAVES) void swin_attn_bwd_mfma_kernel(const unsigned short *__restrict__ qkv,
+                                                                          const float *__restrict__ table,
+                                                                          const unsigned short *__restrict__ dout,
+                                                                          unsigned short *__restrict__ dqkv,
+                                                                          float *__restrict__ dtable, MGeom g,
+                                                                          float scale, int groups) {
+    __shared__ WaveLds lds[WAVES];
+    __shared__ float bias_col[NB], bins[NB];
+    const int h = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = threadIdx.x; b < NB; b += 64 * WAVES) {
+        bias_col[b] = table[b * g.heads + h];
+        bins[b] = 0.f;
+    }
+    WaveLds &L = lds[wave];
+    const int C = g.heads * HP;
+    const int stride = groups * WAVES;
+    const int rounds = (g.nwin + stride - 1) / stride;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int win_raw = (rd * groups + blockIdx.x) * WAVES + wave;
+        const bool live = win_raw < g.nwin;
+        const int win = live ? win_raw : g.nwin - 1;
+        __syncthreads();
+        load_tiles(L, qkv, dout, g, win, h, lane);
+        __syncthreads();
+        // ---- orientation 1: keys on the accumulator rows ------------------------------------------------
+        f32x16 p[2][2];
+        scores_T<true>(L, bias_col, scale, lane, p);
+        // dP^T[jt][it] = V dO^T ; delta[query] = sum_keys P dP ; dS^T = P (dP - delta), kept in dp
+        f32x16 dp[2][2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            float delta = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                f32x16 acc = {0};
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    acc = mfma(row_frag(L.v, 32 * jt, s, lane), row_frag(L.g, 32 * it, s, lane), acc);
+                dp[jt][it] = acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) delta = fmaf(p[jt][it][r], acc[r], delta);
+            }
+            delta += __shfl_xor(delta, 32, 64);
+            if (lane < 32) L.rowstat[0][32 * it + lane] = delta;             // needed again in orientation 2
+            const int i = 32 * it + (lane & 31);
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ds = p[jt][it][r] * (dp[jt][it][r] - delta);
+                    dp[jt][it][r] = ds;
+                    if (live) atomicAdd(&bins[bias_bin(i, 32 * jt + acc_row(r, lane))], ds);
+                }
+        }
+        // dQ[it] = scale * (dS^T tile)^T K
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            f32x16 o = {0};
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) o = mfma(acc_frag(dp[jt][it], s), tr_frag_perm(L.k, 32 * jt + 16 * s, lane), o);
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = 32 * it + acc_row(r, lane);
+                    const __bf16 v = (__bf16)(o[r] * scale);
+                    dqkv[(size_t)L.tok[i] * 3 * C + h * HP + (lane & 31)] = __builtin_bit_cast(unsigned short, v);
+                }
+            }
+        }
+        // ---- orientation 2: queries on the accumulator rows, the key on the lane ----------------------------
+        // S = Q K^T and dP = dO V^T again with the operands swapped (16 MFMAs); the per-query max, 1 / sum and delta
+        // come from orientation 1 through LDS, so the softmax here is elementwise.
+        __syncthreads();                                   // rowstat written by lanes < 32 of this wave
+        f32x16 dvacc[2] = {{0}, {0}}, dkacc[2] = {{0}, {0}};
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            f32x16 s2[2], d2[2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                f32x16 a = {0}, b2 = {0};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    a = mfma(row_frag(L.q, 32 * it, s, lane), row_frag(L.k, 32 * jt, s, lane), a);
+                    b2 = mfma(row_frag(L.g, 32 * it, s, lane), row_frag(L.v, 32 * jt, s, lane), b2);
+                }
+                s2[jt] = a;
+                d2[jt] = b2;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 32 * it + acc_row(r, lane);
+                const int ri = L.region[i];
+                const float delta = L.rowstat[0][i], mx = L.rowstat[1][i], inv = L.rowstat[2][i];
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    const int j = 32 * jt + (lane & 31);
+                    float v = s2[jt][r] * scale + bias_col[bias_bin(i, j)];
+                    if (L.region[j] != ri) v += -100.0f;
+                    const float pr = __expf(v - mx) * inv;                 // P[query][key]
+                    s2[jt][r] = pr;
+                    d2[jt][r] = pr * (d2[jt][r] - delta);                  // dS[query][key]
+                }
+            }
+            // dV[jt] += (P tile)^T dO ; dK[jt] += (dS tile)^T Q     (reduction over the queries of tile it)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    dvacc[jt] = mfma(acc_frag(s2[jt], s), tr_frag_perm(L.g, 32 * it + 16 * s, lane), dvacc[jt]);
+                    dkacc[jt] = mfma(acc_frag(d2[jt], s), tr_frag_perm(L.q, 32 * it + 16 * s, lane), dkacc[jt]);
+                }
+        }
+        if (live) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = 32 * jt + acc_row(r, lane);
+                    unsigned short *row = dqkv + (size_t)L.tok[j] * 3 * C + h * HP + (lane & 31);
+                    const __bf16 dk = (__bf16)(dkacc[jt][r] * scale), dv = (__bf16)dvacc[jt][r];
+                    row[C] = __builtin_bit_cast(unsigned short, dk);
+                    row[2 * C] = __builtin_bit_cast(unsigned short, dv);
+                }
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NB; b += 64 * WAVES) atomicAdd(dtable + b * g.heads + h, bins[b]);
+}
+
+inline int check(int B, int H, int W, int heads, int shift) {
+    SEI_REQUIRE(B > 0 && H >= WS && W >= WS && H % WS == 0 && W % WS == 0 && heads > 0 && heads <= 64);
+    SEI_REQUIRE(shift >= 0 && shift < WS);
+    SEI_REQUIRE((size_t)B * H * W < ((size_t)1 << 31));
+    return SEI_OK;
+}
+
+inline int group_count(int nwin) {
+    int groups = (nwin + WAVES - 1) / WAVES;
+    return groups > 128 ? 128 : groups;                   // x heads workgroups; each loops over its windows
+}
+
+}  // namespace
+
+extern "C" int sei_swin_attn_fwd_bf16(const uint16_t *qkv, const float *table, uint16_t *out, int B, int H, int W,
+                                      int heads, int shift, float scale, void *stream) {
+    SEI_REQUIRE(qkv && table && out);
+    SEI_REQUIRE((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0);
+    if (int rc = check(B, H, W, heads, shift)) return rc;
+    MGeom g{H, W, H / WS, W / WS, shift, heads, B * (H / WS) * (W / WS)};
+    const int groups = group_count(g.nwin);
+    hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
+                       (hipStream_t)stream, qkv, table, out, g, scale, groups);
+    return sei_launch_status();
+}
+
+extern "C" int sei_swin_attn_bwd_bf16(const uint16_t *qkv, const float *table, const uint16_t *dout, uint16_t *dqkv,
+                                      float *dtable, int B, int H, int W, int heads, int shift, float scale,
+                                      void *stream) {
+    SEI_REQUIRE(qkv && table && dout && dqkv && dtable);
+    SEI_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv) & 15) == 0);
+    if (int rc = check(B, H, W, heads, shift)) return rc;
+    MGeom g{H, W, H / WS, W / WS, shift, heads, B * (H / WS) * (W / WS)};
+    const int groups = group_count(g.nwin);
+    hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
+                       (hipStream_t)stream, qkv, table, dout, dqkv, dtable, g, scale, groups);
+    return sei_launch_status();
+}

@@ -230,3 +230,46 @@ def test_proposed_loss_step_with_swinir_vs_oracle(task):
     a = float(graphed(x_dummy, yd))
     b2 = float(graphed(x_dummy, yd))                        # fresh masks / draws reach the replay
     assert np.isfinite(a) and a != b2
+
+
+@pytest.mark.parametrize("shift", [0, 4])
+@pytest.mark.parametrize("B,H,W,heads", [(2, 16, 16, 6), (1, 24, 16, 3), (5, 48, 48, 6)])
+def test_window_attention_mfma_fwd_bwd(B, H, W, heads, shift):
+    """The bf16 MFMA window attention (heads padded 30 -> 32, bf16 in / out) against the float64 reference on the
+    SAME bf16-rounded inputs: outputs and gradients to bf16 resolution, zero pad dims, bias-table gradient."""
+    import _native as N
+    gen = torch.Generator().manual_seed(B + H + shift + heads)
+    M, HP = B * H * W, 32
+    q30 = torch.randn((M, 3, heads, 30), generator=gen)
+    qkv = torch.zeros((M, 3, heads, HP))
+    qkv[..., :30] = q30
+    qkv16 = qkv.reshape(M, 3 * heads * HP).bfloat16()
+    table = torch.randn((225, heads), generator=gen) * 0.5
+    go30 = torch.randn((M, heads, 30), generator=gen)
+    go = torch.zeros((M, heads, HP))
+    go[..., :30] = go30
+    go16 = go.reshape(M, heads * HP).bfloat16()
+    # float64 reference on the rounded values, in the unpadded layout
+    qd = qkv16.double().view(M, 3, heads, HP)[..., :30].reshape(M, 3 * heads * 30).requires_grad_(True)
+    td = table.double().requires_grad_(True)
+    ref = _attention_reference(qd, td, B, H, W, heads, shift)
+    rq, rt = torch.autograd.grad(ref, [qd, td], go16.double().view(M, heads, HP)[..., :30].reshape(M, heads * 30))
+    scale = 30 ** -0.5
+    out16 = torch.full((M, heads * HP), float("nan"), dtype=torch.bfloat16, device="cuda")
+    qc, tc, gc = qkv16.cuda(), table.cuda(), go16.cuda()
+    N.call("sei_swin_attn_fwd_bf16", qc.data_ptr(), tc.data_ptr(), out16.data_ptr(), B, H, W, heads, shift, scale)
+    out = out16.float().cpu().view(M, heads, HP)
+    assert float(out[..., 30:].abs().max()) == 0.0
+    assert relerr(out[..., :30].reshape(M, -1), ref) < 1e-2
+    dqkv16 = torch.full((M, 3 * heads * HP), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dtable = torch.zeros_like(tc)
+    N.call("sei_swin_attn_bwd_bf16", qc.data_ptr(), tc.data_ptr(), gc.data_ptr(), dqkv16.data_ptr(), dtable.data_ptr(),
+           B, H, W, heads, shift, scale)
+    dq = dqkv16.float().cpu().view(M, 3, heads, HP)
+    assert float(dq[..., 30:].abs().max()) == 0.0
+    assert relerr(dq[..., :30].reshape(M, -1), rq) < 2e-2
+    assert relerr(dtable, rt) < 2e-2
+    # run-to-run: the outputs involve no atomics
+    out_b = torch.empty_like(out16)
+    N.call("sei_swin_attn_fwd_bf16", qc.data_ptr(), tc.data_ptr(), out_b.data_ptr(), B, H, W, heads, shift, scale)
+    assert torch.equal(out16, out_b)
