@@ -326,6 +326,34 @@ int sei_unpad_nhwc(const float *xp, const float *res, float *y, int B, int H, in
 int sei_rowscale(const float *x, const float *row_scale, const float *leaky_gate, float *y, size_t M, int N,
                  void *stream);
 
+/* ---- SwinIR throughput (bf16) path: csrc/swin_bf16_kernels.hip, csrc/gemm_bf16nt.hip ----
+ * sei_pack: dst[i] = map[i] >= 0 ? src[map[i]] : 0, as bf16 (to_bf16 = 1) or float: the float32 parameter bucket into
+ * the padded / permuted layouts the bf16 GEMMs read (heads 30 -> 32, channels 180 -> 192, 3x3 weights tap-major).
+ * sei_unpack_add: dst[map[i]] += src[i] for map[i] >= 0: gradients in GEMM-output layout back into the bucket (a
+ * parameter element appears at most once in a map). */
+int sei_pack(const float *src, const int *map, void *dst, size_t n, int to_bf16, void *stream);
+int sei_unpack_add(const float *src, const int *map, float *dst, size_t n, void *stream);
+/* LayerNorm over C <= 256 channels (C % 4 == 0) of float32 rows -> bf16 rows of ldy elements, zeros beyond C. */
+int sei_ln_fwd_bf16_pad(const float *x, const float *gamma, const float *beta, uint16_t *y, float *mean,
+                        float *rstd, size_t rows, int C, int ldy, float eps, void *stream);
+/* Its backward: gx (rows, C) = LN'(gy) (+ res if non-NULL); gy float32 with row stride ldg; ggamma / gbeta += (atomics). */
+int sei_ln_bwd_pad(const float *x, const float *gamma, const float *mean, const float *rstd, const float *gy,
+                   const float *res, float *gx, float *ggamma, float *gbeta, size_t rows, int C, int ldg,
+                   void *stream);
+/* y16[m, :C] = bf16(row_scale[m] * x[m, :]) (row_scale may be NULL), zeros up to ldy; colsum[c] += sum_m of the
+ * scaled rows when non-NULL (the bias gradient of the linear layer whose output gradient this is). */
+int sei_cast_pad_bf16(const float *x, const float *row_scale, uint16_t *y, float *colsum, size_t rows, int C,
+                      int ldy, void *stream);
+/* sei_pad_nhwc with bf16 output and the channel count padded from C to Cp (zeros). */
+int sei_pad_nhwc_bf16(const float *x, uint16_t *xp, int B, int H, int W, int C, int Cp, int guard_rows, void *stream);
+/* 3x3 convolution (stride 1, zero padding 1) as ONE implicit GEMM on that grid: D[r, n] = sum over taps t and
+ * channels c of Ap[r + row_off9[t], c] * B[n, t * cin_pad + c] (+ bias[n]); Ap points at row 0 of the padded grid
+ * (behind the guard rows), cin_pad % 64 == 0, B (N, 9 * cin_pad) bf16 tap-major. The im2col matrix exists only as
+ * LDS tiles: every k-tile of the LDS-DMA stream is a 64-channel slice of one tap, fetched from the same array at that
+ * tap's row shift. Rows r of the border are computed too (discard them: sei_unpad_nhwc). */
+int sei_gemm_bf16nt_conv(const uint16_t *Ap, int cin_pad, const int *row_off9, const uint16_t *B, int ldb,
+                         float *D32, uint16_t *D16, int M, int N, int epilogue, const float *bias, void *stream);
+
 int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, float *exp_avg, float *exp_avg_sq,
                    size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float grad_scale, uint16_t *param_bf16, void *stream);

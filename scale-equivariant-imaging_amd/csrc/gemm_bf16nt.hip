@@ -59,6 +59,10 @@ struct NtArgs {
     // host-side only (the kernels never read them): the caller's explicit tile / band choice of the _ex entry
     // points; 0 = the dispatcher decides. Per call, so the library holds no mutable state.
     int force_tile, force_band;
+    // 3x3 convolution on a zero-bordered grid (sei_gemm_bf16nt_conv): K = 9 * conv_cin; k-tile kt reads A rows
+    // shifted by conv_off[tap], tap = k / conv_cin, at column k - tap * conv_cin. conv_cin = 0: a plain GEMM.
+    int conv_cin;
+    int conv_off[9];
 };
 
 __device__ __forceinline__ unsigned short f2bf(float v) {
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
     const bool split = g.splitk > 1;
     const float *aux1p = nullptr, *aux2p = nullptr;
     if (epi == SEI_EPI_BIAS_RES && (!split || lead)) { aux1p = g.R1; aux2p = g.R2; }
+    else if (epi == SEI_EPI_BIAS_SCALE_RES) aux1p = g.R2;     // D = R2 + R1[row] * (acc + bias); never split
     else if (epi == SEI_EPI_MUL_DGELU) aux1p = g.R1;
     else if (epi == SEI_EPI_ACCUM && !split) aux1p = g.D32;
     float a1[TM][TN][16], a2[TM][TN][16];
@@ -280,6 +285,11 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
     auto stage = [&](int k0, char *dst) {
         const char *ab, *bb;
         if constexpr (ARM) ab = rm_base(g.A, g.A2, g.lda, m0, k0);
+        else if (g.conv_cin > 0) {                         // uniform per k-tile: the tap's row shift (K % BK == 0)
+            const int tap = k0 / g.conv_cin;
+            ab = reinterpret_cast<const char *>(g.A + ((ptrdiff_t)m0 + g.conv_off[tap]) * (ptrdiff_t)g.lda +
+                                                (k0 - tap * g.conv_cin));
+        }
         else ab = k0 + BK <= k_end ? reinterpret_cast<const char *>(g.A + (size_t)m0 * g.lda + k0) : nullptr;
         if (ab) {
 #pragma unroll
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
             const int row_base = m0 + wm * (32 * TM) + 32 * i + 4 * lh;
             float bias = (col_ok && (!split || lead) &&
                           (epi == SEI_EPI_BIAS || epi == SEI_EPI_BIAS_GELU || epi == SEI_EPI_BIAS_RES ||
-                           epi == SEI_EPI_BIAS_ROWSCALE))
+                           epi == SEI_EPI_BIAS_ROWSCALE || epi == SEI_EPI_BIAS_SCALE_RES))
                              ? g.bias[col] : 0.f;
             if constexpr (!PREFETCH_AUX) gather_aux(i, j);
             if (epi == SEI_EPI_BIAS_ROWSCALE) {          // D = acc + bias[n] * R1[m]   (R1: one value per row)
@@ -425,6 +435,7 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
                 }
                 if (epi == SEI_EPI_MUL_DGELU)
                     v *= (g.D16 && !g.D32) ? sei_dgelu_bf16out(a1[i][j][r]) : sei_dgelu(a1[i][j][r]);
+                else if (epi == SEI_EPI_BIAS_SCALE_RES) v = fmaf(v, g.R1[row], a1[i][j][r]);
                 else v += a1[i][j][r] + a2[i][j][r];
                 if (epi == SEI_EPI_BIAS_GELU) g.D2_16[o] = f2bf(sei_gelu_bf16out(v));
                 if (g.D32) g.D32[o] = v;
@@ -573,11 +584,12 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
     SEI_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0);
     SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU ||
                 epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_ACCUM ||
-                epilogue == SEI_EPI_BIAS_ROWSCALE);
+                epilogue == SEI_EPI_BIAS_ROWSCALE || epilogue == SEI_EPI_BIAS_SCALE_RES);
     if (epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU || epilogue == SEI_EPI_BIAS_RES ||
-        epilogue == SEI_EPI_BIAS_ROWSCALE)
+        epilogue == SEI_EPI_BIAS_ROWSCALE || epilogue == SEI_EPI_BIAS_SCALE_RES)
         SEI_REQUIRE(bias);
     if (epilogue == SEI_EPI_BIAS_ROWSCALE) SEI_REQUIRE(R1);
+    if (epilogue == SEI_EPI_BIAS_SCALE_RES) SEI_REQUIRE(R1 && R2 && D32 && !a_rmajor && !b_rmajor);
     if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D2_16);
     if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU) SEI_REQUIRE(R1);
     if (epilogue == SEI_EPI_ACCUM) SEI_REQUIRE(D32 && !D16);
@@ -585,7 +597,10 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
     g.A = A; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
     g.A2 = A; g.B2 = B; g.k_seg = K;                       // one reduction segment
+    g.conv_cin = 0;
     SEI_REQUIRE(tile >= 0 && band >= 0);
+    if (epilogue == SEI_EPI_BIAS_SCALE_RES && tile == 0)                // the quadrant kernel has no such epilogue
+        tile = (N > 128 && N <= 192) ? 6 : 1;
 #ifdef SEI_TUNING
     if (tile == 0) tile = g_tuning_tile;
     if (band == 0) band = g_tuning_band;
@@ -672,6 +687,7 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
         return launch_nt<2, 1, 2, 4, false, true>(g, s);
     }
     switch (tile) {
+        case 6: return launch_nt<1, 3, 4, 2>(g, s);      // 128 x 192 (SwinIR: N = 180 / 360 / 576)
         case 1: return launch_nt<2, 1, 2, 4>(g, s);      // 128 x 128
         case 2: return launch_nt<2, 2, 2, 4>(g, s);      // 128 x 256
         case 3: return launch_nt<3, 2, 2, 4>(g, s);      // 192 x 256
@@ -720,6 +736,7 @@ extern "C" int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, in
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
     g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
+    g.conv_cin = 0;
     SEI_REQUIRE(tile >= 0);
     g.force_band = 0;
 #ifdef SEI_TUNING
@@ -746,4 +763,27 @@ extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int l
                                    const uint16_t *B2, int ldb, float *D32, int M, int N, int K1, int K2,
                                    int accumulate, void *stream) {
     return sei_gemm_bf16nt_dw2_ex(A1, A2, lda, B1, B2, ldb, D32, M, N, K1, K2, accumulate, 0, stream);
+}
+
+// 3x3 convolution (stride 1, zero padding 1) of an NHWC batch as ONE implicit GEMM on the zero-bordered grid of
+// sei_pad_nhwc_bf16: output row r (a pixel of the padded grid) = sum over taps t and channels c of
+// Ap[r + row_off[t]][c] * B[n][t * cin_pad + c]. The im2col matrix exists only as LDS tiles: each k-tile of the
+// LDS-DMA stream is the 64-channel slice of one tap, fetched from the SAME array at that tap's row shift.
+extern "C" int sei_gemm_bf16nt_conv(const uint16_t *Ap, int cin_pad, const int *row_off9, const uint16_t *B, int ldb,
+                                    float *D32, uint16_t *D16, int M, int N, int epilogue, const float *bias,
+                                    void *stream) {
+    SEI_REQUIRE(Ap && row_off9 && B && (D32 || D16) && M > 0 && N > 0 && cin_pad > 0 && cin_pad % BK == 0);
+    SEI_REQUIRE(ldb >= 9 * cin_pad && ldb % 8 == 0 && (((uintptr_t)Ap | (uintptr_t)B) & 15) == 0);
+    SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS);
+    if (epilogue == SEI_EPI_BIAS) SEI_REQUIRE(bias);
+    NtArgs g;
+    g.A = Ap; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = 9 * cin_pad; g.lda = cin_pad; g.ldb = ldb;
+    g.epilogue = epilogue; g.bias = bias; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
+    g.A2 = Ap; g.B2 = B; g.k_seg = g.K;
+    g.force_tile = 0; g.force_band = 0;
+    g.conv_cin = cin_pad;
+    for (int t = 0; t < 9; ++t) g.conv_off[t] = row_off9[t];
+    hipStream_t s = (hipStream_t)stream;
+    if (N > 128 && N <= 192) return launch_nt<1, 3, 4, 2>(g, s);               // 128 x 192: one column tile
+    return launch_nt<2, 1, 2, 4>(g, s);
 }

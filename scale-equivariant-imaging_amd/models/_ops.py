@@ -75,20 +75,22 @@ def gemm(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2
 
 
 def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=None, R2=None, D2_16=None,
-              lda=None, ldb=None, a_rmajor=False, b_rmajor=False, tile=0, band=0):
+              lda=None, ldb=None, a_rmajor=False, b_rmajor=False, tile=0, band=0, flops=None):
     """D[M,N] = op(A16) op(B16) on the direct-to-LDS bf16 kernel. A16 is (M,K) [or (K,M) when a_rmajor],
     B16 is (N,K) [or (K,N) when b_rmajor]; K % 8 == 0. Outputs as given. tile / band: an explicit schedule
-    choice (sei_gemm_bf16nt_ex; tests and tools), 0 = the library's dispatch."""
+    choice (sei_gemm_bf16nt_ex; tests and tools), 0 = the library's dispatch. flops: the algorithmic FLOP count
+    to book for the roofline leg when the operands are zero-padded (default 2 M N K)."""
     if lda is None:
         lda = M if a_rmajor else K
     if ldb is None:
         ldb = Nn if b_rmajor else K
     args = (A16.data_ptr(), lda, int(a_rmajor), B16.data_ptr(), ldb, int(b_rmajor), N.ptr(out32), N.ptr(out16), M, Nn,
             K, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2_16))
+    fl = 2.0 * M * Nn * K if flops is None else float(flops)
     if tile or band:
-        _gemm_call(2.0 * M * Nn * K, "sei_gemm_bf16nt_ex", *args, int(tile), int(band))
+        _gemm_call(fl, "sei_gemm_bf16nt_ex", *args, int(tile), int(band))
     else:
-        _gemm_call(2.0 * M * Nn * K, "sei_gemm_bf16nt", *args)
+        _gemm_call(fl, "sei_gemm_bf16nt", *args)
 
 
 def layer_norm(x2d, gamma, beta):

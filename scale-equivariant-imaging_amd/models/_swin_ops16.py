@@ -1,0 +1,334 @@
+"""SwinIR in throughput (bf16) mode: the same blocks as models/_swin_ops.py on the LDS-DMA bf16 GEMMs
+(`sei_gemm_bf16nt`), the MFMA window attention (`sei_swin_attn_*_bf16`) and the implicit-GEMM 3x3 convolution
+(`sei_gemm_bf16nt_conv`).
+
+Layouts. Tokens stay float32 (B*H*W, 180) between blocks. Every GEMM operand is bf16 with its reduction dimension
+padded to a multiple of 64 and exact zeros in the pad: LayerNorm / cast kernels write (M, 192) rows, attention heads
+are 32 wide (30 + 2 zeros: q | k | v of all heads = 576 columns), convolution inputs live on the zero-bordered
+grid with 192 (or 64 / 256) channels. The weights are re-laid out to match by ONE gather kernel per model call
+(`SwinPack.refresh`: float32 bucket -> bf16 GEMM layouts through an index map), and the weight gradients, which the
+GEMMs accumulate in those layouts, return to the flat gradient bucket through the same map once per backward pass
+(`SwinPack.flush`).
+"""
+import numpy as np
+import torch
+
+import _native as N
+from . import _ops
+from ._ops import (EPI_ACCUM, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_NONE, colsum16_into, colsum_into,
+                   gemm_nt16, grad_of)
+from ._swin_ops import EPI_BIAS_SCALE_RES, LN_EPS, rowscale
+
+CP, HP = 192, 32                # padded embedding width, padded head width
+
+
+def pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class SwinPack:
+    """bf16 GEMM-layout copies of a SwinIR's matrices and float32 staging for their gradients."""
+
+    def __init__(self, model):
+        flat = model.flat_params
+        if flat is None or not flat.is_cuda:
+            raise ValueError("SwinPack needs a SwinIR whose parameters live in the flat bucket on the GPU")
+        self.model = model
+        base, esz = flat.data_ptr(), flat.element_size()
+        wmaps, gmaps, bmaps = [], [], []
+        self._w, self._g, self._b = {}, {}, {}
+        cursor = {"w": 0, "g": 0, "b": 0}
+
+        def index_of(p):                                # flat-bucket index of every element of p, shaped like p
+            off = (p.data_ptr() - base) // esz
+            return off + np.arange(p.numel(), dtype=np.int64).reshape(tuple(p.shape))
+
+        def add(kind, key, imap):
+            store, maps = {"w": (self._w, wmaps), "g": (self._g, gmaps), "b": (self._b, bmaps)}[kind]
+            n = imap.size
+            n_pad = (n + 63) // 64 * 64                 # every block starts on a 128-byte (bf16) boundary
+            store[key] = (cursor[kind], imap.shape)
+            maps.append(np.concatenate([imap.reshape(-1), np.full(n_pad - n, -1, dtype=np.int64)]))
+            cursor[kind] += n_pad
+
+        heads = model.blocks()[0].num_heads
+        C = model.embed_dim
+        hd = C // heads
+        if (C, hd) != (180, 30):
+            raise NotImplementedError("the bf16 SwinIR path is laid out for embed_dim 180 / head_dim 30")
+        head_cols = np.full(heads * HP, -1, dtype=np.int64)              # padded head column -> real column
+        for h in range(heads):
+            head_cols[h * HP:h * HP + hd] = h * hd + np.arange(hd)
+
+        def pad_cols(m, width):                          # (r, c) -> (r, width), -1 beyond c
+            out = np.full((m.shape[0], width), -1, dtype=np.int64)
+            out[:, :m.shape[1]] = m
+            return out
+
+        def pad_rows(m, height):
+            out = np.full((height, m.shape[1]), -1, dtype=np.int64)
+            out[:m.shape[0]] = m
+            return out
+
+        for name, blk in model.named_modules():
+            if type(blk).__name__ != "SwinTransformerBlock":
+                continue
+            a, mlp = blk.attn, blk.mlp
+            wq = index_of(a.qkv.weight)                  # (540, 180)
+            rows = np.concatenate([s * C + head_cols for s in range(3)])          # padded qkv row -> real row (or junk)
+            rows = np.where(np.tile(head_cols, 3) >= 0, rows, -1)
+            mq = np.where(rows[:, None] >= 0, pad_cols(wq, CP)[np.maximum(rows, 0)], -1)
+            bq = np.where(rows >= 0, index_of(a.qkv.bias)[np.maximum(rows, 0)], -1)
+            wp = index_of(a.proj.weight)                 # (180, 180): columns follow the padded heads
+            mp = np.where(head_cols[None, :] >= 0, wp[:, np.maximum(head_cols, 0)], -1)
+            layouts = {"qkv": mq, "proj": pad_rows(mp, CP), "fc1": pad_cols(index_of(mlp.fc1.weight), CP),
+                       "fc2": pad_rows(index_of(mlp.fc2.weight), CP)}
+            for k, m in layouts.items():
+                add("w", f"{name}.{k}", m)
+                add("g", f"{name}.{k}", m)
+            add("b", f"{name}.qkv_bias", bq)
+            add("g", f"{name}.qkv_bias", bq)
+        for name, conv in model.named_modules():
+            if not isinstance(conv, torch.nn.Conv2d) or conv.in_channels % 4 or conv.out_channels % 4:
+                continue
+            w = index_of(conv.weight)                    # (Cout, Cin, 3, 3)
+            Cout, Cin = w.shape[:2]
+            cinp, coutp = pad64(Cin), pad64(Cout)
+            fwd = np.full((Cout, 9, cinp), -1, dtype=np.int64)
+            fwd[:, :, :Cin] = w.reshape(Cout, Cin, 9).transpose(0, 2, 1)
+            bwd = np.full((Cin, 9, coutp), -1, dtype=np.int64)
+            bwd[:, :, :Cout] = w.reshape(Cout, Cin, 9).transpose(1, 2, 0)
+            grd = np.full((9, coutp, cinp), -1, dtype=np.int64)
+            grd[:, :Cout, :Cin] = w.reshape(Cout, Cin, 9).transpose(2, 0, 1)
+            add("w", f"{name}.fwd", fwd.reshape(Cout, 9 * cinp))
+            add("w", f"{name}.bwd", bwd.reshape(Cin, 9 * coutp))
+            add("g", f"{name}.taps", grd)
+        dev = flat.device
+
+        def to_dev(maps):
+            return torch.from_numpy(np.concatenate(maps).astype(np.int32)).to(dev)
+
+        self.wmap, self.gmap, self.bmap = to_dev(wmaps), to_dev(gmaps), to_dev(bmaps)
+        self.wint = torch.zeros(self.wmap.numel(), dtype=torch.bfloat16, device=dev)
+        self.bint = torch.zeros(self.bmap.numel(), dtype=torch.float32, device=dev)
+        self.gint = torch.zeros(self.gmap.numel(), dtype=torch.float32, device=dev)
+        self._flush_queued = False
+        self._key = (base, flat.numel())
+
+    def valid_for(self, model):
+        flat = model.flat_params
+        return flat is not None and self._key == (flat.data_ptr(), flat.numel())
+
+    def refresh(self):
+        """bf16 GEMM layouts <- the float32 parameters (two gather launches; call before every forward)."""
+        flat = self.model.flat_params
+        N.call("sei_pack", flat.data_ptr(), self.wmap.data_ptr(), self.wint.data_ptr(), self.wint.numel(), 1)
+        N.call("sei_pack", flat.data_ptr(), self.bmap.data_ptr(), self.bint.data_ptr(), self.bint.numel(), 0)
+
+    def w(self, key):
+        off, shape = self._w[key]
+        return self.wint[off:off + int(np.prod(shape))].view(shape)
+
+    def b(self, key):
+        off, shape = self._b[key]
+        return self.bint[off:off + int(np.prod(shape))].view(shape)
+
+    def g(self, key):
+        """float32 gradient staging of `key` (GEMM-output layout); arms the end-of-backward flush."""
+        if not self._flush_queued:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+                self._flush_queued = True
+            except RuntimeError:                         # not inside a backward pass: the caller flushes
+                pass
+        off, shape = self._g[key]
+        return self.gint[off:off + int(np.prod(shape))].view(shape)
+
+    def flush(self):
+        """Staged gradients -> the flat gradient bucket (+=), then clear the staging for the next backward pass."""
+        self._flush_queued = False
+        grads = self.model.flat_grads
+        for p in self.model.parameters():                # gradients not attached yet (no zero_grad_flat): attach
+            if p.grad is None:
+                grad_of(p)
+        N.call("sei_unpack_add", self.gint.data_ptr(), self.gmap.data_ptr(), grads.data_ptr(), self.gint.numel())
+        self.gint.zero_()
+
+
+def ln16(x2d, gamma, beta):
+    rows, C = x2d.shape
+    y = torch.empty((rows, CP), dtype=torch.bfloat16, device=x2d.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty_like(mean)
+    N.call("sei_ln_fwd_bf16_pad", x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+           rstd.data_ptr(), rows, C, CP, LN_EPS)
+    return y, mean, rstd
+
+
+def ln_bwd(x2d, gamma, mean, rstd, gy, res, ggamma, gbeta):
+    rows, C = x2d.shape
+    gx = torch.empty_like(x2d)
+    N.call("sei_ln_bwd_pad", x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gy.data_ptr(),
+           N.ptr(res), gx.data_ptr(), ggamma.data_ptr(), gbeta.data_ptr(), rows, C, gy.shape[1])
+    return gx
+
+
+def cast_pad(x2d, rows_scale=None, colsum=None, width=CP):
+    M, C = x2d.shape
+    y = torch.empty((M, width), dtype=torch.bfloat16, device=x2d.device)
+    N.call("sei_cast_pad_bf16", x2d.data_ptr(), N.ptr(rows_scale), y.data_ptr(), N.ptr(colsum), M, C, width)
+    return y
+
+
+class SwinBlockFn16(torch.autograd.Function):
+    """models._swin_ops.SwinBlockFn in bf16 mode; `pack` / `key` give the block's re-laid-out matrices."""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, table, bproj, g2, b2, bm1, bm2, pack, key, heads, shift, drop1, drop2):
+        N.check_tensor(x, "tokens")
+        B, H, W, C = x.shape
+        M = B * H * W
+        x2 = x.view(M, C)
+        wqkv, wproj, w1, w2 = (pack.w(f"{key}.{k}") for k in ("qkv", "proj", "fc1", "fc2"))
+        Ch = w1.shape[0]
+        dev = x.device
+        h1, mean1, rstd1 = ln16(x2, g1, b1)
+        qkv = torch.empty((M, 3 * heads * HP), dtype=torch.bfloat16, device=dev)
+        gemm_nt16(h1, wqkv, M, 3 * heads * HP, CP, EPI_BIAS, out16=qkv, bias=pack.b(f"{key}.qkv_bias"),
+                  flops=2.0 * M * 3 * C * C)
+        a = torch.empty((M, CP), dtype=torch.bfloat16, device=dev)
+        scale = float((C // heads) ** -0.5)
+        N.call("sei_swin_attn_fwd_bf16", qkv.data_ptr(), table.data_ptr(), a.data_ptr(), B, H, W, heads, shift, scale)
+        x1 = torch.empty((M, C), dtype=torch.float32, device=dev)
+        if drop1 is None:
+            gemm_nt16(a, wproj, M, C, CP, EPI_BIAS_RES, out32=x1, bias=bproj, R1=x2, flops=2.0 * M * C * C)
+        else:
+            gemm_nt16(a, wproj, M, C, CP, EPI_BIAS_SCALE_RES, out32=x1, bias=bproj, R1=drop1, R2=x2, flops=2.0 * M * C * C)
+        h2, mean2, rstd2 = ln16(x1, g2, b2)
+        f3 = torch.empty((M, Ch), dtype=torch.float32, device=dev)
+        f4 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
+        gemm_nt16(h2, w1, M, Ch, CP, EPI_BIAS_GELU, out32=f3, bias=bm1, D2_16=f4, flops=2.0 * M * Ch * C)
+        out = torch.empty((M, C), dtype=torch.float32, device=dev)
+        if drop2 is None:
+            gemm_nt16(f4, w2, M, C, Ch, EPI_BIAS_RES, out32=out, bias=bm2, R1=x1)
+        else:
+            gemm_nt16(f4, w2, M, C, Ch, EPI_BIAS_SCALE_RES, out32=out, bias=bm2, R1=drop2, R2=x1)
+        ctx.save_for_backward(x, mean1, rstd1, h1, qkv, a, x1, mean2, rstd2, h2, f3, f4, drop1, drop2)
+        ctx.params = (g1, b1, table, bproj, g2, b2, bm1, bm2)
+        ctx.cfg = (pack, key, heads, shift)
+        return out.view(B, H, W, C)
+
+    @staticmethod
+    def backward(ctx, go):
+        x, mean1, rstd1, h1, qkv, a, x1, mean2, rstd2, h2, f3, f4, drop1, drop2 = ctx.saved_tensors
+        g1, b1, table, bproj, g2, b2, bm1, bm2 = ctx.params
+        pack, key, heads, shift = ctx.cfg
+        B, H, W, C = x.shape
+        M = B * H * W
+        dev = x.device
+        wqkv, wproj, w1, w2 = (pack.w(f"{key}.{k}") for k in ("qkv", "proj", "fc1", "fc2"))
+        Ch = w1.shape[0]
+        go2 = go.contiguous().view(M, C)
+        # MLP branch
+        gy = cast_pad(go2, drop2, grad_of(bm2))
+        gemm_nt16(gy, f4, CP, Ch, M, EPI_ACCUM, out32=pack.g(f"{key}.fc2"), a_rmajor=True, b_rmajor=True,
+                  flops=2.0 * M * Ch * C)
+        gf3 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
+        gemm_nt16(gy, w2, M, Ch, CP, EPI_MUL_DGELU, out16=gf3, R1=f3, b_rmajor=True, flops=2.0 * M * Ch * C)
+        colsum16_into(grad_of(bm1), gf3)
+        gemm_nt16(gf3, h2, Ch, CP, M, EPI_ACCUM, out32=pack.g(f"{key}.fc1"), a_rmajor=True, b_rmajor=True,
+                  flops=2.0 * M * Ch * C)
+        gh2 = torch.empty((M, CP), dtype=torch.float32, device=dev)
+        gemm_nt16(gf3, w1, M, CP, Ch, EPI_NONE, out32=gh2, b_rmajor=True, flops=2.0 * M * Ch * C)
+        gx1 = ln_bwd(x1, g2, mean2, rstd2, gh2, go2, grad_of(g2), grad_of(b2))
+        # attention branch
+        gy = cast_pad(gx1, drop1, grad_of(bproj))
+        gemm_nt16(gy, a, CP, CP, M, EPI_ACCUM, out32=pack.g(f"{key}.proj"), a_rmajor=True, b_rmajor=True,
+                  flops=2.0 * M * C * C)
+        ga = torch.empty((M, CP), dtype=torch.bfloat16, device=dev)
+        gemm_nt16(gy, wproj, M, CP, CP, EPI_NONE, out16=ga, b_rmajor=True, flops=2.0 * M * C * C)
+        dqkv = torch.empty_like(qkv)
+        scale = float((C // heads) ** -0.5)
+        N.call("sei_swin_attn_bwd_bf16", qkv.data_ptr(), table.data_ptr(), ga.data_ptr(), dqkv.data_ptr(),
+               grad_of(table).data_ptr(), B, H, W, heads, shift, scale)
+        colsum16_into(pack.g(f"{key}.qkv_bias"), dqkv)
+        gemm_nt16(dqkv, h1, 3 * heads * HP, CP, M, EPI_ACCUM, out32=pack.g(f"{key}.qkv"), a_rmajor=True, b_rmajor=True,
+                  flops=2.0 * M * 3 * C * C)
+        gh1 = torch.empty((M, CP), dtype=torch.float32, device=dev)
+        gemm_nt16(dqkv, wqkv, M, CP, 3 * heads * HP, EPI_NONE, out32=gh1, b_rmajor=True, flops=2.0 * M * 3 * C * C)
+        gx = ln_bwd(x.view(M, C), g1, mean1, rstd1, gh1, gx1, grad_of(g1), grad_of(b1))
+        return (gx.view(B, H, W, C) if ctx.needs_input_grad[0] else None,) + (None,) * 14
+
+
+_TAPS = [(ky, kx) for ky in range(3) for kx in range(3)]
+_OFFSETS = {}
+
+
+def _tap_offsets(Wp, sign):
+    key = (Wp, sign)
+    if key not in _OFFSETS:
+        import ctypes
+        _OFFSETS[key] = (ctypes.c_int * 9)(*[sign * ((ky - 1) * Wp + (kx - 1)) for ky, kx in _TAPS])
+    return _OFFSETS[key]
+
+
+def _conv_gemm(ap, cin_pad, offsets, wmat, out32, rows, n_out, epi, bias, flops):
+    _ops._gemm_call(flops, "sei_gemm_bf16nt_conv", ap.data_ptr(), cin_pad, offsets,
+                    wmat.data_ptr(), wmat.shape[1], out32.data_ptr(), None, rows, n_out, epi, N.ptr(bias))
+
+
+class Conv3x3GemmFn16(torch.autograd.Function):
+    """models._swin_ops.Conv3x3GemmFn in bf16 mode: ONE implicit GEMM per convolution on the zero-bordered bf16 grid
+    (k-tiles = 64-channel slices of one tap, read from the same array at that tap's row shift), the same for the
+    data gradient with the transposed tap-major weights, and nine reduction-major GEMMs for the weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, act, pack, key):
+        N.check_tensor(x, "conv3x3 input")
+        B, H, W, Cin = x.shape
+        Cout = weight.shape[0]
+        cinp = pad64(Cin)
+        Wp, R = W + 2, B * (H + 2) * (W + 2)
+        guard = Wp + 9                                   # tap shifts (<= Wp + 1) + rounding the row count up to 8
+        xp = torch.empty((R + 2 * guard, cinp), dtype=torch.bfloat16, device=x.device)
+        N.call("sei_pad_nhwc_bf16", x.data_ptr(), xp.data_ptr(), B, H, W, Cin, cinp, guard)
+        outp = torch.empty((R, Cout), dtype=torch.float32, device=x.device)
+        _conv_gemm(xp[guard:], cinp, _tap_offsets(Wp, 1), pack.w(f"{key}.fwd"), outp, R, Cout, EPI_BIAS, bias,
+                   2.0 * B * H * W * Cout * 9 * Cin)
+        y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+        if res is not None:
+            N.check_tensor(res, "conv3x3 residual")
+        N.call("sei_unpad_nhwc", outp.data_ptr(), N.ptr(res), y.data_ptr(), B, H, W, Cout, int(act))
+        ctx.save_for_backward(xp, y if act else None)
+        ctx.params, ctx.cfg = (weight, bias), (B, H, W, Cin, Cout, guard, act, pack, key)
+        return y
+
+    @staticmethod
+    def backward(ctx, go):
+        xp, y_act = ctx.saved_tensors
+        weight, bias = ctx.params
+        B, H, W, Cin, Cout, guard, act, pack, key = ctx.cfg
+        cinp, coutp = pad64(Cin), pad64(Cout)
+        Wp, R, M = W + 2, B * (H + 2) * (W + 2), B * H * W
+        R8 = (R + 7) // 8 * 8
+        go = go.contiguous()
+        gpre = go.view(M, Cout)
+        if act:
+            gpre = rowscale(gpre, None, leaky_gate=y_act.view(M, Cout))
+        colsum_into(grad_of(bias), gpre)
+        gop = torch.empty((R + 2 * guard, coutp), dtype=torch.bfloat16, device=go.device)
+        N.call("sei_pad_nhwc_bf16", gpre.data_ptr(), gop.data_ptr(), B, H, W, Cout, coutp, guard)
+        taps = pack.g(f"{key}.taps")                     # (9, coutp, cinp)
+        for t, (ky, kx) in enumerate(_TAPS):
+            off = guard + (ky - 1) * Wp + (kx - 1)
+            gemm_nt16(gop[guard:guard + R8], xp[off:off + R8], coutp, cinp, R8, EPI_ACCUM, out32=taps[t], a_rmajor=True,
+                      b_rmajor=True, lda=coutp, ldb=cinp, flops=2.0 * M * Cout * Cin)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            dxp = torch.empty((R, Cin), dtype=torch.float32, device=go.device)
+            _conv_gemm(gop[guard:], coutp, _tap_offsets(Wp, -1), pack.w(f"{key}.bwd"), dxp, R, Cin, EPI_NONE, None,
+                       2.0 * M * Cout * 9 * Cin)
+            gx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=go.device)
+            N.call("sei_unpad_nhwc", dxp.data_ptr(), None, gx.data_ptr(), B, H, W, Cin, 0)
+        gres = go if ctx.needs_input_grad[3] else None
+        return gx, None, None, gres, None, None, None

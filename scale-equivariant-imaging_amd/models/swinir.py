@@ -20,7 +20,7 @@ from torch import nn
 
 import _native as N
 from physics._ops import axpy
-from . import _ops, _swin_ops as S
+from . import _ops, _swin_ops as S, _swin_ops16 as S16
 from ._flat import FlatParameterBucket
 
 RGB_MEAN = (0.4488, 0.4371, 0.4040)
@@ -79,10 +79,14 @@ class SwinTransformerBlock(nn.Module):
         m = mw.unsqueeze(1) - mw.unsqueeze(2)
         return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
 
-    def forward(self, x, drop=None):
+    def forward(self, x, drop=None, pack=None):
         """x: (B, H, W, C) tokens; drop: (rows_attn, rows_mlp) per-row stochastic-depth factors or None."""
         a, m = self.attn, self.mlp
         d1, d2 = drop if drop is not None else (None, None)
+        if pack is not None:                            # throughput mode: bf16 GEMM layouts from the pack
+            return S16.SwinBlockFn16.apply(x, self.norm1.weight, self.norm1.bias, a.relative_position_bias_table,
+                                           a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.bias, m.fc2.bias,
+                                           pack, self._sei_key, self.num_heads, self.shift_size, d1, d2)
         return S.SwinBlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.relative_position_bias_table,
                                    a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, self.norm2.weight,
                                    self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
@@ -112,11 +116,19 @@ class RSTB(nn.Module):
         self.residual_group = BasicLayer(dim, input_resolution, depth, num_heads, window_size, mlp_ratio, drop_path)
         self.conv = nn.Conv2d(dim, dim, 3, 1, 1)
 
-    def forward(self, x, drops):
+    def forward(self, x, drops, pack=None):
         res = x
         for blk, drop in zip(self.residual_group.blocks, drops):
-            x = blk(x, drop)
-        return S.Conv3x3GemmFn.apply(x, self.conv.weight, self.conv.bias, res, 0)
+            x = blk(x, drop, pack)
+        return conv3x3(self.conv, x, res, 0, pack)
+
+
+def conv3x3(conv, x, res, act, pack):
+    """A many-channel 3x3 convolution of the backbone on NHWC tokens: the f32 padded-grid form, or (pack given) the
+    bf16 implicit GEMM."""
+    if pack is not None:
+        return S16.Conv3x3GemmFn16.apply(x, conv.weight, conv.bias, res, act, pack, conv._sei_key)
+    return S.Conv3x3GemmFn.apply(x, conv.weight, conv.bias, res, act)
 
 
 class SwinIR(FlatParameterBucket, nn.Module):
@@ -162,6 +174,9 @@ class SwinIR(FlatParameterBucket, nn.Module):
         else:
             self.conv_last = nn.Conv2d(embed_dim, in_chans, 3, 1, 1)
         self.apply(self._init_weights)
+        for name, module in self.named_modules():
+            module._sei_key = name                      # key of the module's matrices in the bf16 pack
+        self._pack = None
         self._init_bucket()
 
     @staticmethod
@@ -206,8 +221,14 @@ class SwinIR(FlatParameterBucket, nn.Module):
         if ph or pw:
             x = F.pad(x, (0, pw, 0, ph), "reflect")
         Hp, Wp = H + ph, W + pw
-        if drop_masks == "draw":
+        if isinstance(drop_masks, str):
             drop_masks = self.draw_drop_masks(B, x.device)
+        pack = None
+        if _ops.get_compute_dtype() == "bf16":           # throughput mode: re-lay out the weights for the bf16 GEMMs
+            if self._pack is None or not self._pack.valid_for(self):
+                self._pack = S16.SwinPack(self)
+            pack = self._pack
+            pack.refresh()
         mean = self.mean.to(x.dtype).expand(B, 3, Hp, Wp).contiguous()
         x = axpy(x.contiguous(), mean, -1.0)             # (x - mean) * img_range, img_range = 1
         first = _ops.Conv3x3Fn.apply(x, self.conv_first.weight, self.conv_first.bias, None, True, False)   # -> NHWC
@@ -221,16 +242,16 @@ class SwinIR(FlatParameterBucket, nn.Module):
             if drop_masks is not None:
                 drops = [None if m is None else tuple(v.to(torch.float32).repeat_interleave(Hp * Wp) for v in m)
                          for m in drop_masks[k:k + n]]
-            t = layer(t, drops)
+            t = layer(t, drops, pack)
             k += n
         t = S.LayerNormFn.apply(t, self.norm.weight, self.norm.bias)
-        feat = S.Conv3x3GemmFn.apply(t, self.conv_after_body.weight, self.conv_after_body.bias, first, 0)
+        feat = conv3x3(self.conv_after_body, t, first, 0, pack)
         if self.upsampler == "pixelshuffle":
             c0 = self.conv_before_upsample[0]
-            f = S.Conv3x3GemmFn.apply(feat, c0.weight, c0.bias, None, 1)
+            f = conv3x3(c0, feat, None, 1, pack)
             for stage in self.upsample:
                 if isinstance(stage, nn.Conv2d):
-                    f = S.Conv3x3GemmFn.apply(f, stage.weight, stage.bias, None, 0)
+                    f = conv3x3(stage, f.contiguous(), None, 0, pack)
                 else:                                   # PixelShuffle on NHWC: a pure permutation (data movement)
                     r = stage.upscale_factor
                     Bf, Hf, Wf, Cf = f.shape
