@@ -102,6 +102,27 @@ def _stream_bytes(name, a):
         return 6 * a[6] * a[7]
     if name == "sei_ln_bwd":
         return 12 * a[8] * a[9]
+    if name == "sei_ln_fwd_bf16_pad":                     # f32 in, bf16 out (padded row)
+        return a[6] * (4 * a[7] + 2 * a[8])
+    if name == "sei_ln_bwd_pad":                          # x, gy (strided), [res], gx
+        return a[9] * (4 * a[10] * (3 if a[5] else 2) + 4 * a[11])
+    if name == "sei_cast_pad_bf16":
+        return a[4] * (4 * a[5] + 2 * a[6])
+    if name in ("sei_pad_nhwc", "sei_unpad_nhwc"):
+        B, H, W, C = (a[2:6] if name == "sei_pad_nhwc" else a[3:7])
+        return 8 * B * H * W * C
+    if name == "sei_pad_nhwc_bf16":
+        B, H, W, C, Cp = a[2:7]
+        return B * H * W * (4 * C + 2 * Cp)
+    if name == "sei_rowscale":
+        return 8 * a[4] * a[5]
+    if name in ("sei_pack", "sei_unpack_add"):
+        return 10 * a[3]
+    if name in ("sei_swin_attn_fwd_bf16", "sei_swin_attn_bwd_bf16", "sei_swin_attn_fwd", "sei_swin_attn_bwd"):
+        bf16, bwd = name.endswith("bf16"), "_bwd" in name
+        B, H, W, heads = (a[5:9] if bwd else a[3:7])
+        width = heads * (32 if bf16 else a[9 if bwd else 7])
+        return B * H * W * width * (2 if bf16 else 4) * (8 if bwd else 4)
     if name == "sei_sepmap2_packed":
         B, Hi, Wi, Ho, Wo, C = a[2:8]
         return 4 * B * C * (Hi * Wi + Ho * Wo)
@@ -144,6 +165,9 @@ _STREAM_FAMILIES = [
     ("dwconv7_* (depthwise 7x7: forward, data and weight gradients)", ("sei_dwconv7_",)),
     ("ln_* (channel LayerNorm forward / backward)", ("sei_ln_",)),
     ("sepmap_* (ideal resamplers)", ("sei_sepmap2",)),
+    ("swin_attn_* (8x8-window attention: qkv in, out / dqkv out)", ("sei_swin_attn_",)),
+    ("pad / unpad / rowscale / pack kernels (padded-grid copies, weight re-layout)",
+     ("sei_pad_nhwc", "sei_unpad_nhwc", "sei_rowscale", "sei_pack", "sei_unpack_add")),
     ("cast / colsum kernels (bf16 copies, bias gradients)", ("sei_cast_", "sei_colsum_")),
     ("conv3x3_* (in / out convolutions)", ("sei_conv3x3_",)),
     ("blur / scale_resample / axpy / sure / mse kernels (physics + loss terms)",

@@ -336,14 +336,18 @@ int sei_unpack_add(const float *src, const int *map, float *dst, size_t n, void 
 /* LayerNorm over C <= 256 channels (C % 4 == 0) of float32 rows -> bf16 rows of ldy elements, zeros beyond C. */
 int sei_ln_fwd_bf16_pad(const float *x, const float *gamma, const float *beta, uint16_t *y, float *mean,
                         float *rstd, size_t rows, int C, int ldy, float eps, void *stream);
-/* Its backward: gx (rows, C) = LN'(gy) (+ res if non-NULL); gy float32 with row stride ldg; ggamma / gbeta += (atomics). */
+/* Its backward: gx (rows, C) = LN'(gy) (+ res if non-NULL); gy float32 with row stride ldg; ggamma / gbeta += through
+ * per-workgroup partial sums in `work` (>= sei_swin_partials_floats(C) floats) folded by a second launch: deterministic,
+ * no atomics. */
+size_t sei_swin_partials_floats(int C);
 int sei_ln_bwd_pad(const float *x, const float *gamma, const float *mean, const float *rstd, const float *gy,
                    const float *res, float *gx, float *ggamma, float *gbeta, size_t rows, int C, int ldg,
-                   void *stream);
+                   float *work, size_t work_floats, void *stream);
 /* y16[m, :C] = bf16(row_scale[m] * x[m, :]) (row_scale may be NULL), zeros up to ldy; colsum[c] += sum_m of the
- * scaled rows when non-NULL (the bias gradient of the linear layer whose output gradient this is). */
+ * scaled rows when non-NULL (the bias gradient of the linear layer whose output gradient this is; partial sums in
+ * `work`, as sei_ln_bwd_pad). */
 int sei_cast_pad_bf16(const float *x, const float *row_scale, uint16_t *y, float *colsum, size_t rows, int C,
-                      int ldy, void *stream);
+                      int ldy, float *work, size_t work_floats, void *stream);
 /* sei_pad_nhwc with bf16 output and the channel count padded from C to Cp (zeros). */
 int sei_pad_nhwc_bf16(const float *x, uint16_t *xp, int B, int H, int W, int C, int Cp, int guard_rows, void *stream);
 /* 3x3 convolution (stride 1, zero padding 1) as ONE implicit GEMM on that grid: D[r, n] = sum over taps t and

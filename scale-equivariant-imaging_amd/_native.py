@@ -71,8 +71,8 @@ SIGNATURES = {
     "sei_pack": [_P, _P, _P, _Z, _I, _P],
     "sei_unpack_add": [_P, _P, _P, _Z, _P],
     "sei_ln_fwd_bf16_pad": [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _F, _P],
-    "sei_ln_bwd_pad": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P],
-    "sei_cast_pad_bf16": [_P, _P, _P, _P, _Z, _I, _I, _P],
+    "sei_ln_bwd_pad": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P, _Z, _P],
+    "sei_cast_pad_bf16": [_P, _P, _P, _P, _Z, _I, _I, _P, _Z, _P],
     "sei_pad_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_gemm_bf16nt_conv": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P],
     "sei_adam_fused": [_P, _P, _I, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P, _P],
@@ -86,6 +86,7 @@ SIZE_QUERIES = {
     "sei_dwconv7_bwd_weight_workspace": [_I, _I, _I, _I],
     "sei_dwconv7_bwd_weight_workspace_ex": [_I, _I, _I, _I, _I],
     "sei_ln_bwd_workspace": [_Z, _I],
+    "sei_swin_partials_floats": [_I],
 }
 ABI_VERSION = 3       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 

@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_pad_kernel(const float *__res
 __global__ __launch_bounds__(256) void ln_bwd_pad_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                           const float *__restrict__ mean, const float *__restrict__ rstd,
                                                           const float *__restrict__ gy, const float *__restrict__ res,
-                                                          float *__restrict__ gx, float *__restrict__ ggamma,
-                                                          float *__restrict__ gbeta, size_t rows, int C, int ldg) {
+                                                          float *__restrict__ gx, float *__restrict__ part,
+                                                          size_t rows, int C, int ldg) {
     __shared__ float4 red[2][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool live = 4 * lane < C;
@@ -141,10 +141,31 @@ __global__ __launch_bounds__(256) void ln_bwd_pad_kernel(const float *__restrict
             a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
             b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
         }
-        atomicAdd(ggamma + 4 * lane + 0, a.x); atomicAdd(ggamma + 4 * lane + 1, a.y);
-        atomicAdd(ggamma + 4 * lane + 2, a.z); atomicAdd(ggamma + 4 * lane + 3, a.w);
-        atomicAdd(gbeta + 4 * lane + 0, b.x); atomicAdd(gbeta + 4 * lane + 1, b.y);
-        atomicAdd(gbeta + 4 * lane + 2, b.z); atomicAdd(gbeta + 4 * lane + 3, b.w);
+        // per-workgroup partial sums [workgroup][2][C]: folded by fold_partials_kernel (no atomics: 2048 workgroups
+        // adding into the same 2 C addresses serialised in L2 and tripled this kernel's time)
+        float *dst = part + (size_t)blockIdx.x * 2 * C;
+        reinterpret_cast<float4 *>(dst)[lane] = a;
+        reinterpret_cast<float4 *>(dst + C)[lane] = b;
+    }
+}
+
+// out[c] += sum over g of part[g][c], c < ncol (ncol = 2 C for LayerNorm: gamma then beta, contiguous outputs not
+// required: out_a for c < split, out_b for the rest)
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float *__restrict__ part, int groups, int ncol,
+                                                             int split, float *__restrict__ out_a,
+                                                             float *__restrict__ out_b) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < ncol)
+        for (int g = wave; g < groups; g += 4) s += part[(size_t)g * ncol + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < ncol) {
+        s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (c < split) out_a[c] += s;
+        else out_b[c - split] += s;
     }
 }
 
@@ -169,7 +190,7 @@ __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float *__restr
         if (4 * lane < ldy)
             reinterpret_cast<ushort4 *>(y + row * ldy)[lane] = make_ushort4(f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w));
     }
-    if (colsum) {
+    if (colsum) {                                          // here: per-workgroup partials [workgroup][C]
         red[wave][lane] = acc;
         __syncthreads();
         if (wave == 0 && live) {
@@ -179,8 +200,7 @@ __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float *__restr
                 const float4 a2 = red[w][lane];
                 a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
             }
-            atomicAdd(colsum + 4 * lane + 0, a.x); atomicAdd(colsum + 4 * lane + 1, a.y);
-            atomicAdd(colsum + 4 * lane + 2, a.z); atomicAdd(colsum + 4 * lane + 3, a.w);
+            reinterpret_cast<float4 *>(colsum + (size_t)blockIdx.x * C)[lane] = a;
         }
     }
 }
@@ -232,27 +252,39 @@ extern "C" int sei_ln_fwd_bf16_pad(const float *x, const float *gamma, const flo
     return sei_launch_status();
 }
 
+constexpr unsigned PART_GROUPS = 1024;                     // workgroups (= partial rows) of the two reducing kernels
+
+extern "C" size_t sei_swin_partials_floats(int C) { return C > 0 ? (size_t)PART_GROUPS * 2 * (size_t)C : 0; }
+
 extern "C" int sei_ln_bwd_pad(const float *x, const float *gamma, const float *mean, const float *rstd, const float *gy,
                               const float *res, float *gx, float *ggamma, float *gbeta, size_t rows, int C, int ldg,
-                              void *stream) {
+                              float *work, size_t work_floats, void *stream) {
     SEI_REQUIRE(x && gamma && mean && rstd && gy && gx && ggamma && gbeta && rows > 0 && C > 0 && C % 4 == 0 && C <= 256);
-    SEI_REQUIRE(ldg >= C && ldg % 4 == 0);
-    SEI_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)gy | (uintptr_t)res | (uintptr_t)gx) & 15) == 0);
-    size_t g = sei_ceil_div(rows, 4 * 16);                 // >= 16 rows per wave: few atomics per parameter
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(ln_bwd_pad_kernel, dim3((unsigned)(g < 1 ? 1 : g)), dim3(256), 0, (hipStream_t)stream, x, gamma,
-                       mean, rstd, gy, res, gx, ggamma, gbeta, rows, C, ldg);
+    SEI_REQUIRE(ldg >= C && ldg % 4 == 0 && work && work_floats >= (size_t)PART_GROUPS * 2 * C);
+    SEI_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)gy | (uintptr_t)res | (uintptr_t)gx | (uintptr_t)work) & 15) == 0);
+    size_t g = sei_ceil_div(rows, 4);
+    if (g > PART_GROUPS) g = PART_GROUPS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ln_bwd_pad_kernel, dim3((unsigned)g), dim3(256), 0, s, x, gamma, mean, rstd, gy, res, gx, work, rows,
+                       C, ldg);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)sei_ceil_div(2 * C, 64)), dim3(256), 0, s,
+                       (const float *)work, (int)g, 2 * C, C, ggamma, gbeta);
     return sei_launch_status();
 }
 
 extern "C" int sei_cast_pad_bf16(const float *x, const float *row_scale, uint16_t *y, float *colsum, size_t rows,
-                                 int C, int ldy, void *stream) {
+                                 int C, int ldy, float *work, size_t work_floats, void *stream) {
     SEI_REQUIRE(x && y && rows > 0 && C > 0 && C % 4 == 0 && C <= 256 && ldy >= C && ldy % 4 == 0 && ldy <= 256);
     SEI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0);
-    size_t g = sei_ceil_div(rows, 4 * 16);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((unsigned)(g < 1 ? 1 : g)), dim3(256), 0, (hipStream_t)stream, x,
-                       row_scale, y, colsum, rows, C, ldy);
+    if (colsum) SEI_REQUIRE(work && work_floats >= (size_t)PART_GROUPS * C && ((uintptr_t)work & 15) == 0);
+    size_t g = sei_ceil_div(rows, 4);
+    if (g > PART_GROUPS) g = PART_GROUPS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((unsigned)g), dim3(256), 0, s, x, row_scale, y, colsum ? work : nullptr,
+                       rows, C, ldy);
+    if (colsum)
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)sei_ceil_div(C, 64)), dim3(256), 0, s, (const float *)work,
+                           (int)g, C, C, colsum, colsum);
     return sei_launch_status();
 }
 

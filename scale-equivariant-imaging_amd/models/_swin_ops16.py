@@ -89,20 +89,26 @@ class SwinPack:
             add("b", f"{name}.qkv_bias", bq)
             add("g", f"{name}.qkv_bias", bq)
         for name, conv in model.named_modules():
-            if not isinstance(conv, torch.nn.Conv2d) or conv.in_channels % 4 or conv.out_channels % 4:
+            if not isinstance(conv, torch.nn.Conv2d):
                 continue
             w = index_of(conv.weight)                    # (Cout, Cin, 3, 3)
             Cout, Cin = w.shape[:2]
-            cinp, coutp = pad64(Cin), pad64(Cout)
-            fwd = np.full((Cout, 9, cinp), -1, dtype=np.int64)
-            fwd[:, :, :Cin] = w.reshape(Cout, Cin, 9).transpose(0, 2, 1)
-            bwd = np.full((Cin, 9, coutp), -1, dtype=np.int64)
-            bwd[:, :, :Cout] = w.reshape(Cout, Cin, 9).transpose(1, 2, 0)
+            cin4, cout4 = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4          # activations carry whole float4 pixels
+            cinp, coutp = pad64(cin4), pad64(cout4)
+            fwd = np.full((cout4, 9, cinp), -1, dtype=np.int64)
+            fwd[:Cout, :, :Cin] = w.reshape(Cout, Cin, 9).transpose(0, 2, 1)
+            bwd = np.full((cin4, 9, coutp), -1, dtype=np.int64)
+            bwd[:Cin, :, :Cout] = w.reshape(Cout, Cin, 9).transpose(1, 2, 0)
             grd = np.full((9, coutp, cinp), -1, dtype=np.int64)
             grd[:, :Cout, :Cin] = w.reshape(Cout, Cin, 9).transpose(2, 0, 1)
-            add("w", f"{name}.fwd", fwd.reshape(Cout, 9 * cinp))
-            add("w", f"{name}.bwd", bwd.reshape(Cin, 9 * coutp))
+            add("w", f"{name}.fwd", fwd.reshape(cout4, 9 * cinp))
+            add("w", f"{name}.bwd", bwd.reshape(cin4, 9 * coutp))
             add("g", f"{name}.taps", grd)
+            if Cout % 4:                                 # conv_last: 3 outputs computed as 4 (the 4th is zero)
+                b4 = np.full(cout4, -1, dtype=np.int64)
+                b4[:Cout] = index_of(conv.bias)
+                add("b", f"{name}.bias4", b4)
+                add("g", f"{name}.bias4", b4)
         dev = flat.device
 
         def to_dev(maps):
@@ -155,6 +161,11 @@ class SwinPack:
         self.gint.zero_()
 
 
+def _partials(C, device):
+    """Scratch for the per-workgroup partial sums of the two reducing kernels."""
+    return torch.empty(N.lib().sei_swin_partials_floats(C), dtype=torch.float32, device=device)
+
+
 def ln16(x2d, gamma, beta):
     rows, C = x2d.shape
     y = torch.empty((rows, CP), dtype=torch.bfloat16, device=x2d.device)
@@ -168,15 +179,19 @@ def ln16(x2d, gamma, beta):
 def ln_bwd(x2d, gamma, mean, rstd, gy, res, ggamma, gbeta):
     rows, C = x2d.shape
     gx = torch.empty_like(x2d)
+    work = _partials(C, x2d.device)
     N.call("sei_ln_bwd_pad", x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gy.data_ptr(),
-           N.ptr(res), gx.data_ptr(), ggamma.data_ptr(), gbeta.data_ptr(), rows, C, gy.shape[1])
+           N.ptr(res), gx.data_ptr(), ggamma.data_ptr(), gbeta.data_ptr(), rows, C, gy.shape[1], work.data_ptr(),
+           work.numel())
     return gx
 
 
 def cast_pad(x2d, rows_scale=None, colsum=None, width=CP):
     M, C = x2d.shape
     y = torch.empty((M, width), dtype=torch.bfloat16, device=x2d.device)
-    N.call("sei_cast_pad_bf16", x2d.data_ptr(), N.ptr(rows_scale), y.data_ptr(), N.ptr(colsum), M, C, width)
+    work = _partials(C, x2d.device) if colsum is not None else None
+    N.call("sei_cast_pad_bf16", x2d.data_ptr(), N.ptr(rows_scale), y.data_ptr(), N.ptr(colsum), M, C, width,
+           N.ptr(work), 0 if work is None else work.numel())
     return y
 
 
@@ -285,16 +300,21 @@ class Conv3x3GemmFn16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, res, act, pack, key):
         N.check_tensor(x, "conv3x3 input")
-        B, H, W, Cin = x.shape
-        Cout = weight.shape[0]
+        B, H, W, Cin = x.shape                           # Cin, Cout: rounded up to whole float4 pixels (conv_first: the
+        wf = pack.w(f"{key}.fwd")                        # image arrives with a zero 4th channel; conv_last: 4th output 0)
+        Cout = wf.shape[0]
+        if (weight.shape[0] + 3) // 4 * 4 != Cout or (weight.shape[1] + 3) // 4 * 4 != Cin:
+            raise ValueError("Conv3x3GemmFn16: activation channels do not match the packed weight")
+        if Cout != weight.shape[0]:
+            bias = pack.b(f"{key}.bias4")
         cinp = pad64(Cin)
         Wp, R = W + 2, B * (H + 2) * (W + 2)
         guard = Wp + 9                                   # tap shifts (<= Wp + 1) + rounding the row count up to 8
         xp = torch.empty((R + 2 * guard, cinp), dtype=torch.bfloat16, device=x.device)
         N.call("sei_pad_nhwc_bf16", x.data_ptr(), xp.data_ptr(), B, H, W, Cin, cinp, guard)
         outp = torch.empty((R, Cout), dtype=torch.float32, device=x.device)
-        _conv_gemm(xp[guard:], cinp, _tap_offsets(Wp, 1), pack.w(f"{key}.fwd"), outp, R, Cout, EPI_BIAS, bias,
-                   2.0 * B * H * W * Cout * 9 * Cin)
+        _conv_gemm(xp[guard:], cinp, _tap_offsets(Wp, 1), wf, outp, R, Cout, EPI_BIAS, bias,
+                   2.0 * B * H * W * weight.shape[0] * 9 * weight.shape[1])
         y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
         if res is not None:
             N.check_tensor(res, "conv3x3 residual")
@@ -315,19 +335,19 @@ class Conv3x3GemmFn16(torch.autograd.Function):
         gpre = go.view(M, Cout)
         if act:
             gpre = rowscale(gpre, None, leaky_gate=y_act.view(M, Cout))
-        colsum_into(grad_of(bias), gpre)
+        colsum_into(grad_of(bias) if Cout == weight.shape[0] else pack.g(f"{key}.bias4"), gpre)
         gop = torch.empty((R + 2 * guard, coutp), dtype=torch.bfloat16, device=go.device)
         N.call("sei_pad_nhwc_bf16", gpre.data_ptr(), gop.data_ptr(), B, H, W, Cout, coutp, guard)
         taps = pack.g(f"{key}.taps")                     # (9, coutp, cinp)
         for t, (ky, kx) in enumerate(_TAPS):
             off = guard + (ky - 1) * Wp + (kx - 1)
             gemm_nt16(gop[guard:guard + R8], xp[off:off + R8], coutp, cinp, R8, EPI_ACCUM, out32=taps[t], a_rmajor=True,
-                      b_rmajor=True, lda=coutp, ldb=cinp, flops=2.0 * M * Cout * Cin)
+                      b_rmajor=True, lda=coutp, ldb=cinp, flops=2.0 * M * weight.shape[0] * weight.shape[1])
         gx = None
         if ctx.needs_input_grad[0]:
             dxp = torch.empty((R, Cin), dtype=torch.float32, device=go.device)
             _conv_gemm(gop[guard:], coutp, _tap_offsets(Wp, -1), pack.w(f"{key}.bwd"), dxp, R, Cin, EPI_NONE, None,
-                       2.0 * M * Cout * 9 * Cin)
+                       2.0 * M * weight.shape[0] * 9 * weight.shape[1])
             gx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=go.device)
             N.call("sei_unpad_nhwc", dxp.data_ptr(), None, gx.data_ptr(), B, H, W, Cin, 0)
         gres = go if ctx.needs_input_grad[3] else None

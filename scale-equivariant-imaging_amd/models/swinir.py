@@ -209,6 +209,14 @@ class SwinIR(FlatParameterBucket, nn.Module):
                 masks.append(tuple(torch.empty(batch, device=device).bernoulli_(keep).div_(keep) for _ in range(2)))
         return masks
 
+    def _last(self, t, res, pack):
+        """conv_last on NHWC tokens -> NCHW image (+ res): the small direct kernel, or in throughput mode the implicit
+        GEMM with a zero 4th output channel that is sliced away."""
+        if pack is None:
+            return _ops.Conv3x3Fn.apply(t, self.conv_last.weight, self.conv_last.bias, res, False, True)
+        y = conv3x3(self.conv_last, t, None, 0, pack)[..., :3].permute(0, 3, 1, 2).contiguous()
+        return y if res is None else axpy(y, res, 1.0)
+
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, x, drop_masks="draw"):
         """x: (B, 3, H, W). drop_masks: "draw" (training: draw them here, eval: none), None, or the list returned by
@@ -231,7 +239,10 @@ class SwinIR(FlatParameterBucket, nn.Module):
             pack.refresh()
         mean = self.mean.to(x.dtype).expand(B, 3, Hp, Wp).contiguous()
         x = axpy(x.contiguous(), mean, -1.0)             # (x - mean) * img_range, img_range = 1
-        first = _ops.Conv3x3Fn.apply(x, self.conv_first.weight, self.conv_first.bias, None, True, False)   # -> NHWC
+        if pack is not None:                            # NHWC image with a zero 4th channel (data movement only)
+            first = conv3x3(self.conv_first, F.pad(x.permute(0, 2, 3, 1), (0, 1)).contiguous(), None, 0, pack)
+        else:
+            first = _ops.Conv3x3Fn.apply(x, self.conv_first.weight, self.conv_first.bias, None, True, False)   # -> NHWC
         t = first
         if self.patch_embed.norm is not None:
             t = S.LayerNormFn.apply(t, self.patch_embed.norm.weight, self.patch_embed.norm.bias)
@@ -257,10 +268,10 @@ class SwinIR(FlatParameterBucket, nn.Module):
                     Bf, Hf, Wf, Cf = f.shape
                     f = f.view(Bf, Hf, Wf, Cf // (r * r), r, r).permute(0, 1, 4, 2, 5, 3).reshape(Bf, Hf * r, Wf * r,
                                                                                                 Cf // (r * r))
-            out = _ops.Conv3x3Fn.apply(f.contiguous(), self.conv_last.weight, self.conv_last.bias, None, False, True)
+            out = self._last(f.contiguous(), None, pack)
             mean_out = self.mean.to(x.dtype).expand(B, 3, Hp * self.upscale, Wp * self.upscale).contiguous()
         else:
-            out = _ops.Conv3x3Fn.apply(feat, self.conv_last.weight, self.conv_last.bias, x, False, True)
+            out = self._last(feat, x, pack)
             mean_out = mean
         out = axpy(out, mean_out, 1.0)                   # x / img_range + mean
         return out[:, :, :H * self.upscale, :W * self.upscale].contiguous()

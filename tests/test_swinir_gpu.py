@@ -316,6 +316,9 @@ def test_swinir_bf16_path_tracks_f32(cfg):
     for k, p in model.named_parameters():
         off = (p.data_ptr() - base) // 4
         a, b = outs["bf16"][1][off:off + p.numel()].double(), outs["f32"][1][off:off + p.numel()].double()
+        if float(b.norm()) == 0.0:                      # a branch dropped for every sample of the batch
+            assert float(a.norm()) == 0.0, k
+            continue
         cos = float(a @ b / (a.norm() * b.norm() + 1e-300))
         worst = min(worst, (cos, k))
         assert 0.5 < float(a.norm() / (b.norm() + 1e-300)) < 2.0, (k, float(a.norm()), float(b.norm()))
