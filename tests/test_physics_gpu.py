@@ -317,8 +317,10 @@ def test_device_resident_pairs(tmp_path):
     for k in range(5):
         x, y = syn[k]
         assert torch.equal(cache.pairs[k][0], x) and torch.equal(cache.pairs[k][1], y)
+    # shards have EQUAL length (wrap-around padding, as torch's DistributedSampler): 5 items over 2 ranks -> 3 + 3
     shard = DeviceResidentPairs(syn, p, crop_size=256, hotfix_sr_crop=True, rank=1, world=2)
-    assert len(shard) == 2 and torch.equal(shard.pairs[0][1], cache.pairs[1][1])
+    assert len(shard) == 3 and torch.equal(shard.pairs[0][1], cache.pairs[1][1])
+    assert torch.equal(shard.pairs[2][1], cache.pairs[0][1])              # index 5 wraps to item 0
     torch.manual_seed(3)
     seen = 0
     for xb, yb in cache.batches(batch_size=2):

@@ -355,9 +355,12 @@ def test_model_factory_surface():
     w = model.get_weights()
     assert "seq.0.in_conv.weight" in w
     model.load_weights({k: v.clone() for k, v in w.items()})
-    args.ProposedModel__architecture = "Transformer"
-    with pytest.raises(NotImplementedError):
+    args.ProposedModel__architecture = "Transformer"               # the reference default: SwinIR (tests/test_swinir_gpu.py)
+    assert type(models.get_model(args, p, "cuda").get_backbone()).__name__ == "SwinIR"
+    args.data_parallel_devices = "0,1"
+    with pytest.raises(NotImplementedError, match="torch.distributed.run --nnodes=1 --nproc-per-node 2"):
         models.get_model(args, p, "cuda")
+    args.data_parallel_devices = None
     args.ProposedModel__architecture = "Nope"
     with pytest.raises(ValueError):
         models.get_model(args, p, "cuda")
