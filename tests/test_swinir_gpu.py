@@ -323,3 +323,26 @@ def test_swinir_bf16_path_tracks_f32(cfg):
         worst = min(worst, (cos, k))
         assert 0.5 < float(a.norm() / (b.norm() + 1e-300)) < 2.0, (k, float(a.norm()), float(b.norm()))
     assert worst[0] > 0.98, worst
+
+
+@pytest.mark.parametrize("extra", [[], ["--compute_dtype", "bf16"], ["--task", "sr", "--sr_factor", "2", "--compute_dtype", "bf16"]])
+def test_train_script_with_the_reference_default_architecture(tmp_path, extra):
+    """`train.py` with the reference's DEFAULT --ProposedModel__architecture (Transformer = SwinIR): proposed loss,
+    hipGraph replay with static stochastic-depth masks, fused Adam, checkpoint with the published key layout."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "run"
+    cmd = [sys.executable, os.path.join(root, "train.py"), "--device", "cuda", "--method", "proposed", "--task",
+           "deblurring", "--kernel", "Gaussian_R2", "--dataset", "synthetic", "--batch_size", "2", "--epochs", "4",
+           "--max_steps", "2", "--out_dir", str(out)] + extra
+    env = dict(os.environ, SEI_TRACE_STEP_KIND="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "step kind: hipGraph replay" in r.stdout
+    rows = open(out / "training.csv").read().strip().splitlines()
+    assert len(rows) == 5 and all(np.isfinite(float(v.split(",")[1])) for v in rows[1:])
+    w = torch.load(out / "weights.pt", map_location="cpu")
+    assert "conv_last.weight" in w and "layers.5.residual_group.blocks.5.attn.relative_position_bias_table" in w
+    assert "layers.0.residual_group.blocks.1.attn_mask" in w          # buffers travel, as in the published weights
