@@ -190,8 +190,8 @@ int sei_ln_bwd(const float *x, const float *gamma, const float *mean, const floa
 #define SEI_EPI_MUL_DGELU 4       /* D = acc * gelu'(R1)                                      */
 #define SEI_EPI_ACCUM 5           /* D += acc   (gradient accumulation)                       */
 #define SEI_EPI_BIAS_ROWSCALE 6   /* D = acc + bias[n]*R1[m]                                  */
-#define SEI_EPI_BIAS_SCALE_RES 7  /* D = R2 + R1[m]*(acc + bias[n])  (stochastic depth: one factor per row; sei_gemm_f32[_ex],
-                                     sei_gemm_bf16_ex / _mixed only)                          */
+#define SEI_EPI_BIAS_SCALE_RES 7  /* D = R2 + R1[m]*(acc + bias[n])  (stochastic depth: one factor per row; not in the
+                                     quadrant-schedule kernel: sei_gemm_bf16nt takes a 128-row tile for it) */
 int sei_gemm_f32(const float *A, const float *B, float *D, int M, int N, int K, int transA,
                  int transB, int epilogue, const float *bias, const float *R1, const float *R2,
                  float *D2, void *stream);
@@ -291,6 +291,19 @@ int sei_colsum_f32(const float *X, float *out, size_t M, int N, void *stream);
  * downsampler (models/_ops.py, DownsampleFn: the bias enters as bias[n] * s[m], s = the resampler's response
  * to a constant image). */
 int sei_colsum_weighted_f32(const float *X, const float *row_weight, float *out, size_t M, int N, void *stream);
+
+/* Fused pointwise MLP of a ConvBlock at the shallow U-Net levels (csrc/mlp_fused.hip; C = 32 or 128; reference:
+ * src/models/convolutional.py:40-51): out (M, C) = res_scale * x + conv3(gelu(conv2(h2))), h2 (M, C) bf16 = the
+ * LayerNorm output, W2 (4C, C) and W3 (C, 4C) the bf16 1x1-convolution weights as stored, b2 / b3 float. The 4C-wide
+ * hidden activation stays in registers (accumulator tiles re-used as MFMA operands).
+ * sei_mlp_fused_bwd: from go (M, C) float: gh2 (M, C) float = gradient w.r.t. h2; go16 (M, C), h4 = gelu(h3) (M, 4C) and
+ * gh3 (M, 4C) in bf16 = the operands of the two weight-gradient GEMMs (h3 = conv2(h2) is recomputed); db3 (C) and
+ * db2 (4C) += the bias gradients. W3T (4C, C) and W2T (C, 4C) are the transposed bf16 weights. */
+int sei_mlp_fused_fwd(const uint16_t *h2, const uint16_t *W2, const float *b2, const uint16_t *W3, const float *b3,
+                      const float *x, float res_scale, float *out, int M, int C, void *stream);
+int sei_mlp_fused_bwd(const float *go, const uint16_t *h2, const uint16_t *W2, const float *b2, const uint16_t *W3T,
+                      const uint16_t *W2T, float *gh2, uint16_t *go16, uint16_t *h4, uint16_t *gh3, float *db3,
+                      float *db2, int M, int C, void *stream);
 
 /* ---- SwinIR building blocks (csrc/swin_kernels.hip; reference: deepinv.models.SwinIR as configured at
  * src/models/__init__.py:51-74 = the official SwinIR network_swinir.py; parity unpinned, see oracle/swinir_path.py).

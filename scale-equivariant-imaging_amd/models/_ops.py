@@ -527,8 +527,18 @@ def use_bf16_blocks(C):
     return _COMPUTE_DTYPE == "bf16" and C % 32 == 0
 
 
+FUSED_MLP_CHANNELS = () if "SEI_NO_FUSED_MLP" in __import__("os").environ else (32, 128)
+
+
+def _transposed16(w16):
+    """(R, C) bf16 -> (C, R) bf16 copy (data movement; the fused MLP backward reads both weights transposed)."""
+    return w16.t().contiguous()
+
+
 class ConvBlockFn16(torch.autograd.Function):
-    """ConvBlockFn with bf16 storage of h2 / h4 / gh3 and the direct-to-LDS GEMMs (C % 64 == 0)."""
+    """ConvBlockFn with bf16 storage of h2 / h4 / gh3 and the direct-to-LDS GEMMs (C % 64 == 0). At the shallow
+    levels (C in FUSED_MLP_CHANNELS) conv2 -> GELU -> conv3 + residual is ONE launch whose 4C-wide hidden activation
+    never reaches HBM (sei_mlp_fused_fwd); the backward recomputes it (sei_mlp_fused_bwd)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, gamma, beta, w2, b2, w3, b3, twice):
@@ -538,6 +548,19 @@ class ConvBlockFn16(torch.autograd.Function):
         h1 = dwconv7(x, w1, b1)
         h2, mean, rstd = layer_norm16(h1.view(M, C), gamma, beta)
         w2_16, w3_16 = shadow(w2), shadow(w3)
+        ctx.fused = C in FUSED_MLP_CHANNELS
+        if ctx.fused:
+            out = torch.empty((M, C), dtype=torch.float32, device=x.device)
+            N.call("sei_mlp_fused_fwd", h2.data_ptr(), w2_16.data_ptr(), b2.data_ptr(), w3_16.data_ptr(), b3.data_ptr(),
+                   x.data_ptr(), 2.0 if twice else 1.0, out.data_ptr(), M, C)
+            if _GEMM_PROFILE is not None:               # counted with the GEMM family (roofline leg): 2 GEMMs of M x 4C x C
+                _GEMM_PROFILE.append((4.0 * M * 4 * C * C, "sei_mlp_fused_fwd",
+                                      (h2.data_ptr(), w2_16.data_ptr(), b2.data_ptr(), w3_16.data_ptr(), b3.data_ptr(),
+                                       x.data_ptr(), 2.0 if twice else 1.0, out.data_ptr(), M, C)))
+            ctx.save_for_backward(x, h1, mean, rstd, h2)
+            ctx.params = (w1, b1, gamma, beta, w2, b2, w3, b3)
+            ctx.twice = twice
+            return out.view(B, H, W, C)
         h3 = torch.empty((M, 4 * C), dtype=torch.float32, device=x.device)
         h4 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device)
         gemm_nt16(h2, w2_16, M, 4 * C, C, EPI_BIAS_GELU, out32=h3, bias=b2, D2_16=h4)
@@ -550,6 +573,8 @@ class ConvBlockFn16(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, go):
+        if ctx.fused:
+            return ConvBlockFn16._backward_fused(ctx, go)
         x, h1, mean, rstd, h2, h3, h4 = ctx.saved_tensors
         w1, b1, gamma, beta, w2, b2, w3, b3 = ctx.params
         B, H, W, C = x.shape
@@ -564,6 +589,35 @@ class ConvBlockFn16(torch.autograd.Function):
         weight_grad16(gh3, h2, grad_of(w2).view(4 * C, C))
         gh2 = torch.empty((M, C), dtype=torch.float32, device=x.device)
         gemm_nt16(gh3, shadow(w2), M, C, 4 * C, EPI_NONE, out32=gh2, b_rmajor=True)
+        gh1 = layer_norm_bwd(h1.view(M, C), gamma, mean, rstd, gh2, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
+        dwconv7_weight_grad(x, gh1, grad_of(w1), grad_of(b1))
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = dwconv7(gh1, w1, None, flip=True, res=go, res_scale=2.0 if ctx.twice else 1.0)
+        return (gx,) + (None,) * 9
+
+
+    @staticmethod
+    def _backward_fused(ctx, go):
+        x, h1, mean, rstd, h2 = ctx.saved_tensors
+        w1, b1, gamma, beta, w2, b2, w3, b3 = ctx.params
+        B, H, W, C = x.shape
+        M = B * H * W
+        go = go.contiguous()
+        dev = x.device
+        w2_16, w3_16 = shadow(w2), shadow(w3)
+        gh2 = torch.empty((M, C), dtype=torch.float32, device=dev)
+        go16 = torch.empty((M, C), dtype=torch.bfloat16, device=dev)
+        h4 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=dev)
+        gh3 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=dev)
+        args = (go.data_ptr(), h2.data_ptr(), w2_16.data_ptr(), b2.data_ptr(), _transposed16(w3_16).data_ptr(),
+                _transposed16(w2_16).data_ptr(), gh2.data_ptr(), go16.data_ptr(), h4.data_ptr(), gh3.data_ptr(),
+                grad_of(b3).data_ptr(), grad_of(b2).data_ptr(), M, C)
+        N.call("sei_mlp_fused_bwd", *args)
+        if _GEMM_PROFILE is not None:                   # 3 GEMM-equivalents: recomputed conv2, dX of conv3, dX of conv2
+            _GEMM_PROFILE.append((4.0 * M * 4 * C * C, "sei_mlp_fused_bwd", args))
+        weight_grad16(go16, h4, grad_of(w3).view(C, 4 * C))
+        weight_grad16(gh3, h2, grad_of(w2).view(4 * C, C))
         gh1 = layer_norm_bwd(h1.view(M, C), gamma, mean, rstd, gh2, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
         dwconv7_weight_grad(x, gh1, grad_of(w1), grad_of(b1))
         gx = None

@@ -698,3 +698,59 @@ def test_layernorm_fwd_bf16_output(ops, rows, C):
     assert float((y16.double().cpu() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) + 1e-6
     assert relerr(mean, x.double().mean(1)) < 1e-5
     assert relerr(rstd, 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-6)) < 1e-5
+
+
+@pytest.mark.parametrize("twice", [False, True])
+@pytest.mark.parametrize("B,H,W,C", [(2, 5, 7, 32), (3, 48, 48, 32), (1, 9, 11, 128), (2, 24, 24, 128)])
+def test_fused_mlp_block_matches_the_unfused_bf16_block(ops, B, H, W, C, twice):
+    """The fused pointwise MLP of the shallow levels (sei_mlp_fused_fwd / _bwd: conv2 -> GELU -> conv3 + residual
+    with the hidden activation in registers, recomputed by the backward) against the unfused bf16 block on the same
+    weights: identical bf16 products and roundings, so outputs and gradients agree to accumulation-order noise; and
+    against a float64 evaluation of the block to bf16 resolution. Ragged pixel counts (not multiples of 32)."""
+    prev = ops.set_compute_dtype("bf16")
+    saved = ops.FUSED_MLP_CHANNELS
+    try:
+        gen = torch.Generator().manual_seed(B + H + C + int(twice))
+        x = torch.randn((B, H, W, C), generator=gen)
+        go = torch.randn((B, H, W, C), generator=gen)
+
+        def params():
+            g2 = torch.Generator().manual_seed(99)
+            mk = lambda *s, sc=1.0: torch.nn.Parameter((torch.randn(s, generator=g2) * sc).cuda())
+            return (mk(C, 1, 7, 7, sc=0.1), mk(C, sc=0.1), mk(C, sc=0.3) , mk(C, sc=0.1), mk(4 * C, C, 1, 1, sc=C ** -0.5),
+                    mk(4 * C, sc=0.1), mk(C, 4 * C, 1, 1, sc=(4 * C) ** -0.5), mk(C, sc=0.1))
+
+        res = {}
+        for mode, chans in (("fused", (32, 128)), ("plain", ())):
+            ops.FUSED_MLP_CHANNELS = chans
+            ops.weights_updated()
+            ps = params()
+            with torch.no_grad():
+                ps[2].add_(1.0)                                  # LayerNorm weight around 1
+            xc = x.cuda().requires_grad_(True)
+            ops.begin_step()
+            y = ops.ConvBlockFn16.apply(xc, *ps, twice)
+            y.backward(go.cuda())
+            ops.flush_weight_grads()
+            torch.cuda.synchronize()
+            res[mode] = (y.detach(), xc.grad, [p.grad.clone() for p in ps])
+        assert relerr(res["fused"][0], res["plain"][0]) < 1e-5
+        assert relerr(res["fused"][1], res["plain"][1]) < 2e-3
+        for a, b in zip(res["fused"][2], res["plain"][2]):
+            assert relerr(a, b) < 2e-3
+        # float64 evaluation of the same block
+        ps = [p.detach().double().cpu().requires_grad_(True) for p in params()]
+        with torch.no_grad():
+            ps[2].add_(1.0)
+        xd = x.double().requires_grad_(True)
+        xn = xd.permute(0, 3, 1, 2)
+        h = F.conv2d(xn, ps[0], ps[1], padding=3, groups=C)
+        h = F.layer_norm(h.permute(0, 2, 3, 1), (C,), ps[2], ps[3], 1e-6).permute(0, 3, 1, 2)
+        h = F.conv2d(F.gelu(F.conv2d(h, ps[4], ps[5])), ps[6], ps[7])
+        ref = ((2.0 if twice else 1.0) * xn + h).permute(0, 2, 3, 1)
+        ref.backward(go.double())
+        assert relerr(res["fused"][0], ref) < 2e-2
+        assert relerr(res["fused"][1], xd.grad) < 3e-2
+    finally:
+        ops.FUSED_MLP_CHANNELS = saved
+        ops.set_compute_dtype(prev)
