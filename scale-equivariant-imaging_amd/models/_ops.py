@@ -610,9 +610,10 @@ class ConvBlockFn16(torch.autograd.Function):
         go16 = torch.empty((M, C), dtype=torch.bfloat16, device=dev)
         h4 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=dev)
         gh3 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=dev)
-        args = (go.data_ptr(), h2.data_ptr(), w2_16.data_ptr(), b2.data_ptr(), _transposed16(w3_16).data_ptr(),
-                _transposed16(w2_16).data_ptr(), gh2.data_ptr(), go16.data_ptr(), h4.data_ptr(), gh3.data_ptr(),
-                grad_of(b3).data_ptr(), grad_of(b2).data_ptr(), M, C)
+        w3t, w2t = _transposed16(w3_16), _transposed16(w2_16)    # (both kept alive until the launch is enqueued)
+        args = (go.data_ptr(), h2.data_ptr(), w2_16.data_ptr(), b2.data_ptr(), w3t.data_ptr(), w2t.data_ptr(),
+                gh2.data_ptr(), go16.data_ptr(), h4.data_ptr(), gh3.data_ptr(), grad_of(b3).data_ptr(),
+                grad_of(b2).data_ptr(), M, C)
         N.call("sei_mlp_fused_bwd", *args)
         if _GEMM_PROFILE is not None:                   # 3 GEMM-equivalents: recomputed conv2, dX of conv3, dX of conv2
             _GEMM_PROFILE.append((4.0 * M * 4 * C * C, "sei_mlp_fused_bwd", args))
