@@ -297,13 +297,13 @@ int sei_colsum_weighted_f32(const float *X, const float *row_weight, float *out,
  * LayerNorm output, W2 (4C, C) and W3 (C, 4C) the bf16 1x1-convolution weights as stored, b2 / b3 float. The 4C-wide
  * hidden activation stays in registers (accumulator tiles re-used as MFMA operands).
  * sei_mlp_fused_bwd: from go (M, C) float: gh2 (M, C) float = gradient w.r.t. h2; go16 (M, C), h4 = gelu(h3) (M, 4C) and
- * gh3 (M, 4C) in bf16 = the operands of the two weight-gradient GEMMs (h3 = conv2(h2) is recomputed); db3 (C) and
- * db2 (4C) += the bias gradients. W3T (4C, C) and W2T (C, 4C) are the transposed bf16 weights. */
+ * gh3 (M, 4C) in bf16 = the operands of the two weight-gradient GEMMs (h3 = conv2(h2) is recomputed). W3T (4C, C) and
+ * W2T (C, 4C) are the transposed bf16 weights. (Bias gradients: column sums of go and gh3, sei_colsum_*.) */
 int sei_mlp_fused_fwd(const uint16_t *h2, const uint16_t *W2, const float *b2, const uint16_t *W3, const float *b3,
                       const float *x, float res_scale, float *out, int M, int C, void *stream);
 int sei_mlp_fused_bwd(const float *go, const uint16_t *h2, const uint16_t *W2, const float *b2, const uint16_t *W3T,
-                      const uint16_t *W2T, float *gh2, uint16_t *go16, uint16_t *h4, uint16_t *gh3, float *db3,
-                      float *db2, int M, int C, void *stream);
+                      const uint16_t *W2T, float *gh2, uint16_t *go16, uint16_t *h4, uint16_t *gh3, int M, int C,
+                      void *stream);
 
 /* ---- SwinIR building blocks (csrc/swin_kernels.hip; reference: deepinv.models.SwinIR as configured at
  * src/models/__init__.py:51-74 = the official SwinIR network_swinir.py; parity unpinned, see oracle/swinir_path.py).

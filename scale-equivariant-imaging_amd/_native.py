@@ -62,7 +62,7 @@ SIGNATURES = {
     "sei_colsum_f32": [_P, _P, _Z, _I, _P],
     "sei_colsum_weighted_f32": [_P, _P, _P, _Z, _I, _P],
     "sei_mlp_fused_fwd": [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P],
-    "sei_mlp_fused_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "sei_mlp_fused_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "sei_swin_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "sei_swin_attn_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "sei_swin_attn_fwd_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],

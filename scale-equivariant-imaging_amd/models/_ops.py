@@ -612,11 +612,12 @@ class ConvBlockFn16(torch.autograd.Function):
         gh3 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=dev)
         w3t, w2t = _transposed16(w3_16), _transposed16(w2_16)    # (both kept alive until the launch is enqueued)
         args = (go.data_ptr(), h2.data_ptr(), w2_16.data_ptr(), b2.data_ptr(), w3t.data_ptr(), w2t.data_ptr(),
-                gh2.data_ptr(), go16.data_ptr(), h4.data_ptr(), gh3.data_ptr(), grad_of(b3).data_ptr(),
-                grad_of(b2).data_ptr(), M, C)
+                gh2.data_ptr(), go16.data_ptr(), h4.data_ptr(), gh3.data_ptr(), M, C)
         N.call("sei_mlp_fused_bwd", *args)
-        if _GEMM_PROFILE is not None:                   # 3 GEMM-equivalents: recomputed conv2, dX of conv3, dX of conv2
+        if _GEMM_PROFILE is not None:                   # booked as the two data-gradient GEMMs it replaces
             _GEMM_PROFILE.append((4.0 * M * 4 * C * C, "sei_mlp_fused_bwd", args))
+        colsum_into(grad_of(b3), go.view(M, C))
+        colsum16_into(grad_of(b2), gh3)
         weight_grad16(go16, h4, grad_of(w3).view(C, 4 * C))
         weight_grad16(gh3, h2, grad_of(w2).view(4 * C, C))
         gh1 = layer_norm_bwd(h1.view(M, C), gamma, mean, rstd, gh2, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
