@@ -527,7 +527,11 @@ def use_bf16_blocks(C):
     return _COMPUTE_DTYPE == "bf16" and C % 32 == 0
 
 
-FUSED_MLP_CHANNELS = () if "SEI_NO_FUSED_MLP" in __import__("os").environ else (32, 128)
+# Levels whose ConvBlock MLP runs as the fused kernel. Measured on MI355X at batch 32 (2B pass): C = 32 wins
+# (forward 40 vs 56 us for the two GEMMs, backward 49 vs 76 us incl. the cast); C = 128 loses (forward 63 vs 51 us,
+# backward 139 vs 70 us): 36,864 pixels are 288 four-wave tiles, one per CU, and nothing overlaps the 16 serial
+# weight slices of a tile. SEI_FUSED_MLP=32,128 / SEI_FUSED_MLP= (empty) override for A/B runs.
+FUSED_MLP_CHANNELS = tuple(int(v) for v in __import__("os").environ.get("SEI_FUSED_MLP", "32").split(",") if v)
 
 
 def _transposed16(w16):
