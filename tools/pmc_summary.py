@@ -37,7 +37,7 @@ def main():
     W = load(f"{src}/pmc_WRITE_SIZE/pmc_counter_collection.csv", "WRITE_SIZE")
     Mb = load(f"{src}/pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_counter_collection.csv", "SQ_VALU_MFMA_BUSY_CYCLES")
     G = load(f"{src}/pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_counter_collection.csv", "GRBM_GUI_ACTIVE")
-    gem = [k for k in F if "gemm_" in k]
+    gem = [k for k in F if "gemm_" in k or "mlp_fwd" in k or "mlp_bwd" in k]
     n = sum(F[k][1] for k in gem)
     fetch = sum(F[k][0] for k in gem) * 1024 * 2          # KiB -> B, x2 (gfx950 wide-stream correction)
     write = sum(W[k][0] for k in gem if k in W) * 1024
@@ -54,12 +54,18 @@ def main():
     json.dump(res, open(out + "_gemm.json", "w"), indent=1)
     with open(out + "_per_kernel.md", "w") as f:
         f.write("# PMC passes of bench.py (bf16, eager launches, 3 steps)\n\n" + __doc__.split("gfx950")[0] + "\n")
-        f.write("| kernel | launches | fetch GB (x2 corrected) | write GB | time ms | MFMA busy fraction |\n|---|---|---|---|---|---|\n")
-        for k in sorted(F, key=lambda k: -F[k][2])[:24]:
+        f.write("GB/s = (FETCH_SIZE x 2 + WRITE_SIZE) / kernel time: beyond-L2 bytes per second (Infinity-Cache hits "
+                "included), to set against the 8 TB/s HBM3E peak for the streaming kernels (dwconv7_*, ln_*, sepmap_*, "
+                "cast / colsum, adam_vec_kernel). Times are under the profiler (lower clocks than the bench).\n\n")
+        f.write("| kernel | launches | fetch GB (x2 corrected) | write GB | time ms | GB/s | frac of 8 TB/s | MFMA busy fraction |\n"
+                "|---|---|---|---|---|---|---|---|\n")
+        for k in sorted(F, key=lambda k: -F[k][2])[:40]:
             mb, ga = Mb.get(k, [0])[0], G.get(k, [0])[0]
             u = f"{mb / (ga / 8 * 1024):.3f}" if ga and mb else "-"
-            f.write(f"| `{k[:70]}` | {F[k][1]} | {F[k][0] * 2048 / 1e9:.2f} | {W.get(k, [0])[0] * 1024 / 1e9:.2f} | "
-                    f"{F[k][2] / 1e6:.2f} | {u} |\n")
+            fb, wb = F[k][0] * 2048, W.get(k, [0])[0] * 1024
+            gbs = (fb + wb) / max(F[k][2], 1)
+            f.write(f"| `{k[:70]}` | {F[k][1]} | {fb / 1e9:.2f} | {wb / 1e9:.2f} | "
+                    f"{F[k][2] / 1e6:.2f} | {gbs:.0f} | {gbs / 8000:.2f} | {u} |\n")
         f.write("\nGEMM family: " + json.dumps(res) + "\n")
     print(json.dumps(res, indent=1))
 
