@@ -91,7 +91,31 @@ struct __attribute__((aligned(16))) WaveLds {
     char q[TILE_BYTES], k[TILE_BYTES], v[TILE_BYTES], g[TILE_BYTES];
     float rowstat[3][NTOK];                               // per query: delta, max, 1 / sum (backward)
     int tok[NTOK], region[NTOK];
+    char st[32 * HP * 2];                                 // one 32 x 32 bf16 result tile on its way out (16-byte stores)
 };
+
+// One 32-token x 32-dim result tile (accumulator layout: column = lane & 31, rows in the registers) to
+// dst[tok[i0 + row]][col0 ..]: through LDS, so that it leaves as 16-byte stores of whole 64-byte rows (two store
+// instructions per tile instead of sixteen 2-byte ones: the epilogue was store-issue-bound).
+__device__ __forceinline__ void store_tile(WaveLds &L, const f32x16 &o, float mul, int lane, unsigned short *dst,
+                                           size_t ld, int col0, int i0, bool live) {
+    unsigned short *st = reinterpret_cast<unsigned short *>(L.st);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const __bf16 v = (__bf16)(o[r] * mul);
+        st[acc_row(r, lane) * HP + (lane & 31)] = __builtin_bit_cast(unsigned short, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // same wave: LDS is in order; this pins the compiler too
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = 16 * pass + (lane >> 2), chunk = lane & 3;
+        const uint4 v = *reinterpret_cast<const uint4 *>(L.st + row * (HP * 2) + chunk * 16);
+        if (live) *reinterpret_cast<uint4 *>(dst + (size_t)L.tok[i0 + row] * ld + col0 + chunk * 8) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // load the three (or four) tiles of one (window, head): lane = token; 4 x 16 bytes per matrix row
 __device__ __forceinline__ void load_tiles(WaveLds &L, const unsigned short *qkv, const unsigned short *dout,
@@ -200,14 +224,7 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_fwd_mfma_kernel(const un
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) o = mfma(acc_frag(p[jt][it], s), tr_frag_perm(L.v, 32 * jt + 16 * s, lane), o);
-            if (live) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = 32 * it + acc_row(r, lane);
-                    const __bf16 v = (__bf16)o[r];
-                    out[(size_t)L.tok[i] * C + h * HP + (lane & 31)] = __builtin_bit_cast(unsigned short, v);
-                }
-            }
+            store_tile(L, o, 1.0f, lane, out, C, h * HP, 32 * it, live);
         }
     }
 }
@@ -274,14 +291,7 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_bwd_mfma_kernel(const un
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) o = mfma(acc_frag(dp[jt][it], s), tr_frag_perm(L.k, 32 * jt + 16 * s, lane), o);
-            if (live) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = 32 * it + acc_row(r, lane);
-                    const __bf16 v = (__bf16)(o[r] * scale);
-                    dqkv[(size_t)L.tok[i] * 3 * C + h * HP + (lane & 31)] = __builtin_bit_cast(unsigned short, v);
-                }
-            }
+            store_tile(L, o, scale, lane, dqkv, 3 * (size_t)C, h * HP, 32 * it, live);
         }
         // ---- orientation 2: queries on the accumulator rows, the key on the lane ----------------------------
         // S = Q K^T and dP = dO V^T again with the operands swapped (16 MFMAs); the per-query max, 1 / sum and delta
@@ -326,17 +336,10 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_bwd_mfma_kernel(const un
                     dkacc[jt] = mfma(acc_frag(d2[jt], s), tr_frag_perm(L.q, 32 * it + 16 * s, lane), dkacc[jt]);
                 }
         }
-        if (live) {
 #pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = 32 * jt + acc_row(r, lane);
-                    unsigned short *row = dqkv + (size_t)L.tok[j] * 3 * C + h * HP + (lane & 31);
-                    const __bf16 dk = (__bf16)(dkacc[jt][r] * scale), dv = (__bf16)dvacc[jt][r];
-                    row[C] = __builtin_bit_cast(unsigned short, dk);
-                    row[2 * C] = __builtin_bit_cast(unsigned short, dv);
-                }
+        for (int jt = 0; jt < 2; ++jt) {
+            store_tile(L, dkacc[jt], scale, lane, dqkv, 3 * (size_t)C, C + h * HP, 32 * jt, live);
+            store_tile(L, dvacc[jt], 1.0f, lane, dqkv, 3 * (size_t)C, 2 * C + h * HP, 32 * jt, live);
         }
     }
     __syncthreads();
