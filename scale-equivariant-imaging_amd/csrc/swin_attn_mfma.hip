@@ -89,7 +89,7 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // per-wave LDS: four [token][32] tiles + bias column of this head + token / region tables
 struct __attribute__((aligned(16))) WaveLds {
     char q[TILE_BYTES], k[TILE_BYTES], v[TILE_BYTES], g[TILE_BYTES];
-    float rowstat[3][NTOK];                               // per query: delta, max, 1 / sum (backward)
+    float rowstat[NTOK][4];                               // per query: delta, max, 1 / sum (backward), pad
     int tok[NTOK], region[NTOK];
     char st[32 * HP * 2];                                 // one 32 x 32 bf16 result tile on its way out (16-byte stores)
 };
@@ -143,11 +143,45 @@ __device__ __forceinline__ void load_tiles(WaveLds &L, const unsigned short *qkv
     }
 }
 
+// ---- elementwise part: what dominated the first version --------------------------------------------------------
+// Measured: 16 MFMAs per item are 0.2 us, the item took 4-5 us, almost all of it integer / LDS work per score element
+// (bias bin, mask region, two table lookups: ~25 VALU instructions x 64 elements per lane). Now:
+//  * bias: bin(i, j) = (iy*15 + ix + 112) - (jy*15 + jx). In the accumulator layout one of the two terms is a
+//    compile-time constant per (tile, register) plus 4 * (lane >> 5), the other a per-lane constant for the whole
+//    kernel: the lookup is ONE ds_read_b32 with an immediate offset from a per-lane base.
+//  * mask (shift 4 only): with window 8 and shift 4 the 3 x 3 regions of calculate_mask reduce, inside a window of the
+//    last window row / column, to "upper / lower half" x "left / right half"; key half and query half are constants
+//    per (query tile, key tile, lane), never per element: the -100 is one per-lane value per tile pair, and windows
+//    away from the last row and column (25 of 36) have none.
+struct LaneGeom {
+    const float *bias_o1[2];      // orientation 1 (keys on rows): base for query tile it; index 108 - c1(jt, r)
+    const float *bias_o2[2];      // orientation 2 (queries on rows): base for key tile jt; index c2(it, r)
+    bool q_low_x[2];              // orientation 1: query column in the right half (ix >= 4), per query tile
+    bool q_low_y[2];              //                query row in the lower half (iy >= 4)
+    bool k_low_x2[2];             // orientation 2: key column in the right half, per key tile
+};
+__device__ __forceinline__ LaneGeom lane_geom(const float *bias_col, int lane) {
+    LaneGeom G;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = 32 * t + (lane & 31), iy = i >> 3, ix = i & 7;
+        G.bias_o1[t] = bias_col + (iy * 15 + ix + 112 - 4 * h) - 108;
+        G.bias_o2[t] = bias_col + 4 * h + 112 - (iy * 15 + ix);          // (here i plays the key on the lane)
+        G.q_low_x[t] = ix >= 4;
+        G.q_low_y[t] = iy >= 4;
+        G.k_low_x2[t] = ix >= 4;
+    }
+    return G;
+}
+__device__ __forceinline__ constexpr int c1(int jt, int r) { return (4 * jt + (r >> 2)) * 15 + (r & 3); }   // jy*15 + jx - 4h
+__device__ __forceinline__ constexpr int c2(int it, int r) { return (4 * it + (r >> 2)) * 15 + (r & 3); }   // iy*15 + ix - 4h
+
 // S^T tiles [jt][it] (rows = keys of tile jt, column = query 32 it + (lane & 31)): scale, bias, mask, softmax over
-// the keys. On return p[jt][it] holds the probabilities; mx / inv_sum per query are returned for the backward.
-template <bool KEEP_STATS>
-__device__ __forceinline__ void scores_T(WaveLds &L, const float *bias_col, float scale, int lane,
-                                         f32x16 (&p)[2][2]) {
+// the keys. On return p[jt][it] holds the probabilities.
+template <bool SHIFTED, bool KEEP_STATS>
+__device__ __forceinline__ void scores_T(WaveLds &L, const LaneGeom &G, float scale, int lane, bool last_row,
+                                         bool last_col, f32x16 (&p)[2][2]) {
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -157,21 +191,21 @@ __device__ __forceinline__ void scores_T(WaveLds &L, const float *bias_col, floa
             for (int s = 0; s < 2; ++s) acc = mfma(row_frag(L.k, 32 * jt, s, lane), row_frag(L.q, 32 * it, s, lane), acc);
             p[jt][it] = acc;
         }
+    const bool k_low_x = (lane >> 5) == 1;               // key column (r & 3) + 4h >= 4
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const int i = 32 * it + (lane & 31);
-        const int ri = L.region[i];
         float mx = -3.0e38f;
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int jt = 0; jt < 2; ++jt) {
+            float pen = 0.f;                             // key row 4 jt + (r >> 2) >= 4  <=>  jt == 1
+            if (SHIFTED && ((last_row && G.q_low_y[it] != (jt == 1)) || (last_col && G.q_low_x[it] != k_low_x))) pen = -100.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int j = 32 * jt + acc_row(r, lane);
-                float v = p[jt][it][r] * scale + bias_col[bias_bin(i, j)];
-                if (L.region[j] != ri) v += -100.0f;
+                const float v = fmaf(p[jt][it][r], scale, G.bias_o1[it][108 - c1(jt, r)]) + pen;
                 p[jt][it][r] = v;
                 mx = fmaxf(mx, v);
             }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
 #pragma unroll
@@ -185,8 +219,8 @@ __device__ __forceinline__ void scores_T(WaveLds &L, const float *bias_col, floa
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
         if (KEEP_STATS && lane < 32) {
-            L.rowstat[1][i] = mx;
-            L.rowstat[2][i] = inv;
+            L.rowstat[32 * it + lane][1] = mx;
+            L.rowstat[32 * it + lane][2] = inv;
         }
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
@@ -195,6 +229,7 @@ __device__ __forceinline__ void scores_T(WaveLds &L, const float *bias_col, floa
     }
 }
 
+template <bool SHIFTED>
 __global__ __launch_bounds__(64 * WAVES) void swin_attn_fwd_mfma_kernel(const unsigned short *__restrict__ qkv,
                                                                           const float *__restrict__ table,
                                                                           unsigned short *__restrict__ out, MGeom g,
@@ -204,6 +239,7 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_fwd_mfma_kernel(const un
     const int h = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int b = threadIdx.x; b < NB; b += 64 * WAVES) bias_col[b] = table[b * g.heads + h];
     WaveLds &L = lds[wave];
+    const LaneGeom G = lane_geom(bias_col, lane);
     const int C = g.heads * HP;
     const int stride = groups * WAVES;
     const int rounds = (g.nwin + stride - 1) / stride;
@@ -211,11 +247,13 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_fwd_mfma_kernel(const un
         const int win_raw = (rd * groups + blockIdx.x) * WAVES + wave;
         const bool live = win_raw < g.nwin;
         const int win = live ? win_raw : g.nwin - 1;
+        const int wloc = win % (g.nwy * g.nwx);
+        const bool last_row = wloc / g.nwx == g.nwy - 1, last_col = wloc % g.nwx == g.nwx - 1;
         __syncthreads();                                   // previous round's LDS reads are done
         load_tiles(L, qkv, nullptr, g, win, h, lane);
         __syncthreads();
         f32x16 p[2][2];
-        scores_T<false>(L, bias_col, scale, lane, p);
+        scores_T<SHIFTED, false>(L, G, scale, lane, last_row, last_col, p);
         // O[it] = sum over keys P[query][key] V[key][d]  =  (P^T tile)^T V
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -229,6 +267,7 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_fwd_mfma_kernel(const un
     }
 }
 
+template <bool SHIFTED>
 __global__ __launch_bounds__(64 * WAVES) void swin_attn_bwd_mfma_kernel(const unsigned short *__restrict__ qkv,
                                                                           const float *__restrict__ table,
                                                                           const unsigned short *__restrict__ dout,
@@ -243,6 +282,10 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_bwd_mfma_kernel(const un
         bins[b] = 0.f;
     }
     WaveLds &L = lds[wave];
+    const LaneGeom G = lane_geom(bias_col, lane);
+    // dS summed over every window this wave walks: element (jt, it, r) of a lane always belongs to the same bias bin
+    // (the bin depends on the positions inside the window only), so the table gradient needs no atomics in the loop
+    f32x16 dsum[2][2] = {{{0}, {0}}, {{0}, {0}}};
     const int C = g.heads * HP;
     const int stride = groups * WAVES;
     const int rounds = (g.nwin + stride - 1) / stride;
@@ -250,12 +293,14 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_bwd_mfma_kernel(const un
         const int win_raw = (rd * groups + blockIdx.x) * WAVES + wave;
         const bool live = win_raw < g.nwin;
         const int win = live ? win_raw : g.nwin - 1;
+        const int wloc = win % (g.nwy * g.nwx);
+        const bool last_row = wloc / g.nwx == g.nwy - 1, last_col = wloc % g.nwx == g.nwx - 1;
         __syncthreads();
         load_tiles(L, qkv, dout, g, win, h, lane);
         __syncthreads();
         // ---- orientation 1: keys on the accumulator rows ------------------------------------------------
         f32x16 p[2][2];
-        scores_T<true>(L, bias_col, scale, lane, p);
+        scores_T<SHIFTED, true>(L, G, scale, lane, last_row, last_col, p);
         // dP^T[jt][it] = V dO^T ; delta[query] = sum_keys P dP ; dS^T = P (dP - delta), kept in dp
         f32x16 dp[2][2];
 #pragma unroll
@@ -272,15 +317,15 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_bwd_mfma_kernel(const un
                 for (int r = 0; r < 16; ++r) delta = fmaf(p[jt][it][r], acc[r], delta);
             }
             delta += __shfl_xor(delta, 32, 64);
-            if (lane < 32) L.rowstat[0][32 * it + lane] = delta;             // needed again in orientation 2
-            const int i = 32 * it + (lane & 31);
+            if (lane < 32) L.rowstat[32 * it + lane][0] = delta;             // needed again in orientation 2
+            const float keep = live ? 1.0f : 0.0f;
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float ds = p[jt][it][r] * (dp[jt][it][r] - delta);
                     dp[jt][it][r] = ds;
-                    if (live) atomicAdd(&bins[bias_bin(i, 32 * jt + acc_row(r, lane))], ds);
+                    dsum[jt][it][r] = fmaf(keep, ds, dsum[jt][it][r]);
                 }
         }
         // dQ[it] = scale * (dS^T tile)^T K
@@ -312,19 +357,21 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_bwd_mfma_kernel(const un
                 s2[jt] = a;
                 d2[jt] = b2;
             }
+            // here the query is the accumulator row: its row / column half is (it == 1) / (lane >> 5)
+            float pen[2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+                pen[jt] = (SHIFTED && ((last_row && (it == 1) != (jt == 1)) ||
+                                       (last_col && ((lane >> 5) == 1) != G.k_low_x2[jt]))) ? -100.0f : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = 32 * it + acc_row(r, lane);
-                const int ri = L.region[i];
-                const float delta = L.rowstat[0][i], mx = L.rowstat[1][i], inv = L.rowstat[2][i];
+                const float4 st = *reinterpret_cast<const float4 *>(L.rowstat[32 * it + acc_row(r, lane)]);   // delta, max, 1/sum
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) {
-                    const int j = 32 * jt + (lane & 31);
-                    float v = s2[jt][r] * scale + bias_col[bias_bin(i, j)];
-                    if (L.region[j] != ri) v += -100.0f;
-                    const float pr = __expf(v - mx) * inv;                 // P[query][key]
+                    const float v = fmaf(s2[jt][r], scale, G.bias_o2[jt][c2(it, r)]) + pen[jt];
+                    const float pr = __expf(v - st.y) * st.z;              // P[query][key]
                     s2[jt][r] = pr;
-                    d2[jt][r] = pr * (d2[jt][r] - delta);                  // dS[query][key]
+                    d2[jt][r] = pr * (d2[jt][r] - st.x);                   // dS[query][key]
                 }
             }
             // dV[jt] += (P tile)^T dO ; dK[jt] += (dS tile)^T Q     (reduction over the queries of tile it)
@@ -342,13 +389,23 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_bwd_mfma_kernel(const un
             store_tile(L, dvacc[jt], 1.0f, lane, dqkv, 3 * (size_t)C, 2 * C + h * HP, 32 * jt, live);
         }
     }
+    // table gradient: one LDS add per element and lane for the whole kernel, then 225 global atomics per workgroup
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = 32 * it + (lane & 31);
+        const int base = (i >> 3) * 15 + (i & 7) + 112 - 4 * (lane >> 5);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(&bins[base - c1(jt, r)], dsum[jt][it][r]);
+    }
     __syncthreads();
     for (int b = threadIdx.x; b < NB; b += 64 * WAVES) atomicAdd(dtable + b * g.heads + h, bins[b]);
 }
 
 inline int check(int B, int H, int W, int heads, int shift) {
     SEI_REQUIRE(B > 0 && H >= WS && W >= WS && H % WS == 0 && W % WS == 0 && heads > 0 && heads <= 64);
-    SEI_REQUIRE(shift >= 0 && shift < WS);
+    SEI_REQUIRE(shift == 0 || shift == WS / 2);           // SwinIR: window 8, shift 0 / 4 (the mask logic relies on it)
     SEI_REQUIRE((size_t)B * H * W < ((size_t)1 << 31));
     return SEI_OK;
 }
@@ -367,8 +424,12 @@ extern "C" int sei_swin_attn_fwd_bf16(const uint16_t *qkv, const float *table, u
     if (int rc = check(B, H, W, heads, shift)) return rc;
     MGeom g{H, W, H / WS, W / WS, shift, heads, B * (H / WS) * (W / WS)};
     const int groups = group_count(g.nwin);
-    hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
-                       (hipStream_t)stream, qkv, table, out, g, scale, groups);
+    if (shift)
+        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel<true>, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
+                           (hipStream_t)stream, qkv, table, out, g, scale, groups);
+    else
+        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel<false>, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
+                           (hipStream_t)stream, qkv, table, out, g, scale, groups);
     return sei_launch_status();
 }
 
@@ -380,7 +441,11 @@ extern "C" int sei_swin_attn_bwd_bf16(const uint16_t *qkv, const float *table, c
     if (int rc = check(B, H, W, heads, shift)) return rc;
     MGeom g{H, W, H / WS, W / WS, shift, heads, B * (H / WS) * (W / WS)};
     const int groups = group_count(g.nwin);
-    hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
-                       (hipStream_t)stream, qkv, table, dout, dqkv, dtable, g, scale, groups);
+    if (shift)
+        hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel<true>, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
+                           (hipStream_t)stream, qkv, table, dout, dqkv, dtable, g, scale, groups);
+    else
+        hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel<false>, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
+                           (hipStream_t)stream, qkv, table, dout, dqkv, dtable, g, scale, groups);
     return sei_launch_status();
 }
