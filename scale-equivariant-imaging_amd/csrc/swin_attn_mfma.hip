@@ -117,31 +117,40 @@ __device__ __forceinline__ void store_tile(WaveLds &L, const f32x16 &o, float mu
     __builtin_amdgcn_wave_barrier();
 }
 
-// load the three (or four) tiles of one (window, head): lane = token; 4 x 16 bytes per matrix row
-__device__ __forceinline__ void load_tiles(WaveLds &L, const unsigned short *qkv, const unsigned short *dout,
-                                           const MGeom &g, int win, int h, int lane) {
-    int tok, region;
-    win_token(g, win, lane, tok, region);
-    L.tok[lane] = tok;
-    L.region[lane] = region;
-    const int C = g.heads * HP;
-    const uint4 *src = reinterpret_cast<const uint4 *>(qkv + (size_t)tok * 3 * C + h * HP);
-    uint4 *dq = reinterpret_cast<uint4 *>(L.q + lane * HP * 2);
-    uint4 *dk = reinterpret_cast<uint4 *>(L.k + lane * HP * 2);
-    uint4 *dv = reinterpret_cast<uint4 *>(L.v + lane * HP * 2);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        dq[c] = src[c];
-        dk[c] = src[C / 8 + c];
-        dv[c] = src[2 * C / 8 + c];
+// The tiles of one (window, head), lane = token (4 x 16 bytes per matrix row), in two halves so that the global loads
+// of item t+1 are in flight while item t computes: FETCH (global -> registers) and COMMIT (registers -> LDS). Plain
+// named registers (a struct passed by reference ended up in scratch memory).
+#define SWIN_FETCH(WIN, WITH_G)                                                                              \
+    {                                                                                                        \
+        win_token(g, (WIN), lane, s_tok, s_region);                                                          \
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(qkv + (size_t)s_tok * 3 * C + h * HP);            \
+        s_q0 = src_[0]; s_q1 = src_[1]; s_q2 = src_[2]; s_q3 = src_[3];                                      \
+        s_k0 = src_[C / 8]; s_k1 = src_[C / 8 + 1]; s_k2 = src_[C / 8 + 2]; s_k3 = src_[C / 8 + 3];          \
+        s_v0 = src_[C / 4]; s_v1 = src_[C / 4 + 1]; s_v2 = src_[C / 4 + 2]; s_v3 = src_[C / 4 + 3];          \
+        if (WITH_G) {                                                                                        \
+            const uint4 *gs_ = reinterpret_cast<const uint4 *>(dout + (size_t)s_tok * C + h * HP);           \
+            s_g0 = gs_[0]; s_g1 = gs_[1]; s_g2 = gs_[2]; s_g3 = gs_[3];                                      \
+        }                                                                                                    \
     }
-    if (dout) {
-        const uint4 *gs = reinterpret_cast<const uint4 *>(dout + (size_t)tok * C + h * HP);
-        uint4 *dg = reinterpret_cast<uint4 *>(L.g + lane * HP * 2);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dg[c] = gs[c];
+#define SWIN_COMMIT(WITH_G)                                                                                  \
+    {                                                                                                        \
+        L.tok[lane] = s_tok;                                                                                 \
+        L.region[lane] = s_region;                                                                           \
+        uint4 *d_ = reinterpret_cast<uint4 *>(L.q + lane * HP * 2);                                          \
+        d_[0] = s_q0; d_[1] = s_q1; d_[2] = s_q2; d_[3] = s_q3;                                              \
+        d_ = reinterpret_cast<uint4 *>(L.k + lane * HP * 2);                                                 \
+        d_[0] = s_k0; d_[1] = s_k1; d_[2] = s_k2; d_[3] = s_k3;                                              \
+        d_ = reinterpret_cast<uint4 *>(L.v + lane * HP * 2);                                                 \
+        d_[0] = s_v0; d_[1] = s_v1; d_[2] = s_v2; d_[3] = s_v3;                                              \
+        if (WITH_G) {                                                                                        \
+            d_ = reinterpret_cast<uint4 *>(L.g + lane * HP * 2);                                             \
+            d_[0] = s_g0; d_[1] = s_g1; d_[2] = s_g2; d_[3] = s_g3;                                          \
+        }                                                                                                    \
     }
-}
+#define SWIN_STAGE_REGS                                                                                      \
+    uint4 s_q0, s_q1, s_q2, s_q3, s_k0, s_k1, s_k2, s_k3, s_v0, s_v1, s_v2, s_v3, s_g0, s_g1, s_g2, s_g3;  \
+    int s_tok, s_region;                                                                                     \
+    (void)s_g0; (void)s_g1; (void)s_g2; (void)s_g3;
 
 // ---- elementwise part: what dominated the first version --------------------------------------------------------
 // Measured: 16 MFMAs per item are 0.2 us, the item took 4-5 us, almost all of it integer / LDS work per score element
@@ -243,15 +252,19 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_fwd_mfma_kernel(const un
     const int C = g.heads * HP;
     const int stride = groups * WAVES;
     const int rounds = (g.nwin + stride - 1) / stride;
+    auto window_of = [&](int rd) { return min((rd * groups + (int)blockIdx.x) * WAVES + wave, g.nwin - 1); };
+    const unsigned short *dout = nullptr;
+    SWIN_STAGE_REGS
+    SWIN_FETCH(window_of(0), false)
     for (int rd = 0; rd < rounds; ++rd) {
-        const int win_raw = (rd * groups + blockIdx.x) * WAVES + wave;
-        const bool live = win_raw < g.nwin;
-        const int win = live ? win_raw : g.nwin - 1;
+        const bool live = (rd * groups + (int)blockIdx.x) * WAVES + wave < g.nwin;
+        const int win = window_of(rd);
         const int wloc = win % (g.nwy * g.nwx);
         const bool last_row = wloc / g.nwx == g.nwy - 1, last_col = wloc % g.nwx == g.nwx - 1;
         __syncthreads();                                   // previous round's LDS reads are done
-        load_tiles(L, qkv, nullptr, g, win, h, lane);
+        SWIN_COMMIT(false)
         __syncthreads();
+        if (rd + 1 < rounds) SWIN_FETCH(window_of(rd + 1), false)      // in flight under the MFMAs
         f32x16 p[2][2];
         scores_T<SHIFTED, false>(L, G, scale, lane, last_row, last_col, p);
         // O[it] = sum over keys P[query][key] V[key][d]  =  (P^T tile)^T V
@@ -289,15 +302,18 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_bwd_mfma_kernel(const un
     const int C = g.heads * HP;
     const int stride = groups * WAVES;
     const int rounds = (g.nwin + stride - 1) / stride;
+    auto window_of = [&](int rd) { return min((rd * groups + (int)blockIdx.x) * WAVES + wave, g.nwin - 1); };
+    SWIN_STAGE_REGS
+    SWIN_FETCH(window_of(0), true)
     for (int rd = 0; rd < rounds; ++rd) {
-        const int win_raw = (rd * groups + blockIdx.x) * WAVES + wave;
-        const bool live = win_raw < g.nwin;
-        const int win = live ? win_raw : g.nwin - 1;
+        const bool live = (rd * groups + (int)blockIdx.x) * WAVES + wave < g.nwin;
+        const int win = window_of(rd);
         const int wloc = win % (g.nwy * g.nwx);
         const bool last_row = wloc / g.nwx == g.nwy - 1, last_col = wloc % g.nwx == g.nwx - 1;
         __syncthreads();
-        load_tiles(L, qkv, dout, g, win, h, lane);
+        SWIN_COMMIT(true)
         __syncthreads();
+        if (rd + 1 < rounds) SWIN_FETCH(window_of(rd + 1), true)
         // ---- orientation 1: keys on the accumulator rows ------------------------------------------------
         f32x16 p[2][2];
         scores_T<SHIFTED, true>(L, G, scale, lane, last_row, last_col, p);
