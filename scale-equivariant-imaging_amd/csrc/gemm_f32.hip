@@ -3,16 +3,15 @@
 //
 //   D[M,N] = op(A)[M,K] * op(B)[K,N]  (+ fused epilogue)
 //
-// MFMA: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, bit-exact fmaf chain, 64 FLOP/clk/SIMD =
-// 157 TFLOP/s chip peak). One workgroup = WM x WN waves, each wave owns TM x TN accumulator tiles of
-// 32x32. K is walked in steps of BK = 16: the next A/B tiles are prefetched from HBM/L2 into
-// registers while the current ones are consumed from LDS (issue-early / write-late staging).
+// MFMA: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak). One workgroup =
+// WM x WN waves, each wave owns TM x TN accumulator tiles of 32x32. K is walked in steps of BK = 32: the next A/B tiles
+// are prefetched from HBM/L2 into registers while the current ones are consumed from LDS (issue-early / write-late).
 //
-// LDS image is k-major for both operands -- As[k][m], Bs[k][n] with a row pad of 4 floats -- so the
-// MFMA fragment read (lane l supplies A[m = l&31][k = l>>5], B[k = l>>5][n = l&31]) is a
-// consecutive-lane ds_read_b32: conflict-free for either global layout. A K-contiguous global
-// operand is transposed on its way into LDS (float4 global load -> 4 scalar LDS writes, 2-way bank
-// aliasing which ds_write_b32 absorbs); an M/N-contiguous one is stored with ds_write_b128.
+// The MFMA takes k = 0 from lanes 0-31 and k = 1 from lanes 32-63.  Which k of the tile those are is free as long as A and
+// B agree, so step kk of a tile feeds k = kk from the low lane half and k = BK/2 + kk from the high half: a lane then needs
+// BK/2 CONSECUTIVE k of its row.  A K-contiguous global operand is therefore kept as it lies, s[o][k] with a row stride of
+// BK + 4 floats (ds_write_b128 in, ds_read_b128 out, 36-float stride = conflict-free for 16-lane b128 groups); an
+// M/N-contiguous one is stored k-major, s[k][o] with a row pad of 4, and read with consecutive-lane ds_read_b32.
 //
 // Roofline: compute-bound on the f32 MFMA pipe for the U-Net shapes (arithmetic intensity >= 64
 // FLOP/B at the 128x128 tile); algorithmic FLOPs = 2*M*N*K per call.
@@ -22,9 +21,10 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 16;
-constexpr int PAD = 4;
-
+#ifndef SEI_F32_BK
+#define SEI_F32_BK 32
+#endif
+constexpr int BK = SEI_F32_BK;
 struct GemmArgs {
     const float *A, *B;
     float *D;
@@ -47,13 +47,31 @@ struct TileLoader {
 
     __device__ __forceinline__ static void load(float4 (&v)[NV], const float *__restrict__ base, int ld,
                                                 int o0, int k0, int o_lim, int k_lim, bool aligned) {
+        // Interior k-tiles of an aligned operand take unconditional float4 loads: an outer index past the edge is clamped
+        // onto the last valid row (or the last aligned group of four) -- what it fetches only ever reaches accumulator rows /
+        // columns that the epilogue does not store.  The test is wave-uniform, so the main loop carries one scalar branch
+        // instead of a divergent region per load.
+        if (aligned && k0 + BK <= k_lim && o_lim >= 4 && (ROWS * BK / 4) % NT == 0) {
+#pragma unroll
+            for (int it = 0; it < NV; ++it) {
+                const int f = threadIdx.x + it * NT;
+                if (KCONTIG) {
+                    const int o = min(o0 + f / (BK / 4), o_lim - 1), k = k0 + ((f % (BK / 4)) << 2);
+                    v[it] = *reinterpret_cast<const float4 *>(base + (size_t)o * ld + k);
+                } else {
+                    const int k = k0 + f / (ROWS / 4), o = min(o0 + ((f % (ROWS / 4)) << 2), o_lim - 4);
+                    v[it] = *reinterpret_cast<const float4 *>(base + (size_t)k * ld + o);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
             const int f = threadIdx.x + it * NT;
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
             if (f < ROWS * BK / 4) {
                 if (KCONTIG) {
-                    const int o = o0 + (f >> 2), k = k0 + ((f & 3) << 2);
+                    const int o = o0 + f / (BK / 4), k = k0 + ((f % (BK / 4)) << 2);
                     if (o < o_lim) {
                         const float *p = base + (size_t)o * ld + k;
                         if (aligned && k + 3 < k_lim) {
@@ -84,24 +102,34 @@ struct TileLoader {
         }
     }
 
-    // registers -> LDS image s[k][o], row stride ROWS + PAD
+    // LDS image: s[o][k] for a K-contiguous source, s[k][o] otherwise (see the file header)
+    static constexpr int LD = KCONTIG ? BK + 4 : ROWS + 4;
+    static constexpr int SIZE = KCONTIG ? ROWS * LD : BK * LD;
+
     __device__ __forceinline__ static void store(const float4 (&v)[NV], float *__restrict__ s) {
-        constexpr int LD = ROWS + PAD;
 #pragma unroll
         for (int it = 0; it < NV; ++it) {
             const int f = threadIdx.x + it * NT;
             if (f < ROWS * BK / 4) {
                 if (KCONTIG) {
-                    const int o = f >> 2, k = (f & 3) << 2;
-                    s[(k + 0) * LD + o] = v[it].x;
-                    s[(k + 1) * LD + o] = v[it].y;
-                    s[(k + 2) * LD + o] = v[it].z;
-                    s[(k + 3) * LD + o] = v[it].w;
+                    const int o = f / (BK / 4), k = (f % (BK / 4)) << 2;
+                    *reinterpret_cast<float4 *>(s + o * LD + k) = v[it];
                 } else {
                     const int k = f / (ROWS / 4), o = (f % (ROWS / 4)) << 2;
                     *reinterpret_cast<float4 *>(s + k * LD + o) = v[it];
                 }
             }
+        }
+    }
+
+    // MFMA operand values of outer index o for the steps 4q .. 4q+3 of the tile, lane half lh
+    __device__ __forceinline__ static void fragment(float (&out)[4], const float *__restrict__ s, int o, int lh, int q) {
+        if (KCONTIG) {
+            const float4 t = *reinterpret_cast<const float4 *>(s + o * LD + lh * (BK / 2) + 4 * q);
+            out[0] = t.x, out[1] = t.y, out[2] = t.z, out[3] = t.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[e] = s[(lh * (BK / 2) + 4 * q + e) * LD + o];
         }
     }
 };
@@ -110,12 +138,10 @@ template <int TM, int TN, int WM, int WN, bool TRANSA, bool TRANSB>
 __global__ __launch_bounds__(WM *WN * 64) void gemm_f32_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int LDA = BM + PAD, LDB = BN + PAD;
-    __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
-
     using LA = TileLoader<BM, NT, !TRANSA>;   // A (M,K) row-major is K-contiguous when !TRANSA
     using LB = TileLoader<BN, NT, TRANSB>;    // B (N,K) row-major is K-contiguous when TRANSB
+    __shared__ __attribute__((aligned(16))) float As[LA::SIZE];
+    __shared__ __attribute__((aligned(16))) float Bs[LB::SIZE];
 
     const int zb = blockIdx.z / g.splitk, zs = blockIdx.z - zb * g.splitk;
     const float *__restrict__ A = g.A + (size_t)zb * g.strideA;
@@ -146,6 +172,9 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_f32_kernel(GemmArgs g) {
     LA::load(ra, A, lda, m0, k_begin, M, k_end, a_al);
     LB::load(rb, B, ldb, n0, k_begin, N, k_end, b_al);
 
+    // One LDS image per operand, two barriers per k-tile; the second workgroup of the CU fills the matrix pipe across them.
+    // (Two images and one barrier, the next tile written in front of the last quarter of the MFMAs, measured SLOWER on
+    // every U-Net shape -- 33.6 vs 27.9 ms over tools/bench_gemm.py's list -- and is not kept.)
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         __syncthreads();                 // previous tile fully consumed
         LA::store(ra, As);
@@ -155,20 +184,20 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_f32_kernel(GemmArgs g) {
             LA::load(ra, A, lda, m0, k0 + BK, M, k_end, a_al);
             LB::load(rb, B, ldb, n0, k0 + BK, N, k_end, b_al);
         }
-        const float *as = As + lh * LDA + wm * (32 * TM) + li;
-        const float *bs = Bs + lh * LDB + wn * (32 * TN) + li;
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
+        for (int q = 0; q < BK / 8; ++q) {
+            float a[TM][4], b[TN][4];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[(2 * kk) * LDA + 32 * i];
+            for (int i = 0; i < TM; ++i) LA::fragment(a[i], As, wm * (32 * TM) + 32 * i + li, lh, q);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[(2 * kk) * LDB + 32 * j];
+            for (int j = 0; j < TN; ++j) LB::fragment(b[j], Bs, wn * (32 * TN) + 32 * j + li, lh, q);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
         }
     }
 
