@@ -93,6 +93,18 @@ int sei_scale_resample_bwd(const float *gy, float *gx, const float *rate, const 
                            int B, int C, int Hi, int Wi, int H, int W, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Nearest-neighbour rotation about the image centre: the `Rotations` option of the equivariant loss
+ * (src/losses/__init__.py:84-91 -> deepinv.transform.Rotate -> torchvision.transforms.functional.rotate with
+ * its defaults: NEAREST, no expand, zero fill).  x, y: (planes, H, W).  (t00 t01; t10 t11) is the linear part
+ * of torchvision's inverse affine matrix for the angle, rounded to float32 by the caller:
+ * (cos a, -sin a; sin a, cos a) with a = the angle in radians.  _bwd accumulates into a zero-filled gx.
+ * ------------------------------------------------------------------------------------------- */
+int sei_rotate_nearest_fwd(const float *x, float *y, int planes, int H, int W, float t00, float t01, float t10,
+                           float t11, void *stream);
+int sei_rotate_nearest_bwd(const float *gy, float *gx, int planes, int H, int W, float t00, float t01, float t10,
+                           float t11, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Loss-side streaming kernels.
  * sei_axpy: out = a + alpha*b  (GaussianNoise y + sigma*n, deepinv; SURE probe y + tau*b,
  *           src/losses/sure.py:24).

@@ -143,6 +143,38 @@ def scale_transform_normal(x, rate, antialias):
         for k in range(x.shape[0])])
 
 
+def rotate_nearest(x, angle):
+    """deepinv.transform.Rotate's resampler (src/losses/__init__.py:84-91 -> torchvision rotate(x, angle) with its
+    defaults) [torchvision absent -> restated from recollection of its tensor path, UNPINNED]: inverse affine matrix
+    (cos a, -sin a, 0; sin a, cos a, 0) in float32, base grid of pixel centres about the image centre, rows divided
+    by (W/2, H/2), one bmm, then F.grid_sample(nearest, zeros, align_corners=False)."""
+    import math
+    B, C, H, W = x.shape
+    a = math.radians(angle)
+    theta = torch.tensor([math.cos(a), -math.sin(a), 0.0, math.sin(a), math.cos(a), 0.0], dtype=x.dtype).reshape(1, 2, 3)
+    base = torch.empty(1, H, W, 3, dtype=x.dtype)
+    base[..., 0].copy_(torch.linspace(-W * 0.5 + 0.5, W * 0.5 + 0.5 - 1, steps=W))
+    base[..., 1].copy_(torch.linspace(-H * 0.5 + 0.5, H * 0.5 + 0.5 - 1, steps=H).unsqueeze(-1))
+    base[..., 2].fill_(1)
+    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * W, 0.5 * H], dtype=x.dtype)
+    grid = base.view(1, H * W, 3).bmm(rescaled).view(1, H, W, 2).expand(B, H, W, 2)
+    return F.grid_sample(x, grid, mode="nearest", padding_mode="zeros", align_corners=False)
+
+
+def rotate_source_margin(shape, angle):
+    """Distance of every output pixel's source coordinate from the nearest rounding tie (.5), in float64: where this is
+    tiny, float32 evaluation order decides the neighbour and two correct implementations may differ."""
+    import math
+    H, W = shape
+    a = math.radians(angle)
+    j = torch.arange(W, dtype=torch.float64) + 0.5 - W / 2
+    i = (torch.arange(H, dtype=torch.float64) + 0.5 - H / 2).unsqueeze(-1)
+    ix = math.cos(a) * j - math.sin(a) * i + W / 2 - 0.5
+    iy = math.sin(a) * j + math.cos(a) * i + H / 2 - 0.5
+    tie = lambda v: ((v - torch.floor(v)) - 0.5).abs()
+    return torch.minimum(tie(ix), tie(iy))
+
+
 # ----------------------------------------------------------------------------------------------
 # U-Net (src/models/convolutional.py), functional over the reference's state_dict key layout
 # ----------------------------------------------------------------------------------------------

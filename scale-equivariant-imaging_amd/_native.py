@@ -32,6 +32,8 @@ SIGNATURES = {
     "sei_resample_sepband": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P],
     "sei_scale_resample_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_scale_resample_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sei_rotate_nearest_fwd": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
+    "sei_rotate_nearest_bwd": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
     "sei_axpy": [_P, _P, _F, _P, _Z, _P],
     "sei_sure_terms": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     "sei_mse_terms": [_P, _P, _Z, _F, _P, _P, _P, _P],

@@ -265,6 +265,44 @@ __global__ __launch_bounds__(256) void scale_resample_bwd_kernel(
     }
 }
 
+// ---- nearest-neighbour rotation about the image centre (deepinv.transform.Rotate -> torchvision rotate) ------------
+// Source pixel of output (i, j), in the arithmetic of torchvision's tensor path: base grid xg = j + 0.5 - W/2,
+// yg = i + 0.5 - H/2 (its linspace is exact: half-integers), theta rows divided by (W/2, H/2), the three-term product of
+// the bmm, then grid_sample's un-normalisation ((g + 1) * size - 1) / 2 and nearbyint (ties to even); out-of-range
+// sources read as zero.  All float32, unfused (the file is built with -ffp-contract=off).
+struct RotateMap {
+    float r00, r10, r01, r11;   // theta[0][0] / (W/2), theta[0][1] / (W/2), theta[1][0] / (H/2), theta[1][1] / (H/2)
+};
+
+__device__ __forceinline__ int rotate_source(int p, int H, int W, const RotateMap &m) {
+    const int i = p / W, j = p - i * W;
+    const float xg = ((float)j + 0.5f) - 0.5f * (float)W, yg = ((float)i + 0.5f) - 0.5f * (float)H;
+    const float gx = xg * m.r00 + yg * m.r10, gy = xg * m.r01 + yg * m.r11;
+    const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    const float nx = nearbyintf(ix), ny = nearbyintf(iy);
+    if (!(nx >= 0.f && nx <= (float)(W - 1) && ny >= 0.f && ny <= (float)(H - 1))) return -1;
+    return (int)ny * W + (int)nx;
+}
+
+__global__ __launch_bounds__(256) void rotate_nearest_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                 int planes, int H, int W, RotateMap m) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const int src = rotate_source(p, H, W, m);
+    for (int c = blockIdx.y; c < planes; c += gridDim.y)
+        y[(size_t)c * H * W + p] = src < 0 ? 0.f : x[(size_t)c * H * W + src];
+}
+
+__global__ __launch_bounds__(256) void rotate_nearest_bwd_kernel(const float *__restrict__ gy, float *__restrict__ gx,
+                                                                 int planes, int H, int W, RotateMap m) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const int src = rotate_source(p, H, W, m);
+    if (src < 0) return;
+    for (int c = blockIdx.y; c < planes; c += gridDim.y)      // several outputs may share a source pixel
+        atomicAdd(gx + (size_t)c * H * W + src, gy[(size_t)c * H * W + p]);
+}
+
 // pick a tile so that tile + halo fits comfortably in LDS and small images are one tile
 inline void blur_tiles(int H, int W, int kv, int kh, int &th, int &tw) {
     th = H < 64 ? H : 64;
@@ -351,5 +389,30 @@ extern "C" int sei_scale_resample_bwd(const float *gy, float *gx, const float *r
     const float two_over_h = (float)(2.0 / (double)H), two_over_w = (float)(2.0 / (double)W);
     hipLaunchKernelGGL(scale_resample_bwd_kernel, dim3((unsigned)sei_ceil_div(total, 256)), dim3(256), 0,
                        (hipStream_t)stream, gy, gx, rate, center, B, C, Hi, Wi, H, W, two_over_h, two_over_w);
+    return sei_launch_status();
+}
+
+static RotateMap rotate_map(const float theta[4], int H, int W) {
+    const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    return RotateMap{theta[0] / hw, theta[1] / hw, theta[2] / hh, theta[3] / hh};
+}
+
+extern "C" int sei_rotate_nearest_fwd(const float *x, float *y, int planes, int H, int W, float t00, float t01,
+                                      float t10, float t11, void *stream) {
+    SEI_REQUIRE(x && y && x != y && planes > 0 && H > 0 && W > 0 && (size_t)H * W < (1u << 30));
+    const float theta[4] = {t00, t01, t10, t11};
+    const dim3 grid((unsigned)sei_ceil_div((size_t)H * W, 256), (unsigned)(planes < 1024 ? planes : 1024));
+    hipLaunchKernelGGL(rotate_nearest_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, planes, H, W,
+                       rotate_map(theta, H, W));
+    return sei_launch_status();
+}
+
+extern "C" int sei_rotate_nearest_bwd(const float *gy, float *gx, int planes, int H, int W, float t00, float t01,
+                                      float t10, float t11, void *stream) {
+    SEI_REQUIRE(gy && gx && gx != gy && planes > 0 && H > 0 && W > 0 && (size_t)H * W < (1u << 30));
+    const float theta[4] = {t00, t01, t10, t11};
+    const dim3 grid((unsigned)sei_ceil_div((size_t)H * W, 256), (unsigned)(planes < 1024 ? planes : 1024));
+    hipLaunchKernelGGL(rotate_nearest_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gy, gx, planes, H, W,
+                       rotate_map(theta, H, W));
     return sei_launch_status();
 }

@@ -6,8 +6,9 @@
 for `--dataset div2k` and `--dataset single_image` (PNG decode through PIL, the resize through the banded HIP
 resampler). `--dataset synthetic` is this build's own file-less stand-in with the same (x, y) contract
 (uniform-noise images through the real physics operator): it is what bench.py and the GPU tests use, since no
-image data ships with the repository. Not rebuilt: urban100 / ct / fmd readers, the Noise2Inverse transform and
-the HOMOGENEOUS_SWINIR environment switches (SwinIR-only).
+image data ships with the repository. The `noise2inverse` flag travels as upstream: the training wrapper stores and
+ignores it, the test wrapper trims deblurring measurements to even sizes for noise2inverse.py's row slicing.
+Not rebuilt: urban100 / ct / fmd readers.
 """
 import torch
 from torch.nn import Module
@@ -61,8 +62,7 @@ class PrepareTrainingPairs(Module):
 class TrainingDataset(BaseDataset):
     def __init__(self, synthetic_dataset, physics, css, noise2inverse, prepare_training_pairs, _HOTFIX):
         super().__init__()
-        if noise2inverse:
-            raise NotImplementedError("--method noise2inverse: its dataset transform is outside this build")
+        self.noise2inverse = noise2inverse                  # stored and never read, as upstream (:63)
         self.synthetic_dataset = synthetic_dataset
         self.physics = physics
         self.css = css
@@ -86,13 +86,14 @@ class TrainingDataset(BaseDataset):
 class TestDataset(BaseDataset):
     def __init__(self, synthetic_dataset, noise2inverse, physics):
         super().__init__()
-        if noise2inverse:
-            raise NotImplementedError("--noise2inverse evaluation is outside this build")
+        self.noise2inverse = noise2inverse
         self.synthetic_dataset = synthetic_dataset
         self.physics = physics
 
     def __getitem__(self, index):
         x, y = self.synthetic_dataset[index]
+        if self.noise2inverse and self.physics.task == "deblurring":     # even height and width (reference :112-118)
+            y = y[:, :2 * (y.shape[1] // 2), :2 * (y.shape[2] // 2)]
         if x.shape != y.shape:                              # crop x to a multiple of y's size (reference :121-128)
             h, w = y.shape[1], y.shape[2]
             f = self.physics.rate if self.physics.task == "sr" else 1

@@ -3,7 +3,7 @@
 `get_loss(args, physics)` -> module with forward(x, y, model) -> 0-dim tensor. The hot path is
 method "proposed": crop the batch to 48x48 (Loss.forward), then SURE + scale-equivariant loss
 (ProposedLoss). `supervised`, `css`, `noise2inverse` and `sure` keep their surface (thin model(y) + one
-loss term); the R2R alternative and the Rotate/Shift transforms are outside this build's scope.
+loss term); the R2R alternative and the Rotate / Shift transforms sit behind the same ProposedLoss surface.
 
 One build-side optimisation, on by default and exactly equivalent per image: the two network passes
 that do not depend on each other -- model(y) and model(y + tau*b) -- run as ONE batch of 2B images
@@ -18,7 +18,7 @@ from torch.nn.functional import l1_loss
 
 from crop import CropPair
 from physics._ops import axpy
-from transforms import ScalingTransform, Shift
+from transforms import CombinedTransform, Rotate, ScalingTransform, Shift
 from .ei import EILoss, SupLoss, mse
 from .r2r import R2REILoss
 from .sure import SureGaussianLoss, draw_probe
@@ -125,10 +125,10 @@ class ProposedLoss(Module):
             ei_transform = ScalingTransform(**blueprint[ScalingTransform.__name__])
         elif transforms == "Shifts":
             ei_transform = Shift()
-        elif transforms in ("Rotations+Shifts", "Rotations"):
-            raise NotImplementedError(f"--ProposedLoss__transforms {transforms}: deepinv's Rotate resamples through "
-                                      "kornia.geometry.rotate, which is neither in the reference tree nor "
-                                      "importable here (unpinned); Scaling_Transforms and Shifts are available")
+        elif transforms == "Rotations+Shifts":
+            ei_transform = CombinedTransform([Rotate(), Shift()])
+        elif transforms == "Rotations":
+            ei_transform = Rotate()
         else:
             raise ValueError(f"Unknown transforms: {transforms}")
         assert sure_alternative in [None, "r2r"]

@@ -5,6 +5,8 @@ bicubic grid sampling and reflection padding. The reference materialises a (B,H,
 F.grid_sample; here `sei_scale_resample_fwd` generates the grid in-kernel from (rate, centre).
 Random draws keep the reference's order and distributions (rand(B) then rand(B,2) on x's device).
 """
+import math
+
 import torch
 from torch.nn import Module
 
@@ -169,6 +171,56 @@ class Shift(Module):
         sx = torch.arange(-h_max, h_max)[torch.randperm(2 * h_max)][: self.n_trans]
         sy = torch.arange(-w_max, w_max)[torch.randperm(2 * w_max)][: self.n_trans]
         return torch.cat([torch.roll(x, [int(a), int(b)], [-2, -1]) for a, b in zip(sx, sy)], dim=0)
+
+
+class _RotateNearest(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, theta):
+        N.check_tensor(x, "x")
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        N.call("sei_rotate_nearest_fwd", x.data_ptr(), y.data_ptr(), B * C, H, W, *theta)
+        ctx.theta = theta
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, C, H, W = g.shape
+        gx = torch.zeros_like(g)
+        N.call("sei_rotate_nearest_bwd", g.data_ptr(), gx.data_ptr(), B * C, H, W, *ctx.theta)
+        return gx, None
+
+
+class Rotate(Module):
+    """Random rotation about the image centre (deepinv.transform.Rotate at v0.2.0, the `Rotations` option of
+    src/losses/__init__.py:84-91; restated from recollection of its source -- deepinv and torchvision are absent,
+    unpinned): with the default group (degrees=360) one whole-degree angle per transform is taken from 1..359 by a
+    random permutation on the CPU generator, and the batch is rotated by torchvision's `rotate` defaults (nearest
+    neighbour, same canvas, zero fill), here `sei_rotate_nearest_fwd`."""
+
+    def __init__(self, n_trans=1, degrees=360):
+        super().__init__()
+        self.n_trans, self.group_size = n_trans, degrees
+
+    def sample(self):
+        if self.group_size == 360:
+            angles = torch.arange(0, 360)[1:][torch.randperm(359)]
+        else:
+            angles = torch.arange(0, 360, int(360 / (self.group_size + 1)))[1:][torch.randperm(self.group_size)]
+        return [float(a) for a in angles[: self.n_trans]]
+
+    @staticmethod
+    def matrix(angle):
+        """Linear part of torchvision's inverse affine matrix for rotate(img, angle), as float32 values."""
+        a = math.radians(angle)
+        return tuple(float(torch.tensor(v, dtype=torch.float32)) for v in
+                     (math.cos(a), -math.sin(a), math.sin(a), math.cos(a)))
+
+    def forward(self, x, params=None):
+        angles = self.sample() if params is None else params
+        x = x.contiguous()
+        return torch.cat([_RotateNearest.apply(x, self.matrix(a)) for a in angles], dim=0)
 
 
 class CombinedTransform(Module):

@@ -7,9 +7,10 @@
 For every test pair: x_hat = model(y) under no_grad (the same HIP forward as training, any image size), then
 quantise to 8 bits and clamp x, y, x_hat (reference :140-148), PSNR on the luma channel (src/metrics.py), and
 the reference's summary lines. In scope: the Proposed model family, `--dataset div2k | single_image | synthetic`
-or a directory of PNG measurements, `--save_images`, `--save_psf`, `--indices`, `--print_all_metrics`.
-Out of scope and refused: DIP / PnP / BM3D / DiffPIR / DPS / TV baselines, `--noise2inverse`, `--r2r`
-(SURVEY section 2); SSIM and LPIPS are printed as nan (torchmetrics / pyiqa are not rebuilt).
+or a directory of PNG measurements, `--save_images`, `--save_psf`, `--indices`, `--print_all_metrics`,
+`--noise2inverse` (src/noise2inverse.py's sliced evaluation around the same backbone) and `--r2r`.
+Out of scope and refused: DIP / PnP / BM3D / DiffPIR / DPS / TV baselines; SSIM and LPIPS are
+printed as nan (torchmetrics / pyiqa are not rebuilt).
 """
 import os
 import sys
@@ -73,8 +74,8 @@ def main(argv=None):
     torch.manual_seed(0)
     np.random.seed(0)
     args = build_parser().parse_args(argv)
-    if args.noise2inverse or args.r2r or args.model_kind == "dip":
-        raise NotImplementedError("--noise2inverse / --r2r / DIP evaluation are outside the hot path of this build")
+    if args.model_kind == "dip":
+        raise NotImplementedError("DIP evaluation is outside the hot path of this build")
     from models import _ops as model_ops
     model_ops.set_compute_dtype(args.compute_dtype)
 
@@ -112,7 +113,22 @@ def main(argv=None):
         x = x.unsqueeze(0) if x is not None else None
         y = y.unsqueeze(0)
         with torch.no_grad():
-            x_hat = model(y.contiguous())
+            if args.noise2inverse:                            # reference demo/test.py:116-126
+                from noise2inverse import Noise2InverseModel
+                if physics.task != "deblurring" and not hasattr(physics, "A_dagger"):
+                    raise NotImplementedError("--noise2inverse needs physics.A_dagger outside deblurring")
+                wrapped = Noise2InverseModel(backbone=lambda v: model(v.contiguous()), task=physics.task,
+                                             physics_filter=getattr(physics, "filter", None),
+                                             degradation_inverse_fn=getattr(physics, "A_dagger", None))
+                x_hat = wrapped(y)
+            elif args.r2r:                                    # :127-134
+                x_hat = torch.zeros_like(x)
+                for _ in range(args.r2r_itercount):
+                    pert = torch.randn_like(y) * physics.noise_model.sigma
+                    x_hat += model((y + 0.5 * pert).contiguous())
+                x_hat /= args.r2r_itercount
+            else:
+                x_hat = model(y.contiguous())
         x = quantize_and_clamp(x) if x is not None else None
         y = quantize_and_clamp(y)
         x_hat = quantize_and_clamp(x_hat)

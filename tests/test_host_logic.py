@@ -385,8 +385,7 @@ def test_dataset_wrappers_follow_the_reference(tmp_path):
     prep = datasets.PrepareTrainingPairs(types.SimpleNamespace(task="deblurring"), 32, "center")
     xc, yc = prep(torch.zeros(3, 64, 80), torch.zeros(3, 64, 80))
     assert xc.shape == (3, 32, 32) and yc.shape == (3, 32, 32)
-    with pytest.raises(NotImplementedError):
-        datasets.TestDataset(FakeSynthetic(), True, sr)
+    assert datasets.TestDataset(FakeSynthetic(), True, sr)[0][1].shape == (3, 50, 33)       # even-size trim: deblurring only
     args = types.SimpleNamespace(dataset="urban100", method="proposed", GroundTruthDataset__datasets_dir=str(tmp_path),
                                  GroundTruthDataset__download=False, GroundTruthDataset__size=256,
                                  GroundTruthDataset__split="train", memoize_gt=False,
@@ -434,3 +433,89 @@ def test_swinir_module_tree_matches_the_published_layout():
     masks = m.draw_drop_masks(4, "cpu")
     assert masks[0] is None and len(masks) == 36
     assert all(abs(v) < 1e-6 or abs(v - 1 / 0.9) < 1e-5 for v in masks[-1][0].tolist())
+
+
+def test_published_weight_files_load_into_the_default_backbone(tmp_path):
+    """N2 (src/training.py:34-46, src/models/__init__.py:161-170): the authors' weight files are `backbone.state_dict()`
+    of the deepinv SwinIR -- official parameter names plus the `attn_mask` / `relative_position_index` buffers -- stored
+    bare or under "params".  A file with that key set (values from the oracle's seeded init; the network is not
+    reachable from here) loads strictly through get_weights -> Model.load_weights, lands in the flat bucket, and
+    get_weights() hands back the same keys, so files written here are readable upstream."""
+    sys.path.insert(0, ROOT)
+    import train
+    import training
+    from models import get_model
+    from oracle import swinir_path as sp
+    torch.manual_seed(1)
+    published = dict(sp.swinir_init_state_dict(2))
+    for i in range(6):
+        for j in range(6):
+            blk = f"layers.{i}.residual_group.blocks.{j}."
+            published[blk + "attn.relative_position_index"] = sp.relative_position_index()
+            if j % 2:
+                published[blk + "attn_mask"] = sp.shift_mask(48, 48)
+    a = train.build_parser().parse_args(["--task", "sr", "--sr_factor", "2", "--method", "proposed", "--out_dir", "o"])
+    assert a.ProposedModel__architecture == "Transformer"
+    for wrap in (False, True):
+        path = str(tmp_path / f"Proposed_sr_x2_{int(wrap)}.pt")
+        torch.save({"params": published} if wrap else published, path)
+        model = get_model(a, physics=None, device="cpu")
+        model.load_weights(training.get_weights(path, "cpu"))
+        back = model.get_weights()
+        assert set(back) == set(published)
+        assert all(torch.equal(back[k], published[k]) for k in published)
+        bb = model.get_backbone()
+        w = model.get_parameter("model.model.conv_last.weight")            # the path demo/train.py:180-184 addresses
+        assert w.data_ptr() == bb.conv_last.weight.data_ptr() and torch.equal(w, published["conv_last.weight"])
+        bb.flatten_parameters()                                            # what .to(device) does
+        w = model.get_parameter("model.model.conv_last.weight")
+        lo = w.data_ptr() - bb.flat_params.data_ptr()
+        assert 0 <= lo < bb.flat_params.numel() * 4 and torch.equal(w, published["conv_last.weight"])
+    bad = dict(published)
+    bad.pop("conv_last.bias")
+    with pytest.raises(RuntimeError):
+        model.load_weights(bad)
+
+
+def test_noise2inverse_glue_matches_reference_golden(golden):
+    """src/noise2inverse.py restated in noise2inverse.py against G12 (generated from the reference, tools/gen_golden.py):
+    row slices through the FFT inverse filter, the X:1 (target, input) pair under numpy seed 3, and the summed
+    reconstruction.  The Gaussian filter divides by ~1e-9, so only the same FFT on the same host reproduces the values
+    -- on the CPU this is an equality."""
+    import noise2inverse as n2i
+    g = golden("g12_noise2inverse")
+    y, k = torch.from_numpy(g["y"]), torch.from_numpy(g["kernel"])
+    parts = n2i.ImageSlices(num_splits=4, task="deblurring", physics_filter=k, degradation_inverse_fn=None)(y)
+    for j, part in enumerate(parts):
+        np.testing.assert_allclose(part.numpy(), g[f"slice{j}"], rtol=1e-5, atol=0)
+    masks = n2i.ImageSlices(4, "sr", None, lambda v: v).measurement_slices(y)
+    assert torch.equal(sum(masks), y) and float(masks[1][:, :, 0::4].abs().max()) == 0.0
+    assert torch.equal(masks[1][:, :, 1::4], y[:, :, 1::4])
+    np.random.seed(3)
+    tgt, inp = n2i.Noise2InverseTransform("deblurring", k, None)(None, y)
+    assert int(g["pair.index"]) in range(4)
+    np.testing.assert_allclose(tgt.numpy(), g["pair.tgt"], rtol=1e-5)
+    np.testing.assert_allclose(inp.numpy(), g["pair.inp"], rtol=1e-5)
+    model = n2i.Noise2InverseModel(lambda v: 0.25 * v + 0.1 * v * v, "deblurring", k, None)
+    np.testing.assert_allclose(model(y).numpy(), g["model.x_hat"], rtol=1e-5)
+    assert len(model.compute_inputs(y)) == 4
+    up = n2i.ImageSlices(num_splits=4, task="sr", physics_filter=None, degradation_inverse_fn=lambda v: 2.0 * v)
+    np.testing.assert_array_equal(up(y)[1].numpy(), g["sr.slice1"])
+    # dataset wrappers: the training one ignores the flag, the test one trims deblurring measurements to even sizes
+    import datasets
+
+    class Pairs:
+        def __getitem__(self, i):
+            return torch.zeros(3, 9, 7), torch.ones(3, 9, 7)
+
+        def __len__(self):
+            return 1
+
+    phys = type("P", (), {"task": "deblurring", "rate": 1})()
+    x, yy = datasets.TestDataset(Pairs(), noise2inverse=True, physics=phys)[0]
+    assert yy.shape == (3, 8, 6) and x.shape == (3, 8, 6)
+    x, yy = datasets.TestDataset(Pairs(), noise2inverse=False, physics=phys)[0]
+    assert yy.shape == (3, 9, 7)
+    tr = datasets.TrainingDataset(Pairs(), phys, css=False, noise2inverse=True, prepare_training_pairs=lambda a, b: (a, b),
+                                  _HOTFIX=False)
+    assert tr[0][1].shape == (3, 9, 7) and tr.noise2inverse

@@ -165,7 +165,10 @@ def test_loss_surface_and_methods():
         get_loss(args, p)
     args.method = "proposed"
     args.ProposedLoss__transforms = "Rotations"
-    with pytest.raises(NotImplementedError):
+    val = get_loss(args, p)(x=x, y=y, model=model)
+    assert val.dim() == 0 and torch.isfinite(val)
+    args.ProposedLoss__transforms = "Reflections"
+    with pytest.raises(ValueError):
         get_loss(args, p)
     # SR: margin 0, x/y size ratio from physics.rate, 48 -> 96 crops
     args = ref_args(task="sr", sr_factor=2, kernel=None)
@@ -394,7 +397,9 @@ def test_other_methods_vs_oracle(method):
 
 @pytest.mark.parametrize("flags,graphed", [
     (["--method", "supervised"], True), (["--method", "css"], True), (["--method", "sure"], True),
+    (["--method", "noise2inverse"], True),
     (["--method", "proposed", "--ProposedLoss__transforms", "Shifts"], False),
+    (["--method", "proposed", "--ProposedLoss__transforms", "Rotations+Shifts"], False),
     (["--method", "proposed", "--ScalingTransform__kind", "normal"], False),
     (["--method", "proposed", "--ScalingTransform__antialias", "--batch_size", "1"], False)])
 def test_train_script_methods_and_transforms(tmp_path, flags, graphed):
@@ -484,6 +489,87 @@ def test_r2r_alternative_and_shift_transform_match_oracle():
     assert torch.equal(out, torch.roll(x, [sx, sy], [-2, -1]))
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 48, 48), (1, 2, 37, 53)])
+def test_rotate_transform_vs_oracle(shape):
+    """sei_rotate_nearest_fwd/bwd against the oracle's restatement of torchvision's rotate (nearest, zero fill): equal
+    wherever the source coordinate is not within 1e-4 of a rounding tie (there float32 evaluation order decides);
+    the backward is the exact transpose of the forward map."""
+    import transforms
+    gen = torch.Generator().manual_seed(21)
+    x = torch.rand(shape, generator=gen)
+    g = torch.randn(shape, generator=gen)
+    t = transforms.Rotate()
+    for angle in (1.0, 37.0, 45.0, 90.0, 123.0, 180.0, 270.0, 359.0):
+        xd = x.cuda().requires_grad_(True)
+        out = t(xd, params=[angle])
+        ref = tp.rotate_nearest(x, angle)
+        differs = (out.cpu() != ref).any(dim=0).any(dim=0)
+        margin = tp.rotate_source_margin(shape[-2:], angle)
+        assert not bool((differs & (margin > 1e-4)).any()), angle
+        assert float(differs.float().mean()) < 0.01, angle
+        out.backward(g.cuda())
+        lhs = float((out.detach().double() * g.cuda().double()).sum())
+        rhs = float((xd.grad.double() * x.cuda().double()).sum())
+        assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs)), (angle, lhs, rhs)     # f32 sums where outputs share a source
+        if not bool(differs.any()):
+            xr = x.clone().requires_grad_(True)
+            tp.rotate_nearest(xr, angle).backward(g)
+            assert torch.allclose(xd.grad.cpu(), xr.grad, atol=1e-6), angle
+    assert torch.equal(t(x.cuda(), params=[90.0]).cpu(), torch.rot90(x, 1, (-2, -1))) if shape[-1] == shape[-2] else True
+    torch.manual_seed(3)
+    drawn = t.sample()
+    torch.manual_seed(3)
+    assert drawn == [float(torch.arange(0, 360)[1:][torch.randperm(359)][0])] and 1.0 <= drawn[0] <= 359.0
+
+
+@pytest.mark.parametrize("which", ["Rotations", "Rotations+Shifts"])
+def test_equivariant_loss_with_rotations_vs_oracle(which):
+    """--ProposedLoss__transforms Rotations / Rotations+Shifts (src/losses/__init__.py:84-91): the EI term on the same
+    weights, angle, shifts and injected measurement noise as the oracle; value and every weight-gradient norm."""
+    import physics
+    import models
+    import transforms
+    from losses import get_loss
+    args = ref_args(ProposedLoss__transforms=which)
+    p = physics.get_physics(args, "cuda")
+    torch.manual_seed(0)
+    model = models.get_model(args, p, "cuda").to("cuda")
+    lf = get_loss(args, p)
+    ei = lf.loss.ei
+    kinds = [type(v) for v in ei.T.transforms] if which.endswith("Shifts") else [type(ei.T)]
+    assert kinds == ([transforms.Rotate, transforms.Shift] if which.endswith("Shifts") else [transforms.Rotate])
+    assert not lf.loss.graph_safe
+    gen = torch.Generator().manual_seed(6)
+    y = torch.rand((2, 3, 48, 48), generator=gen)
+    n = torch.randn((2, 3, 48, 48), generator=gen)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.get_weights().items()}
+    net = lambda v: tp.unet_forward(sd, v, scales=3)
+    k2 = tp.blur_kernel("Gaussian_R2")
+    A = lambda v: tp.blur_fft(v, k2)
+    for seed in range(77, 177):                       # a draw whose sources all sit clear of a rounding tie
+        torch.manual_seed(seed)
+        if float(tp.rotate_source_margin((48, 48), transforms.Rotate().sample()[0]).min()) > 2e-4:   # float32 coordinate error is ~1e-5
+            break
+    else:
+        raise AssertionError("no tie-free angle among 100 seeds")
+    shift = transforms.Shift()
+
+    def oracle_transform(t):
+        out = tp.rotate_nearest(t, transforms.Rotate().sample()[0])
+        return shift(out) if which.endswith("Shifts") else out
+
+    torch.manual_seed(seed)
+    ref, _, _ = tp.ei_loss(net(y), A, net, oracle_transform, 5 / 255, n=n)
+    ref.backward()
+    model.get_backbone().zero_grad_flat()
+    torch.manual_seed(seed)
+    val = ei(x_net=model(y.cuda()), physics=p, model=model, noise=n.cuda())
+    val.backward()
+    assert rel(val, ref) < 1e-4, (float(val), float(ref))
+    for name, prm in model.get_backbone().named_parameters():
+        assert relerr(prm.grad, sd[name].grad) < 2e-3, (name, relerr(prm.grad, sd[name].grad))
+
+
 def test_psnr_y_metric_and_registration():
     """metrics.psnr_fn on the GPU (sei_luma_sqerr) against the oracle's luma PSNR; centre-crop registration."""
     import metrics
@@ -548,6 +634,14 @@ def test_train_on_files_then_evaluate(tmp_path):
         return torch.from_numpy(np.asarray(Image.open(p_), dtype=np.float64).transpose(2, 0, 1) / 255.0)
     again = float(tp.psnr_y(load(res / "estimates" / "0.png"), load(res / "ground_truth" / "0.png")))
     assert abs(again - per[0]) < 0.011
+    # the sliced Noise2Inverse evaluation and the R2R average around the same backbone (demo/test.py:116-134)
+    for flags in (["--noise2inverse"], ["--r2r", "--r2r_itercount", "2"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "test.py"), *common, "--dataset", "div2k",
+                            "--GroundTruthDataset__datasets_dir", str(tmp_path / "data"), "--weights",
+                            str(out / "weights.pt"), "--indices", "1", *flags], capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0 and "N: 1" in r.stdout, r.stdout + r.stderr
+        assert np.isfinite(float([ln for ln in r.stdout.splitlines() if ln.startswith("PSNR:")][0].split()[1]))
 
 
 def test_graft_smoke():

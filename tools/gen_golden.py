@@ -111,6 +111,35 @@ def _fwd_vjp(fn, x, seed):
     return y.detach(), ct, gx.detach()
 
 
+def gen_noise2inverse():
+    """G12: src/noise2inverse.py (numpy / torch only, imported by path).  Row slices + FFT inverse filter
+    (ImageSlices, deblurring), the X:1 training pair of Noise2InverseTransform (numpy seed 3) and the summed
+    reconstruction of Noise2InverseModel around a fixed pointwise backbone."""
+    os.makedirs(OUT, exist_ok=True)
+    n2i = _load_by_path("ref_noise2inverse", os.path.join(REF_SRC, "noise2inverse.py"))
+    kernels = _load_by_path("ref_kernels", os.path.join(REF_SRC, "physics", "kernels.py"))
+    kernel = kernels.get_kernel("Gaussian_R2")[None, None].to(torch.float32)
+    y = _rand((2, 3, 16, 20), 31)
+    arrs = {"y": _np(y), "kernel": _np(kernel)}
+    slicer = n2i.ImageSlices(num_splits=4, task="deblurring", physics_filter=kernel, degradation_inverse_fn=None)
+    for j, t in enumerate(slicer(y)):
+        arrs[f"slice{j}"] = _np(t)
+    tr = n2i.Noise2InverseTransform(task="deblurring", physics_filter=kernel, degradation_inverse_fn=None)
+    np.random.seed(3)
+    tgt, inp = tr(None, y)
+    arrs["pair.tgt"], arrs["pair.inp"] = _np(tgt), _np(inp)
+    np.random.seed(3)
+    arrs["pair.index"] = np.asarray(np.random.randint(0, 4))
+    backbone = lambda v: 0.25 * v + 0.1 * v * v
+    model = n2i.Noise2InverseModel(backbone=backbone, task="deblurring", physics_filter=kernel,
+                                   degradation_inverse_fn=None)
+    arrs["model.x_hat"] = _np(model(y))
+    # the non-deblurring branch: the caller's pseudo-inverse stands in for the FFT filter
+    up = n2i.ImageSlices(num_splits=4, task="sr", physics_filter=None, degradation_inverse_fn=lambda v: 2.0 * v)
+    arrs["sr.slice1"] = _np(up(y)[1])
+    _save("g12_noise2inverse", **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _install_deepinv_shell()
@@ -476,4 +505,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["--only", "g12"]:
+        gen_noise2inverse()
+    else:
+        main()
+        gen_noise2inverse()
