@@ -154,7 +154,7 @@ inline DwTiling dw_tiling(int B, int H, int W) {
 }
 
 template <bool WEIGHT_GRAD>
-__global__ __launch_bounds__(DW_THREADS) void dwconv7_tiled_kernel(
+__global__ __launch_bounds__(DW_THREADS, 3) void dwconv7_tiled_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
     const float *__restrict__ res, float res_scale, float *__restrict__ y, const float *__restrict__ gy,
     float *__restrict__ part, int H, int W, int C, int flip, int th, int tw, int tiles_i, int tiles_j,
@@ -168,8 +168,15 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv7_tiled_kernel(
     float acc_w[49];
     float acc_b = 0.f;
     if (!WEIGHT_GRAD) {
+        // The 32 x 49 weights of the channel group are one contiguous run of w: fetched coalesced into LDS, then each
+        // lane picks its channel's row (stride 49 floats: odd, conflict-free).  Read straight from global memory the 49
+        // per-lane loads are 32-line gathers, ~3 us per workgroup that does ~5 us of arithmetic.
+        const int nw = min(DT_CC, C - c0) * 49;
+        for (int e = threadIdx.x; e < nw; e += DW_THREADS) lds[e] = w[(size_t)c0 * 49 + e];
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 49; ++t) wr[t] = c_ok ? w[(size_t)c * 49 + (flip ? 48 - t : t)] : 0.f;
+        for (int t = 0; t < 49; ++t) wr[t] = c_ok ? lds[cl * 49 + (flip ? 48 - t : t)] : 0.f;
+        __syncthreads();
     } else {
 #pragma unroll
         for (int t = 0; t < 49; ++t) acc_w[t] = 0.f;
@@ -293,7 +300,13 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv7_whole_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
     const float *__restrict__ res, float res_scale, float *__restrict__ y, const float *__restrict__ gy,
     float *__restrict__ part, int B, int C, int flip, int imgs_per_thread) {
-    const int c = blockIdx.x * DW_THREADS + threadIdx.x;
+    __shared__ float wl[WEIGHT_GRAD ? 1 : DW_THREADS * 49];
+    const int c0 = blockIdx.x * DW_THREADS, c = c0 + threadIdx.x;
+    if (!WEIGHT_GRAD) {      // the workgroup's weights are one contiguous run of w: coalesced into LDS, rows picked below
+        const int nw = min(DW_THREADS, C - c0) * 49;
+        for (int e = threadIdx.x; e < nw; e += DW_THREADS) wl[e] = w[(size_t)c0 * 49 + e];
+        __syncthreads();
+    }
     if (c >= C) return;
     const int b0 = blockIdx.y * imgs_per_thread, b1 = min(B, b0 + imgs_per_thread);
     constexpr int LO = (S >= 4) ? 0 : 4 - S, HI = 6 - LO;       // taps that can reach the image: |d-3| <= S-1
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(DW_THREADS) void dwconv7_whole_kernel(
     for (int t = 0; t < 49; ++t) {
         const int di = t / 7, dj = t % 7;
         const bool used = di >= LO && di <= HI && dj >= LO && dj <= HI;
-        if (!WEIGHT_GRAD) wr[t] = used ? w[(size_t)c * 49 + (flip ? 48 - t : t)] : 0.f;
+        if (!WEIGHT_GRAD) wr[t] = used ? wl[threadIdx.x * 49 + (flip ? 48 - t : t)] : 0.f;
         else acc_w[t] = 0.f;
     }
     const float bv = (!WEIGHT_GRAD && bias) ? bias[c] : 0.f;
@@ -436,15 +449,19 @@ inline DwWgradPlan dw_wgrad_plan(int B, int H, int W, int C, int seg) {
     if (p.path == DW_TILED) {
         p.tiling = dw_tiling(B, H, W);
         p.gy = (unsigned)sei_ceil_div(C, DT_CC);
-        // ~2048 workgroups in all keeps the machine full and the partial count (gx) small
-        size_t want = 2048 / p.gy > 0 ? 2048 / p.gy : 1;
+        size_t want = 768 / p.gy > 0 ? 768 / p.gy : 1;          // one resident round: 256 CUs x 3 workgroups
         if (want < 64) want = 64;
         p.tiles_per_block = (int)sei_ceil_div(p.tiling.ntiles, want);
         p.gx = (unsigned)sei_ceil_div(p.tiling.ntiles, (size_t)p.tiles_per_block);
         p.nparts = p.gx;
     } else if (p.path == DW_WHOLE3 || p.path == DW_WHOLE6) {
         p.gx = (unsigned)sei_ceil_div(C, DW_THREADS);
-        size_t want = 1024 / p.gx > 0 ? 1024 / p.gx : 1;       // image groups
+        // image groups = partial sets.  Each set is 50 x C floats written here and read back by the finish kernel, against
+        // H x W x C floats of x and of gy per image: keep the partials below about half of the input bytes, but at least
+        // 8 groups (and ~256 workgroups) so the chip still has waves to hide the strided image loads behind.
+        size_t want = (size_t)B * H * W / 64;
+        if (want < 8) want = 8;
+        if (want * p.gx < 256) want = sei_ceil_div(256, p.gx);
         if (want > (size_t)B) want = B;
         p.imgs_per_thread = (int)sei_ceil_div(B, want);
         p.gy = (unsigned)sei_ceil_div(B, p.imgs_per_thread);
