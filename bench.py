@@ -144,6 +144,9 @@ def _stream_bytes(name, a):
         return 4 * B * H * W * (Ci + Co)
     if name == "sei_adam_fused":
         return a[5] * (24 + (2 if a[2] else 4) + (2 if a[-1] else 0))
+    if name == "sei_gemm_bf16nt_dw2_adam":                # param / exp_avg / exp_avg_sq in and out, shadow out, operands
+        M, Nn, K1, K2 = a[11:15]
+        return M * Nn * (24 + (2 if a[9] else 0)) + 2 * (K1 + K2) * (M + Nn)
     if name == "sei_blur_sep_circ":
         return 8 * a[6] * a[7] * a[8]
     if name in ("sei_scale_resample_fwd", "sei_scale_resample_bwd"):
@@ -162,6 +165,8 @@ def _stream_bytes(name, a):
 
 _STREAM_FAMILIES = [
     ("adam_vec_kernel (fused Adam over the flat bucket)", ("sei_adam_fused",)),
+    ("gemm_bf16nt_kernel<..., ADAM> (deep-level weight gradients whose epilogue applies the Adam step)",
+     ("sei_gemm_bf16nt_dw2_adam",)),
     ("dwconv7_* (depthwise 7x7: forward, data and weight gradients)", ("sei_dwconv7_",)),
     ("ln_* (channel LayerNorm forward / backward)", ("sei_ln_",)),
     ("sepmap_* (ideal resamplers)", ("sei_sepmap2",)),
@@ -257,7 +262,9 @@ class Leg:
             ys = 256 if opt.full256 else CROP
             early = reducer is not None and os.environ.get("SEI_NO_EARLY_RELEASE") != "1"
             self.graphed = graphed = GraphedLossStep(loss_fn, model, optimizer, (opt.batch, 3, ys, ys),
-                                                     early_release=early)
+                                                     early_release=early,
+                                                     fuse_optimizer=world == 1 and opt.fuse_optimizer,
+                                                     fuse_min_numel=opt.fuse_min_numel)
             if early and graphed.early_grads is not None:        # the bottleneck block's gradients leave early
                 self.early_event = graphed.early_grads[0]
                 reducer.set_early_range(graphed.early_grads[1:])
@@ -288,12 +295,20 @@ class Leg:
         from models import _ops
         _ops.profile_gemms(True)
         _native.record_calls(True)
-        if self.graphed is not None and self.graphed.store_weight_grads:
-            self.backbone.zero_grad_flat(store_weight_grads=True)
-        else:
-            self.optimizer.zero_grad()
-        keep = self.loss_fn(x=self.x, y=self.y, model=self.model)
-        keep.backward(retain_graph=True)       # keeps the saved activations (GEMM operands) alive for the replay
+        fused = self.graphed is not None and bool(self.graphed.fused_views)
+        if fused:                              # as the captured step: the bottleneck pair is stepped inside its GEMMs
+            _ops.set_fused_adam(*self.graphed.fused_table)
+            self.optimizer.prepare_step()
+        try:
+            if self.graphed is not None and self.graphed.store_weight_grads:
+                self.backbone.zero_grad_flat(store_weight_grads=True)
+            else:
+                self.optimizer.zero_grad()
+            keep = self.loss_fn(x=self.x, y=self.y, model=self.model)
+            keep.backward(retain_graph=True)   # keeps the saved activations (GEMM operands) alive for the replay
+        finally:
+            if fused:
+                _ops.set_fused_adam(None, None)
         if self.reducer is not None:
             self.reducer.reduce_async()
         self.optimizer.step()
@@ -304,8 +319,13 @@ class Leg:
 
 
 def gemm_roofline(records, dtype, reps=3):
+    """MFMA-bound family. The weight-gradient GEMMs that carry the optimizer step in their epilogue move 26 bytes per
+    output element under 1.7 kFLOP of matrix work: they are HBM-bound and are booked with the streaming families
+    (stream_roofline), FLOPs and all; re-issuing them here would also step their weights again."""
     import _native
     total_ms, flops = 0.0, 0.0
+    riding = sum(fl for fl, entry, _ in records if entry == "sei_gemm_bf16nt_dw2_adam")
+    records = [r for r in records if r[1] != "sei_gemm_bf16nt_dw2_adam"]
     for fl, entry, cargs in records:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         _native.call(entry, *cargs)                 # warm
@@ -335,6 +355,7 @@ def gemm_roofline(records, dtype, reps=3):
             "frac": round(achieved / peak, 4), "traffic": None, "traffic_source": None,
             "launches_per_step": len(records), "avg_launch_us": round(1e3 * total_ms / len(records), 2),
             "gemm_ms_per_step": round(total_ms, 2), "algorithmic_gflop_per_step": round(flops / 1e9, 1),
+            "gflop_per_step_inside_hbm_bound_launches": round(riding / 1e9, 1),
             "timed_with": "HIP events on the launch stream around back-to-back re-issues of every GEMM launch of one "
                           "step (recorded arguments), right after the timed region"}
 
@@ -357,6 +378,10 @@ def main():
     ap.add_argument("--grad-comm", choices=["auto", "f32", "bf16"], default="auto",
                     help="dtype of the all-reduced gradient bucket (auto: bf16 in bf16 mode, f32 in f32 mode)")
     ap.add_argument("--grad-comm-mode", choices=["all_reduce", "rs_ag"], default="all_reduce")
+    ap.add_argument("--fuse-optimizer", action=argparse.BooleanOptionalAction, default=True,
+                    help="one GPU, bf16, hipGraph: apply Adam to the 1x1-convolution weights of the two deepest levels (94 %% "
+                         "of the parameters) in the epilogue of the GEMM that produces their gradient")
+    ap.add_argument("--fuse-min-numel", type=int, default=1 << 24, help="smallest weight that takes its step that way")
     ap.add_argument("--graph", action=argparse.BooleanOptionalAction, default=True,
                     help="replay forward+backward as one hipGraph (the eager launch path otherwise)")
     ap.add_argument("--task", choices=["deblurring", "sr"], default="deblurring",
@@ -388,6 +413,7 @@ def main():
 
     sr = opt.task == "sr"
     leg = Leg(opt, opt.dtype, device, rank, world)
+    fused_opt = leg.graphed is not None and bool(leg.graphed.fused_views)
     elapsed, loss_value = leg.timed(opt.warmup, opt.steps, fence)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -456,7 +482,9 @@ def main():
                                     ("NOT cropped (full-256 series)" if opt.full256 else "cropped to 48 in Loss.forward") +
                                     f", ConvolutionalModel hidden={opt.hidden} scales={opt.scales}"),
                        "parameters": nparams, "batch_per_gpu": opt.batch, "global_batch": opt.batch * world,
-                       "parallelism": f"dp{world}", "optimizer": "Adam (fused, flat bucket)",
+                       "parallelism": f"dp{world}",
+                       "optimizer": "Adam (fused, flat bucket" + ("; the deep levels' weights are stepped in the epilogue "
+                                                                  "of their weight-gradient GEMMs)" if fused_opt else ")"),
                        "grad_allreduce": None if world == 1 else
                        f"{str(comm_dtype).replace('torch.', '')}, {opt.grad_comm_mode}",
                        "launch": ("hipGraph replay of forward+backward (random draws made eagerly into static buffers)"

@@ -32,7 +32,7 @@ extern "C" {
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
-#define SEI_ABI_VERSION 3
+#define SEI_ABI_VERSION 4
 int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
@@ -386,6 +386,22 @@ int sei_gemm_bf16nt_conv(const uint16_t *Ap, int cin_pad, const int *row_off9, c
 int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, float *exp_avg, float *exp_avg_sq,
                    size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float grad_scale, uint16_t *param_bf16, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer step inside the weight-gradient GEMM (one GPU, bf16 mode; demo/train.py:157-186 + :262-270 fused):
+ * sei_gemm_bf16nt_dw2_adam computes the same two-segment product as sei_gemm_bf16nt_dw2 -- the COMPLETE
+ * gradient of an (M, N) weight for this step -- and, instead of storing it, applies torch.optim.Adam's update to
+ * param / exp_avg / exp_avg_sq (and the bf16 shadow, optional) in the epilogue: the 4 B/parameter gradient is
+ * neither written nor read back.  Identical per-element arithmetic to sei_adam_fused with grad_scale = 1.
+ * hyper: DEVICE array of 6 floats for this step, {beta1, beta2, eps, weight_decay, lr / (1 - beta1^t),
+ * 1 / sqrt(1 - beta2^t)}; sei_adam_scalars fills a HOST array with exactly the values sei_adam_fused derives from
+ * (lr, betas, eps, weight_decay, step), so that fused and separate steps agree bit for bit.
+ * ------------------------------------------------------------------------------------------- */
+int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1, const uint16_t *B2,
+                             int ldb, float *param, float *exp_avg, float *exp_avg_sq, uint16_t *param_bf16,
+                             const float *hyper, int M, int N, int K1, int K2, void *stream);
+int sei_adam_scalars(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float *out6_host,
+                     void *stream);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,7 @@ SIGNATURES = {
     "sei_gemm_bf16nt_dw2": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "sei_gemm_bf16nt_ex": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     "sei_gemm_bf16nt_dw2_ex": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sei_gemm_bf16nt_dw2_adam": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sei_sepmap2": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P],
     "sei_sepmap2_packed": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P],
     "sei_colsum_f32": [_P, _P, _Z, _I, _P],
@@ -80,6 +81,7 @@ SIGNATURES = {
     "sei_pad_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_gemm_bf16nt_conv": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P],
     "sei_adam_fused": [_P, _P, _I, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P, _P],
+    "sei_adam_scalars": [_F, _F, _F, _F, _F, _I, _P, _P],
 }
 
 _lib = None
@@ -92,7 +94,7 @@ SIZE_QUERIES = {
     "sei_ln_bwd_workspace": [_Z, _I],
     "sei_swin_partials_floats": [_I],
 }
-ABI_VERSION = 3       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
+ABI_VERSION = 4       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 
 
 class NativeLibraryError(RuntimeError):

@@ -63,7 +63,24 @@ struct NtArgs {
     // shifted by conv_off[tap], tap = k / conv_cin, at column k - tap * conv_cin. conv_cin = 0: a plain GEMM.
     int conv_cin;
     int conv_off[9];
+    // Adam applied in the epilogue (sei_gemm_bf16nt_dw2_adam, ADAM instantiations only): the accumulator IS the
+    // complete gradient of element (m, n); parameter, both moments and the bf16 shadow share D's (M, N) layout.
+    // adam_h (device): beta1, beta2, eps, weight_decay, step_size, 1/sqrt(bias_correction2) of this step.
+    float *adam_p, *adam_m, *adam_v;
+    unsigned short *adam_p16;
+    const float *adam_h;
 };
+
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float *p) {
+    const nt_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float *p, const float4 v) {
+    nt_f32x4 t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_f32x4 *>(p));
+}
 
 __device__ __forceinline__ unsigned short f2bf(float v) {
     const __bf16 b = (__bf16)v;
@@ -143,7 +160,7 @@ __device__ __forceinline__ void wait_vmcnt() {          // counted wait: at most
     else static_assert(N < 0, "add the immediate");
 }
 
-template <int TM, int TN, int WM, int WN, bool ARM, bool BRM, int NSTAGE = 2>
+template <int TM, int TN, int WM, int WN, bool ARM, bool BRM, int NSTAGE = 2, bool ADAM = false>
 __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(NtArgs g) {
     static_assert(WM * WN == NWAVES, "8 waves per workgroup");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -399,6 +416,70 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
         wait_vmcnt<0>();
     }
 
+    // ---- epilogue: optimizer step on the finished gradient tile (never split over K) ---------------------------
+    // The tile goes through LDS in two halves of 64 rows x 128 columns (32 KB, the operand stage that the loop has
+    // finished with): accumulators in, whole rows out, so that every access to the four parameter-sized streams is
+    // 16 bytes per lane on 512 contiguous bytes of a row (8 per lane for the bf16 shadow) -- 26 bytes move per output
+    // element and nothing else bounds this launch.
+    if constexpr (ADAM) {
+        static_assert(TM == 2 && TN == 1 && WM == 2 && WN == 4, "the row patch below is laid out for the 128 x 128 tile");
+        const float beta1 = g.adam_h[0], beta2 = g.adam_h[1], eps = g.adam_h[2], wd = g.adam_h[3];
+        const float step_size = g.adam_h[4], inv_bc2_sqrt = g.adam_h[5];
+        float *patch = reinterpret_cast<float *>(smem);              // [64][128]
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_s_barrier();                            // operands (h = 0) / the previous half are done with
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        patch[(32 * i + 4 * lh + (r & 3) + 8 * (r >> 2)) * 128 + 32 * wn + li] = acc[i][0][r];
+            }
+            __syncthreads();
+#pragma unroll 1
+          for (int kk = 0; kk < 4; kk += 2) {                        // two quads at a time: registers for 3 workgroups / CU
+            float4 gq[2], pq[2], mq[2], vq[2];
+            size_t off[2];
+            bool ok[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {                            // 6 independent 16-byte loads per lane in flight
+                const int idx = threadIdx.x + NT * (kk + k), r = idx >> 5, c4 = idx & 31;
+                const int row = m0 + 64 * h + r, col = n0 + 4 * c4;
+                ok[k] = row < M && col < N;                          // N % 8 == 0: a quad is all in or all out
+                off[k] = ok[k] ? (size_t)row * N + col : 0;
+                gq[k] = *reinterpret_cast<const float4 *>(patch + r * 128 + 4 * c4);
+                // streamed once per step: non-temporal, so that they do not push the GEMM operands out of L2 / MALL
+                pq[k] = nt_load4(g.adam_p + off[k]);
+                mq[k] = nt_load4(g.adam_m + off[k]);
+                vq[k] = nt_load4(g.adam_v + off[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!ok[k]) continue;
+                float4 o;
+                o.x = sei_adam_element(pq[k].x, gq[k].x, mq[k].x, vq[k].x, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                o.y = sei_adam_element(pq[k].y, gq[k].y, mq[k].y, vq[k].y, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                o.z = sei_adam_element(pq[k].z, gq[k].z, mq[k].z, vq[k].z, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                o.w = sei_adam_element(pq[k].w, gq[k].w, mq[k].w, vq[k].w, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                nt_store4(g.adam_m + off[k], mq[k]);
+                nt_store4(g.adam_v + off[k], vq[k]);
+                nt_store4(g.adam_p + off[k], o);
+                if (g.adam_p16) {
+                    uint2 w;
+                    w.x = (unsigned)f2bf(o.x) | ((unsigned)f2bf(o.y) << 16);
+                    w.y = (unsigned)f2bf(o.z) | ((unsigned)f2bf(o.w) << 16);
+                    typedef unsigned nt_u32x2 __attribute__((ext_vector_type(2)));
+                    nt_u32x2 t;
+                    t.x = w.x; t.y = w.y;
+                    __builtin_nontemporal_store(t, reinterpret_cast<nt_u32x2 *>(g.adam_p16 + off[k]));
+                }
+            }
+          }
+        }
+        return;
+    }
+
     // ---- epilogue -----------------------------------------------------------------------------------
     // Per 32x32 accumulator tile: the auxiliary values are already in registers (prefetched above) or are
     // gathered first (16 independent loads in flight); then compute and store. Interleaving the loads with
@@ -460,7 +541,7 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, s
 #endif
 #include "gemm_bf16pq.h"
 
-template <int TM, int TN, int WM, int WN, bool ARM = false, bool BRM = false, int NSTAGE = 2>
+template <int TM, int TN, int WM, int WN, bool ARM = false, bool BRM = false, int NSTAGE = 2, bool ADAM = false>
 int launch_nt(NtArgs &g, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     g.tiles_m = (int)sei_ceil_div(g.M, BM);
@@ -480,7 +561,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
     g.k_per_split = g.K;
     const bool splittable = g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
                             g.epilogue == SEI_EPI_BIAS_RES || g.epilogue == SEI_EPI_ACCUM;
-    if (splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
+    if (!ADAM && splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
         // Wave-quantisation-aware split: a launch takes ceil(tiles*sk / slots) rounds of workgroups, each
         // round costing (k-tiles per split + a fixed prologue/epilogue/atomics overhead); pick the cheapest sk.
         constexpr size_t STAGE_BYTES = NSTAGE * (size_t)(BM + BN) * ROW_BYTES;
@@ -513,7 +594,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
     const size_t per_split = g.tiles_per_xcd ? 8 * (size_t)g.tiles_per_xcd : tiles;
-    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE>), dim3((unsigned)(per_split * g.splitk)),
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE, ADAM>), dim3((unsigned)(per_split * g.splitk)),
                        dim3(NT), 0, s, g);
     return sei_launch_status();
 }
@@ -656,6 +737,7 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
 #endif
     if (tile == 15 && !a_rmajor && !b_rmajor) return launch_nt<2, 1, 2, 4, false, false, 1>(g, s);   // 1 stage
     if (tile == 16 && a_rmajor && b_rmajor) return launch_nt<2, 2, 2, 4, true, true>(g, s);   // 128 x 256
+    if (tile == 17 && a_rmajor && b_rmajor) return launch_nt<2, 2, 2, 4, true, true, 1>(g, s);   // 128 x 256, 1 stage
     if (tile == 15) {
         if (a_rmajor && b_rmajor) return launch_nt<2, 1, 2, 4, true, true, 1>(g, s);
         if (b_rmajor) return launch_nt<2, 1, 2, 4, false, true, 1>(g, s);
@@ -757,6 +839,28 @@ extern "C" int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, in
     }
     if (K1 + K2 <= 1024) return launch_nt<2, 1, 2, 4, true, true, 1>(g, (hipStream_t)stream);   // as sei_gemm_bf16nt
     return launch_nt<2, 1, 2, 4, true, true>(g, (hipStream_t)stream);
+}
+
+extern "C" int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
+                                        const uint16_t *B2, int ldb, float *param, float *exp_avg, float *exp_avg_sq,
+                                        uint16_t *param_bf16, const float *hyper, int M, int N, int K1, int K2,
+                                        void *stream) {
+    SEI_REQUIRE(A1 && A2 && B1 && B2 && param && exp_avg && exp_avg_sq && hyper && M > 0 && N > 0 && K1 > 0 && K2 > 0);
+    SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
+    SEI_REQUIRE((K1 + K2) % 8 == 0);
+    SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
+    SEI_REQUIRE((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
+                ((uintptr_t)param_bf16 & 7) == 0);              // the epilogue moves whole quads
+    NtArgs g;
+    g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
+    g.D32 = param; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
+    g.epilogue = SEI_EPI_NONE;
+    g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
+    g.conv_cin = 0;
+    g.force_tile = 0; g.force_band = 0;
+    g.adam_p = param; g.adam_m = exp_avg; g.adam_v = exp_avg_sq; g.adam_p16 = param_bf16; g.adam_h = hyper;
+    if (K1 + K2 <= 1024) return launch_nt<2, 1, 2, 4, true, true, 1, true>(g, (hipStream_t)stream);
+    return launch_nt<2, 1, 2, 4, true, true, 2, true>(g, (hipStream_t)stream);
 }
 
 extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,

@@ -80,3 +80,14 @@ __device__ __forceinline__ float sei_dgelu_bf16out(float x) {
     sei_phi_pdf_bf16out(x, cdf, pdf);
     return fmaf(x, pdf, cdf);
 }
+
+// One element of torch.optim.Adam (single-tensor form): lerp for exp_avg, addcmul for exp_avg_sq.
+__device__ __forceinline__ float sei_adam_element(float pi, float gi, float &mi, float &vi, float beta1, float beta2,
+                                              float eps, float wd, float step_size, float inv_bc2_sqrt) {
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    mi = mi + (gi - mi) * (1.f - beta1);
+    vi = fmaf(beta2, vi, (1.f - beta2) * gi * gi);
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    return pi - step_size * (mi / denom);
+}
+

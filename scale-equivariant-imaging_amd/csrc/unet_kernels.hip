@@ -1075,16 +1075,6 @@ __device__ __forceinline__ float grad_value(const unsigned short *g, size_t i) {
     return __uint_as_float((unsigned)g[i] << 16);
 }
 
-// One element of torch.optim.Adam (single-tensor form): lerp for exp_avg, addcmul for exp_avg_sq.
-__device__ __forceinline__ float adam_element(float pi, float gi, float &mi, float &vi, float beta1, float beta2,
-                                              float eps, float wd, float step_size, float inv_bc2_sqrt) {
-    if (wd != 0.f) gi = fmaf(wd, pi, gi);
-    mi = mi + (gi - mi) * (1.f - beta1);
-    vi = fmaf(beta2, vi, (1.f - beta2) * gi * gi);
-    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
-    return pi - step_size * (mi / denom);
-}
-
 template <typename G>
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const G *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, size_t n,
@@ -1094,7 +1084,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float mi = m[i], vi = v[i];
-        const float pn = adam_element(p[i], grad_value(g, i) * gscale, mi, vi, beta1, beta2, eps, wd, step_size,
+        const float pn = sei_adam_element(p[i], grad_value(g, i) * gscale, mi, vi, beta1, beta2, eps, wd, step_size,
                                       inv_bc2_sqrt);
         m[i] = mi;
         v[i] = vi;
@@ -1123,10 +1113,10 @@ __global__ __launch_bounds__(256) void adam_vec_kernel(float *__restrict__ p, co
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     auto update = [&](size_t q, const float4 pq, float4 mq, float4 vq, const float4 gq) {
         float4 o;
-        o.x = adam_element(pq.x, gq.x * gscale, mq.x, vq.x, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
-        o.y = adam_element(pq.y, gq.y * gscale, mq.y, vq.y, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
-        o.z = adam_element(pq.z, gq.z * gscale, mq.z, vq.z, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
-        o.w = adam_element(pq.w, gq.w * gscale, mq.w, vq.w, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+        o.x = sei_adam_element(pq.x, gq.x * gscale, mq.x, vq.x, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+        o.y = sei_adam_element(pq.y, gq.y * gscale, mq.y, vq.y, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+        o.z = sei_adam_element(pq.z, gq.z * gscale, mq.z, vq.z, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+        o.w = sei_adam_element(pq.w, gq.w * gscale, mq.w, vq.w, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
         reinterpret_cast<float4 *>(m)[q] = mq;
         reinterpret_cast<float4 *>(v)[q] = vq;
         reinterpret_cast<float4 *>(p)[q] = o;
@@ -1482,6 +1472,18 @@ extern "C" int sei_colsum_weighted_f32(const float *X, const float *row_weight, 
                                        void *stream) {
     SEI_REQUIRE(X && row_weight && out && M > 0 && N > 0);
     return launch_colsum(X, row_weight, out, M, N, stream);
+}
+
+extern "C" int sei_adam_scalars(float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                float *out6, void *stream) {
+    (void)stream;                                    // host arithmetic only; the argument keeps the call convention
+    SEI_REQUIRE(out6 && step > 0);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    out6[0] = beta1; out6[1] = beta2; out6[2] = eps; out6[3] = weight_decay;
+    out6[4] = (float)((double)lr / bc1);
+    out6[5] = (float)(1.0 / sqrt(bc2));
+    return 0;
 }
 
 extern "C" int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, float *exp_avg, float *exp_avg_sq,

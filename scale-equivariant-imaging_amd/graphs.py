@@ -49,8 +49,11 @@ def _copy_nested(dst, src):
 
 class GraphedLossStep:
     def __init__(self, loss_module, model, optimizer, crop_shape, warmup=3, store_weight_grads=True,
-                 early_release=False):
-        """loss_module: a `losses.Loss`; crop_shape: (B, 3, S, S) of the cropped measurement y."""
+                 early_release=False, fuse_optimizer=False, fuse_min_numel=1 << 24):
+        """loss_module: a `losses.Loss`; crop_shape: (B, 3, S, S) of the cropped measurement y.
+        fuse_optimizer: apply the optimizer step of the stored weight gradients of at least `fuse_min_numel` elements
+        inside the GEMM that produces them (optim.FlatAdam.fuse_weight_updates; one GPU, bf16 mode, a loss whose
+        model calls all merge into one weight-gradient GEMM per weight)."""
         self.loss_module = loss_module
         self.inner = loss_module.loss                # method-level loss working on cropped tensors
         self.model = model
@@ -104,12 +107,32 @@ class GraphedLossStep:
         self.early_grads = None
         if self.store_weight_grads and early_release:
             self.early_grads = self._plan_early_release(_ops)
+        self.fused_views, self.fused_table = [], None
+        if fuse_optimizer and self.store_weight_grads and hasattr(optimizer, "fuse_weight_updates") \
+                and _ops.get_compute_dtype() == "bf16" and getattr(optimizer, "reducer", None) is None:
+            grads = self.backbone.flat_grads
+            base, esz = grads.data_ptr(), grads.element_size()
+            for prm in self.backbone.parameters():
+                g = prm._sei_grad_view
+                if prm.dim() == 4 and prm.shape[2:] == (1, 1) and prm.numel() >= fuse_min_numel \
+                        and g.data_ptr() in _ops.weight_grad_views():
+                    self.fused_views.append(g.view(prm.shape[0], prm.shape[1]))
+            if self.fused_views:
+                self.fused_table = optimizer.fuse_weight_updates(self.fused_views)
+                _ops.set_fused_adam(*self.fused_table)
         self.graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(self.graph):
                 self.static_loss = fwd_bwd()
+            if self.fused_views and _ops.fused_adam_launches() != {v.data_ptr() for v in self.fused_views}:
+                raise RuntimeError("fused optimizer step: not every registered weight was updated by the captured step")
+        except Exception:
+            if self.fused_views:
+                optimizer.unfuse_weight_updates()
+            raise
         finally:
             _ops.set_weight_grad_milestone(None, None)
+            _ops.set_fused_adam(None, None)
         self.backbone.zero_grad_flat()
 
     def _plan_early_release(self, _ops):
@@ -151,5 +174,7 @@ class GraphedLossStep:
         self._draw(draws)
         if not self._ops.plain_shadow_is_current(self.backbone):   # weights changed by something other than FlatAdam
             self._ops.refresh_plain_shadow(self.backbone)
+        if self.fused_views:
+            self.optimizer.prepare_step()          # the step's Adam scalars, read by the fused GEMM epilogues
         self.graph.replay()
         return self.static_loss

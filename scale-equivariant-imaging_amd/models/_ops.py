@@ -466,9 +466,38 @@ def _launch_weight_grad(grad2d, pairs):
                 _DW["milestone_done"] = True
 
 
+def set_fused_adam(table, hyper):
+    """Optimizer step inside the weight-gradient GEMM (optim.FlatAdam.fuse_weight_updates): `table` maps the
+    data_ptr of a gradient view to the (param, exp_avg, exp_avg_sq, bf16 shadow or None) views of the same shape,
+    `hyper` is the device array of the step's six Adam scalars. The step's single, merged, storing launch into such a
+    gradient applies the update instead of writing the gradient (sei_gemm_bf16nt_dw2_adam); None switches it off."""
+    _DW["adam"] = (dict(table), hyper) if table else None
+    _DW["adam_launched"] = set()
+
+
+def fused_adam_launches():
+    """data_ptrs whose update was applied inside a GEMM since set_fused_adam."""
+    return set(_DW.get("adam_launched", ()))
+
+
 def _launch_weight_grad_inner(grad2d, pairs, store):
     key = grad2d.data_ptr()
     Np, Kp = grad2d.shape
+    fused = _DW.get("adam")
+    if fused is not None and key in fused[0]:
+        # the update replaces the stored gradient only when this launch IS the step's whole gradient
+        complete = store and len(pairs) == 2 and len(pairs) == _DW["uses"]
+        (g1, x1), (g2, x2) = pairs if len(pairs) == 2 else (pairs[0], pairs[0])
+        K1, K2 = g1.shape[0], g2.shape[0]
+        if not complete or (K1 + K2) % 8 != 0 or key in _DW["adam_launched"]:
+            raise RuntimeError("fused optimizer step: a weight registered with set_fused_adam did not receive its "
+                               "gradient as one merged storing GEMM (different loss / batch / call count than planned)")
+        prm, m1, v1, sh = fused[0][key]
+        _DW["adam_launched"].add(key)
+        _gemm_call(2.0 * Np * Kp * (K1 + K2), "sei_gemm_bf16nt_dw2_adam", g1.data_ptr(), g2.data_ptr(), Np,
+                   x1.data_ptr(), x2.data_ptr(), Kp, prm.data_ptr(), m1.data_ptr(), v1.data_ptr(), N.ptr(sh),
+                   fused[1].data_ptr(), Np, Kp, K1, K2)
+        return
     if len(pairs) == 2:
         (g1, x1), (g2, x2) = pairs
         K1, K2 = g1.shape[0], g2.shape[0]
@@ -585,14 +614,16 @@ class ConvBlockFn16(torch.autograd.Function):
         M = B * H * W
         go = go.contiguous()
         go2 = go.view(M, C)
+        # Each weight's data gradient goes BEFORE its weight gradient: with the optimizer step fused into the weight-
+        # gradient GEMM (set_fused_adam) that launch rewrites the weight's bf16 shadow, which the data gradient reads.
         go16 = cast16(go2, colsum_into_=grad_of(b3))
-        weight_grad16(go16, h4, grad_of(w3).view(C, 4 * C))
         gh3 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device)
         gemm_nt16(go16, shadow(w3), M, 4 * C, C, EPI_MUL_DGELU, out16=gh3, R1=h3, b_rmajor=True)   # (go W3) gelu'
+        weight_grad16(go16, h4, grad_of(w3).view(C, 4 * C))
         colsum16_into(grad_of(b2), gh3)
-        weight_grad16(gh3, h2, grad_of(w2).view(4 * C, C))
         gh2 = torch.empty((M, C), dtype=torch.float32, device=x.device)
         gemm_nt16(gh3, shadow(w2), M, C, 4 * C, EPI_NONE, out32=gh2, b_rmajor=True)
+        weight_grad16(gh3, h2, grad_of(w2).view(4 * C, C))
         gh1 = layer_norm_bwd(h1.view(M, C), gamma, mean, rstd, gh2, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
         dwconv7_weight_grad(x, gh1, grad_of(w1), grad_of(b1))
         gx = None
@@ -663,9 +694,9 @@ class DownsampleFn16(torch.autograd.Function):
         go2 = go.contiguous().view(Mo, Co)
         colsum_into(grad_of(b), go2, row_weight=s)
         go16 = cast16(go2)
-        weight_grad16(go16, u16, grad_of(w).view(Co, C))
         gu = torch.empty((Mo, C), dtype=torch.float32, device=x.device)
         gemm_nt16(go16, shadow(w), Mo, C, Co, EPI_NONE, out32=gu, b_rmajor=True)
+        weight_grad16(go16, u16, grad_of(w).view(Co, C))           # after the data gradient: see ConvBlockFn16.backward
         gh = sepmap2(gu.view(B, Ho, Wo, C), ctx.mats_t, H, W).view(M, C)
         gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
         return (gx if ctx.needs_input_grad[0] else None), None, None, None, None, None
@@ -704,9 +735,9 @@ class UpsampleFn16(torch.autograd.Function):
         go = go.contiguous()
         go2 = go.view(M, Co)
         go16 = cast16(go2, colsum_into_=grad_of(b))
-        weight_grad16(go16, h, grad_of(w).view(Co, C))
         gh = torch.empty((M, C), dtype=torch.float32, device=u.device)
         gemm_nt16(go16, shadow(w), M, C, Co, EPI_NONE, out32=gh, b_rmajor=True)
+        weight_grad16(go16, h, grad_of(w).view(Co, C))             # after the data gradient: see ConvBlockFn16.backward
         gu = layer_norm_bwd(u.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta))
         gx = None
         if ctx.needs_input_grad[0]:

@@ -28,6 +28,69 @@ class FlatAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         self.backbone.zero_grad_flat()
+        self._eager_grads = True          # an eager backward pass follows: its gradients cover the whole bucket
+
+    # -- optimizer step inside the weight-gradient GEMMs (one GPU, bf16 mode, captured step) ----------------------
+    def fuse_weight_updates(self, grad_views):
+        """grad_views: 2-D views into the flat gradient bucket whose step is to be applied by the GEMM that
+        produces them (graphs.GraphedLossStep: the two deepest levels, 94 % of the bucket at defaults -- the 4-byte
+        gradient round trip and 26 of Adam's 30 bytes per parameter move into that GEMM's epilogue, under its MFMA
+        work). `step()` then covers the rest of the bucket; `prepare_step()` must run before every captured step so
+        that the device scalars the epilogue reads belong to the step about to be taken. Returns the table for
+        models._ops.set_fused_adam."""
+        if self.reducer is not None:
+            raise ValueError("fused weight updates need the complete gradient on this GPU (no gradient exchange)")
+        from models import _ops
+        flat, grads = self.backbone.flat_params, self.backbone.flat_grads
+        st = self.state[flat]
+        shadow = getattr(self.backbone, "flat_shadow", None) if _ops.get_compute_dtype() == "bf16" else None
+        table, ranges = {}, []
+        for gv in grad_views:
+            off = (gv.data_ptr() - grads.data_ptr()) // grads.element_size()
+            n = gv.numel()
+            if not (0 <= off and off + n <= grads.numel()) or gv.dim() != 2 or not gv.is_contiguous():
+                raise ValueError("fused weight updates: not a contiguous 2-D view of the flat gradient bucket")
+            if off % 4 or gv.shape[1] % 8 or (flat.data_ptr() | st["exp_avg"].data_ptr() | st["exp_avg_sq"].data_ptr()) % 16:
+                raise ValueError("fused weight updates: the epilogue moves aligned quads (bucket offset % 4, columns % 8)")
+            pick = lambda buf: buf[off:off + n].view(gv.shape)
+            table[gv.data_ptr()] = (pick(flat), pick(st["exp_avg"]), pick(st["exp_avg_sq"]),
+                                    None if shadow is None else pick(shadow))
+            ranges.append((off, off + n))
+        self._fused_ranges = sorted(ranges)
+        self._hyper_host = torch.empty(6, dtype=torch.float32).pin_memory()
+        self._hyper_dev = torch.zeros(6, dtype=torch.float32, device=flat.device)
+        self._prepared_for = None
+        return table, self._hyper_dev
+
+    def unfuse_weight_updates(self):
+        self._fused_ranges = None
+
+    def prepare_step(self):
+        """Scalars of the NEXT step (lr of the moment, bias corrections of step + 1) -> the device array read by the
+        fused epilogues; enqueued on the current stream, i.e. in front of the replay that uses them."""
+        if not getattr(self, "_fused_ranges", None):
+            return
+        group, st = self.param_groups[0], self.state[self.backbone.flat_params]
+        b1, b2 = group["betas"]
+        N.call("sei_adam_scalars", float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+               float(group["weight_decay"]), int(st["step"]) + 1, self._hyper_host.data_ptr())
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        self._prepared_for = int(st["step"]) + 1
+        self._eager_grads = False
+
+    def _step_bounds(self, total, whole=False):
+        """The bucket minus the ranges whose update a GEMM epilogue has applied."""
+        fused = getattr(self, "_fused_ranges", None)
+        if not fused or whole:
+            return [(0, total)]
+        out, pos = [], 0
+        for lo, hi in fused:
+            if lo > pos:
+                out.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < total:
+            out.append((pos, total))
+        return out
 
     # -- checkpoint interchange ----------------------------------------------------------------
     _TORCH_ADAM_GROUP = {"amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
@@ -94,9 +157,20 @@ class FlatAdam(torch.optim.Optimizer):
         group = self.param_groups[0]
         st = self.state[flat]
         st["step"] += 1
+        whole = False
+        if getattr(self, "_fused_ranges", None) and self._prepared_for != st["step"]:
+            # not a replayed step: fine after zero_grad() + an eager backward pass (a short last batch), which wrote every
+            # gradient the ordinary way; anything else would step the fused weights on gradients nobody computed
+            if not getattr(self, "_eager_grads", False):
+                st["step"] -= 1
+                raise RuntimeError("FlatAdam.step(): part of this step is applied inside the captured backward pass, "
+                                   "which was not replayed with prepare_step() for this step "
+                                   "(graphs.GraphedLossStep does both)")
+            whole = True
+        self._eager_grads = False
         b1, b2 = group["betas"]
         world = 1
-        bounds = [(0, flat.numel())]
+        bounds = self._step_bounds(flat.numel(), whole)
         grads_16 = False
         if self.reducer is not None:
             from parallel import world_size

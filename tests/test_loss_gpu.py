@@ -747,6 +747,73 @@ def test_graphed_training_tracks_eager_training(dtype):
         _ops.set_compute_dtype(prev)
 
 
+def test_optimizer_step_inside_the_weight_gradient_gemm():
+    """GraphedLossStep(fuse_optimizer=True): the bottleneck pair's Adam update is applied by the epilogue of the GEMM
+    that computes their (merged, complete) gradient instead of storing it. Four steps against the same run with the
+    separate optimizer step, same seeds and draws: losses, parameters and both moments agree to the rounding of the
+    gradient sum -- the accumulator the epilogue consumes is the value that would have been stored, and the per-element
+    arithmetic is sei_adam_fused's. Also: step() without the replay that carries its other half raises."""
+    import bench
+    import physics
+    import models
+    from graphs import GraphedLossStep
+    from losses import get_loss
+    from models import _ops
+    from optim import FlatAdam
+    prev = _ops.set_compute_dtype("bf16")
+    try:
+        runs = {}
+        for fuse in (False, True):
+            args = bench.reference_args("cuda", 8, 3)
+            torch.manual_seed(0)
+            p = physics.get_physics(args, "cuda")
+            model = models.get_model(args, p, "cuda").to("cuda")
+            bb = model.get_backbone()
+            lf = get_loss(args, p)
+            opt = FlatAdam(model, lr=3e-4)
+            x = torch.rand(8, 3, 256, 256, device="cuda")
+            torch.cuda.manual_seed(7)
+            y = p(x)
+            g = GraphedLossStep(lf, model, opt, (8, 3, 48, 48), fuse_optimizer=fuse, fuse_min_numel=60000)
+            assert len(g.fused_views) == (2 if fuse else 0)
+            if fuse:
+                assert sorted(tuple(v.shape) for v in g.fused_views) == [(128, 512), (512, 128)]
+                covered = sum(hi - lo for lo, hi in opt._step_bounds(bb.flat_params.numel()))
+                assert covered == bb.flat_params.numel() - 2 * 65536
+            torch.manual_seed(31)
+            torch.cuda.manual_seed(32)
+            losses = []
+            for k in range(4):
+                if k == 2:
+                    opt.param_groups[0]["lr"] = 1e-4               # a scheduler step between replays
+                losses.append(float(g(x, y)))
+                opt.step()
+            st = opt.state[bb.flat_params]
+            runs[fuse] = (losses, bb.flat_params.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                          bb.flat_shadow.clone())
+            if fuse:
+                with pytest.raises(RuntimeError):
+                    opt.step()                                     # no replay carried the fused half of this step
+                before = bb.flat_params.clone()
+                opt.zero_grad()                                    # an eager step in between (a short last batch)
+                lf(x=x, y=y, model=model).backward()
+                opt.step()
+                lo, hi = opt._fused_ranges[0]
+                assert not torch.equal(before[lo:hi], bb.flat_params[lo:hi])       # stepped with the whole bucket
+                assert opt.state[bb.flat_params]["step"] == 5
+        # (at this size the separate path's storing GEMM splits K over float atomics, so the two runs differ by the
+        # rounding of that sum; tests/test_unet_gpu.py::test_weight_gradient_gemm_with_the_adam_epilogue has the equality)
+        assert runs[False][0][0] == runs[True][0][0]
+        assert all(abs(a - b) < 1e-4 * abs(a) for a, b in zip(runs[False][0], runs[True][0])), (runs[False][0], runs[True][0])
+        apart = (runs[True][1] - runs[False][1]).abs()
+        # Adam's first steps are sign-like: a weight whose gradient is rounding-small may go the other way in one run
+        assert float(apart.mean()) < 2e-6 and float((apart > 3e-5).float().mean()) < 1e-3, (float(apart.mean()), float(apart.max()))
+        assert relerr(runs[True][2], runs[False][2]) < 1e-3 and relerr(runs[True][3], runs[False][3]) < 1e-3
+        assert runs[True][0][-1] < runs[True][0][0]
+    finally:
+        _ops.set_compute_dtype(prev)
+
+
 def test_merged_and_stored_weight_grads_match_plain_accumulation():
     """bf16 mode, default network shape (hidden 32, reduced to 4 scales): the gradients of one proposed-loss
     step are the same whether the two model calls' weight gradients are accumulated one GEMM per call

@@ -754,3 +754,38 @@ def test_fused_mlp_block_matches_the_unfused_bf16_block(ops, B, H, W, C, twice):
     finally:
         ops.FUSED_MLP_CHANNELS = saved
         ops.set_compute_dtype(prev)
+
+
+def test_weight_gradient_gemm_with_the_adam_epilogue():
+    """sei_gemm_bf16nt_dw2_adam == sei_gemm_bf16nt_dw2 (store) followed by sei_adam_fused over the same (M, N) range:
+    parameters, moments and the bf16 shadow bit for bit where the storing GEMM does not split K (768 whole tiles, one-
+    stage and two-stage loops), to float32 rounding of the gradient on a ragged shape that it does split;
+    sei_adam_scalars hands the epilogue the scalars sei_adam_fused derives itself."""
+    import ctypes
+    import _native as N
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for (M, Nn, K1, K2, exact) in ((2048, 6144, 96, 200, True), (2048, 6144, 640, 1032, True), (136, 520, 96, 200, False)):
+        A1, A2 = ((0.05 * torch.randn((k, M), device="cuda", generator=gen)).bfloat16() for k in (K1, K2))
+        B1, B2 = (torch.randn((k, Nn), device="cuda", generator=gen).bfloat16() for k in (K1, K2))
+        p0 = 0.02 * torch.randn((M, Nn), device="cuda", generator=gen)
+        host = (ctypes.c_float * 6)()
+        N.call("sei_adam_scalars", 2e-4, 0.9, 0.99, 1e-8, 0.01, 5, ctypes.cast(host, ctypes.c_void_p))
+        hyper = torch.tensor(list(host), device="cuda")
+        state = lambda: (p0.clone(), torch.full_like(p0, 1e-3), torch.full_like(p0, 1e-5),
+                         torch.zeros((M, Nn), device="cuda", dtype=torch.bfloat16))
+        pa, ma, va, sa = state()
+        grad = torch.empty((M, Nn), device="cuda")
+        N.call("sei_gemm_bf16nt_dw2", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), Nn, grad.data_ptr(),
+               M, Nn, K1, K2, 0)
+        N.call("sei_adam_fused", pa.data_ptr(), grad.data_ptr(), 0, ma.data_ptr(), va.data_ptr(), M * Nn, 2e-4, 0.9, 0.99,
+               1e-8, 0.01, 5, 1.0, sa.data_ptr())
+        pb, mb, vb, sb = state()
+        N.call("sei_gemm_bf16nt_dw2_adam", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), Nn,
+               pb.data_ptr(), mb.data_ptr(), vb.data_ptr(), sb.data_ptr(), hyper.data_ptr(), M, Nn, K1, K2)
+        assert float((pa - p0).abs().max()) > 1e-5
+        for a, b in ((pa, pb), (ma, mb), (va, vb), (sa, sb)):
+            assert torch.equal(a, b) if exact else relerr(a.float(), b.float()) < 1e-2 and relerr(ma, mb) < 1e-5
+        pc, mc, vc, _ = state()                                   # without a shadow
+        N.call("sei_gemm_bf16nt_dw2_adam", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), Nn,
+               pc.data_ptr(), mc.data_ptr(), vc.data_ptr(), None, hyper.data_ptr(), M, Nn, K1, K2)
+        assert torch.equal(pc, pb)

@@ -82,6 +82,9 @@ def build_parser():
     flag("--compute_dtype", choices=["f32", "bf16"], default="f32",
          help="1x1-conv GEMM arithmetic: f32 (reference precision) or bf16 MFMA with f32 accumulation")
     flag("--hip_graph", default=True, **onoff)
+    flag("--fuse_optimizer_step", default=True, **onoff,
+         help="one GPU, bf16, hipGraph replay: weights of at least 2^24 elements (the U-Net's two deepest levels) take their "
+              "Adam step in the epilogue of the GEMM that computes their gradient (optim.FlatAdam.fuse_weight_updates)")
     flag("--grad_comm_dtype", choices=["f32", "bf16"], default="f32",
          help="dtype of the all-reduced gradient bucket under torch.distributed.run: f32 (exact sum, default) or "
               "bf16 (half the xGMI bytes; the sum runs in bf16, its rounding grows with the number of ranks; "
@@ -221,7 +224,8 @@ def main(argv=None):
                     early = reducer is not None and os.environ.get("SEI_NO_EARLY_RELEASE") != "1"
                     graphed = GraphedLossStep(loss, model, optimizer,
                                               (args.batch_size, y.shape[1], args.Loss__crop_size, args.Loss__crop_size),
-                                              early_release=early)
+                                              early_release=early,
+                                              fuse_optimizer=world == 1 and args.fuse_optimizer_step)
                     if early and graphed.early_grads is not None:
                         early_event = graphed.early_grads[0]
                         reducer.set_early_range(graphed.early_grads[1:])
