@@ -1219,7 +1219,7 @@ inline LnBwdPlan ln_bwd_plan(size_t rows, int C) {
         p.kind = 1;
         const size_t sweeps = sei_ceil_div(rows, (size_t)(LN_THREADS / p.G));
         size_t cap = ((size_t)1 << 20) / (2 * (size_t)C);     // <= 1M partial floats
-        if (cap > 2048) cap = 2048;
+        if (cap > 512) cap = 512;                             // two workgroups per CU stream at full rate; fewer partials to fold
         p.grid = (unsigned)(sweeps < cap ? sweeps : cap);
         p.nparts = p.grid;
         return p;

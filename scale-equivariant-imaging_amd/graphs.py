@@ -49,7 +49,7 @@ def _copy_nested(dst, src):
 
 class GraphedLossStep:
     def __init__(self, loss_module, model, optimizer, crop_shape, warmup=3, store_weight_grads=True,
-                 early_release=False, fuse_optimizer=False, fuse_min_numel=1 << 24):
+                 early_release=False, fuse_optimizer=False, fuse_min_numel=1 << 24, store_min_numel=1 << 20):
         """loss_module: a `losses.Loss`; crop_shape: (B, 3, S, S) of the cropped measurement y.
         fuse_optimizer: apply the optimizer step of the stored weight gradients of at least `fuse_min_numel` elements
         inside the GEMM that produces them (optim.FlatAdam.fuse_weight_updates; one GPU, bf16 mode, a loss whose
@@ -100,7 +100,8 @@ class GraphedLossStep:
         _ops.refresh_plain_shadow(self.backbone)
         # The warm-up steps showed which gradients are written by the merged weight-gradient GEMMs; the
         # captured step stores those instead of accumulating and zeroes only the rest of the bucket.
-        self.store_weight_grads = store_weight_grads and self.backbone.plan_weight_grad_store() is not None
+        self.store_weight_grads = store_weight_grads and \
+            self.backbone.plan_weight_grad_store(store_min_numel) is not None
         # Early release of the largest gradients: an EXTERNAL event recorded inside the captured backward right
         # after the two largest adjacent weight gradients (the bottleneck block: 83 % of the bucket at defaults)
         # have been written; `early_grads` = (event, start, stop) in bucket elements, or None.

@@ -82,17 +82,20 @@ class FlatParameterBucket:
         else:
             for off, n in ranges:
                 self.flat_grads[off:off + n].zero_()
-        _ops.begin_step(store=ranges is not None)
+        _ops.begin_step(store=ranges is not None, store_min=getattr(self, "_sei_store_min", 0))
         for p in self.parameters():
             p.grad = p._sei_grad_view
 
-    def plan_weight_grad_store(self):
+    def plan_weight_grad_store(self, min_numel=1 << 20):
         """After at least one eager step: the parts of the gradient bucket that still need zeroing when the
-        weight gradients recorded by models/_ops.py are stored rather than accumulated."""
+        weight gradients recorded by models/_ops.py are stored rather than accumulated. Only gradients of at least
+        `min_numel` elements are stored: a small one costs nothing to zero with its neighbours, while its GEMM is a
+        split-K launch whose STORING form needs a zero-fill launch of its own in front."""
         base, esz = self.flat_grads.data_ptr(), self.flat_grads.element_size()
         total = self.flat_grads.numel()
+        self._sei_store_min = int(min_numel)
         skip = sorted(((ptr - base) // esz, n) for ptr, n in _ops.weight_grad_views().items()
-                      if base <= ptr < base + total * esz)
+                      if base <= ptr < base + total * esz and n >= min_numel)
         ranges, pos = [], 0
         for off, n in skip:
             if off > pos:

@@ -421,14 +421,16 @@ def note_forward():
         _DW["uses"] += 1
 
 
-def begin_step(store=False):
-    """Start of a step (zero_grad): nothing parked, no model call counted, no gradient written yet."""
+def begin_step(store=False, store_min=0):
+    """Start of a step (zero_grad): nothing parked, no model call counted, no gradient written yet. store: the
+    first launch of the step into a weight gradient of at least store_min elements stores (it was not zeroed)."""
     flush_weight_grads()
     _DW["uses"] = 0
     _DW["arrivals"].clear()
     _DW["written"].clear()
     _DW["milestone_done"] = False
     _DW["store"] = bool(store)
+    _DW["store_min"] = int(store_min)
 
 
 def set_weight_grad_merging(enabled):
@@ -453,7 +455,7 @@ def set_weight_grad_milestone(keys, event):
 
 def _launch_weight_grad(grad2d, pairs):
     key = grad2d.data_ptr()
-    store = _DW["store"] and key not in _DW["written"]
+    store = _DW["store"] and key not in _DW["written"] and grad2d.numel() >= _DW.get("store_min", 0)
     _DW["written"].add(key)
     try:
         _launch_weight_grad_inner(grad2d, pairs, store)
