@@ -151,19 +151,32 @@ __global__ __launch_bounds__(256) void ln_bwd_pad_kernel(const float *__restrict
 
 // out[c] += sum over g of part[g][c], c < ncol (ncol = 2 C for LayerNorm: gamma then beta, contiguous outputs not
 // required: out_a for c < split, out_b for the rest)
+// A workgroup owns 16 consecutive columns and splits the groups over 16 interleaved slices, four independent loads
+// per slice in flight; the slices meet in LDS in a fixed order (bitwise reproducible). (First version: 64 columns per
+// workgroup, four slices of 256-512 DEPENDENT loads each -- 64 us per fold, 12 % of the SwinIR step.)
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float *__restrict__ part, int groups, int ncol,
                                                              int split, float *__restrict__ out_a,
                                                              float *__restrict__ out_b) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < ncol)
-        for (int g = wave; g < groups; g += 4) s += part[(size_t)g * ncol + c];
-    red[wave][lane] = s;
+    __shared__ float red[16][16];
+    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < ncol) {
+        int g = slice;
+        for (; g + 48 < groups; g += 64) {
+            s0 += part[(size_t)g * ncol + c];
+            s1 += part[(size_t)(g + 16) * ncol + c];
+            s2 += part[(size_t)(g + 32) * ncol + c];
+            s3 += part[(size_t)(g + 48) * ncol + c];
+        }
+        for (; g < groups; g += 16) s0 += part[(size_t)g * ncol + c];
+    }
+    red[slice][el] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wave == 0 && c < ncol) {
-        s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (slice == 0 && c < ncol) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][el];
         if (c < split) out_a[c] += s;
         else out_b[c - split] += s;
     }
@@ -252,7 +265,7 @@ extern "C" int sei_ln_fwd_bf16_pad(const float *x, const float *gamma, const flo
     return sei_launch_status();
 }
 
-constexpr unsigned PART_GROUPS = 1024;                     // workgroups (= partial rows) of the two reducing kernels
+constexpr unsigned PART_GROUPS = 512;                      // workgroups (= partial rows) of the two reducing kernels
 
 extern "C" size_t sei_swin_partials_floats(int C) { return C > 0 ? (size_t)PART_GROUPS * 2 * (size_t)C : 0; }
 
@@ -267,7 +280,7 @@ extern "C" int sei_ln_bwd_pad(const float *x, const float *gamma, const float *m
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(ln_bwd_pad_kernel, dim3((unsigned)g), dim3(256), 0, s, x, gamma, mean, rstd, gy, res, gx, work, rows,
                        C, ldg);
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)sei_ceil_div(2 * C, 64)), dim3(256), 0, s,
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)sei_ceil_div(2 * C, 16)), dim3(256), 0, s,
                        (const float *)work, (int)g, 2 * C, C, ggamma, gbeta);
     return sei_launch_status();
 }
@@ -283,7 +296,7 @@ extern "C" int sei_cast_pad_bf16(const float *x, const float *row_scale, uint16_
     hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((unsigned)g), dim3(256), 0, s, x, row_scale, y, colsum ? work : nullptr,
                        rows, C, ldy);
     if (colsum)
-        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)sei_ceil_div(C, 64)), dim3(256), 0, s, (const float *)work,
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)sei_ceil_div(C, 16)), dim3(256), 0, s, (const float *)work,
                            (int)g, C, C, colsum, colsum);
     return sei_launch_status();
 }
