@@ -431,15 +431,17 @@ def main():
         roofline = gemm_roofline(records, opt.dtype)
         roofline_hbm = stream_roofline(log)
         del keep
-        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_gemm.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r02_g_pmc_gemm.json")
         default_cfg = (opt.dtype == "bf16" and not sr and not opt.full256 and opt.hidden == 32 and opt.scales == 5
                        and opt.batch == 32 and opt.arch == "unet")
         if default_cfg and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))                 # PMC counters cannot be read live; see the file
             roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
             roofline["traffic_source"] = ("bytes beyond L2 per GEMM launch from committed rocprofv3 --pmc passes of "
-                                          "this command (profiles/r02_pmc_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, "
-                                          "gfx950 corrections)")
+                                          "`bench.py --no-graph` (profiles/r02_g_pmc_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, "
+                                          "gfx950 corrections); that eager step issues every GEMM, the deep levels' weight "
+                                          "gradients included, without the optimizer fusion of the captured step -- their "
+                                          "fused form is in profiles/r02_h_pmc_fused_adam_gemm.md")
         accounted = roofline["gemm_ms_per_step"] + sum(f["ms_per_step"] for f in roofline_hbm)
         roofline_hbm.append({"kernel": "not attributed (torch fills / adds / copies / RNG, zero fills inside GEMM "
                                        "entry points are counted with the GEMMs, launch gaps)",
