@@ -264,7 +264,8 @@ class Leg:
             self.graphed = graphed = GraphedLossStep(loss_fn, model, optimizer, (opt.batch, 3, ys, ys),
                                                      early_release=early,
                                                      fuse_optimizer=world == 1 and opt.fuse_optimizer,
-                                                     fuse_min_numel=opt.fuse_min_numel)
+                                                     fuse_min_numel=opt.fuse_min_numel,
+                                                     direct_bf16_grads=opt.direct_bf16_grads)
             if early and graphed.early_grads is not None:        # the bottleneck block's gradients leave early
                 self.early_event = graphed.early_grads[0]
                 reducer.set_early_range(graphed.early_grads[1:])
@@ -272,7 +273,7 @@ class Leg:
             def step():
                 loss = graphed(x, y)
                 if reducer is not None:
-                    reducer.reduce_async(early=self.early_event)
+                    reducer.reduce_async(early=self.early_event, direct=bool(graphed.direct_views))
                 optimizer.step()
                 return loss
 
@@ -381,6 +382,9 @@ def main():
     ap.add_argument("--fuse-optimizer", action=argparse.BooleanOptionalAction, default=True,
                     help="one GPU, bf16, hipGraph: apply Adam to the 1x1-convolution weights of the two deepest levels (94 %% "
                          "of the parameters) in the epilogue of the GEMM that produces their gradient")
+    ap.add_argument("--direct-bf16-grads", action=argparse.BooleanOptionalAction, default=True,
+                    help="N > 1 with a bf16 exchange: the deep levels' weight-gradient GEMMs write bf16 into the exchange "
+                         "buffer (no float32 copy, no cast pass)")
     ap.add_argument("--fuse-min-numel", type=int, default=1 << 24, help="smallest weight that takes its step that way")
     ap.add_argument("--graph", action=argparse.BooleanOptionalAction, default=True,
                     help="replay forward+backward as one hipGraph (the eager launch path otherwise)")

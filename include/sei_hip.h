@@ -403,6 +403,13 @@ int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, int lda, co
 int sei_adam_scalars(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float *out6_host,
                      void *stream);
 
+/* The same two-segment weight gradient STORED as bf16 (whole-row 8-byte quads): with several GPUs and a bf16-compressed
+ * gradient exchange the gradient is written straight into the exchange buffer (parallel.FlatGradientReducer.comm) --
+ * no float32 copy of it, no cast pass (2.6 GB read + 1.3 GB written per step at the default size). Same rounding
+ * (round-to-nearest-even of the float32 accumulator) as sei_cast_bf16 of the stored float32 gradient. */
+int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1, const uint16_t *B2,
+                                int ldb, uint16_t *D16, int M, int N, int K1, int K2, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

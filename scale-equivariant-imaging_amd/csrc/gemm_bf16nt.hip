@@ -160,7 +160,7 @@ __device__ __forceinline__ void wait_vmcnt() {          // counted wait: at most
     else static_assert(N < 0, "add the immediate");
 }
 
-template <int TM, int TN, int WM, int WN, bool ARM, bool BRM, int NSTAGE = 2, bool ADAM = false>
+template <int TM, int TN, int WM, int WN, bool ARM, bool BRM, int NSTAGE = 2, int ROWEPI = 0>
 __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(NtArgs g) {
     static_assert(WM * WN == NWAVES, "8 waves per workgroup");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -421,7 +421,35 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
     // finished with): accumulators in, whole rows out, so that every access to the four parameter-sized streams is
     // 16 bytes per lane on 512 contiguous bytes of a row (8 per lane for the bf16 shadow) -- 26 bytes move per output
     // element and nothing else bounds this launch.
-    if constexpr (ADAM) {
+    if constexpr (ROWEPI == 2) {                                     // the gradient itself, as bf16 quads on whole rows
+        static_assert(TM == 2 && TN == 1 && WM == 2 && WN == 4, "the row patch below is laid out for the 128 x 128 tile");
+        float *patch = reinterpret_cast<float *>(smem);              // [64][128]
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_s_barrier();
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        patch[(32 * i + 4 * lh + (r & 3) + 8 * (r >> 2)) * 128 + 32 * wn + li] = acc[i][0][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = threadIdx.x + NT * k, r = idx >> 5, c4 = idx & 31;
+                const int row = m0 + 64 * h + r, col = n0 + 4 * c4;
+                if (row >= M || col >= N) continue;                  // N % 8 == 0: a quad is all in or all out
+                const float4 v = *reinterpret_cast<const float4 *>(patch + r * 128 + 4 * c4);
+                uint2 w;
+                w.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+                w.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+                *reinterpret_cast<uint2 *>(g.D16 + (size_t)row * N + col) = w;
+            }
+        }
+        return;
+    }
+    if constexpr (ROWEPI == 1) {
         static_assert(TM == 2 && TN == 1 && WM == 2 && WN == 4, "the row patch below is laid out for the 128 x 128 tile");
         const float beta1 = g.adam_h[0], beta2 = g.adam_h[1], eps = g.adam_h[2], wd = g.adam_h[3];
         const float step_size = g.adam_h[4], inv_bc2_sqrt = g.adam_h[5];
@@ -541,7 +569,7 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, s
 #endif
 #include "gemm_bf16pq.h"
 
-template <int TM, int TN, int WM, int WN, bool ARM = false, bool BRM = false, int NSTAGE = 2, bool ADAM = false>
+template <int TM, int TN, int WM, int WN, bool ARM = false, bool BRM = false, int NSTAGE = 2, int ROWEPI = 0>
 int launch_nt(NtArgs &g, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     g.tiles_m = (int)sei_ceil_div(g.M, BM);
@@ -561,7 +589,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
     g.k_per_split = g.K;
     const bool splittable = g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
                             g.epilogue == SEI_EPI_BIAS_RES || g.epilogue == SEI_EPI_ACCUM;
-    if (!ADAM && splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
+    if (ROWEPI == 0 && splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
         // Wave-quantisation-aware split: a launch takes ceil(tiles*sk / slots) rounds of workgroups, each
         // round costing (k-tiles per split + a fixed prologue/epilogue/atomics overhead); pick the cheapest sk.
         constexpr size_t STAGE_BYTES = NSTAGE * (size_t)(BM + BN) * ROW_BYTES;
@@ -594,7 +622,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
     const size_t per_split = g.tiles_per_xcd ? 8 * (size_t)g.tiles_per_xcd : tiles;
-    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE, ADAM>), dim3((unsigned)(per_split * g.splitk)),
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE, ROWEPI>), dim3((unsigned)(per_split * g.splitk)),
                        dim3(NT), 0, s, g);
     return sei_launch_status();
 }
@@ -859,8 +887,27 @@ extern "C" int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, 
     g.conv_cin = 0;
     g.force_tile = 0; g.force_band = 0;
     g.adam_p = param; g.adam_m = exp_avg; g.adam_v = exp_avg_sq; g.adam_p16 = param_bf16; g.adam_h = hyper;
-    if (K1 + K2 <= 1024) return launch_nt<2, 1, 2, 4, true, true, 1, true>(g, (hipStream_t)stream);
-    return launch_nt<2, 1, 2, 4, true, true, 2, true>(g, (hipStream_t)stream);
+    if (K1 + K2 <= 1024) return launch_nt<2, 1, 2, 4, true, true, 1, 1>(g, (hipStream_t)stream);
+    return launch_nt<2, 1, 2, 4, true, true, 2, 1>(g, (hipStream_t)stream);
+}
+
+extern "C" int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
+                                           const uint16_t *B2, int ldb, uint16_t *D16, int M, int N, int K1, int K2,
+                                           void *stream) {
+    SEI_REQUIRE(A1 && A2 && B1 && B2 && D16 && M > 0 && N > 0 && K1 > 0 && K2 > 0);
+    SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
+    SEI_REQUIRE((K1 + K2) % 8 == 0);
+    SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0 && ((uintptr_t)D16 & 7) == 0);
+    NtArgs g;
+    g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
+    g.D32 = nullptr; g.D16 = D16; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
+    g.epilogue = SEI_EPI_NONE;
+    g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
+    g.conv_cin = 0;
+    g.force_tile = 0; g.force_band = 0;
+    g.adam_p = nullptr; g.adam_m = nullptr; g.adam_v = nullptr; g.adam_p16 = nullptr; g.adam_h = nullptr;
+    if (K1 + K2 <= 1024) return launch_nt<2, 1, 2, 4, true, true, 1, 2>(g, (hipStream_t)stream);
+    return launch_nt<2, 1, 2, 4, true, true, 2, 2>(g, (hipStream_t)stream);
 }
 
 extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,

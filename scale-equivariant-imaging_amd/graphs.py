@@ -49,11 +49,15 @@ def _copy_nested(dst, src):
 
 class GraphedLossStep:
     def __init__(self, loss_module, model, optimizer, crop_shape, warmup=3, store_weight_grads=True,
-                 early_release=False, fuse_optimizer=False, fuse_min_numel=1 << 24, store_min_numel=1 << 20):
+                 early_release=False, fuse_optimizer=False, fuse_min_numel=1 << 24, store_min_numel=1 << 20,
+                 direct_bf16_grads=True):
         """loss_module: a `losses.Loss`; crop_shape: (B, 3, S, S) of the cropped measurement y.
         fuse_optimizer: apply the optimizer step of the stored weight gradients of at least `fuse_min_numel` elements
         inside the GEMM that produces them (optim.FlatAdam.fuse_weight_updates; one GPU, bf16 mode, a loss whose
-        model calls all merge into one weight-gradient GEMM per weight)."""
+        model calls all merge into one weight-gradient GEMM per weight).
+        direct_bf16_grads: with a reducer whose exchange buffer is bf16, the same weights' gradients are written into
+        that buffer as bf16 by their GEMM (`self.direct_views`; the caller passes reduce_async(direct=True) after a
+        replayed step)."""
         self.loss_module = loss_module
         self.inner = loss_module.loss                # method-level loss working on cropped tensors
         self.model = model
@@ -121,19 +125,45 @@ class GraphedLossStep:
             if self.fused_views:
                 self.fused_table = optimizer.fuse_weight_updates(self.fused_views)
                 _ops.set_fused_adam(*self.fused_table)
+        # Several GPUs with a bf16-compressed exchange: the same weights' gradients go to the exchange buffer as bf16
+        # (no float32 copy, no cast pass); the reducer is told which slices not to cast after a replayed step.
+        self.direct_views = []
+        reducer = getattr(optimizer, "reducer", None)
+        if direct_bf16_grads and self.store_weight_grads and reducer is not None and reducer.comm is not reducer.flat \
+                and reducer.comm.dtype == torch.bfloat16 and _ops.get_compute_dtype() == "bf16":
+            grads = self.backbone.flat_grads
+            table, ranges = {}, []
+            for prm in self.backbone.parameters():
+                g = prm._sei_grad_view
+                off = (g.data_ptr() - grads.data_ptr()) // grads.element_size()
+                if prm.dim() == 4 and prm.shape[2:] == (1, 1) and prm.numel() >= fuse_min_numel and off % 4 == 0 \
+                        and prm.shape[1] % 8 == 0 and g.data_ptr() in _ops.weight_grad_views():
+                    view = g.view(prm.shape[0], prm.shape[1])
+                    table[view.data_ptr()] = reducer.comm[off:off + prm.numel()].view(prm.shape[0], prm.shape[1])
+                    ranges.append((off, off + prm.numel()))
+                    self.direct_views.append(view)
+            if table:
+                reducer.set_direct_ranges(ranges)
+                _ops.set_direct_bf16_grads(table)
         self.graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(self.graph):
                 self.static_loss = fwd_bwd()
+            if self.direct_views and _ops.direct_bf16_launches() != {v.data_ptr() for v in self.direct_views}:
+                raise RuntimeError("bf16 gradients into the exchange buffer: not every registered weight was written "
+                                   "by the captured step")
             if self.fused_views and _ops.fused_adam_launches() != {v.data_ptr() for v in self.fused_views}:
                 raise RuntimeError("fused optimizer step: not every registered weight was updated by the captured step")
         except Exception:
             if self.fused_views:
                 optimizer.unfuse_weight_updates()
+            if self.direct_views:
+                reducer.set_direct_ranges([])
             raise
         finally:
             _ops.set_weight_grad_milestone(None, None)
             _ops.set_fused_adam(None, None)
+            _ops.set_direct_bf16_grads(None)
         self.backbone.zero_grad_flat()
 
     def _plan_early_release(self, _ops):

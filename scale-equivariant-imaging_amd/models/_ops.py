@@ -477,6 +477,19 @@ def set_fused_adam(table, hyper):
     _DW["adam_launched"] = set()
 
 
+def set_direct_bf16_grads(table):
+    """Several GPUs, bf16-compressed exchange (parallel.FlatGradientReducer): `table` maps the data_ptr of a gradient
+    view to the bf16 view of the exchange buffer with the same shape. The step's single, merged, storing launch into
+    such a gradient writes bf16 there (sei_gemm_bf16nt_dw2_bf16out) and nothing into the float32 bucket, which the
+    reducer then does not cast for those ranges; None switches it off."""
+    _DW["direct16"] = dict(table) if table else None
+    _DW["direct16_launched"] = set()
+
+
+def direct_bf16_launches():
+    return set(_DW.get("direct16_launched", ()))
+
+
 def fused_adam_launches():
     """data_ptrs whose update was applied inside a GEMM since set_fused_adam."""
     return set(_DW.get("adam_launched", ()))
@@ -499,6 +512,18 @@ def _launch_weight_grad_inner(grad2d, pairs, store):
         _gemm_call(2.0 * Np * Kp * (K1 + K2), "sei_gemm_bf16nt_dw2_adam", g1.data_ptr(), g2.data_ptr(), Np,
                    x1.data_ptr(), x2.data_ptr(), Kp, prm.data_ptr(), m1.data_ptr(), v1.data_ptr(), N.ptr(sh),
                    fused[1].data_ptr(), Np, Kp, K1, K2)
+        return
+    direct = _DW.get("direct16")
+    if direct is not None and key in direct:
+        complete = store and len(pairs) == 2 and len(pairs) == _DW["uses"]
+        (g1, x1), (g2, x2) = pairs if len(pairs) == 2 else (pairs[0], pairs[0])
+        K1, K2 = g1.shape[0], g2.shape[0]
+        if not complete or (K1 + K2) % 8 != 0 or key in _DW["direct16_launched"]:
+            raise RuntimeError("bf16 gradients written into the exchange buffer: a registered weight did not receive its "
+                               "gradient as one merged storing GEMM (different loss / batch / call count than planned)")
+        _DW["direct16_launched"].add(key)
+        _gemm_call(2.0 * Np * Kp * (K1 + K2), "sei_gemm_bf16nt_dw2_bf16out", g1.data_ptr(), g2.data_ptr(), Np,
+                   x1.data_ptr(), x2.data_ptr(), Kp, direct[key].data_ptr(), Np, Kp, K1, K2)
         return
     if len(pairs) == 2:
         (g1, x1), (g2, x2) = pairs

@@ -78,7 +78,17 @@ class FlatGradientReducer:
         self.comm = flat_grads if comm_dtype == flat_grads.dtype else torch.empty_like(flat_grads, dtype=comm_dtype)
         self._chunk = max(1, (chunk_mib << 20) // self.comm.element_size())
         self._side = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
+        self.direct_ranges = []       # slices of the bucket that the producer writes into `comm` itself (see below)
+        self._direct_now = False
         self.set_early_range(early_range)
+
+    def set_direct_ranges(self, ranges):
+        """[(start, stop)]: with a compressed exchange, gradients that the backward pass writes as bf16 straight into
+        `self.comm` (graphs.GraphedLossStep: the weight-gradient GEMMs of the deep levels). A step that did so calls
+        reduce_async(direct=True), and the cast from the float32 bucket skips those slices."""
+        if ranges and self.comm is self.flat:
+            raise ValueError("direct bf16 gradients need a compressed (bf16) exchange buffer")
+        self.direct_ranges = sorted((int(a), int(b)) for a, b in ranges or [])
 
     def set_early_range(self, early_range):
         """(Re)plan the chunks; see __init__. Call before the first reduce_async of a step."""
@@ -102,7 +112,19 @@ class FlatGradientReducer:
     def _cast(self, s, e):
         if self.comm is self.flat:
             return
-        if self.flat.is_cuda:
+        pos = s
+        for a, b in (self.direct_ranges if self._direct_now else []):      # already bf16 in comm
+            a, b = max(a, s), min(b, e)
+            if a >= b:
+                continue
+            if a > pos:
+                self._cast_run(pos, a)
+            pos = max(pos, b)
+        if pos < e:
+            self._cast_run(pos, e)
+
+    def _cast_run(self, s, e):
+        if self.flat.is_cuda and s % 4 == 0:                # sei_cast_bf16 moves aligned quads
             import _native as N
             N.call("sei_cast_bf16", self.flat[s:e].data_ptr(), self.comm[s:e].data_ptr(), e - s)
         else:
@@ -124,10 +146,12 @@ class FlatGradientReducer:
             return
         self._work[k] = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def reduce_async(self, early=None):
+    def reduce_async(self, early=None, direct=False):
         """Cast (if compressed) and all-reduce every chunk asynchronously. early: an event with .wait(stream)
         after which `early_range` is final -- that range is handled on a side stream waiting only for the event,
-        the rest on the current stream (i.e. after everything enqueued so far)."""
+        the rest on the current stream (i.e. after everything enqueued so far). direct: this step's backward pass
+        wrote `direct_ranges` into the exchange buffer itself."""
+        self._direct_now = bool(direct) and bool(self.direct_ranges)
         self._work = [None] * len(self.bounds)
         single = world_size() == 1
         if early is not None and self.early_range is not None and self._side is not None:

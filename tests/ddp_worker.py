@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--mode", default="all_reduce")
     ap.add_argument("--comm", default="f32")
+    ap.add_argument("--direct-min", type=int, default=0,
+                    help=">0: weight gradients of at least this many elements are stored (store_min_numel=0) and, with "
+                         "--comm bf16, written into the exchange buffer as bf16 by their GEMM")
     opt = ap.parse_args()
 
     import parallel                                     # before any GPU call: spawns nothing, reads the env
@@ -59,7 +62,11 @@ def main():
     x = torch.rand((G, 3, 256, 256), generator=gen)
     y = x + 5 / 255 * torch.randn((G, 3, 256, 256), generator=gen)
     xs, ys = x[lo:lo + B].cuda(), y[lo:lo + B].cuda()
-    graphed = GraphedLossStep(lf, model, optim, (B, 3, 48, 48)) if opt.graph else None
+    kw = dict(store_min_numel=0, fuse_min_numel=opt.direct_min) if opt.direct_min > 0 else dict(direct_bf16_grads=False)
+    graphed = GraphedLossStep(lf, model, optim, (B, 3, 48, 48), **kw) if opt.graph else None
+    direct = graphed is not None and bool(graphed.direct_views)
+    if opt.direct_min > 0 and opt.comm == "bf16" and world > 1 and opt.dtype == "bf16":
+        assert len(graphed.direct_views) == 2, len(graphed.direct_views)
     losses, grads0 = [], None
     for step in range(opt.steps):
         b = torch.randn((G, 3, 36, 36), generator=gen)
@@ -77,7 +84,7 @@ def main():
             val = lf(x=xs, y=ys, model=model, draws=draws)
             val.backward()
         if reducer is not None:
-            reducer.reduce_async()
+            reducer.reduce_async(direct=direct)
             reducer.wait_all()
         if step == 0:
             g = (reducer.comm if reducer is not None else bb.flat_grads).float() / world

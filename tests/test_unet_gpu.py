@@ -789,3 +789,23 @@ def test_weight_gradient_gemm_with_the_adam_epilogue():
         N.call("sei_gemm_bf16nt_dw2_adam", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), Nn,
                pc.data_ptr(), mc.data_ptr(), vc.data_ptr(), None, hyper.data_ptr(), M, Nn, K1, K2)
         assert torch.equal(pc, pb)
+
+
+def test_weight_gradient_gemm_with_bf16_output():
+    """sei_gemm_bf16nt_dw2_bf16out == the bf16 rounding of the float32 gradient sei_gemm_bf16nt_dw2 stores (no K split
+    at 768 whole tiles; ragged tiles to rounding): what the reducer's cast pass would have put into the exchange buffer."""
+    import _native as N
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    for (M, Nn, K1, K2, exact) in ((2048, 6144, 96, 200, True), (2048, 6144, 640, 1032, True), (136, 520, 96, 200, False)):
+        A1, A2 = ((0.05 * torch.randn((k, M), device="cuda", generator=gen)).bfloat16() for k in (K1, K2))
+        B1, B2 = (torch.randn((k, Nn), device="cuda", generator=gen).bfloat16() for k in (K1, K2))
+        grad = torch.empty((M, Nn), device="cuda")
+        N.call("sei_gemm_bf16nt_dw2", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), Nn, grad.data_ptr(),
+               M, Nn, K1, K2, 0)
+        out = torch.full((M, Nn), float("nan"), device="cuda", dtype=torch.bfloat16)
+        N.call("sei_gemm_bf16nt_dw2_bf16out", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), Nn,
+               out.data_ptr(), M, Nn, K1, K2)
+        if exact:
+            assert torch.equal(out, grad.bfloat16())
+        else:
+            assert relerr(out.float(), grad) < 1e-2 and bool(torch.isfinite(out.float()).all())

@@ -31,5 +31,9 @@ for (M, Nn, K1, K2) in ((8192, 32768, 288, 576), (32768, 8192, 288, 576), (2048,
     same = all(torch.equal(a, b) for a, b in ((pa, pb), (ma, mb), (va, vb), (sa, sb)))
     moved = float((pa - p0).abs().max())
     tg = timeit(lambda: N.call("sei_gemm_bf16nt_dw2", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), Nn, grad.data_ptr(), M, Nn, K1, K2, 0))
+    o16 = torch.empty((M, Nn), device="cuda", dtype=torch.bfloat16)
+    t16 = timeit(lambda: N.call("sei_gemm_bf16nt_dw2_bf16out", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), Nn, o16.data_ptr(), M, Nn, K1, K2))
+    tc = timeit(lambda: N.call("sei_cast_bf16", grad.data_ptr(), o16.data_ptr(), M * Nn))
+    print(f"    bf16-output GEMM {t16:6.0f} us (f32 store {tg:6.0f} us + cast pass {tc:6.0f} us)")
     ts, tf = timeit(separate), timeit(fused)
     print(f"{M}x{Nn}x({K1}+{K2}): bit-identical {same} (max |dp| {moved:.2e})  GEMM alone {tg:6.0f} us  GEMM + Adam {ts:6.0f} us  fused {tf:6.0f} us", flush=True)

@@ -239,7 +239,8 @@ def main(argv=None):
                 print("step kind: hipGraph replay" if used_graph else "step kind: eager")
                 trace_step_kind = False
             if reducer is not None:
-                reducer.reduce_async(early=early_event if used_graph else None)
+                reducer.reduce_async(early=early_event if used_graph else None,
+                                     direct=used_graph and bool(graphed.direct_views))
                 if not isinstance(optimizer, FlatAdam):
                     reducer.wait_all()
                     backbone.flat_grads /= world
