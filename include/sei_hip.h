@@ -119,6 +119,10 @@ int sei_rotate_nearest_bwd(const float *gy, float *gx, int planes, int H, int W,
  * ------------------------------------------------------------------------------------------- */
 #define SEI_REDUCE_BLOCKS 256
 int sei_axpy(const float *a, const float *b, float alpha, float *out, size_t n, void *stream);
+/* base[off_k .. off_k + len_k) = 0 for up to 8 (off, len) pairs of elements (HOST array of 2 * count values): the gaps of
+ * the flat gradient bucket between the weight gradients that the captured step stores, in ONE launch (optimizer.zero_grad,
+ * demo/train.py:258). */
+int sei_zero_ranges(float *base, const unsigned long long *off_len_pairs, int count, void *stream);
 int sei_sure_terms(const float *y, const float *y1, const float *y2, const float *b, int planes,
                    int H, int W, int margin_div, int margin_mse, float tau, float c_mse,
                    float c_div, float *out2, float *g1, float *g2, float *work, void *stream);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "sei_rotate_nearest_fwd": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
     "sei_rotate_nearest_bwd": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
     "sei_axpy": [_P, _P, _F, _P, _Z, _P],
+    "sei_zero_ranges": [_P, _P, _I, _P],
     "sei_sure_terms": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     "sei_mse_terms": [_P, _P, _Z, _F, _P, _P, _P, _P],
     "sei_luma_sqerr": [_P, _P, _Z, _P, _P, _P],

@@ -116,7 +116,37 @@ inline int reduce_blocks(size_t n) {
     return (int)g;
 }
 
+// zero up to 8 slices of one buffer in one launch (the gaps of the gradient bucket between the stored weight gradients)
+struct ZeroRanges {
+    unsigned long long off[8], len[8], start[9];     // start: prefix sums of the lengths (in elements)
+    int count;
+};
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float *__restrict__ base, ZeroRanges r) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < r.start[r.count]; i += stride) {
+        int k = 0;
+        while (k + 1 < r.count && i >= r.start[k + 1]) ++k;
+        base[r.off[k] + (i - r.start[k])] = 0.f;
+    }
+}
 }  // namespace
+
+extern "C" int sei_zero_ranges(float *base, const unsigned long long *off_len_pairs, int count, void *stream) {
+    SEI_REQUIRE(base && off_len_pairs && count > 0 && count <= 8);
+    ZeroRanges r;
+    r.count = count;
+    r.start[0] = 0;
+    for (int k = 0; k < count; ++k) {
+        r.off[k] = off_len_pairs[2 * k];
+        r.len[k] = off_len_pairs[2 * k + 1];
+        r.start[k + 1] = r.start[k] + r.len[k];
+    }
+    if (r.start[count] == 0) return 0;
+    size_t grid = sei_ceil_div((size_t)r.start[count], 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, base, r);
+    return sei_launch_status();
+}
 
 extern "C" int sei_axpy(const float *a, const float *b, float alpha, float *out, size_t n, void *stream) {
     SEI_REQUIRE(a && b && out && n > 0);

@@ -79,6 +79,13 @@ class FlatParameterBucket:
         ranges = self._sei_zero_ranges if store_weight_grads else None
         if ranges is None:
             self.flat_grads.zero_()
+        elif self.flat_grads.is_cuda:
+            import ctypes
+            import _native as N
+            for k in range(0, len(ranges), 8):                   # one launch per 8 gaps (three or four gaps at defaults)
+                part = ranges[k:k + 8]
+                pairs = (ctypes.c_ulonglong * (2 * len(part)))(*[v for off_n in part for v in off_n])
+                N.call("sei_zero_ranges", self.flat_grads.data_ptr(), ctypes.cast(pairs, ctypes.c_void_p), len(part))
         else:
             for off, n in ranges:
                 self.flat_grads[off:off + n].zero_()

@@ -592,7 +592,10 @@ FUSED_MLP_CHANNELS = tuple(int(v) for v in __import__("os").environ.get("SEI_FUS
 
 def _transposed16(w16):
     """(R, C) bf16 -> (C, R) bf16 copy (data movement; the fused MLP backward reads both weights transposed)."""
-    return w16.t().contiguous()
+    R, C = w16.shape
+    wt = torch.empty((C, R), dtype=torch.bfloat16, device=w16.device)
+    N.call("sei_cast_transpose_bf16", w16.data_ptr(), 1, None, wt.data_ptr(), R, C, R, None)
+    return wt
 
 
 class ConvBlockFn16(torch.autograd.Function):
