@@ -25,3 +25,13 @@ for lvl in range(5):
         t1 = timeit(lambda: N.call("sei_cast_transpose_bf16", X.data_ptr(), 0, Y.data_ptr(), None, M, C, M, cs.data_ptr()))
         t2 = timeit(lambda: N.call("sei_cast_transpose_bf16", X.data_ptr(), 0, Y.data_ptr(), None, M, C, M, None))
         print(f"M={M} C={C}: with colsum {t1:6.1f} us ({M*C*6/t1/1e6:5.2f} TB/s), cast only {t2:6.1f} us")
+print("f32 column sums (plain and row-weighted):")
+for lvl in range(5):
+    M = 64 * (48 >> lvl if lvl < 4 else 3) ** 2; C = 32 << (2 * lvl)
+    X = torch.randn((M, C), device="cuda"); out = torch.zeros(C, device="cuda"); w = torch.rand(M, device="cuda")
+    t1 = timeit(lambda: N.call("sei_colsum_f32", X.data_ptr(), out.data_ptr(), M, C))
+    t2 = timeit(lambda: N.call("sei_colsum_weighted_f32", X.data_ptr(), w.data_ptr(), out.data_ptr(), M, C))
+    out.zero_(); N.call("sei_colsum_weighted_f32", X.data_ptr(), w.data_ptr(), out.data_ptr(), M, C)
+    ref = (X.double() * w.double()[:, None]).sum(0)
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    print(f"M={M} C={C}: plain {t1:6.1f} us ({M*C*4/t1/1e6:5.2f} TB/s), weighted {t2:6.1f} us, err {err:.1e}")
