@@ -265,7 +265,7 @@ extern "C" int sei_ln_fwd_bf16_pad(const float *x, const float *gamma, const flo
     return sei_launch_status();
 }
 
-constexpr unsigned PART_GROUPS = 512;                      // workgroups (= partial rows) of the two reducing kernels
+constexpr unsigned PART_GROUPS = 1024;                     // workgroups (= partial rows) of the two reducing kernels
 
 extern "C" size_t sei_swin_partials_floats(int C) { return C > 0 ? (size_t)PART_GROUPS * 2 * (size_t)C : 0; }
 
