@@ -411,8 +411,9 @@ def cast16(x2d, colsum_into_=None):
 # of accumulating, and zero_grad skips those gradients -- valid because the captured step writes every one
 # of them exactly this way on every replay.
 # ---------------------------------------------------------------------------------------------
-_DW = {"uses": 0, "arrivals": {}, "parked": {}, "written": set(), "store": False, "flush_queued": False,
-       "merge": True, "seen": {}}
+_DW = {"uses": 0, "arrivals": {}, "parked": {}, "written": set(), "store": False, "store_min": 0,
+       "flush_queued": False, "merge": True, "seen": {}, "milestone": None, "milestone_done": False,
+       "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set()}
 
 
 def note_forward():
@@ -455,13 +456,13 @@ def set_weight_grad_milestone(keys, event):
 
 def _launch_weight_grad(grad2d, pairs):
     key = grad2d.data_ptr()
-    store = _DW["store"] and key not in _DW["written"] and grad2d.numel() >= _DW.get("store_min", 0)
+    store = _DW["store"] and key not in _DW["written"] and grad2d.numel() >= _DW["store_min"]
     _DW["written"].add(key)
     try:
         _launch_weight_grad_inner(grad2d, pairs, store)
     finally:
-        ms = _DW.get("milestone")
-        if ms is not None and key in ms[0] and ms[0] <= _DW["written"] and not _DW.get("milestone_done"):
+        ms = _DW["milestone"]
+        if ms is not None and key in ms[0] and ms[0] <= _DW["written"] and not _DW["milestone_done"]:
             # every gradient of the milestone has had its (single, merged) launch of this step
             if all(_DW["arrivals"].get(k, 0) >= max(_DW["uses"], 1) for k in ms[0]):
                 ms[1].record()
@@ -487,18 +488,18 @@ def set_direct_bf16_grads(table):
 
 
 def direct_bf16_launches():
-    return set(_DW.get("direct16_launched", ()))
+    return set(_DW["direct16_launched"])
 
 
 def fused_adam_launches():
     """data_ptrs whose update was applied inside a GEMM since set_fused_adam."""
-    return set(_DW.get("adam_launched", ()))
+    return set(_DW["adam_launched"])
 
 
 def _launch_weight_grad_inner(grad2d, pairs, store):
     key = grad2d.data_ptr()
     Np, Kp = grad2d.shape
-    fused = _DW.get("adam")
+    fused = _DW["adam"]
     if fused is not None and key in fused[0]:
         # the update replaces the stored gradient only when this launch IS the step's whole gradient
         complete = store and len(pairs) == 2 and len(pairs) == _DW["uses"]
@@ -513,7 +514,7 @@ def _launch_weight_grad_inner(grad2d, pairs, store):
                    x1.data_ptr(), x2.data_ptr(), Kp, prm.data_ptr(), m1.data_ptr(), v1.data_ptr(), N.ptr(sh),
                    fused[1].data_ptr(), Np, Kp, K1, K2)
         return
-    direct = _DW.get("direct16")
+    direct = _DW["direct16"]
     if direct is not None and key in direct:
         complete = store and len(pairs) == 2 and len(pairs) == _DW["uses"]
         (g1, x1), (g2, x2) = pairs if len(pairs) == 2 else (pairs[0], pairs[0])

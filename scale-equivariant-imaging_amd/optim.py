@@ -25,6 +25,12 @@ class FlatAdam(torch.optim.Optimizer):
         super().__init__([backbone.flat_params], defaults)
         flat = backbone.flat_params
         self.state[flat] = {"step": 0, "exp_avg": torch.zeros_like(flat), "exp_avg_sq": torch.zeros_like(flat)}
+        # optimizer step inside the weight-gradient GEMMs (fuse_weight_updates): slices of the bucket stepped there,
+        # the step number the device scalars were prepared for, and whether an eager backward pass filled the bucket
+        self._fused_ranges = None
+        self._prepared_for = None
+        self._eager_grads = False
+        self._hyper_host = self._hyper_dev = None
 
     def zero_grad(self, set_to_none=True):
         self.backbone.zero_grad_flat()
@@ -68,7 +74,7 @@ class FlatAdam(torch.optim.Optimizer):
     def prepare_step(self):
         """Scalars of the NEXT step (lr of the moment, bias corrections of step + 1) -> the device array read by the
         fused epilogues; enqueued on the current stream, i.e. in front of the replay that uses them."""
-        if not getattr(self, "_fused_ranges", None):
+        if not self._fused_ranges:
             return
         group, st = self.param_groups[0], self.state[self.backbone.flat_params]
         b1, b2 = group["betas"]
@@ -80,7 +86,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     def _step_bounds(self, total, whole=False):
         """The bucket minus the ranges whose update a GEMM epilogue has applied."""
-        fused = getattr(self, "_fused_ranges", None)
+        fused = self._fused_ranges
         if not fused or whole:
             return [(0, total)]
         out, pos = [], 0
@@ -158,10 +164,10 @@ class FlatAdam(torch.optim.Optimizer):
         st = self.state[flat]
         st["step"] += 1
         whole = False
-        if getattr(self, "_fused_ranges", None) and self._prepared_for != st["step"]:
+        if self._fused_ranges and self._prepared_for != st["step"]:
             # not a replayed step: fine after zero_grad() + an eager backward pass (a short last batch), which wrote every
             # gradient the ordinary way; anything else would step the fused weights on gradients nobody computed
-            if not getattr(self, "_eager_grads", False):
+            if not self._eager_grads:
                 st["step"] -= 1
                 raise RuntimeError("FlatAdam.step(): part of this step is applied inside the captured backward pass, "
                                    "which was not replayed with prepare_step() for this step "
