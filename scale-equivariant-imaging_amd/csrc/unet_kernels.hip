@@ -1482,13 +1482,22 @@ extern "C" int sei_sepmap2_packed(const float *x, float *y, int B, int Hi, int W
     const size_t rows = (size_t)B * Hi, nw = rows * C, nh = (size_t)B * Wo * C;
     SEI_REQUIRE(sei_ceil_div(nw, SM_THREADS) < (1u << 31) && sei_ceil_div(nh, SM_THREADS) < (1u << 31));
     const dim3 gw((unsigned)sei_ceil_div(nw, SM_THREADS)), gh((unsigned)sei_ceil_div(nh, SM_THREADS));
-    if (Wo % 12 == 0)
+    // 24 outputs per thread where the extent and the workgroup count allow: half the passes over the input (the H pass
+    // re-reads the two-plane intermediate Ho / OT times, at the fine levels 75 MB each time): 24->48 at C = 128 87 -> 71 us,
+    // 12->24 at C = 512 58 -> 49 us (tools/exp_sepmap.py)
+    if (Wo % 24 == 0 && (size_t)gw.x * (Wo / 24) >= 1024)      // (fewer workgroups than that: 48->24 at C = 32 ran 50 vs 31 us)
+        hipLaunchKernelGGL(sepmap_w_packed_kernel<24>, dim3(gw.x, Wo / 24), dim3(SM_THREADS), 0, s, x, work, RW, rows, Hi,
+                           Wi, Wo, wo_pad, C);
+    else if (Wo % 12 == 0)
         hipLaunchKernelGGL(sepmap_w_packed_kernel<12>, dim3(gw.x, Wo / 12), dim3(SM_THREADS), 0, s, x, work, RW, rows, Hi,
                            Wi, Wo, wo_pad, C);
     else
         hipLaunchKernelGGL(sepmap_w_packed_kernel<8>, dim3(gw.x, (unsigned)sei_ceil_div(Wo, 8)), dim3(SM_THREADS), 0, s, x,
                            work, RW, rows, Hi, Wi, Wo, wo_pad, C);
-    if (Ho % 12 == 0)
+    if (Ho % 24 == 0 && (size_t)gh.x * (Ho / 24) >= 1024)
+        hipLaunchKernelGGL(sepmap_h_packed_kernel<24>, dim3(gh.x, Ho / 24), dim3(SM_THREADS), 0, s, (const float *)work, y,
+                           LH, B, Hi, Ho, ho_pad, (size_t)Wo * C);
+    else if (Ho % 12 == 0)
         hipLaunchKernelGGL(sepmap_h_packed_kernel<12>, dim3(gh.x, Ho / 12), dim3(SM_THREADS), 0, s, (const float *)work, y,
                            LH, B, Hi, Ho, ho_pad, (size_t)Wo * C);
     else

@@ -11,12 +11,14 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 B = 64
 for lvl in range(4):
-    H = 48 >> lvl; C = 32 << lvl
-    for kind in ("down", "up"):
+    H = 48 >> lvl; C = 32 << (2 * lvl)
+    for kind in ("down", "up", "up_bwd"):
         if kind == "down":
-            Hi, Ho, Cc = H, H // 2, 2 * C          # Downsample: 1x1 conv to 2C first, then the map
+            Hi, Ho, Cc = H, H // 2, C              # Downsample: LayerNorm, the map on C channels, then the 1x1 conv
+        elif kind == "up":
+            Hi, Ho, Cc = H // 2, H, 4 * C          # Upsample: the map on the deeper level's 4C channels, then LN + conv
         else:
-            Hi, Ho, Cc = H // 2, H, 2 * C
+            Hi, Ho, Cc = H, H // 2, 4 * C          # its data gradient: the transposed map
         x = torch.randn((B, Hi, Hi, Cc), device="cuda")
         mats = [torch.randn((Ho, Hi), device="cuda") for _ in range(4)]
         mats = tuple(mats) + _mats.pack_for_kernel(mats, "cuda")
