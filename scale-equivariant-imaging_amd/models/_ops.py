@@ -413,7 +413,7 @@ def cast16(x2d, colsum_into_=None):
 # ---------------------------------------------------------------------------------------------
 _DW = {"uses": 0, "arrivals": {}, "parked": {}, "written": set(), "store": False, "store_min": 0,
        "flush_queued": False, "merge": True, "seen": {}, "milestone": None, "milestone_done": False,
-       "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set()}
+       "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set(), "flops_per_row": {}}
 
 
 def note_forward():
@@ -526,18 +526,19 @@ def _launch_weight_grad_inner(grad2d, pairs, store):
         _gemm_call(2.0 * Np * Kp * (K1 + K2), "sei_gemm_bf16nt_dw2_bf16out", g1.data_ptr(), g2.data_ptr(), Np,
                    x1.data_ptr(), x2.data_ptr(), Kp, direct[key].data_ptr(), Np, Kp, K1, K2)
         return
+    per_row = _DW["flops_per_row"].get(key) or 2.0 * Np * Kp
     if len(pairs) == 2:
         (g1, x1), (g2, x2) = pairs
         K1, K2 = g1.shape[0], g2.shape[0]
         if (K1 + K2) % 8 == 0:
-            _gemm_call(2.0 * Np * Kp * (K1 + K2), "sei_gemm_bf16nt_dw2", g1.data_ptr(), g2.data_ptr(), Np,
+            _gemm_call(per_row * (K1 + K2), "sei_gemm_bf16nt_dw2", g1.data_ptr(), g2.data_ptr(), Np,
                        x1.data_ptr(), x2.data_ptr(), Kp, grad2d.data_ptr(), Np, Kp, K1, K2, 0 if store else 1)
             return
     for gy16, x16 in pairs:
         rows = gy16.shape[0]
         if rows % 8 == 0:
             gemm_nt16(gy16, x16, Np, Kp, rows, EPI_NONE if store else EPI_ACCUM, out32=grad2d, a_rmajor=True,
-                      b_rmajor=True)
+                      b_rmajor=True, flops=per_row * rows)
         else:       # a pixel count the LDS-DMA kernel cannot chunk (e.g. 9 bottleneck pixels x batch 2): staged kernel
             gemm_mixed(gy16, x16, Np, Kp, rows, 1, 0, EPI_NONE if store else EPI_ACCUM, out=grad2d)
         store = False
@@ -551,11 +552,13 @@ def flush_weight_grads():
         _launch_weight_grad(grad2d, [(gy16, x16)])
 
 
-def weight_grad16(gy16, x16, grad2d):
+def weight_grad16(gy16, x16, grad2d, flops_per_row=None):
     """grad (N', K') += gy^T x, gy16 (M, N') and x16 (M, K') bf16 as stored: both read reduction-major.
-    May park the pair until the step's other model call reaches the same weight (see above)."""
+    May park the pair until the step's other model call reaches the same weight (see above). flops_per_row: the
+    algorithmic FLOPs per reduction row to book for the roofline leg when the operands are zero-padded (2 N' K')."""
     key = grad2d.data_ptr()
     _DW["seen"][key] = grad2d.numel()
+    _DW["flops_per_row"][key] = flops_per_row
     n = _DW["arrivals"].get(key, 0) + 1
     _DW["arrivals"][key] = n
     partner = _DW["parked"].pop(key, None)

@@ -16,7 +16,7 @@ import torch
 import _native as N
 from . import _ops
 from ._ops import (EPI_ACCUM, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_NONE, colsum16_into, colsum_into,
-                   gemm_nt16, grad_of)
+                   gemm_nt16, grad_of, weight_grad16)
 from ._swin_ops import EPI_BIAS_SCALE_RES, LN_EPS, rowscale
 
 CP, HP = 192, 32                # padded embedding width, padded head width
@@ -153,6 +153,7 @@ class SwinPack:
     def flush(self):
         """Staged gradients -> the flat gradient bucket (+=), then clear the staging for the next backward pass."""
         self._flush_queued = False
+        _ops.flush_weight_grads()                        # pairs still parked for a partner that never came
         grads = self.model.flat_grads
         for p in self.model.parameters():                # gradients not attached yet (no zero_grad_flat): attach
             if p.grad is None:
@@ -246,20 +247,17 @@ class SwinBlockFn16(torch.autograd.Function):
         go2 = go.contiguous().view(M, C)
         # MLP branch
         gy = cast_pad(go2, drop2, grad_of(bm2))
-        gemm_nt16(gy, f4, CP, Ch, M, EPI_ACCUM, out32=pack.g(f"{key}.fc2"), a_rmajor=True, b_rmajor=True,
-                  flops=2.0 * M * Ch * C)
+        weight_grad16(gy, f4, pack.g(f"{key}.fc2"), flops_per_row=2.0 * Ch * C)
         gf3 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
         gemm_nt16(gy, w2, M, Ch, CP, EPI_MUL_DGELU, out16=gf3, R1=f3, b_rmajor=True, flops=2.0 * M * Ch * C)
         colsum16_into(grad_of(bm1), gf3)
-        gemm_nt16(gf3, h2, Ch, CP, M, EPI_ACCUM, out32=pack.g(f"{key}.fc1"), a_rmajor=True, b_rmajor=True,
-                  flops=2.0 * M * Ch * C)
+        weight_grad16(gf3, h2, pack.g(f"{key}.fc1"), flops_per_row=2.0 * Ch * C)
         gh2 = torch.empty((M, CP), dtype=torch.float32, device=dev)
         gemm_nt16(gf3, w1, M, CP, Ch, EPI_NONE, out32=gh2, b_rmajor=True, flops=2.0 * M * Ch * C)
         gx1 = ln_bwd(x1, g2, mean2, rstd2, gh2, go2, grad_of(g2), grad_of(b2))
         # attention branch
         gy = cast_pad(gx1, drop1, grad_of(bproj))
-        gemm_nt16(gy, a, CP, CP, M, EPI_ACCUM, out32=pack.g(f"{key}.proj"), a_rmajor=True, b_rmajor=True,
-                  flops=2.0 * M * C * C)
+        weight_grad16(gy, a, pack.g(f"{key}.proj"), flops_per_row=2.0 * C * C)
         ga = torch.empty((M, CP), dtype=torch.bfloat16, device=dev)
         gemm_nt16(gy, wproj, M, CP, CP, EPI_NONE, out16=ga, b_rmajor=True, flops=2.0 * M * C * C)
         dqkv = torch.empty_like(qkv)
@@ -267,8 +265,7 @@ class SwinBlockFn16(torch.autograd.Function):
         N.call("sei_swin_attn_bwd_bf16", qkv.data_ptr(), table.data_ptr(), ga.data_ptr(), dqkv.data_ptr(),
                grad_of(table).data_ptr(), B, H, W, heads, shift, scale)
         colsum16_into(pack.g(f"{key}.qkv_bias"), dqkv)
-        gemm_nt16(dqkv, h1, 3 * heads * HP, CP, M, EPI_ACCUM, out32=pack.g(f"{key}.qkv"), a_rmajor=True, b_rmajor=True,
-                  flops=2.0 * M * 3 * C * C)
+        weight_grad16(dqkv, h1, pack.g(f"{key}.qkv"), flops_per_row=2.0 * 3 * C * C)
         gh1 = torch.empty((M, CP), dtype=torch.float32, device=dev)
         gemm_nt16(dqkv, wqkv, M, CP, 3 * heads * HP, EPI_NONE, out32=gh1, b_rmajor=True, flops=2.0 * M * 3 * C * C)
         gx = ln_bwd(x.view(M, C), g1, mean1, rstd1, gh1, gx1, grad_of(g1), grad_of(b1))
@@ -341,8 +338,8 @@ class Conv3x3GemmFn16(torch.autograd.Function):
         taps = pack.g(f"{key}.taps")                     # (9, coutp, cinp)
         for t, (ky, kx) in enumerate(_TAPS):
             off = guard + (ky - 1) * Wp + (kx - 1)
-            gemm_nt16(gop[guard:guard + R8], xp[off:off + R8], coutp, cinp, R8, EPI_ACCUM, out32=taps[t], a_rmajor=True,
-                      b_rmajor=True, lda=coutp, ldb=cinp, flops=2.0 * M * weight.shape[0] * weight.shape[1])
+            weight_grad16(gop[guard:guard + R8], xp[off:off + R8], taps[t],
+                          flops_per_row=2.0 * M * weight.shape[0] * weight.shape[1] / R8)
         gx = None
         if ctx.needs_input_grad[0]:
             dxp = torch.empty((R, Cin), dtype=torch.float32, device=go.device)
