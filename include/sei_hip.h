@@ -362,9 +362,11 @@ int sei_rowscale(const float *x, const float *row_scale, const float *leaky_gate
  * parameter element appears at most once in a map). */
 int sei_pack(const float *src, const int *map, void *dst, size_t n, int to_bf16, void *stream);
 int sei_unpack_add(const float *src, const int *map, float *dst, size_t n, void *stream);
-/* LayerNorm over C <= 256 channels (C % 4 == 0) of float32 rows -> bf16 rows of ldy elements, zeros beyond C. */
+/* LayerNorm over C <= 256 channels (C % 4 == 0) of float32 rows -> bf16 rows of ldy elements, zeros beyond C; with
+ * ones_col (ldy > C) column C holds 1.0, so that the weight gradient dY^T [LN(x) | 1] of the linear layer behind it
+ * carries that layer's bias gradient in its column C (no separate column-sum pass over dY). */
 int sei_ln_fwd_bf16_pad(const float *x, const float *gamma, const float *beta, uint16_t *y, float *mean,
-                        float *rstd, size_t rows, int C, int ldy, float eps, void *stream);
+                        float *rstd, size_t rows, int C, int ldy, float eps, int ones_col, void *stream);
 /* Its backward: gx (rows, C) = LN'(gy) (+ res if non-NULL); gy float32 with row stride ldg; ggamma / gbeta += through
  * per-workgroup partial sums in `work` (>= sei_swin_partials_floats(C) floats) folded by a second launch: deterministic,
  * no atomics. */

@@ -77,7 +77,7 @@ SIGNATURES = {
     "sei_rowscale": [_P, _P, _P, _P, _Z, _I, _P],
     "sei_pack": [_P, _P, _P, _Z, _I, _P],
     "sei_unpack_add": [_P, _P, _P, _Z, _P],
-    "sei_ln_fwd_bf16_pad": [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _F, _P],
+    "sei_ln_fwd_bf16_pad": [_P, _P, _P, _P, _P, _P, _Z, _I, _I, _F, _I, _P],
     "sei_ln_bwd_pad": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P, _Z, _P],
     "sei_cast_pad_bf16": [_P, _P, _P, _P, _Z, _I, _I, _P, _Z, _P],
     "sei_pad_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

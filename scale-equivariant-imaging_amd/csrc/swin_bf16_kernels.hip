@@ -48,9 +48,12 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_pad_kernel(const float *__res
                                                                const float *__restrict__ beta,
                                                                unsigned short *__restrict__ y, float *__restrict__ mean,
                                                                float *__restrict__ rstd, size_t rows, int C, int ldy,
-                                                               float eps) {
+                                                               float eps, int ones_col) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool live = 4 * lane < C;
+    // ones_col: padding column C holds 1.0 -- the weight-gradient GEMM that reduces over these rows then leaves the
+    // column sums of its other operand (= the layer's bias gradient) in column C of its output, for nothing
+    const unsigned short pad0 = (ones_col && 4 * lane == C) ? (unsigned short)0x3F80 : (unsigned short)0;
     float4 gm = make_float4(0.f, 0.f, 0.f, 0.f), bt = gm;
     if (live) {
         gm = reinterpret_cast<const float4 *>(gamma)[lane];
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_pad_kernel(const float *__res
             rstd[row] = rs;
         }
         if (4 * lane < ldy) {
-            ushort4 o = make_ushort4(0, 0, 0, 0);
+            ushort4 o = make_ushort4(pad0, 0, 0, 0);
             if (live) {
                 o.x = f2bf(dx * rs * gm.x + bt.x);
                 o.y = f2bf(dy * rs * gm.y + bt.y);
@@ -256,12 +259,13 @@ extern "C" int sei_unpack_add(const float *src, const int *map, float *dst, size
 }
 
 extern "C" int sei_ln_fwd_bf16_pad(const float *x, const float *gamma, const float *beta, uint16_t *y, float *mean,
-                                   float *rstd, size_t rows, int C, int ldy, float eps, void *stream) {
+                                   float *rstd, size_t rows, int C, int ldy, float eps, int ones_col, void *stream) {
     SEI_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0 && C % 4 == 0 && C <= 256);
+    SEI_REQUIRE(!ones_col || ldy > C);
     SEI_REQUIRE(ldy >= C && ldy % 4 == 0 && ldy <= 256 && (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0 &&
                 ((uintptr_t)y & 7) == 0);
     hipLaunchKernelGGL(ln_fwd_bf16_pad_kernel, dim3(stream_grid(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
-                       beta, y, mean, rstd, rows, C, ldy, eps);
+                       beta, y, mean, rstd, rows, C, ldy, eps, ones_col);
     return sei_launch_status();
 }
 

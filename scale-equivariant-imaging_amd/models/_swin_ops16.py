@@ -83,11 +83,17 @@ class SwinPack:
             mp = np.where(head_cols[None, :] >= 0, wp[:, np.maximum(head_cols, 0)], -1)
             layouts = {"qkv": mq, "proj": pad_rows(mp, CP), "fc1": pad_cols(index_of(mlp.fc1.weight), CP),
                        "fc2": pad_rows(index_of(mlp.fc2.weight), CP)}
+            # gradient layouts: as the weights, plus -- for the two layers fed by a LayerNorm, whose padded rows carry a
+            # column of ones (ln16) -- the bias in column C: dY^T [h | 1] puts the bias gradient there
+            grads = dict(layouts)
+            grads["qkv"] = mq.copy()
+            grads["qkv"][:, C] = bq
+            grads["fc1"] = layouts["fc1"].copy()
+            grads["fc1"][:, C] = index_of(mlp.fc1.bias)
             for k, m in layouts.items():
                 add("w", f"{name}.{k}", m)
-                add("g", f"{name}.{k}", m)
+                add("g", f"{name}.{k}", grads[k])
             add("b", f"{name}.qkv_bias", bq)
-            add("g", f"{name}.qkv_bias", bq)
         for name, conv in model.named_modules():
             if not isinstance(conv, torch.nn.Conv2d):
                 continue
@@ -172,8 +178,10 @@ def ln16(x2d, gamma, beta):
     y = torch.empty((rows, CP), dtype=torch.bfloat16, device=x2d.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
     rstd = torch.empty_like(mean)
+    # column C of the padded rows holds 1.0: the weight gradient of the linear layer behind (gy^T [h | 1]) then has that
+    # layer's bias gradient in its column C (SwinPack maps it onto the bias); the weights' own padding columns are zero
     N.call("sei_ln_fwd_bf16_pad", x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
-           rstd.data_ptr(), rows, C, CP, LN_EPS)
+           rstd.data_ptr(), rows, C, CP, LN_EPS, 1)
     return y, mean, rstd
 
 
@@ -250,8 +258,7 @@ class SwinBlockFn16(torch.autograd.Function):
         weight_grad16(gy, f4, pack.g(f"{key}.fc2"), flops_per_row=2.0 * Ch * C)
         gf3 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
         gemm_nt16(gy, w2, M, Ch, CP, EPI_MUL_DGELU, out16=gf3, R1=f3, b_rmajor=True, flops=2.0 * M * Ch * C)
-        colsum16_into(grad_of(bm1), gf3)
-        weight_grad16(gf3, h2, pack.g(f"{key}.fc1"), flops_per_row=2.0 * Ch * C)
+        weight_grad16(gf3, h2, pack.g(f"{key}.fc1"), flops_per_row=2.0 * Ch * C)      # (+ the bias gradient, column C)
         gh2 = torch.empty((M, CP), dtype=torch.float32, device=dev)
         gemm_nt16(gf3, w1, M, CP, Ch, EPI_NONE, out32=gh2, b_rmajor=True, flops=2.0 * M * Ch * C)
         gx1 = ln_bwd(x1, g2, mean2, rstd2, gh2, go2, grad_of(g2), grad_of(b2))
@@ -264,8 +271,7 @@ class SwinBlockFn16(torch.autograd.Function):
         scale = float((C // heads) ** -0.5)
         N.call("sei_swin_attn_bwd_bf16", qkv.data_ptr(), table.data_ptr(), ga.data_ptr(), dqkv.data_ptr(),
                grad_of(table).data_ptr(), B, H, W, heads, shift, scale)
-        colsum16_into(pack.g(f"{key}.qkv_bias"), dqkv)
-        weight_grad16(dqkv, h1, pack.g(f"{key}.qkv"), flops_per_row=2.0 * 3 * C * C)
+        weight_grad16(dqkv, h1, pack.g(f"{key}.qkv"), flops_per_row=2.0 * 3 * C * C)   # (+ the bias gradient, column C)
         gh1 = torch.empty((M, CP), dtype=torch.float32, device=dev)
         gemm_nt16(dqkv, wqkv, M, CP, 3 * heads * HP, EPI_NONE, out32=gh1, b_rmajor=True, flops=2.0 * M * 3 * C * C)
         gx = ln_bwd(x.view(M, C), g1, mean1, rstd1, gh1, gx1, grad_of(g1), grad_of(b1))
