@@ -413,6 +413,15 @@ int sei_adam_scalars(float lr, float beta1, float beta2, float eps, float weight
  * gradient exchange the gradient is written straight into the exchange buffer (parallel.FlatGradientReducer.comm) --
  * no float32 copy of it, no cast pass (2.6 GB read + 1.3 GB written per step at the default size). Same rounding
  * (round-to-nearest-even of the float32 accumulator) as sei_cast_bf16 of the stored float32 gradient. */
+/* The weight gradient of a 3x3 convolution on the zero-bordered grid (sei_gemm_bf16nt_conv), all taps in ONE launch:
+ * D32 + t * tap_ld (M x N, float32) (+)= sum over rows r of A[r, :]^T B[r + tap_rows[t], :] for t < ntaps <= 9 -- the same
+ * dY (A1 / A2: the step's two model calls, K1 / K2 grid rows; K2 = 0 for one) against the padded input grids B1 / B2
+ * shifted by each tap's row offset (negative offsets reach into the guard rows in front of the grid).
+ * Reference: the nine (ky, kx) slices of Conv2d.weight.grad, torch's conv2d backward (deepinv SwinIR's 3x3 convs). */
+int sei_gemm_bf16nt_dw2_taps(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1, const uint16_t *B2,
+                             int ldb, float *D32, int M, int N, int K1, int K2, int accumulate, int ntaps,
+                             const int *tap_rows, long long tap_ld, void *stream);
+
 int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1, const uint16_t *B2,
                                 int ldb, uint16_t *D16, int M, int N, int K1, int K2, void *stream);
 

@@ -69,6 +69,12 @@ struct NtArgs {
     float *adam_p, *adam_m, *adam_v;
     unsigned short *adam_p16;
     const float *adam_h;
+    // A batch of GEMMs in one launch that differ in the ROW at which a reduction-major B starts and in their output
+    // (sei_gemm_bf16nt_dw2_taps: the nine taps of a 3x3 convolution's weight gradient, every one the same dY against the
+    // padded input grid shifted by the tap): batch t reads B / B2 from row batch_row[t] on and writes D32 + t * batch_ld.
+    int batch;
+    int batch_row[9];
+    long long batch_ld;
 };
 
 typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
@@ -184,6 +190,20 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
     // plain order instead -- consecutive blocks = consecutive tiles, then the next K split -- so that the splits
     // of a tile spread over all XCDs (with the XCD order every working block had bid % 8 == 0: one XCD).
     int bid = blockIdx.x;
+    // (the argument block itself is never written: a modified copy would leave the scalar registers for scratch memory)
+    // ROWEPI == 3 marks the batched instantiation (plain epilogue): everywhere else the three pointers below ARE the
+    // arguments, and the compiler keeps the register budget of the unbatched kernel (the one-stage weight-gradient loop
+    // went from 78 to 102 VGPRs, i.e. from three workgroups per CU to two, with a run-time test here).
+    const unsigned short *Bp = g.B, *B2p = g.B2;
+    float *D32p = g.D32;
+    if constexpr (ROWEPI == 3) {
+        const int per = gridDim.x / g.batch, bt = bid / per;
+        bid -= bt * per;
+        const ptrdiff_t shift = (ptrdiff_t)g.batch_row[bt] * g.ldb;
+        Bp += shift;
+        B2p += shift;
+        D32p += (size_t)bt * g.batch_ld;
+    }
     int zs, ord;
     if (g.tiles_per_xcd == 0) {
         const int ntile = g.tiles_m * g.tiles_n;
@@ -231,7 +251,7 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
     if (epi == SEI_EPI_BIAS_RES && (!split || lead)) { aux1p = g.R1; aux2p = g.R2; }
     else if (epi == SEI_EPI_BIAS_SCALE_RES) aux1p = g.R2;     // D = R2 + R1[row] * (acc + bias); never split
     else if (epi == SEI_EPI_MUL_DGELU) aux1p = g.R1;
-    else if (epi == SEI_EPI_ACCUM && !split) aux1p = g.D32;
+    else if (epi == SEI_EPI_ACCUM && !split) aux1p = D32p;
     float a1[TM][TN][16], a2[TM][TN][16];
     auto gather_aux = [&](int i, int j) {
         const int col = n0 + wn * (32 * TN) + 32 * j + li;
@@ -318,8 +338,8 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
             if constexpr (ARM) stage_tile_rmajor(g.A, g.A2, g.k_seg, g.lda, m0, M, k0, k_end, dst, wave, lane);
             else stage_tile<BM>(g.A, g.lda, m0, M, k0, k_end, dst, wave, lane);
         }
-        if constexpr (BRM) bb = rm_base(g.B, g.B2, g.ldb, n0, k0);
-        else bb = k0 + BK <= k_end ? reinterpret_cast<const char *>(g.B + (size_t)n0 * g.ldb + k0) : nullptr;
+        if constexpr (BRM) bb = rm_base(Bp, B2p, g.ldb, n0, k0);
+        else bb = k0 + BK <= k_end ? reinterpret_cast<const char *>(Bp + (size_t)n0 * g.ldb + k0) : nullptr;
         if (bb) {
 #pragma unroll
             for (int e = 0; e < NPB; ++e)
@@ -328,10 +348,10 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
         } else if constexpr (BRM) {
 #pragma unroll
             for (int im = 0; im < BN / 128; ++im)           // 16 KB image per 128 columns
-                stage_tile_rmajor(g.B, g.B2, g.k_seg, g.ldb, n0 + 128 * im, N, k0, k_end,
+                stage_tile_rmajor(Bp, B2p, g.k_seg, g.ldb, n0 + 128 * im, N, k0, k_end,
                                   dst + BM * ROW_BYTES + im * 16384, wave, lane);
         } else {
-            stage_tile<BN>(g.B, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
+            stage_tile<BN>(Bp, g.ldb, n0, N, k0, k_end, dst + BM * ROW_BYTES, wave, lane);
         }
     };
     const int sw = (li >> 1) & 7;                              // swizzle key of this lane's rows
@@ -539,15 +559,15 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
                 const size_t o = (size_t)row * N + col;
                 float v = acc[i][j][r] + bias;
                 if (split) {
-                    atomicAdd(g.D32 + o, v + a1[i][j][r] + a2[i][j][r]);
+                    atomicAdd(D32p + o, v + a1[i][j][r] + a2[i][j][r]);
                     continue;
                 }
                 if (epi == SEI_EPI_MUL_DGELU)
-                    v *= (g.D16 && !g.D32) ? sei_dgelu_bf16out(a1[i][j][r]) : sei_dgelu(a1[i][j][r]);
+                    v *= (g.D16 && !D32p) ? sei_dgelu_bf16out(a1[i][j][r]) : sei_dgelu(a1[i][j][r]);
                 else if (epi == SEI_EPI_BIAS_SCALE_RES) v = fmaf(v, g.R1[row], a1[i][j][r]);
                 else v += a1[i][j][r] + a2[i][j][r];
                 if (epi == SEI_EPI_BIAS_GELU) g.D2_16[o] = f2bf(sei_gelu_bf16out(v));
-                if (g.D32) g.D32[o] = v;
+                if (D32p) D32p[o] = v;
                 if (g.D16) g.D16[o] = f2bf(v);
             }
         }
@@ -575,7 +595,8 @@ int launch_nt(NtArgs &g, hipStream_t s) {
     g.tiles_m = (int)sei_ceil_div(g.M, BM);
     g.tiles_n = (int)sei_ceil_div(g.N, BN);
     const size_t tiles = (size_t)g.tiles_m * g.tiles_n;
-    SEI_REQUIRE(tiles < ((size_t)1 << 27));
+    const size_t nbatch = g.batch > 1 ? (size_t)g.batch : 1;
+    SEI_REQUIRE(tiles * nbatch < ((size_t)1 << 27));
     {
         constexpr size_t STAGE_BYTES = NSTAGE * (size_t)(BM + BN) * ROW_BYTES;
         const double conc = 32.0 * (STAGE_BYTES <= 40 * 1024 ? 3 : (STAGE_BYTES <= 80 * 1024 ? 2 : 1));   // tiles in flight per XCD
@@ -589,7 +610,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
     g.k_per_split = g.K;
     const bool splittable = g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
                             g.epilogue == SEI_EPI_BIAS_RES || g.epilogue == SEI_EPI_ACCUM;
-    if (ROWEPI == 0 && splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
+    if ((ROWEPI == 0 || ROWEPI == 3) && splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
         // Wave-quantisation-aware split: a launch takes ceil(tiles*sk / slots) rounds of workgroups, each
         // round costing (k-tiles per split + a fixed prologue/epilogue/atomics overhead); pick the cheapest sk.
         constexpr size_t STAGE_BYTES = NSTAGE * (size_t)(BM + BN) * ROW_BYTES;
@@ -602,7 +623,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         double best = 1e30;
         size_t best_sk = 1;
         for (size_t sk = 1; sk <= max_sk; ++sk) {
-            const double rounds = (double)sei_ceil_div(tiles * sk, slots);
+            const double rounds = (double)sei_ceil_div(tiles * nbatch * sk, slots);
             const double cost = rounds * ((double)sei_ceil_div(ktiles, sk) + overhead + (sk > 1 ? 2.0 : 0.0));
             if (cost < best * 0.97) {            // prefer fewer splits unless the gain is real
                 best = cost;
@@ -615,6 +636,7 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         }
     }
     if (g.splitk > 1 && g.epilogue != SEI_EPI_ACCUM) {      // ACCUM adds into the running gradient as it is
+        if (nbatch > 1) return SEI_ERR_BAD_ARG;             // (batched launches accumulate or run unsplit)
         const size_t n = (size_t)g.M * g.N;
         size_t zg = sei_ceil_div(n / 4 + 1, 256);
         if (zg > 2048) zg = 2048;
@@ -622,7 +644,8 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
     const size_t per_split = g.tiles_per_xcd ? 8 * (size_t)g.tiles_per_xcd : tiles;
-    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE, ROWEPI>), dim3((unsigned)(per_split * g.splitk)),
+    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE, ROWEPI>),
+                       dim3((unsigned)(per_split * g.splitk * nbatch)),
                        dim3(NT), 0, s, g);
     return sei_launch_status();
 }
@@ -707,6 +730,7 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
     g.A2 = A; g.B2 = B; g.k_seg = K;                       // one reduction segment
     g.conv_cin = 0;
+    g.batch = 1;
     SEI_REQUIRE(tile >= 0 && band >= 0);
     if (epilogue == SEI_EPI_BIAS_SCALE_RES && tile == 0)                // the quadrant kernel has no such epilogue
         tile = (N > 128 && N <= 192) ? 6 : 1;
@@ -847,6 +871,7 @@ extern "C" int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, in
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
     g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
     g.conv_cin = 0;
+    g.batch = 1;
     SEI_REQUIRE(tile >= 0);
     g.force_band = 0;
 #ifdef SEI_TUNING
@@ -885,6 +910,7 @@ extern "C" int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, 
     g.epilogue = SEI_EPI_NONE;
     g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
     g.conv_cin = 0;
+    g.batch = 1;
     g.force_tile = 0; g.force_band = 0;
     g.adam_p = param; g.adam_m = exp_avg; g.adam_v = exp_avg_sq; g.adam_p16 = param_bf16; g.adam_h = hyper;
     if (K1 + K2 <= 1024) return launch_nt<2, 1, 2, 4, true, true, 1, 1>(g, (hipStream_t)stream);
@@ -904,10 +930,32 @@ extern "C" int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A
     g.epilogue = SEI_EPI_NONE;
     g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
     g.conv_cin = 0;
+    g.batch = 1;
     g.force_tile = 0; g.force_band = 0;
     g.adam_p = nullptr; g.adam_m = nullptr; g.adam_v = nullptr; g.adam_p16 = nullptr; g.adam_h = nullptr;
     if (K1 + K2 <= 1024) return launch_nt<2, 1, 2, 4, true, true, 1, 2>(g, (hipStream_t)stream);
     return launch_nt<2, 1, 2, 4, true, true, 2, 2>(g, (hipStream_t)stream);
+}
+
+extern "C" int sei_gemm_bf16nt_dw2_taps(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
+                                        const uint16_t *B2, int ldb, float *D32, int M, int N, int K1, int K2,
+                                        int accumulate, int ntaps, const int *tap_rows, long long tap_ld, void *stream) {
+    SEI_REQUIRE(A1 && A2 && B1 && B2 && D32 && tap_rows && M > 0 && N > 0 && K1 > 0 && K2 >= 0);
+    SEI_REQUIRE(ntaps >= 1 && ntaps <= 9 && tap_ld >= (long long)M * N);
+    SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
+    SEI_REQUIRE((K1 + K2) % 8 == 0);
+    SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
+    NtArgs g;
+    g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
+    g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
+    g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
+    g.bias = nullptr; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
+    g.conv_cin = 0;
+    g.force_tile = 0; g.force_band = 0;
+    g.batch = ntaps;
+    for (int t = 0; t < 9; ++t) g.batch_row[t] = t < ntaps ? tap_rows[t] : 0;
+    g.batch_ld = tap_ld;
+    return launch_nt<2, 1, 2, 4, true, true, 2, 3>(g, (hipStream_t)stream);
 }
 
 extern "C" int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
@@ -928,6 +976,7 @@ extern "C" int sei_gemm_bf16nt_conv(const uint16_t *Ap, int cin_pad, const int *
     SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS);
     if (epilogue == SEI_EPI_BIAS) SEI_REQUIRE(bias);
     NtArgs g;
+    g.batch = 1;
     g.A = Ap; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = 9 * cin_pad; g.lda = cin_pad; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
     g.A2 = Ap; g.B2 = B; g.k_seg = g.K;

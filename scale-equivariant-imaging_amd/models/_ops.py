@@ -413,7 +413,7 @@ def cast16(x2d, colsum_into_=None):
 # ---------------------------------------------------------------------------------------------
 _DW = {"uses": 0, "arrivals": {}, "parked": {}, "written": set(), "store": False, "store_min": 0,
        "flush_queued": False, "merge": True, "seen": {}, "milestone": None, "milestone_done": False,
-       "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set(), "flops_per_row": {}}
+       "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set(), "flops_per_row": {}, "taps": {}}
 
 
 def note_forward():
@@ -498,7 +498,7 @@ def fused_adam_launches():
 
 def _launch_weight_grad_inner(grad2d, pairs, store):
     key = grad2d.data_ptr()
-    Np, Kp = grad2d.shape
+    Np, Kp = grad2d.shape[-2:]
     fused = _DW["adam"]
     if fused is not None and key in fused[0]:
         # the update replaces the stored gradient only when this launch IS the step's whole gradient
@@ -526,6 +526,17 @@ def _launch_weight_grad_inner(grad2d, pairs, store):
         _gemm_call(2.0 * Np * Kp * (K1 + K2), "sei_gemm_bf16nt_dw2_bf16out", g1.data_ptr(), g2.data_ptr(), Np,
                    x1.data_ptr(), x2.data_ptr(), Kp, direct[key].data_ptr(), Np, Kp, K1, K2)
         return
+    taps = _DW["taps"].get(key)
+    if taps is not None:                               # (T, N', K') gradient: every tap in one launch
+        T, Np, Kp = grad2d.shape
+        (g1, x1), (g2, x2) = pairs if len(pairs) == 2 else (pairs[0], pairs[0])
+        K1, K2 = g1.shape[0], (g2.shape[0] if len(pairs) == 2 else 0)
+        per_row = _DW["flops_per_row"].get(key) or 2.0 * T * Np * Kp
+        if (K1 + K2) % 8 != 0:
+            raise ValueError("weight_grad16 with taps: the reduction length must be a multiple of 8 rows")
+        _gemm_call(per_row * (K1 + K2), "sei_gemm_bf16nt_dw2_taps", g1.data_ptr(), g2.data_ptr(), Np, x1.data_ptr(),
+                   x2.data_ptr(), Kp, grad2d.data_ptr(), Np, Kp, K1, K2, 0 if store else 1, T, taps, Np * Kp)
+        return
     per_row = _DW["flops_per_row"].get(key) or 2.0 * Np * Kp
     if len(pairs) == 2:
         (g1, x1), (g2, x2) = pairs
@@ -552,13 +563,18 @@ def flush_weight_grads():
         _launch_weight_grad(grad2d, [(gy16, x16)])
 
 
-def weight_grad16(gy16, x16, grad2d, flops_per_row=None):
+def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None):
     """grad (N', K') += gy^T x, gy16 (M, N') and x16 (M, K') bf16 as stored: both read reduction-major.
     May park the pair until the step's other model call reaches the same weight (see above). flops_per_row: the
-    algorithmic FLOPs per reduction row to book for the roofline leg when the operands are zero-padded (2 N' K')."""
+    algorithmic FLOPs per reduction row to book for the roofline leg when the operands are zero-padded (2 N' K').
+    tap_rows (a ctypes int array of T row offsets): grad2d is (T, N', K') and slice t is gy^T x[rows shifted by
+    tap_rows[t]] -- the taps of a 3x3 convolution's weight gradient in one launch (sei_gemm_bf16nt_dw2_taps); x16 is
+    the un-shifted window of a grid with guard rows on both sides."""
     key = grad2d.data_ptr()
     _DW["seen"][key] = grad2d.numel()
     _DW["flops_per_row"][key] = flops_per_row
+    if tap_rows is not None:
+        _DW["taps"][key] = tap_rows
     n = _DW["arrivals"].get(key, 0) + 1
     _DW["arrivals"][key] = n
     partner = _DW["parked"].pop(key, None)

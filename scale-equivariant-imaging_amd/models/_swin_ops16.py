@@ -341,11 +341,9 @@ class Conv3x3GemmFn16(torch.autograd.Function):
         colsum_into(grad_of(bias) if Cout == weight.shape[0] else pack.g(f"{key}.bias4"), gpre)
         gop = torch.empty((R + 2 * guard, coutp), dtype=torch.bfloat16, device=go.device)
         N.call("sei_pad_nhwc_bf16", gpre.data_ptr(), gop.data_ptr(), B, H, W, Cout, coutp, guard)
-        taps = pack.g(f"{key}.taps")                     # (9, coutp, cinp)
-        for t, (ky, kx) in enumerate(_TAPS):
-            off = guard + (ky - 1) * Wp + (kx - 1)
-            weight_grad16(gop[guard:guard + R8], xp[off:off + R8], taps[t],
-                          flops_per_row=2.0 * M * weight.shape[0] * weight.shape[1] / R8)
+        taps = pack.g(f"{key}.taps")                     # (9, coutp, cinp): one launch for the nine taps
+        weight_grad16(gop[guard:guard + R8], xp[guard:guard + R8], taps,
+                      flops_per_row=2.0 * M * weight.shape[0] * 9 * weight.shape[1] / R8, tap_rows=_tap_offsets(Wp, 1))
         gx = None
         if ctx.needs_input_grad[0]:
             dxp = torch.empty((R, Cin), dtype=torch.float32, device=go.device)

@@ -346,3 +346,40 @@ def test_train_script_with_the_reference_default_architecture(tmp_path, extra):
     w = torch.load(out / "weights.pt", map_location="cpu")
     assert "conv_last.weight" in w and "layers.5.residual_group.blocks.5.attn.relative_position_bias_table" in w
     assert "layers.0.residual_group.blocks.1.attn_mask" in w          # buffers travel, as in the published weights
+
+
+def test_conv_weight_gradient_taps_in_one_launch():
+    """sei_gemm_bf16nt_dw2_taps == nine accumulating sei_gemm_bf16nt_dw2 launches on the row-shifted grid (two K
+    segments = the step's two model calls, and one), to the rounding of the split-K sums."""
+    import ctypes
+    import _native as N
+    Wp, C = 18, 192
+    offs = [(ky - 1) * Wp + (kx - 1) for ky in range(3) for kx in range(3)]
+    rows_c = (ctypes.c_int * 9)(*offs)
+    guard = Wp + 9
+    gen = torch.Generator(device="cuda").manual_seed(8)
+
+    def grid(count):
+        R8 = (count * Wp * Wp + 7) // 8 * 8
+        return (R8, (0.1 * torch.randn((R8, C), device="cuda", generator=gen)).bfloat16(),
+                torch.randn((R8 + 2 * guard, C), device="cuda", generator=gen).bfloat16())
+
+    K1, g1, x1 = grid(6)
+    K2, g2, x2 = grid(3)
+    for two in (True, False):
+        ref = torch.zeros((9, C, C), device="cuda")
+        out = torch.zeros((9, C, C), device="cuda")
+        for t, o in enumerate(offs):
+            if two:
+                N.call("sei_gemm_bf16nt_dw2", g1.data_ptr(), g2.data_ptr(), C, x1[guard + o:].data_ptr(),
+                       x2[guard + o:].data_ptr(), C, ref[t].data_ptr(), C, C, K1, K2, 1)
+            else:
+                N.call("sei_gemm_bf16nt_ex", g1.data_ptr(), C, 1, x1[guard + o:].data_ptr(), C, 1, ref[t].data_ptr(), None,
+                       C, C, K1, 5, None, None, None, None, 0, 0)
+        N.call("sei_gemm_bf16nt_dw2_taps", g1.data_ptr(), g2.data_ptr() if two else g1.data_ptr(), C, x1[guard:].data_ptr(),
+               x2[guard:].data_ptr() if two else x1[guard:].data_ptr(), C, out.data_ptr(), C, C, K1, K2 if two else 0, 1, 9,
+               ctypes.cast(rows_c, ctypes.c_void_p), C * C)
+        assert relerr(out, ref) < 1e-5, relerr(out, ref)
+        dense = torch.einsum("rm,rn->mn", g1.float(), x1[guard + offs[5]:guard + offs[5] + K1].float())
+        if not two:
+            assert relerr(out[5], dense) < 1e-4
