@@ -380,7 +380,7 @@ def main():
                     help="dtype of the all-reduced gradient bucket (auto: bf16 in bf16 mode, f32 in f32 mode)")
     ap.add_argument("--grad-comm-mode", choices=["all_reduce", "rs_ag"], default="all_reduce")
     ap.add_argument("--fuse-optimizer", action=argparse.BooleanOptionalAction, default=True,
-                    help="one GPU, bf16, hipGraph: apply Adam to the 1x1-convolution weights of the two deepest levels (94 %% "
+                    help="one GPU, bf16, hipGraph: apply Adam to the 1x1-convolution weights of the two deepest levels (98.8 %% "
                          "of the parameters) in the epilogue of the GEMM that produces their gradient")
     ap.add_argument("--direct-bf16-grads", action=argparse.BooleanOptionalAction, default=True,
                     help="N > 1 with a bf16 exchange: the deep levels' weight-gradient GEMMs write bf16 into the exchange "

@@ -119,8 +119,9 @@ class GraphedLossStep:
             base, esz = grads.data_ptr(), grads.element_size()
             for prm in self.backbone.parameters():
                 g = prm._sei_grad_view
-                if prm.dim() == 4 and prm.shape[2:] == (1, 1) and prm.numel() >= fuse_min_numel \
-                        and g.data_ptr() in _ops.weight_grad_views():
+                off = (g.data_ptr() - base) // esz
+                if prm.dim() == 4 and prm.shape[2:] == (1, 1) and prm.numel() >= fuse_min_numel and off % 4 == 0 \
+                        and prm.shape[1] % 8 == 0 and g.data_ptr() in _ops.merged_weight_grads():
                     self.fused_views.append(g.view(prm.shape[0], prm.shape[1]))
             if self.fused_views:
                 self.fused_table = optimizer.fuse_weight_updates(self.fused_views)
@@ -137,7 +138,7 @@ class GraphedLossStep:
                 g = prm._sei_grad_view
                 off = (g.data_ptr() - grads.data_ptr()) // grads.element_size()
                 if prm.dim() == 4 and prm.shape[2:] == (1, 1) and prm.numel() >= fuse_min_numel and off % 4 == 0 \
-                        and prm.shape[1] % 8 == 0 and g.data_ptr() in _ops.weight_grad_views():
+                        and prm.shape[1] % 8 == 0 and g.data_ptr() in _ops.merged_weight_grads():
                     view = g.view(prm.shape[0], prm.shape[1])
                     table[view.data_ptr()] = reducer.comm[off:off + prm.numel()].view(prm.shape[0], prm.shape[1])
                     ranges.append((off, off + prm.numel()))

@@ -413,7 +413,7 @@ def cast16(x2d, colsum_into_=None):
 # ---------------------------------------------------------------------------------------------
 _DW = {"uses": 0, "arrivals": {}, "parked": {}, "written": set(), "store": False, "store_min": 0,
        "flush_queued": False, "merge": True, "seen": {}, "milestone": None, "milestone_done": False,
-       "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set(), "flops_per_row": {}, "taps": {}}
+       "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set(), "flops_per_row": {}, "taps": {}, "merged_ok": {}}
 
 
 def note_forward():
@@ -496,9 +496,18 @@ def fused_adam_launches():
     return set(_DW["adam_launched"])
 
 
+def merged_weight_grads():
+    """data_ptrs of the gradients whose last launch carried the step's COMPLETE gradient as one two-segment GEMM (the
+    condition for applying the optimizer step, or writing bf16, in that launch: graphs.GraphedLossStep reads this after
+    its warm-up steps -- a batch whose pixel counts do not add up to a multiple of 8 rows is served by other launches)."""
+    return {k for k, ok in _DW["merged_ok"].items() if ok}
+
+
 def _launch_weight_grad_inner(grad2d, pairs, store):
     key = grad2d.data_ptr()
     Np, Kp = grad2d.shape[-2:]
+    _DW["merged_ok"][key] = (len(pairs) == 2 and len(pairs) == _DW["uses"]
+                             and (pairs[0][0].shape[0] + pairs[1][0].shape[0]) % 8 == 0)
     fused = _DW["adam"]
     if fused is not None and key in fused[0]:
         # the update replaces the stored gradient only when this launch IS the step's whole gradient

@@ -39,7 +39,7 @@ class FlatAdam(torch.optim.Optimizer):
     # -- optimizer step inside the weight-gradient GEMMs (one GPU, bf16 mode, captured step) ----------------------
     def fuse_weight_updates(self, grad_views):
         """grad_views: 2-D views into the flat gradient bucket whose step is to be applied by the GEMM that
-        produces them (graphs.GraphedLossStep: the two deepest levels, 94 % of the bucket at defaults -- the 4-byte
+        produces them (graphs.GraphedLossStep: the two deepest levels, 98.8 % of the bucket at defaults -- the 4-byte
         gradient round trip and 26 of Adam's 30 bytes per parameter move into that GEMM's epilogue, under its MFMA
         work). `step()` then covers the rest of the bucket; `prepare_step()` must run before every captured step so
         that the device scalars the epilogue reads belong to the step about to be taken. Returns the table for

@@ -921,3 +921,67 @@ def test_early_gradient_release_from_inside_the_graph():
             opt.step()
     finally:
         _ops.set_compute_dtype(prev)
+
+
+def test_fused_optimizer_step_on_the_default_network():
+    """The 645 M-parameter network, one captured step with and without the optimizer step inside the deep levels'
+    weight-gradient GEMMs (same weights, crops and draws): loss, the eight fused weights and their first moments
+    agree to the run-to-run noise of the step itself (split-K float atomics in the forward pass), the rest of the
+    bucket likewise. At batch 2 the bottleneck reductions (36 + 18 rows) are not a multiple of 8: the
+    merged launch does not exist, nothing is fused, and the step still runs."""
+    import bench
+    import physics
+    import models
+    from graphs import GraphedLossStep
+    from losses import get_loss
+    from models import _ops
+    from optim import FlatAdam
+    prev = _ops.set_compute_dtype("bf16")
+    try:
+        args = bench.reference_args("cuda", 32, 5)
+        runs = {}
+        for fuse in (False, True):
+            torch.manual_seed(0)
+            p = physics.get_physics(args, "cuda")
+            model = models.get_model(args, p, "cuda").to("cuda")
+            bb = model.get_backbone()
+            lf = get_loss(args, p)
+            opt = FlatAdam(model, lr=1e-4)
+            x = torch.rand(8, 3, 256, 256, device="cuda")
+            torch.cuda.manual_seed(7)
+            y = p(x)
+            g = GraphedLossStep(lf, model, opt, (8, 3, 48, 48), fuse_optimizer=fuse)
+            if fuse:
+                assert len(g.fused_views) == 8, [tuple(v.shape) for v in g.fused_views]
+                ranges = list(opt._fused_ranges)          # the bottleneck pair + level 3's two blocks, down and up conv
+                assert sum(hi - lo for lo, hi in ranges) == 2 * 8192 * 32768 + 6 * 2048 * 8192      # 98.8 % of the bucket
+            torch.manual_seed(31)
+            torch.cuda.manual_seed(32)
+            loss = float(g(x, y))
+            opt.step()
+            st = opt.state[bb.flat_params]
+            runs[fuse] = (loss, bb.flat_params, st["exp_avg"], st["exp_avg_sq"], bb.flat_shadow)
+            del g, opt, model, lf
+        # (two runs of the SAME step already differ in the sixth digit: the deep levels' forward GEMMs split K over float
+        # atomics; the bit-for-bit statement lives at kernel level, tests/test_unet_gpu.py)
+        assert abs(runs[False][0] - runs[True][0]) < 1e-4 * runs[False][0]
+        for lo, hi in ranges:
+            assert relerr(runs[True][2][lo:hi], runs[False][2][lo:hi]) < 2e-2           # exp_avg = 0.1 * gradient
+            moved = (runs[True][1][lo:hi] - runs[False][1][lo:hi]).abs()
+            assert float(moved.mean()) < 2e-6 and float(moved.max()) <= 2.1e-4          # at most one first Adam step apart
+        assert relerr(runs[True][1], runs[False][1]) < 1e-3
+        del runs
+        torch.cuda.empty_cache()
+        # a batch whose bottleneck rows do not merge into one launch: no fusion, same result as the plain step
+        torch.manual_seed(0)
+        p = physics.get_physics(args, "cuda")
+        model = models.get_model(args, p, "cuda").to("cuda")
+        lf = get_loss(args, p)
+        opt = FlatAdam(model, lr=1e-4)
+        x = torch.rand(2, 3, 256, 256, device="cuda")
+        g = GraphedLossStep(lf, model, opt, (2, 3, 48, 48), fuse_optimizer=True)
+        assert all(tuple(v.shape) not in ((8192, 32768), (32768, 8192)) for v in g.fused_views)
+        assert torch.isfinite(g(x, p(x)))
+        opt.step()
+    finally:
+        _ops.set_compute_dtype(prev)
