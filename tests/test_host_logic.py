@@ -260,6 +260,32 @@ def _reducer_worker(rank, world, port, numel, chunk_mib, q):
     red16.wait_all()
     want16 = sum(torch.randn(numel, generator=torch.Generator().manual_seed(200 + k)).bfloat16().float() for k in range(w))
     assert red16.comm.dtype == torch.bfloat16 and (red16.comm.float() - want16).abs().max() < 0.05
+    # slices the producer writes into the bf16 exchange buffer itself (direct ranges): the cast skips them after a step
+    # that did so, and casts them as usual after one that did not (an eager step)
+    g4 = torch.randn(numel, generator=torch.Generator().manual_seed(400 + r))
+    red_d = parallel.FlatGradientReducer(g4, chunk_mib=chunk_mib, comm_dtype=torch.bfloat16)
+    red_d._chunk = 200_000
+    red_d.set_early_range((300_000, 700_004))
+    direct = [(300_000, 500_000), (600_000, 700_000)]
+    red_d.set_direct_ranges(direct)
+    for lo, hi in direct:                                 # what the weight-gradient GEMMs would have stored
+        red_d.comm[lo:hi] = float(r + 1)
+    g4_marked = g4.clone()
+    for lo, hi in direct:
+        g4[lo:hi] = 1000.0                                # the float32 bucket holds junk there: it must not be cast
+    red_d.reduce_async(direct=True)
+    red_d.wait_all()
+    got = red_d.comm.float()
+    want4 = sum(torch.randn(numel, generator=torch.Generator().manual_seed(400 + k)).bfloat16().float() for k in range(w))
+    for lo, hi in direct:
+        assert float((got[lo:hi] - sum(range(1, w + 1))).abs().max()) == 0.0
+        want4[lo:hi] = got[lo:hi]
+    assert (got - want4).abs().max() < 0.05
+    g4.copy_(g4_marked)
+    red_d.reduce_async(direct=False)                      # an eager step: everything comes from the float32 bucket
+    red_d.wait_all()
+    want4e = sum(torch.randn(numel, generator=torch.Generator().manual_seed(400 + k)).bfloat16().float() for k in range(w))
+    assert (red_d.comm.float() - want4e).abs().max() < 0.05
     # reduce-scatter + all-gather mode: same sums; the ragged last chunk falls back to all_reduce
     g3 = torch.randn(numel, generator=torch.Generator().manual_seed(300 + r))
     red_rs = parallel.FlatGradientReducer(g3, chunk_mib=chunk_mib, mode="rs_ag")
