@@ -408,6 +408,10 @@ int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, int lda, co
                              const float *hyper, int M, int N, int K1, int K2, void *stream);
 int sei_adam_scalars(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float *out6_host,
                      void *stream);
+/* the same values written to a DEVICE array by a launch on `stream` (what a training loop calls before every replay of
+ * a captured step: stream-ordered, nothing on the host to overwrite while the GPU lags behind) */
+int sei_adam_scalars_to_device(float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                               float *dev6, void *stream);
 
 /* The same two-segment weight gradient STORED as bf16 (whole-row 8-byte quads): with several GPUs and a bf16-compressed
  * gradient exchange the gradient is written straight into the exchange buffer (parallel.FlatGradientReducer.comm) --

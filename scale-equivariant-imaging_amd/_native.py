@@ -85,6 +85,7 @@ SIGNATURES = {
     "sei_gemm_bf16nt_conv": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P],
     "sei_adam_fused": [_P, _P, _I, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P, _P],
     "sei_adam_scalars": [_F, _F, _F, _F, _F, _I, _P, _P],
+    "sei_adam_scalars_to_device": [_F, _F, _F, _F, _F, _I, _P, _P],
 }
 
 _lib = None

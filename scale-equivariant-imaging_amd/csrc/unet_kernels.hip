@@ -1556,6 +1556,26 @@ extern "C" int sei_adam_scalars(float lr, float beta1, float beta2, float eps, f
     return 0;
 }
 
+namespace {
+struct Six { float v[6]; };
+__global__ void store_six_kernel(float *dst, Six s) {
+    if (threadIdx.x < 6) dst[threadIdx.x] = s.v[threadIdx.x];
+}
+}  // namespace
+
+// The same six scalars into a DEVICE array, as arguments of a one-wave kernel: ordered on the stream like any other launch
+// (a host buffer copied asynchronously could be overwritten for step t+1 before the copy of step t has run -- the host
+// runs ahead of a queue of replayed graphs).
+extern "C" int sei_adam_scalars_to_device(float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                          float *dev6, void *stream) {
+    SEI_REQUIRE(dev6 && step > 0);
+    Six s;
+    const int rc = sei_adam_scalars(lr, beta1, beta2, eps, weight_decay, step, s.v, nullptr);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(store_six_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dev6, s);
+    return sei_launch_status();
+}
+
 extern "C" int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, float *exp_avg, float *exp_avg_sq,
                               size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                               float grad_scale, uint16_t *param_bf16, void *stream) {

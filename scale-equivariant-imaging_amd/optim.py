@@ -30,7 +30,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._fused_ranges = None
         self._prepared_for = None
         self._eager_grads = False
-        self._hyper_host = self._hyper_dev = None
+        self._hyper_dev = None
 
     def zero_grad(self, set_to_none=True):
         self.backbone.zero_grad_flat()
@@ -63,7 +63,6 @@ class FlatAdam(torch.optim.Optimizer):
                                     None if shadow is None else pick(shadow))
             ranges.append((off, off + n))
         self._fused_ranges = sorted(ranges)
-        self._hyper_host = torch.empty(6, dtype=torch.float32).pin_memory()
         self._hyper_dev = torch.zeros(6, dtype=torch.float32, device=flat.device)
         self._prepared_for = None
         return table, self._hyper_dev
@@ -73,14 +72,15 @@ class FlatAdam(torch.optim.Optimizer):
 
     def prepare_step(self):
         """Scalars of the NEXT step (lr of the moment, bias corrections of step + 1) -> the device array read by the
-        fused epilogues; enqueued on the current stream, i.e. in front of the replay that uses them."""
+        fused epilogues; a launch on the current stream, i.e. ordered in front of the replay that uses them."""
         if not self._fused_ranges:
             return
         group, st = self.param_groups[0], self.state[self.backbone.flat_params]
         b1, b2 = group["betas"]
-        N.call("sei_adam_scalars", float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-               float(group["weight_decay"]), int(st["step"]) + 1, self._hyper_host.data_ptr())
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        # as launch arguments, not through a host buffer: the host runs steps ahead of the GPU, and a pinned buffer copied
+        # asynchronously would already hold a later step's scalars when the copy finally executes
+        N.call("sei_adam_scalars_to_device", float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+               float(group["weight_decay"]), int(st["step"]) + 1, self._hyper_dev.data_ptr())
         self._prepared_for = int(st["step"]) + 1
         self._eager_grads = False
 
