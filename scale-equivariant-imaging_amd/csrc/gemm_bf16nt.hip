@@ -166,6 +166,12 @@ __device__ __forceinline__ void wait_vmcnt() {          // counted wait: at most
     else static_assert(N < 0, "add the immediate");
 }
 
+// the row-patch epilogue (ROWEPI == 4) needs one wave row of the tile (32 TM rows x BN floats) inside the operand stages
+template <int TM, int TN, int WM, int WN, int NSTAGE>
+constexpr bool patch_fits() {
+    return (NSTAGE * (32 * TM * WM + 32 * TN * WN) * ROW_BYTES) / (32 * TN * WN * 4) >= 32 * TM;
+}
+
 template <int TM, int TN, int WM, int WN, bool ARM, bool BRM, int NSTAGE = 2, int ROWEPI = 0>
 __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(NtArgs g) {
     static_assert(WM * WN == NWAVES, "8 waves per workgroup");
@@ -528,6 +534,107 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
         return;
     }
 
+    // ---- epilogue through an LDS row patch (ROWEPI == 4: unsplit launches with N % 4 == 0 and aligned arrays) -----------
+    // The accumulators go through the operand stages (free after the loop) in passes of whole wave rows, and every
+    // thread then owns quads of a row: residual / GELU' inputs arrive as 16-byte loads on contiguous row segments, float32
+    // results leave as 16-byte and bf16 results as 8-byte stores. The element-wise epilogue below issues one 4- or 2-byte
+    // access per value and lane and is bound by that instruction count wherever K is short.
+    if constexpr (ROWEPI == 4 && patch_fits<TM, TN, WM, WN, NSTAGE>()) {
+        constexpr int ROWS_WM = 32 * TM;
+        constexpr int LDS_ROWS = (NSTAGE * STAGE) / (BN * 4);
+        constexpr int GW = LDS_ROWS >= WM * ROWS_WM ? WM : (LDS_ROWS >= 2 * ROWS_WM && WM >= 2 ? 2 : 1);
+        static_assert(LDS_ROWS >= ROWS_WM && WM % GW == 0, "one wave row of the tile fits the operand stages");
+        constexpr int RP = GW * ROWS_WM, QPR = BN / 4, TOTAL = RP * QPR;
+        float *patch = reinterpret_cast<float *>(smem);
+        const bool to_bf16_only = g.D16 != nullptr && D32p == nullptr;
+#pragma unroll 1
+        for (int pass = 0; pass < WM / GW; ++pass) {
+            __builtin_amdgcn_s_barrier();                            // operands / the previous pass are done with
+            if (wm / GW == pass) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            patch[((wm % GW) * ROWS_WM + 32 * i + 4 * lh + (r & 3) + 8 * (r >> 2)) * BN + wn * (32 * TN) +
+                                  32 * j + li] = acc[i][j][r];
+            }
+            __syncthreads();
+            // quads per thread and round: two (loads of both in flight before the first store); one in the one-stage loop,
+            // whose three workgroups per CU live on 85 VGPRs
+            constexpr int U = NSTAGE == 1 ? 1 : 2;
+#pragma unroll 1
+            for (int base = threadIdx.x; base < TOTAL; base += U * NT) {
+                float4 v[U], r1[U], r2[U];
+                size_t off[U];
+                int rowi[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = base + u * NT;
+                    const int r = idx / QPR, c4 = idx - r * QPR;
+                    const int row = m0 + pass * RP + r, col = n0 + 4 * c4;
+                    ok[u] = idx < TOTAL && row < M && col < N;                  // N % 4 == 0: a quad is all in or all out
+                    off[u] = ok[u] ? (size_t)row * N + col : 0;
+                    rowi[u] = ok[u] ? row : 0;
+                    v[u] = *reinterpret_cast<const float4 *>(patch + (idx < TOTAL ? r * BN + 4 * c4 : 0));
+                    r1[u] = r2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (epi == SEI_EPI_BIAS || epi == SEI_EPI_BIAS_GELU || epi == SEI_EPI_BIAS_RES ||
+                        epi == SEI_EPI_BIAS_ROWSCALE || epi == SEI_EPI_BIAS_SCALE_RES) {
+                        const int cb = ok[u] ? col : 0;
+                        float4 b = make_float4(g.bias[cb], g.bias[cb + 1], g.bias[cb + 2], g.bias[cb + 3]);
+                        if (epi == SEI_EPI_BIAS_ROWSCALE) {
+                            const float sc = g.R1[rowi[u]];
+                            b.x *= sc; b.y *= sc; b.z *= sc; b.w *= sc;
+                        }
+                        v[u].x += b.x; v[u].y += b.y; v[u].z += b.z; v[u].w += b.w;
+                    }
+                    if (epi == SEI_EPI_BIAS_RES || epi == SEI_EPI_MUL_DGELU)
+                        r1[u] = *reinterpret_cast<const float4 *>(g.R1 + off[u]);
+                    else if (epi == SEI_EPI_ACCUM) r1[u] = *reinterpret_cast<const float4 *>(D32p + off[u]);
+                    if (epi == SEI_EPI_BIAS_SCALE_RES || (epi == SEI_EPI_BIAS_RES && g.R2))
+                        r2[u] = *reinterpret_cast<const float4 *>(g.R2 + off[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!ok[u]) continue;
+                    float4 o = v[u];
+                    if (epi == SEI_EPI_MUL_DGELU) {
+                        if (to_bf16_only) {
+                            o.x *= sei_dgelu_bf16out(r1[u].x); o.y *= sei_dgelu_bf16out(r1[u].y);
+                            o.z *= sei_dgelu_bf16out(r1[u].z); o.w *= sei_dgelu_bf16out(r1[u].w);
+                        } else {
+                            o.x *= sei_dgelu(r1[u].x); o.y *= sei_dgelu(r1[u].y);
+                            o.z *= sei_dgelu(r1[u].z); o.w *= sei_dgelu(r1[u].w);
+                        }
+                    } else if (epi == SEI_EPI_BIAS_SCALE_RES) {
+                        const float sc = g.R1[rowi[u]];
+                        o.x = fmaf(o.x, sc, r2[u].x); o.y = fmaf(o.y, sc, r2[u].y);
+                        o.z = fmaf(o.z, sc, r2[u].z); o.w = fmaf(o.w, sc, r2[u].w);
+                    } else {
+                        o.x += r1[u].x + r2[u].x; o.y += r1[u].y + r2[u].y;
+                        o.z += r1[u].z + r2[u].z; o.w += r1[u].w + r2[u].w;
+                    }
+                    if (epi == SEI_EPI_BIAS_GELU) {
+                        uint2 w;
+                        w.x = (unsigned)f2bf(sei_gelu_bf16out(o.x)) | ((unsigned)f2bf(sei_gelu_bf16out(o.y)) << 16);
+                        w.y = (unsigned)f2bf(sei_gelu_bf16out(o.z)) | ((unsigned)f2bf(sei_gelu_bf16out(o.w)) << 16);
+                        *reinterpret_cast<uint2 *>(g.D2_16 + off[u]) = w;
+                    }
+                    if (D32p) *reinterpret_cast<float4 *>(D32p + off[u]) = o;
+                    if (g.D16) {
+                        uint2 w;
+                        w.x = (unsigned)f2bf(o.x) | ((unsigned)f2bf(o.y) << 16);
+                        w.y = (unsigned)f2bf(o.z) | ((unsigned)f2bf(o.w) << 16);
+                        *reinterpret_cast<uint2 *>(g.D16 + off[u]) = w;
+                    }
+                }
+            }
+        }
+        return;
+    }
+
     // ---- epilogue -----------------------------------------------------------------------------------
     // Per 32x32 accumulator tile: the auxiliary values are already in registers (prefetched above) or are
     // gathered first (16 independent loads in flight); then compute and store. Interleaving the loads with
@@ -644,6 +751,17 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
     const size_t per_split = g.tiles_per_xcd ? 8 * (size_t)g.tiles_per_xcd : tiles;
+    if constexpr (ROWEPI == 0 && patch_fits<TM, TN, WM, WN, NSTAGE>()) {
+        // unsplit launches whose rows can be moved as aligned quads take the row-patch epilogue
+        const auto al = [](const void *p, uintptr_t m) { return (reinterpret_cast<uintptr_t>(p) & m) == 0; };
+        const bool r1_rows = g.epilogue == SEI_EPI_BIAS_ROWSCALE || g.epilogue == SEI_EPI_BIAS_SCALE_RES;
+        if (g.splitk == 1 && g.N % 4 == 0 && al(g.D32, 15) && al(g.D16, 7) && al(g.D2_16, 7) && (r1_rows || al(g.R1, 15)) &&
+            al(g.R2, 15) && !g.force_band) {
+            hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE, 4>), dim3((unsigned)per_split), dim3(NT),
+                               0, s, g);
+            return sei_launch_status();
+        }
+    }
     hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE, ROWEPI>),
                        dim3((unsigned)(per_split * g.splitk * nbatch)),
                        dim3(NT), 0, s, g);
