@@ -178,6 +178,7 @@ _STREAM_FAMILIES = [
     ("blur / scale_resample / axpy / sure / mse kernels (physics + loss terms)",
      ("sei_blur_", "sei_scale_resample_", "sei_axpy", "sei_sure_terms", "sei_mse_terms", "sei_resample_")),
 ]
+PMC_TRAFFIC_FILE = "r02_g_pmc_gemm.json"      # the committed PMC pass `roofline.traffic` is read from
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -233,8 +234,8 @@ class Leg:
         if world > 1:
             parallel.broadcast_parameters(backbone.flat_params)
         self.loss_fn = loss_fn = get_loss(args, physics)
-        self.comm_dtype = torch.bfloat16 if (dtype == "bf16" and opt.grad_comm == "auto") or opt.grad_comm == "bf16" \
-            else torch.float32
+        # "auto" = f32, train.py's own default (--grad_comm_dtype f32): the bf16-compressed exchange is opt-in in both
+        self.comm_dtype = torch.bfloat16 if opt.grad_comm == "bf16" else torch.float32
         self.reducer = reducer = parallel.FlatGradientReducer(backbone.flat_grads, comm_dtype=self.comm_dtype,
                                                               mode=opt.grad_comm_mode) if world > 1 else None
         self.optimizer = optimizer = FlatAdam(model, lr=1e-4, betas=(0.9, 0.999), reducer=reducer)
@@ -265,7 +266,7 @@ class Leg:
                                                      early_release=early,
                                                      fuse_optimizer=world == 1 and opt.fuse_optimizer,
                                                      fuse_min_numel=opt.fuse_min_numel,
-                                                     direct_bf16_grads=opt.direct_bf16_grads)
+                                                     direct_bf16_grads=opt.direct_bf16_grads, count_nodes=True)
             if early and graphed.early_grads is not None:        # the bottleneck block's gradients leave early
                 self.early_event = graphed.early_grads[0]
                 reducer.set_early_range(graphed.early_grads[1:])
@@ -288,6 +289,30 @@ class Leg:
             last = self.step()
         fence()
         return time.perf_counter() - t0, float(last.detach())
+
+    def snapshot_state(self):
+        st = self.optimizer.state[self.backbone.flat_params]
+        shadow = getattr(self.backbone, "flat_shadow", None)
+        return (self.backbone.flat_params.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(),
+                None if shadow is None else shadow.clone(), int(st["step"]))
+
+    def restore_state(self, state):
+        from models import _ops
+        st = self.optimizer.state[self.backbone.flat_params]
+        self.backbone.flat_params.copy_(state[0])
+        st["exp_avg"].copy_(state[1])
+        st["exp_avg_sq"].copy_(state[2])
+        st["step"] = state[4]
+        if state[3] is not None:
+            self.backbone.flat_shadow.copy_(state[3])
+        _ops.weights_updated(self.backbone, plain_shadow_written=state[3] is not None)
+        torch.cuda.synchronize()
+
+    def graph_nodes(self):
+        """Kernel nodes of the captured step (each costs ~1.5 us of launch structure on replay), or None when eager."""
+        if self.graphed is None or self.graphed.node_counts is None:
+            return None
+        return self.graphed.node_counts[0]
 
     def record_one_step(self):
         """One eager step with every native call logged (streaming families) and every GEMM launch recorded with its
@@ -361,6 +386,33 @@ def gemm_roofline(records, dtype, reps=3):
                           "step (recorded arguments), right after the timed region"}
 
 
+def rooflines(leg, dtype, ms_step, pmc_traffic=False):
+    """Roofline legs of one configured job, after its timed region: one eager step records every launch's entry point
+    and arguments (the tensors stay alive in the autograd graph / the allocator's pool), then each family is re-issued
+    back to back between HIP events on the launch stream: device time with a full queue, free of host-side gaps, same
+    shapes and data as the timed steps. Re-issued optimizer launches (the Adam kernel, the weight-gradient GEMMs whose
+    epilogue applies the step) would step the weights again with the same scalars, so the job's parameters, moments and
+    bf16 shadow are put back afterwards."""
+    state = leg.snapshot_state()
+    keep, records, log = leg.record_one_step()
+    roofline = gemm_roofline(records, dtype)
+    roofline_hbm = stream_roofline(log)
+    del keep
+    leg.restore_state(state)
+    pmc_file = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+    if pmc_traffic and os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))                 # PMC counters cannot be read live; see the file
+        roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
+        roofline["traffic_source"] = pmc.get("traffic_source") or (
+            f"bytes beyond L2 per GEMM launch from committed rocprofv3 --pmc passes (profiles/{PMC_TRAFFIC_FILE}: "
+            "FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections)")
+    accounted = roofline["gemm_ms_per_step"] + sum(f["ms_per_step"] for f in roofline_hbm)
+    roofline_hbm.append({"kernel": "not attributed (torch fills / adds / copies / RNG, zero fills inside GEMM "
+                                   "entry points are counted with the GEMMs, launch gaps)",
+                         "ms_per_step": round(ms_step - accounted, 3)})
+    return roofline, roofline_hbm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,7 +429,8 @@ def main():
     ap.add_argument("--secondary", action=argparse.BooleanOptionalAction, default=True,
                     help="N=1: also time a short run in the reference's own arithmetic (float32 GEMMs)")
     ap.add_argument("--grad-comm", choices=["auto", "f32", "bf16"], default="auto",
-                    help="dtype of the all-reduced gradient bucket (auto: bf16 in bf16 mode, f32 in f32 mode)")
+                    help="dtype of the exchanged gradient bucket (auto = f32, as train.py's --grad_comm_dtype default; bf16 is the "
+                         "opt-in compressed exchange of both)")
     ap.add_argument("--grad-comm-mode", choices=["all_reduce", "rs_ag"], default="all_reduce")
     ap.add_argument("--fuse-optimizer", action=argparse.BooleanOptionalAction, default=True,
                     help="one GPU, bf16, hipGraph: apply Adam to the 1x1-convolution weights of the two deepest levels (98.8 %% "
@@ -425,47 +478,53 @@ def main():
     elapsed = float(t.item())
     ms_step = 1e3 * elapsed / opt.steps
 
-    # Roofline legs, after the timed region: one eager step records every launch's entry point and arguments (the
-    # tensors stay alive in the autograd graph / the allocator's pool), then each family is re-issued back to back
-    # between HIP events on the launch stream: device time with a full queue, free of host-side gaps, same shapes
-    # and data as the timed steps.
-    roofline, roofline_hbm = None, None
+    roofline, roofline_hbm = (None, None)
     if opt.profile_gemms:
-        keep, records, log = leg.record_one_step()
-        roofline = gemm_roofline(records, opt.dtype)
-        roofline_hbm = stream_roofline(log)
-        del keep
-        pmc_file = os.path.join(ROOT, "profiles", "r02_g_pmc_gemm.json")
         default_cfg = (opt.dtype == "bf16" and not sr and not opt.full256 and opt.hidden == 32 and opt.scales == 5
                        and opt.batch == 32 and opt.arch == "unet")
-        if default_cfg and os.path.exists(pmc_file):
-            pmc = json.load(open(pmc_file))                 # PMC counters cannot be read live; see the file
-            roofline["traffic"] = round(pmc["traffic_bytes_per_launch"])
-            roofline["traffic_source"] = ("bytes beyond L2 per GEMM launch from committed rocprofv3 --pmc passes of "
-                                          "`bench.py --no-graph` (profiles/r02_g_pmc_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, "
-                                          "gfx950 corrections); that eager step issues every GEMM, the deep levels' weight "
-                                          "gradients included, without the optimizer fusion of the captured step -- their "
-                                          "fused form is in profiles/r02_h_pmc_fused_adam_gemm.md")
-        accounted = roofline["gemm_ms_per_step"] + sum(f["ms_per_step"] for f in roofline_hbm)
-        roofline_hbm.append({"kernel": "not attributed (torch fills / adds / copies / RNG, zero fills inside GEMM "
-                                       "entry points are counted with the GEMMs, launch gaps)",
-                             "ms_per_step": round(ms_step - accounted, 3)})
+        roofline, roofline_hbm = rooflines(leg, opt.dtype, ms_step, pmc_traffic=default_cfg)
+    graph_nodes = leg.graph_nodes()
 
+    nparams, side, comm_dtype = leg.nparams, leg.side, leg.comm_dtype
+    graphed_early = leg.early_event is not None
     secondary = None
-    if opt.secondary and world == 1 and opt.dtype == "bf16" and not opt.full256 and opt.arch == "unet":
-        del leg                                             # frees the bf16 job's buckets before the f32 one
+    if opt.secondary and world == 1 and opt.dtype == "bf16" and not opt.full256 and opt.arch == "unet" and not sr:
+        del leg                                             # frees the bf16 job's buckets before the next one
         torch.cuda.empty_cache()
+        secondary = {}
         leg32 = Leg(opt, "f32", device, rank, world)
         el32, loss32 = leg32.timed(2, 5, fence)
-        secondary = {"f32": {"value": round(opt.batch * 5 / el32, 2), "unit": "images/s", "steps": 5, "warmup": 2,
-                             "ms_per_step": round(1e3 * el32 / 5, 2), "dtype": "f32",
-                             "note": "same workload and launch path with exact-f32 MFMA GEMMs: the reference's own "
-                                     "arithmetic, the mode every parity claim is made in", "final_loss": loss32}}
-        nparams, side, comm_dtype, graphed_early = leg32.nparams, leg32.side, leg32.comm_dtype, False
+        secondary["f32"] = {"value": round(opt.batch * 5 / el32, 2), "unit": "images/s", "steps": 5, "warmup": 2,
+                            "ms_per_step": round(1e3 * el32 / 5, 2), "dtype": "f32",
+                            "note": "same workload and launch path with exact-f32 MFMA GEMMs: the reference's own "
+                                    "arithmetic, the mode every parity claim is made in", "final_loss": loss32}
         del leg32
-    else:
-        nparams, side, comm_dtype = leg.nparams, leg.side, leg.comm_dtype
-        graphed_early = leg.early_event is not None
+        torch.cuda.empty_cache()
+        # BASELINE configs[2] and configs[4] on the same line: short runs (2 warm-up + 5 timed steps) of the same
+        # launch path, each with its own roofline objects
+        for key, over, what in (
+                ("sr4", dict(task="sr", sr_factor=4, arch="unet"),
+                 "BASELINE configs[2]: super-resolution x4 noise=5, proposed loss, pairs 192x192 / 48x48, the same "
+                 "ConvolutionalModel with its x4 pre-upsampler (the network runs at 192x192: 16x the pixels of configs[1])"),
+                ("swinir_sr2", dict(task="sr", sr_factor=2, arch="swinir"),
+                 "BASELINE configs[4] on one GPU: SwinIR backbone (embed 180, 6 x 6 blocks, window 8: deepinv.models.SwinIR "
+                 "as src/models/__init__.py:51-74, training mode with stochastic depth), sr x2, proposed loss, pairs 96x96 / "
+                 "48x48; PARITY UNPINNED (deepinv / timm absent: oracle/swinir_path.py restates the published network)")):
+            o2 = argparse.Namespace(**vars(opt))
+            for k_, v_ in over.items():
+                setattr(o2, k_, v_)
+            leg2 = Leg(o2, "bf16", device, rank, world)
+            el2, loss2 = leg2.timed(2, 5, fence)
+            ms2 = 1e3 * el2 / 5
+            entry = {"value": round(opt.batch * 5 / el2, 2), "unit": "images/s", "steps": 5, "warmup": 2,
+                     "ms_per_step": round(ms2, 2), "dtype": "bf16", "workload": what, "parameters": leg2.nparams,
+                     "batch": opt.batch, "final_loss": loss2}
+            if opt.profile_gemms:
+                entry["roofline"], entry["roofline_hbm"] = rooflines(leg2, "bf16", ms2)
+            entry["graph_kernel_nodes_per_step"] = leg2.graph_nodes()
+            secondary[key] = entry
+            del leg2
+            torch.cuda.empty_cache()
 
     if rank == 0:
         images = opt.batch * world * opt.steps
@@ -498,6 +557,7 @@ def main():
                        "final_loss": loss_value},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
+            "graph_kernel_nodes_per_step": graph_nodes,
         }
         if secondary is not None:
             out["secondary"] = secondary

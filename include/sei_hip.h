@@ -32,7 +32,7 @@ extern "C" {
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
-#define SEI_ABI_VERSION 4
+#define SEI_ABI_VERSION 5
 int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
@@ -45,6 +45,9 @@ int sei_event_create(void **event);
 int sei_event_destroy(void *event);
 int sei_event_record_external(void *event, void *stream);
 int sei_stream_wait_event(void *stream, void *event);
+
+/* Measurement aid (bench.py): node counts of a captured hipGraph_t -- kernel nodes and all nodes. */
+int sei_graph_node_counts(void *graph, int *kernel_nodes, int *all_nodes);
 
 /* ---------------------------------------------------------------------------------------------
  * Physics: circular blur.

@@ -26,6 +26,7 @@ SIGNATURES = {
     "sei_event_destroy": [_P],
     "sei_event_record_external": [_P, _P],
     "sei_stream_wait_event": [_P, _P],
+    "sei_graph_node_counts": [_P, _P, _P],
     "sei_build_target": [_c.c_char_p, _I],
     "sei_blur_sep_circ": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_blur_dense_circ": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -98,7 +99,7 @@ SIZE_QUERIES = {
     "sei_ln_bwd_workspace": [_Z, _I],
     "sei_swin_partials_floats": [_I],
 }
-ABI_VERSION = 4       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
+ABI_VERSION = 5       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 
 
 class NativeLibraryError(RuntimeError):
@@ -177,6 +178,15 @@ def call(name, *args):
         else:
             what = f"hipError_t {rc}"
         raise NativeLibraryError(f"{name} failed: {what}")
+
+
+def graph_kernel_nodes(graph):
+    """(kernel nodes, all nodes) of a torch.cuda.CUDAGraph captured with keep_graph=True."""
+    kernels, total = _c.c_int(0), _c.c_int(0)
+    rc = lib().sei_graph_node_counts(_c.c_void_p(int(graph.raw_cuda_graph())), _c.byref(kernels), _c.byref(total))
+    if rc != 0:
+        raise NativeLibraryError(f"sei_graph_node_counts failed: hipError_t {rc}")
+    return kernels.value, total.value
 
 
 class ExternalEvent:

@@ -8,8 +8,13 @@ resampler). `--dataset synthetic` is this build's own file-less stand-in with th
 (uniform-noise images through the real physics operator): it is what bench.py and the GPU tests use, since no
 image data ships with the repository. The `noise2inverse` flag travels as upstream: the training wrapper stores and
 ignores it, the test wrapper trims deblurring measurements to even sizes for noise2inverse.py's row slicing.
-Not rebuilt: urban100 / ct / fmd readers.
+The HOMOGENEOUS_SWINIR environment switch is honoured on this side too (reference :21-27,35-40,79-82 and
+synthetic_dataset.py:43-53): super-resolution measurements are upsampled to x's size with plain bicubic interpolation
+and training pairs are same-size 48-pixel crops, matching the upscale-1 SwinIR of models/__init__.py and the un-cropped
+Loss of losses/__init__.py. Not rebuilt: urban100 / ct / fmd readers.
 """
+from os import environ
+
 import torch
 from torch.nn import Module
 from torch.utils.data import Dataset as BaseDataset
@@ -17,7 +22,7 @@ from torch.utils.data import Dataset as BaseDataset
 from crop import CropPair
 from .ground_truth import GroundTruthDataset
 from .single_image import SingleImageDataset
-from .synthetic_dataset import SyntheticDataset
+from .synthetic_dataset import SyntheticDataset, homogeneous_measurement
 
 
 class SyntheticPairs(BaseDataset):
@@ -38,9 +43,12 @@ class SyntheticPairs(BaseDataset):
         x = torch.rand((3, self.size, self.size), generator=g).to(self.device)
         manager = getattr(self.physics, "__manager")
         y = manager.randomly_degrade(x[None], seed=index)[0]
+        y = homogeneous_measurement(manager, x, y)
         if self.css:                                        # as TrainingDataset below (reference :70-76)
             x, y = y, manager.randomly_degrade(y[None].contiguous(), seed=None)[0]
         if self.hotfix:
+            if "HOMOGENEOUS_SWINIR" in environ:             # same-size pairs: 48 / 48 crops (reference :21-40,79-82)
+                return CropPair(location="random", size=48)(x, y, xy_size_ratio=1)
             return CropPair(location="random", size=48)(x, y, xy_size_ratio=self.physics.rate)
         return x, y
 
@@ -53,9 +61,13 @@ class PrepareTrainingPairs(Module):
         self.physics = physics
         self.crop_size = crop_size
         self.crop_location = crop_location
+        if "HOMOGENEOUS_SWINIR" in environ:                 # reference :21-27: 48-pixel training crops
+            self.crop_size = 48
 
     def forward(self, x, y):
         ratio = self.physics.rate if self.physics.task == "sr" else 1
+        if "HOMOGENEOUS_SWINIR" in environ:                 # reference :35-40: x and y have the same size
+            ratio = 1
         return CropPair(location=self.crop_location, size=self.crop_size)(x, y, xy_size_ratio=ratio)
 
 
@@ -76,6 +88,8 @@ class TrainingDataset(BaseDataset):
             z = manager.randomly_degrade(y.unsqueeze(0).contiguous(), seed=None).squeeze(0)
             x, y = y, z
         if self.important_unnamed_flag:                     # SR: 48 / 48*rate crops before batching (:78-85)
+            if "HOMOGENEOUS_SWINIR" in environ:             # (:79-82: the same-size 48 / 48 crop instead)
+                return self.prepare_training_pairs(x, y)
             return CropPair(location="random", size=48)(x, y, xy_size_ratio=self.physics.rate)
         return self.prepare_training_pairs(x, y)
 

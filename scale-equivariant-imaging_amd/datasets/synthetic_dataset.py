@@ -1,7 +1,19 @@
 """(x, y) pairs: ground truth + its seeded synthetic measurement (reference: src/datasets/synthetic_dataset.py)."""
+from os import environ
+
 from torch.utils.data import Dataset
 
 from .ground_truth import GroundTruthDataset
+
+
+def homogeneous_measurement(physics_manager, x, y):
+    """HOMOGENEOUS_SWINIR (reference :43-53): for super-resolution the low-resolution measurement is brought to x's
+    size by plain bicubic interpolation (F.interpolate(y, x.shape[-2:], mode="bicubic", align_corners=False)), so that
+    the upscale-1 SwinIR of models/__init__.py maps same-size images; a no-op otherwise."""
+    if "HOMOGENEOUS_SWINIR" not in environ or physics_manager.task != "sr":
+        return y
+    from physics._ops import resample_to_size
+    return resample_to_size(y.contiguous(), x.shape[-2], x.shape[-1], antialias=False)
 
 
 class SyntheticDataset(Dataset):
@@ -21,6 +33,7 @@ class SyntheticDataset(Dataset):
         else:
             seed = None
         y = self.physics_manager.randomly_degrade(x.unsqueeze(0).contiguous(), seed=seed).squeeze(0)
+        y = homogeneous_measurement(self.physics_manager, x, y)
         return x, y
 
     def __len__(self):

@@ -50,14 +50,16 @@ def _copy_nested(dst, src):
 class GraphedLossStep:
     def __init__(self, loss_module, model, optimizer, crop_shape, warmup=3, store_weight_grads=True,
                  early_release=False, fuse_optimizer=False, fuse_min_numel=1 << 24, store_min_numel=1 << 20,
-                 direct_bf16_grads=True):
+                 direct_bf16_grads=True, count_nodes=False):
         """loss_module: a `losses.Loss`; crop_shape: (B, 3, S, S) of the cropped measurement y.
         fuse_optimizer: apply the optimizer step of the stored weight gradients of at least `fuse_min_numel` elements
         inside the GEMM that produces them (optim.FlatAdam.fuse_weight_updates; one GPU, bf16 mode, a loss whose
         model calls all merge into one weight-gradient GEMM per weight).
         direct_bf16_grads: with a reducer whose exchange buffer is bf16, the same weights' gradients are written into
         that buffer as bf16 by their GEMM (`self.direct_views`; the caller passes reduce_async(direct=True) after a
-        replayed step)."""
+        replayed step).
+        count_nodes: keep the captured hipGraph_t long enough to count its nodes (`self.node_counts` = (kernel nodes,
+        all nodes); bench.py reports them: a kernel node costs ~1.5 us of launch structure per replay)."""
         self.loss_module = loss_module
         self.inner = loss_module.loss                # method-level loss working on cropped tensors
         self.model = model
@@ -146,7 +148,8 @@ class GraphedLossStep:
             if table:
                 reducer.set_direct_ranges(ranges)
                 _ops.set_direct_bf16_grads(table)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True) if count_nodes else torch.cuda.CUDAGraph()
+        self.node_counts = None
         try:
             with torch.cuda.graph(self.graph):
                 self.static_loss = fwd_bwd()
@@ -155,6 +158,10 @@ class GraphedLossStep:
                                    "by the captured step")
             if self.fused_views and _ops.fused_adam_launches() != {v.data_ptr() for v in self.fused_views}:
                 raise RuntimeError("fused optimizer step: not every registered weight was updated by the captured step")
+            if count_nodes:
+                import _native
+                self.node_counts = _native.graph_kernel_nodes(self.graph)
+                self.graph.instantiate()
         except Exception:
             if self.fused_views:
                 optimizer.unfuse_weight_updates()

@@ -33,6 +33,13 @@ def _stochastic_depth_masks(model, batch):
     return draw(batch) if draw is not None else None
 
 
+def _concat_masks(first, second):
+    """Two B-sized mask sets -> one for the pass of 2B images that runs both calls at once."""
+    if first is None or second is None:
+        return first if second is None else second
+    return [None if a is None else tuple(torch.cat([u, v]) for u, v in zip(a, b)) for a, b in zip(first, second)]
+
+
 def _with_masks(model, masks):
     """`model` as a callable that hands `masks` to the backbone (extra positional arguments ignored, as Model)."""
     if masks is None:
@@ -163,11 +170,12 @@ class ProposedLoss(Module):
         if not self.graph_safe:
             return None
         B = y.shape[0]
-        drop = []
-        if not self.fuse_passes:
-            drop.append(_stochastic_depth_masks(model, B))                      # model(y)
+        first = _stochastic_depth_masks(model, B)                               # model(y)
         draws = {"b": draw_probe(y, self.sure.div_margin)}
-        drop.append(_stochastic_depth_masks(model, B if not self.fuse_passes else 2 * B))   # model(y + tau b) / both
+        second = _stochastic_depth_masks(model, B)                              # model(y + tau b)
+        # the reference's order whatever the pass structure (masks, probe, masks): a seeded run consumes the device
+        # generator exactly as the literal call sequence does; the fused 2B pass takes the two sets side by side
+        drop = [_concat_masks(first, second)] if self.fuse_passes else [first, second]
         draws["rate"], draws["center"] = self.ei.T.sample(B, y.device, y.dtype)
         draws["noise"] = torch.randn_like(y)
         drop.append(_stochastic_depth_masks(model, B))                          # model(y2) of the EI branch
@@ -195,8 +203,8 @@ class ProposedLoss(Module):
                 else:
                     loss = loss + loss_fn(x=x, x_net=x_net, y=y, physics=self.physics, model=model)
             return loss
-        # Same arithmetic and the same RNG draw order (probe b first: the network consumes no random
-        # numbers), but model(y) and model(y + tau b) share one pass of 2B images.
+        # Same arithmetic and the same RNG draw order (`draw`: masks of model(y), probe b, masks of model(y + tau b)),
+        # but model(y) and model(y + tau b) share one pass of 2B images.
         B = y.shape[0]
         b = draws["b"] if draws is not None else draw_probe(y, self.sure.div_margin)
         both = calls[0](torch.cat([y, axpy(y, b, self.sure.tau)], dim=0))

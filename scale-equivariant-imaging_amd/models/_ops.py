@@ -444,6 +444,9 @@ def weight_grad_views(reset=False):
     seen = dict(_DW["seen"])
     if reset:
         _DW["seen"].clear()
+        _DW["taps"].clear()
+        _DW["merged_ok"].clear()
+        _DW["flops_per_row"].clear()
     return seen
 
 
@@ -584,6 +587,8 @@ def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None):
     _DW["flops_per_row"][key] = flops_per_row
     if tap_rows is not None:
         _DW["taps"][key] = tap_rows
+    else:
+        _DW["taps"].pop(key, None)          # the address may have belonged to a freed model's tap-major gradient
     n = _DW["arrivals"].get(key, 0) + 1
     _DW["arrivals"][key] = n
     partner = _DW["parked"].pop(key, None)

@@ -77,6 +77,21 @@ def plain_bicubic_matrix(n_in, scale_factor):
     return m
 
 
+def plain_bicubic_matrix_to_size(n_in, n_out):
+    """Dense (n_out, n_in) matrix of F.interpolate(size=n_out, mode='bicubic', align_corners=False): as
+    plain_bicubic_matrix with the scale ATen derives from the sizes (n_in / n_out)."""
+    scale = float(n_in) / float(n_out)
+    m = np.zeros((n_out, n_in))
+    for o in range(n_out):
+        src = scale * (o + 0.5) - 0.5
+        f = floor(src)
+        t = src - f
+        co = (_cubic(t + 1.0, -0.75), _cubic(t, -0.75), _cubic(1.0 - t, -0.75), _cubic(2.0 - t, -0.75))
+        for d in range(4):
+            m[o, min(max(int(f) - 1 + d, 0), n_in - 1)] += co[d]
+    return m
+
+
 def to_band(dense):
     """Dense (n_out, n_in) -> (weights (n_out, nb) f32, lo (n_out,) i32, nb, max step of lo).
     Band starts are made non-decreasing (a row whose leading weights are exact zeros of the cubic

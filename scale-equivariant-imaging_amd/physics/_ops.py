@@ -117,15 +117,18 @@ class SeparableResampleOp:
 _RESIZE_AXES = {}
 
 
-def resample_to_size(x, out_h, out_w):
-    """Antialiased bicubic resize of (.., H, W) float32 GPU images to (out_h, out_w) in one launch of the banded
-    separable resampler (the GroundTruthDataset resize, datasets/ground_truth.py). No autograd."""
+def resample_to_size(x, out_h, out_w, antialias=True):
+    """Bicubic resize of (.., H, W) float32 GPU images to (out_h, out_w) in one launch of the banded separable
+    resampler: antialiased (the GroundTruthDataset resize, datasets/ground_truth.py) or plain
+    F.interpolate(size=.., mode="bicubic", align_corners=False) (the HOMOGENEOUS_SWINIR measurement upsampling,
+    src/datasets/synthetic_dataset.py:43-53). No autograd."""
     planes, H, W = _as_planes(x)
+    build = _bands.aa_bicubic_matrix_to_size if antialias else _bands.plain_bicubic_matrix_to_size
 
     def axis(n_in, n_out):
-        key = (n_in, n_out, str(x.device))
+        key = (n_in, n_out, str(x.device), bool(antialias))
         if key not in _RESIZE_AXES:
-            w, lo, nb, step = _bands.to_band(_bands.aa_bicubic_matrix_to_size(n_in, n_out))
+            w, lo, nb, step = _bands.to_band(build(n_in, n_out))
             _RESIZE_AXES[key] = (torch.from_numpy(w).to(x.device), torch.from_numpy(lo).to(x.device), nb, step)
         return _RESIZE_AXES[key]
 

@@ -429,6 +429,41 @@ def test_dataset_wrappers_follow_the_reference(tmp_path):
         datasets.get_dataset(args, "validate", phys, "cpu")
 
 
+def test_homogeneous_swinir_dataset_switches(monkeypatch):
+    """HOMOGENEOUS_SWINIR (src/datasets/__init__.py:21-27,35-40,79-82; synthetic_dataset.py:43-53): 48-pixel same-size
+    training crops, and the plain bicubic size-based interpolation matrix of the measurement upsampling against
+    F.interpolate(size=..., mode="bicubic", align_corners=False) itself (float64, also for a non-integer ratio)."""
+    import types
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    import datasets
+    from physics import _bands
+    g = torch.Generator().manual_seed(4)
+    for (h, w, oh, ow) in ((24, 30, 48, 60), (128, 192, 256, 385), (17, 16, 51, 49)):
+        y = torch.rand((1, 2, h, w), generator=g, dtype=torch.float64)
+        ref = F.interpolate(y, (oh, ow), mode="bicubic", align_corners=False)
+        Wv, Wh = _bands.plain_bicubic_matrix_to_size(h, oh), _bands.plain_bicubic_matrix_to_size(w, ow)
+        assert np.abs(Wv @ y.numpy() @ Wh.T - ref.numpy()).max() < 1e-12
+    assert np.array_equal(_bands.plain_bicubic_matrix_to_size(24, 48), _bands.plain_bicubic_matrix(24, 2))
+
+    class SameSize(torch.utils.data.Dataset):
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return torch.rand(3, 100, 120), torch.rand(3, 100, 120)
+
+    sr = types.SimpleNamespace(task="sr", rate=2)
+    monkeypatch.setenv("HOMOGENEOUS_SWINIR", "1")
+    prep = datasets.PrepareTrainingPairs(sr, 256, "random")
+    assert prep.crop_size == 48
+    xt, yt = datasets.TrainingDataset(SameSize(), sr, False, False, prep, True)[0]
+    assert xt.shape == yt.shape == (3, 48, 48)
+    monkeypatch.delenv("HOMOGENEOUS_SWINIR")
+    assert datasets.PrepareTrainingPairs(sr, 256, "random").crop_size == 256
+
+
 # ------------------------------------------------------------------ SwinIR (host side; parity unpinned, see the oracle)
 def test_swinir_module_tree_matches_the_published_layout():
     """Parameter / buffer names, shapes and counts of the official SwinIR for the reference's constructor arguments

@@ -230,11 +230,14 @@ def test_default_unet_step_vs_oracle():
 
 
 def test_timed_configuration_vs_oracle():
-    """The configuration bench.py times -- bf16 GEMMs, hipGraph replay, the fused 2B pass, merged and STORED weight
-    gradients, the 1x1 convolution behind the ideal downsampler, the default 645 M-parameter network (hidden 32,
-    5 scales) -- value-pinned against the float64 oracle on the same weights, crop and injected randomness (B = 2):
-    restored images within 0.01 dB PSNR-Y, loss within bf16 rounding, every parameter gradient aligned with the
-    oracle's (cosine), the large GEMM weights (99.9 % of the parameters) to > 0.999."""
+    """The configuration bench.py times, INCLUDING its optimizer step -- bf16 GEMMs, hipGraph replay, the fused 2B pass,
+    merged and STORED weight gradients, the 1x1 convolution behind the ideal downsampler, the default 645 M-parameter
+    network (hidden 32, 5 scales) and, at B = 8 (72 + 144 bottleneck rows: the merged launch the bench times exists),
+    torch.optim.Adam applied to the two deepest levels' weights in the epilogue of their weight-gradient GEMMs
+    (`fuse_optimizer=True`, demo/train.py:262-268) -- value-pinned against the float64 oracle on the same weights, crop
+    and injected randomness: restored images within 0.01 dB PSNR-Y, loss within bf16 rounding, every parameter gradient
+    aligned with the oracle's (cosine; for the fused weights the gradient is read back from exp_avg = 0.1 g after the
+    first step), and the POST-STEP parameters / moments against the oracle's torch.optim.Adam step in float64."""
     import bench
     import metrics
     import models
@@ -255,25 +258,40 @@ def test_timed_configuration_vs_oracle():
         bb = model.get_backbone()
         lf = get_loss(args, p)
         lf.loss.keep_outputs = True
-        opt = FlatAdam(model, lr=1e-4)
+        lr = 1e-4
+        opt = FlatAdam(model, lr=lr)
         gen = torch.Generator().manual_seed(11)
-        B = 2
+        B = 8
         x = torch.rand((B, 3, 256, 256), generator=gen)
         k = tp.blur_kernel("Gaussian_R2")
         A = lambda v: tp.blur_fft(v, k)
         y = A(x) + 5 / 255 * torch.randn((B, 3, 256, 256), generator=gen)
         b_int = torch.randn((B, 3, 36, 36), generator=gen)
         noise = torch.randn((B, 3, 48, 48), generator=gen)
-        rate, center = torch.tensor([0.75, 0.5]), torch.tensor([[0.3, -0.2], [-0.5, 0.6]])
-        graphed = GraphedLossStep(lf, model, opt, (B, 3, 48, 48))
+        rate = torch.tensor([0.75, 0.5, 0.5, 0.75, 0.75, 0.5, 0.75, 0.5])
+        center = 2 * torch.rand((B, 2), generator=gen) - 1
+        graphed = GraphedLossStep(lf, model, opt, (B, 3, 48, 48), fuse_optimizer=True)
         assert graphed.store_weight_grads and bb._sei_zero_ranges is not None
+        assert len(graphed.fused_views) == 8                     # levels 3 and 4: 98.8 % of the parameters
+        fused_ranges = list(opt._fused_ranges)
+        assert sum(hi - lo for lo, hi in fused_ranges) == 2 * 8192 * 32768 + 6 * 2048 * 8192
         xd, yd = x.cuda(), y.cuda()
         draws = {"b": embed_probe(graphed.static_y, b_int.cuda(), 6), "rate": rate.cuda(), "center": center.cuda(),
                  "noise": noise.cuda()}
-        for _ in range(2):                                  # the second replay is the one checked (stale state shows)
+        st = opt.state[bb.flat_params]
+        start = bb.flat_params.clone()
+        for _ in range(2):                                  # the second pass is the one checked (stale state shows):
+            bb.flat_params.copy_(start)                     # every replay steps the deep weights, so rewind first
+            st["exp_avg"].zero_()
+            st["exp_avg_sq"].zero_()
+            st["step"] = 0
+            _ops.refresh_plain_shadow(bb)
             bb.flat_grads.fill_(float("nan"))
             torch.manual_seed(5)                            # the crop offsets
             loss = float(graphed(xd, yd, draws=draws))
+            opt.step()
+        torch.cuda.synchronize()
+        assert st["step"] == 1
         x_net = lf.loss.kept["x_net"].float().cpu()
         torch.manual_seed(5)
         xc, yc = tp.crop_pair(x, y, 48, 1)
@@ -288,19 +306,60 @@ def test_timed_configuration_vs_oracle():
             assert d < 0.01, d
         assert relerr(x_net, aux["x_net"]) < 2e-2
         assert abs(loss - float(ref)) < 2e-2 * abs(float(ref)), (loss, float(ref))
-        assert torch.isfinite(bb.flat_grads).all()
-        worst_big, worst_small = 1.0, 1.0
+        # gradients: the stored ones from the bucket, the fused ones from the first moment (exp_avg = (1 - beta1) g)
+        base, esz = bb.flat_grads.data_ptr(), 4
+        in_fused = lambda off: any(lo <= off < hi for lo, hi in fused_ranges)
+        worst_big, worst_small, n_fused = 1.0, 1.0, 0
         for name, prm in bb.named_parameters():
-            g, r = prm.grad.double().flatten().cpu(), sd[name].grad.flatten()
+            off = (prm._sei_grad_view.data_ptr() - base) // esz
+            if in_fused(off):
+                g = (st["exp_avg"][off:off + prm.numel()].double() / 0.1).cpu()
+                n_fused += 1
+            else:
+                g = prm.grad.double().flatten().cpu()
+                assert torch.isfinite(g).all(), name
+            r = sd[name].grad.flatten()
             cos = float(g @ r / (g.norm() * r.norm()))
             if prm.dim() == 4 and prm.shape[-1] == 1 and prm.numel() >= 4096:
                 worst_big = min(worst_big, cos)
             else:
                 worst_small = min(worst_small, cos)
             assert cos > 0.99, (name, cos)
-        assert worst_big > 0.999, worst_big
-        print(f"timed configuration vs f64 oracle: loss {loss:.6f} vs {float(ref):.6f}; gradient cosine "
-              f">= {worst_big:.5f} (1x1 weights), >= {worst_small:.5f} (others)")
+            assert abs(float(g.norm() / r.norm()) - 1) < 2e-2, (name, float(g.norm()), float(r.norm()))
+        assert n_fused == 8 and worst_big > 0.999, (n_fused, worst_big)
+        # the optimizer step itself: torch.optim.Adam in float64 on the oracle's gradients (demo/train.py:157-186,266-268)
+        ref_opt = torch.optim.Adam(list(sd.values()), lr=lr, betas=(0.9, 0.999))
+        before = {n: v.detach().clone() for n, v in sd.items()}
+        ref_opt.step()
+        worst_m, worst_v, worst_dp, flips = 1.0, 1.0, 1.0, 0.0
+        for name, prm in bb.named_parameters():
+            off = (prm.data_ptr() - bb.flat_params.data_ptr()) // 4
+            n = prm.numel()
+            rs = ref_opt.state[sd[name]]
+            m = st["exp_avg"][off:off + n].double().cpu()
+            v = st["exp_avg_sq"][off:off + n].double().cpu()
+            rm, rv = rs["exp_avg"].flatten(), rs["exp_avg_sq"].flatten()
+            dp = prm.detach().double().flatten().cpu() - before[name].flatten()
+            rdp = (sd[name].detach() - before[name]).flatten()
+            # the first Adam step moves every weight by lr * g / (|g| + eps): at most lr, whatever the gradient
+            assert float(dp.abs().max()) <= lr * (1 + 1e-3) and float((dp - rdp).abs().max()) <= 2 * lr * (1 + 1e-3), name
+            big = prm.dim() == 4 and prm.shape[-1] == 1 and n >= 4096
+            cm, cv = float(m @ rm / (m.norm() * rm.norm())), float(v @ rv / (v.norm() * rv.norm()))
+            cdp = float(dp @ rdp / (dp.norm() * rdp.norm()))
+            assert cm > 0.99 and cv > 0.98 and cdp > 0.9, (name, cm, cv, cdp)
+            if big:
+                worst_m, worst_v, worst_dp = min(worst_m, cm), min(worst_v, cv), min(worst_dp, cdp)
+                # where the oracle's gradient is not within bf16 noise of zero, the step has the oracle's sign
+                sure_sign = rm.abs() > 0.1 * rm.abs().mean()
+                flips = max(flips, float((torch.sign(dp[sure_sign]) != torch.sign(rdp[sure_sign])).double().mean()))
+        assert worst_m > 0.999 and worst_v > 0.998, (worst_m, worst_v)
+        assert worst_dp > 0.97 and flips < 0.02, (worst_dp, flips)
+        # the bf16 shadow the next forward reads is the rounded new parameter
+        assert torch.equal(bb.flat_shadow, bb.flat_params.bfloat16())
+        print(f"timed configuration (B = 8, Adam inside the deep weight-gradient GEMMs) vs f64 oracle: loss {loss:.6f} vs "
+              f"{float(ref):.6f}; gradient cosine >= {worst_big:.5f} (1x1 weights), >= {worst_small:.5f} (others); "
+              f"post-step exp_avg cosine >= {worst_m:.5f}, exp_avg_sq >= {worst_v:.5f}, parameter-step cosine >= "
+              f"{worst_dp:.4f}, sign flips on non-negligible gradients <= {flips:.4f}")
     finally:
         _ops.set_compute_dtype(prev)
 
@@ -351,6 +410,80 @@ def test_sr4_composite_step_vs_oracle(net):
         gn, rn = float(params[name].grad.double().norm()), float(v.grad.double().norm())
         worst = max(worst, abs(gn - rn) / rn)
     assert worst < 1e-4, worst
+
+
+def test_sr4_bf16_graphed_step_vs_oracle():
+    """BASELINE configs[2] as it is benchmarked (`bench.py --task sr`, bf16): the default 645 M-parameter network with its
+    x4 pre-upsampler, x4 antialiased downsampling physics, SURE margin 0, paired crop, bf16 GEMMs, hipGraph replay with
+    merged + stored weight gradients -- against the FLOAT64 oracle on the same weights, crop (16: the network runs at
+    64x64) and injected draws: restored images within 0.01 dB PSNR-Y, loss within bf16 rounding, gradient cosines."""
+    import bench
+    import metrics
+    import models
+    import physics
+    from graphs import GraphedLossStep
+    from losses import get_loss
+    from models import _ops
+    from optim import FlatAdam
+    prev = _ops.set_compute_dtype("bf16")
+    try:
+        crop, B = 16, 2
+        args = ref_args(task="sr", sr_factor=4, kernel=None, Loss__crop_size=crop, ConvolutionalModel__hidden_channels=32,
+                        ConvolutionalModel__scales=5)
+        p = physics.get_physics(args, "cuda")
+        torch.manual_seed(0)
+        model = models.get_model(args, p, "cuda")
+        sd = {k: v.detach().double().requires_grad_(True) for k, v in model.get_weights().items()}
+        model.to("cuda")
+        bb = model.get_backbone()
+        lf = get_loss(args, p)
+        lf.loss.keep_outputs = True
+        assert lf.loss.sure.margin == 0 and lf.xy_size_ratio == 4
+        opt = FlatAdam(model, lr=1e-4)
+        gen = torch.Generator().manual_seed(3)
+        x = torch.rand((B, 3, 4 * crop, 4 * crop), generator=gen)
+        y = tp.downsample_aa(x, 4) + 5 / 255 * torch.randn((B, 3, crop, crop), generator=gen)
+        b = torch.randn((B, 3, crop, crop), generator=gen)
+        noise = torch.randn((B, 3, crop, crop), generator=gen)
+        rate, center = torch.tensor([0.5, 0.75]), torch.tensor([[-0.4, 0.1], [0.7, -0.6]])
+        graphed = GraphedLossStep(lf, model, opt, (B, 3, crop, crop))
+        assert graphed.store_weight_grads
+        draws = {"b": b.cuda(), "rate": rate.cuda(), "center": center.cuda(), "noise": noise.cuda()}
+        xd, yd = x.cuda(), y.cuda()
+        for _ in range(2):
+            bb.flat_grads.fill_(float("nan"))
+            torch.manual_seed(9)
+            loss = float(graphed(xd, yd, draws=draws))
+        x_net = lf.loss.kept["x_net"].float().cpu()
+        torch.manual_seed(9)
+        xc, yc = tp.crop_pair(x, y, crop, 4)
+        assert torch.equal(graphed.static_y.cpu(), yc.contiguous())
+        ref, aux = tp.proposed_loss(yc.contiguous().double(), lambda v: tp.downsample_aa(v, 4),
+                                    lambda v: tp.unet_forward(sd, v, scales=5, upsampling_rate=4), 5 / 255, margin=0,
+                                    rate=rate.double(), center=center.double().view(B, 1, 1, 2), b=b.double(),
+                                    n=noise.double())
+        ref.backward()
+        assert aux["x_net"].shape == (B, 3, 4 * crop, 4 * crop) == x_net.shape
+        for i in range(B):
+            d = abs(float(metrics.psnr_fn(x_net[i], xc[i])) - float(tp.psnr_y(aux["x_net"][i].detach(), xc[i].double())))
+            assert d < 0.01, d
+        assert relerr(x_net, aux["x_net"]) < 2e-2
+        assert abs(loss - float(ref)) < 2e-2 * abs(float(ref)), (loss, float(ref))
+        assert torch.isfinite(bb.flat_grads).all()
+        worst_big, worst_small = 1.0, 1.0
+        for name, prm in bb.named_parameters():
+            g, r = prm.grad.double().flatten().cpu(), sd[name].grad.flatten()
+            cos = float(g @ r / (g.norm() * r.norm()))
+            if prm.dim() == 4 and prm.shape[-1] == 1 and prm.numel() >= 4096:
+                worst_big = min(worst_big, cos)
+            else:
+                worst_small = min(worst_small, cos)
+            assert cos > 0.99, (name, cos)
+        assert worst_big > 0.999, worst_big
+        print(f"SR x4 bf16 graphed step vs f64 oracle: loss {loss:.6f} vs {float(ref):.6f}; gradient cosine >= "
+              f"{worst_big:.5f} (1x1 weights), >= {worst_small:.5f} (others)")
+    finally:
+        _ops.set_compute_dtype(prev)
 
 
 @pytest.mark.parametrize("method", ["supervised", "css", "sure"])

@@ -232,6 +232,100 @@ def test_proposed_loss_step_with_swinir_vs_oracle(task):
     assert np.isfinite(a) and a != b2
 
 
+def test_swinir_timed_configuration_vs_oracle():
+    """BASELINE configs[4] as bench.py times it (`--arch swinir --task sr --sr-factor 2`, bf16): the FULL-depth network
+    (6 x 6 blocks, 11.75 M parameters, src/models/__init__.py:51-74) in TRAINING mode with injected stochastic-depth
+    masks, the throughput path (bf16 LDS-DMA GEMMs on re-laid-out weights, MFMA window attention, implicit-GEMM 3x3
+    convolutions), the whole proposed-loss step (x2 antialiased physics, SURE margin 0, scale-EI), replayed from a
+    hipGraph -- against the FLOAT64 oracle (oracle/swinir_path.py: PARITY UNPINNED, a restatement of the published
+    network; deepinv / timm are absent) on the same weights, masks and draws: restored images within 0.01 dB PSNR-Y, loss
+    within bf16 rounding, per-parameter gradient cosines."""
+    import bench
+    import metrics
+    import physics
+    from graphs import GraphedLossStep
+    from losses import get_loss
+    from models import _ops
+    from models.swinir import SwinIR
+    from optim import FlatAdam
+    from oracle import torch_path as tp
+    prev = _ops.set_compute_dtype("bf16")
+    try:
+        depths = (6,) * 6
+        args = bench.reference_args("cuda", task="sr", sr_factor=2)
+        p = physics.get_physics(args, "cuda")
+        lf = get_loss(args, p)
+        lf.loss.keep_outputs = True
+        torch.manual_seed(4)
+        model = SwinIR(upscale=2, upsampler="pixelshuffle", depths=depths, num_heads=(6,) * 6)
+        assert sum(q.numel() for q in model.parameters()) == 11_752_487
+        gen = torch.Generator().manual_seed(8)
+        with torch.no_grad():                       # make every parameter matter (LayerNorm / bias defaults are 1 / 0)
+            for k_, v in model.named_parameters():
+                if k_.endswith("bias") or "norm" in k_:
+                    v.add_(0.05 * torch.randn(v.shape, generator=gen))
+        sd = {k_: v.detach().double().requires_grad_(True) for k_, v in model.state_dict().items()
+              if v.dtype.is_floating_point and "attn_mask" not in k_}
+        model = model.cuda().train()
+        B = 2
+        x = torch.rand((B, 3, 96, 96), generator=gen)
+        y = tp.downsample_aa(x, 2) + 5 / 255 * torch.randn((B, 3, 48, 48), generator=gen)
+        b = torch.randn((B, 3, 48, 48), generator=gen)
+        noise = torch.randn((B, 3, 48, 48), generator=gen)
+        rate, center = torch.tensor([0.5, 0.75]), torch.tensor([[0.2, -0.3], [-0.6, 0.4]])
+        masks = [sp.draw_drop_masks(B, depths=depths, generator=gen, dtype=torch.float64) for _ in range(3)]
+        assert any(m is not None and float(min(v.min() for v in m)) == 0.0 for mm in masks for m in mm)   # some branch is dropped
+        calls = iter(masks)
+        ref_model = lambda v: sp.swinir_forward(sd, v, upscale=2, drop_masks=next(calls), depths=depths)
+        ref, aux = tp.proposed_loss(y.double(), lambda v: tp.downsample_aa(v, 2), ref_model, 5 / 255, margin=0,
+                                    rate=rate.double(), center=center.double().view(B, 1, 1, 2), b=b.double(),
+                                    n=noise.double())
+        ref.backward()
+
+        def dev(m):
+            return None if m is None else tuple(v.float().cuda() for v in m)
+
+        both = [None if a is None else tuple(torch.cat([u, v]).float().cuda() for u, v in zip(a, b_))
+                for a, b_ in zip(masks[0], masks[1])]
+        draws = {"b": b.cuda(), "rate": rate.cuda(), "center": center.cuda().view(B, 1, 1, 2), "noise": noise.cuda(),
+                 "drop": [both, [dev(m) for m in masks[2]]]}
+        opt = FlatAdam(model, lr=1e-4)
+        lf.crop_fn = None                            # the pair already has the training crop's size (48 / 96)
+        graphed = GraphedLossStep(lf, model, opt, (B, 3, 48, 48))
+        xd, yd = x.cuda(), y.cuda()
+        for _ in range(2):
+            model.flat_grads.fill_(float("nan"))
+            loss = float(graphed(xd, yd, draws=draws))
+        torch.cuda.synchronize()
+        x_net = lf.loss.kept["x_net"].float().cpu()
+        assert x_net.shape == aux["x_net"].shape == (B, 3, 96, 96)
+        for i in range(B):
+            d = abs(float(metrics.psnr_fn(x_net[i], x[i])) - float(tp.psnr_y(aux["x_net"][i].detach(), x[i].double())))
+            assert d < 0.01, d
+        assert relerr(x_net, aux["x_net"]) < 2e-2, relerr(x_net, aux["x_net"])
+        assert abs(loss - float(ref)) < 2e-2 * abs(float(ref)), (loss, float(ref))
+        assert torch.isfinite(model.flat_grads).all()
+        worst_w, worst_o = (1.0, ""), (1.0, "")
+        for name, prm in model.named_parameters():
+            g, r = prm.grad.double().flatten().cpu(), sd[name].grad.flatten()
+            if float(r.norm()) == 0.0:
+                assert float(g.norm()) == 0.0, name
+                continue
+            cos = float(g @ r / (g.norm() * r.norm()))
+            assert abs(float(g.norm() / r.norm()) - 1) < 5e-2, (name, float(g.norm()), float(r.norm()))
+            if name.endswith("weight") and prm.dim() >= 2:          # the GEMM operands: linear layers and convolutions
+                worst_w = min(worst_w, (cos, name))
+            else:
+                worst_o = min(worst_o, (cos, name))
+        print(f"SwinIR sr x2, full depth, train mode, bf16 + hipGraph vs f64 oracle (unpinned): loss {loss:.6f} vs "
+              f"{float(ref):.6f}; gradient cosine >= {worst_w[0]:.5f} ({worst_w[1]}) for GEMM weights, >= {worst_o[0]:.5f} "
+              f"({worst_o[1]}) for biases / LayerNorm / bias tables")
+        assert worst_w[0] > 0.999, worst_w
+        assert worst_o[0] > 0.99, worst_o
+    finally:
+        _ops.set_compute_dtype(prev)
+
+
 @pytest.mark.parametrize("shift", [0, 4])
 @pytest.mark.parametrize("B,H,W,heads", [(2, 16, 16, 6), (1, 24, 16, 3), (5, 48, 48, 6)])
 def test_window_attention_mfma_fwd_bwd(B, H, W, heads, shift):
