@@ -93,6 +93,9 @@ def _stream_bytes(name, a):
     if name in ("sei_dwconv7_fwd", "sei_dwconv7_fwd_ex"):
         B, H, W, C = a[6:10]
         return (8 + (4 if a[3] else 0)) * B * H * W * C
+    if name == "sei_dwconv7_ln_fwd":                      # x in, h1 (f32) + h2 (bf16 / f32) out
+        B, H, W, C = a[10:14]
+        return (8 + (2 if a[7] else 4)) * B * H * W * C
     if name in ("sei_dwconv7_bwd_weight", "sei_dwconv7_bwd_weight_ex"):
         B, H, W, C = a[4:8]
         return 8 * B * H * W * C

@@ -190,6 +190,23 @@ int sei_dwconv7_fwd_ex(const float *x, const float *w, const float *bias, const 
 size_t sei_dwconv7_bwd_weight_workspace_ex(int B, int H, int W, int C, int seg);
 int sei_dwconv7_bwd_weight_ex(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
                               int W, int C, float *work, size_t work_floats, int seg, void *stream);
+/* (sei_dwconv7_fwd_ex only: seg = 65 takes the first LDS-tiled kernel, seg = 66 the pipelined LDS-DMA kernel
+ * (H, W >= 8, C % 32 == 0, 16-byte aligned x / w; SEI_ERR_BAD_ARG otherwise) that seg = 0 prefers from 1024
+ * (tile, channel group) stages on; all three agree bit for bit.)
+ *
+ * ConvBlock.conv1 -> LayerNorm (src/models/convolutional.py:36-39 with :21-30) in one call:
+ *   h1 = dwconv7(x) + bias (f32, kept: the LayerNorm backward re-reads it), h2 = LN_C(h1) * gamma + beta as bf16
+ *   (out16 = 1) or f32, mean / rstd per pixel. C = 32 on images of at least 8 x 8: ONE launch (a workgroup owns all
+ *   channels of its pixels; LDS-DMA double-buffered halo tiles, half-wave transposing reductions); any other shape:
+ *   sei_dwconv7_fwd followed by sei_ln_fwd[_bf16]. sei_dwconv7_ln_fwd_launches tells which (1 or 2).
+ *   _ex: fuse = 0 as above, 1 = the fused launch (C = 32 or 128, else SEI_ERR_BAD_ARG), 2 = the two launches. */
+int sei_dwconv7_ln_fwd(const float *x, const float *w, const float *bias, const float *gamma, const float *beta,
+                       float *h1, void *h2, int out16, float *mean, float *rstd, int B, int H, int W, int C,
+                       float eps, void *stream);
+int sei_dwconv7_ln_fwd_ex(const float *x, const float *w, const float *bias, const float *gamma, const float *beta,
+                          float *h1, void *h2, int out16, float *mean, float *rstd, int B, int H, int W, int C,
+                          float eps, int fuse, void *stream);
+size_t sei_dwconv7_ln_fwd_launches(int B, int H, int W, int C);
 
 int sei_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
                float *rstd, size_t rows, int C, float eps, void *stream);

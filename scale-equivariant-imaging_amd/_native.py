@@ -46,6 +46,8 @@ SIGNATURES = {
     "sei_dwconv7_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P],
     "sei_dwconv7_fwd_ex": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_dwconv7_bwd_weight_ex": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _I, _P],
+    "sei_dwconv7_ln_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P],
+    "sei_dwconv7_ln_fwd_ex": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "sei_ln_fwd": [_P, _P, _P, _P, _P, _P, _Z, _I, _F, _P],
     "sei_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P, _Z, _P],
     "sei_gemm_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -97,6 +99,7 @@ SIZE_QUERIES = {
     "sei_dwconv7_bwd_weight_workspace": [_I, _I, _I, _I],
     "sei_dwconv7_bwd_weight_workspace_ex": [_I, _I, _I, _I, _I],
     "sei_ln_bwd_workspace": [_Z, _I],
+    "sei_dwconv7_ln_fwd_launches": [_I, _I, _I, _I],
     "sei_swin_partials_floats": [_I],
 }
 ABI_VERSION = 5       # SEI_ABI_VERSION of include/sei_hip.h this table was written against

@@ -486,11 +486,17 @@ inline DwWgradPlan dw_wgrad_plan(int B, int H, int W, int C, int seg) {
 extern "C" int sei_dwconv7_fwd_ex(const float *x, const float *w, const float *bias, const float *res,
                                   float res_scale, float *y, int B, int H, int W, int C, int flip, int seg,
                                   void *stream) {
-    SEI_REQUIRE(x && w && y && x != y && B > 0 && H > 0 && W > 0 && C > 0 && seg >= 0 && seg <= 64);
-    const int gseg = seg > 0 ? seg : DW_SEG;
+    SEI_REQUIRE(x && w && y && x != y && B > 0 && H > 0 && W > 0 && C > 0 && seg >= 0 && seg <= 66);
     hipStream_t s = (hipStream_t)stream;
+    // seg 65 / 66: the first tiled kernel / the pipelined kernel, explicitly (tests compare them bit for bit)
+    if (seg == 66) return sei_dwconv7_pipe_launch(x, w, bias, res, res_scale, y, B, H, W, C, flip, s);
+    const bool old_tiled = seg == 65;
+    if (old_tiled) seg = 0;
+    const int gseg = seg > 0 ? seg : DW_SEG;
     const float *nof = nullptr;
     float *nom = nullptr;
+    if (!old_tiled && dw_path(H, W, C, seg) == DW_TILED && sei_dwconv7_pipe_eligible(x, w, B, H, W, C))
+        return sei_dwconv7_pipe_launch(x, w, bias, res, res_scale, y, B, H, W, C, flip, s);
     switch (dw_path(H, W, C, seg)) {
         case DW_TILED: {
             const DwTiling t = dw_tiling(B, H, W);

@@ -91,3 +91,12 @@ __device__ __forceinline__ float sei_adam_element(float pi, float gi, float &mi,
     return pi - step_size * (mi / denom);
 }
 
+
+// dwconv_pipe.hip: the pipelined depthwise 7x7 kernel (internal linkage between translation units, not part of the ABI)
+int sei_dwconv7_pipe_launch(const float *x, const float *w, const float *bias, const float *res, float res_scale,
+                            float *y, int B, int H, int W, int C, int flip, hipStream_t s);
+bool sei_dwconv7_pipe_eligible(const float *x, const float *w, int B, int H, int W, int C);
+bool sei_dwconv7_ln_fused_eligible(const float *x, const float *w, int B, int H, int W, int C);
+int sei_dwconv7_ln_fused_launch(const float *x, const float *w, const float *bias, const float *gamma,
+                                const float *beta, float *h1, void *h2, int out16, float *mean, float *rstd, int B, int H,
+                                int W, int C, float eps, hipStream_t s);

@@ -134,6 +134,25 @@ def dwconv7(x, w, bias, flip=False, res=None, res_scale=1.0, seg=0):
     return y
 
 
+def dwconv7_ln(x, w, bias, gamma, beta, out16, fuse=0):
+    """ConvBlock.conv1 -> LayerNorm (reference convolutional.py:36-39) through sei_dwconv7_ln_fwd: one fused launch
+    at the first level (C = 32), the depthwise kernel + the stand-alone LayerNorm elsewhere (fuse: 1 / 2 force either
+    form; tests). Returns h1 (f32, NHWC), h2 ((M, C) bf16 when out16 else f32), mean, rstd."""
+    B, H, W, C = x.shape
+    M = B * H * W
+    h1 = torch.empty_like(x)
+    h2 = torch.empty((M, C), dtype=torch.bfloat16 if out16 else torch.float32, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    args = (x.data_ptr(), w.data_ptr(), N.ptr(bias), gamma.data_ptr(), beta.data_ptr(), h1.data_ptr(), h2.data_ptr(),
+            int(out16), mean.data_ptr(), rstd.data_ptr(), B, H, W, C, LN_EPS)
+    if fuse:
+        N.call("sei_dwconv7_ln_fwd_ex", *args, int(fuse))
+    else:
+        N.call("sei_dwconv7_ln_fwd", *args)
+    return h1, h2, mean, rstd
+
+
 def dwconv7_weight_grad(x, gy, gw, gb, seg=0):
     B, H, W, C = x.shape
     need = N.lib().sei_dwconv7_bwd_weight_workspace_ex(B, H, W, C, int(seg))
@@ -172,8 +191,7 @@ class ConvBlockFn(torch.autograd.Function):
         x = _nhwc(x)
         B, H, W, C = x.shape
         M = B * H * W
-        h1 = dwconv7(x, w1, b1)
-        h2, mean, rstd = layer_norm(h1.view(M, C), gamma, beta)
+        h1, h2, mean, rstd = dwconv7_ln(x, w1, b1, gamma, beta, out16=False)
         h4 = torch.empty((M, 4 * C), dtype=torch.float32, device=x.device)
         h3 = gemm(h2, w2, M, 4 * C, C, 0, 1, EPI_BIAS_GELU, bias=b2, D2=h4)
         out = gemm(h4, w3, M, C, 4 * C, 0, 1, EPI_BIAS_RES, bias=b3, R1=x, R2=x if twice else None)
@@ -642,8 +660,7 @@ class ConvBlockFn16(torch.autograd.Function):
         x = _nhwc(x)
         B, H, W, C = x.shape
         M = B * H * W
-        h1 = dwconv7(x, w1, b1)
-        h2, mean, rstd = layer_norm16(h1.view(M, C), gamma, beta)
+        h1, h2, mean, rstd = dwconv7_ln(x, w1, b1, gamma, beta, out16=True)
         w2_16, w3_16 = shadow(w2), shadow(w3)
         ctx.fused = C in FUSED_MLP_CHANNELS
         if ctx.fused:

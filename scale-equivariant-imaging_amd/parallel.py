@@ -60,7 +60,9 @@ class FlatGradientReducer:
         rank's 1/world share, then an all-gather of the shares: the two halves of an all-reduce as separate
         collectives, each of which moves 1/world of the chunk per peer -- on a fully connected xGMI node all 7
         links carry one share each; chunks whose length is not a multiple of world_size fall
-        back to all_reduce).
+        back to all_reduce) or "sharded" (what optim.FlatAdam turns "rs_ag" into: only the reduce-scatter half runs
+        here; the optimizer steps this rank's share of every chunk and all-gathers the UPDATED weights instead of the
+        gradients -- `shard`, `own_slice`, `gather` below).
 
         comm_dtype=torch.bfloat16 compresses the exchanged gradients (half the xGMI bytes): the f32
         bucket is cast once into `self.comm`, which is what gets summed and what the optimizer reads.
@@ -80,6 +82,8 @@ class FlatGradientReducer:
         self._side = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
         self.direct_ranges = []       # slices of the bucket that the producer writes into `comm` itself (see below)
         self._direct_now = False
+        self._splits = []             # extra positions no chunk may straddle (set_splits)
+        self._gather_work = []
         self.set_early_range(early_range)
 
     def set_direct_ranges(self, ranges):
@@ -90,21 +94,29 @@ class FlatGradientReducer:
             raise ValueError("direct bf16 gradients need a compressed (bf16) exchange buffer")
         self.direct_ranges = sorted((int(a), int(b)) for a, b in ranges or [])
 
+    def set_splits(self, positions):
+        """Positions of the bucket that no chunk may straddle (optim.FlatAdam: where the weights that the next forward
+        pass reads from their bf16 copy begin -- chunks on either side all-gather different buffers). Re-plans."""
+        n = self.flat.numel()
+        self._splits = sorted({int(p) for p in positions if 0 < int(p) < n})
+        self.set_early_range(self.early_range)
+
     def set_early_range(self, early_range):
         """(Re)plan the chunks; see __init__. Call before the first reduce_async of a step."""
         n = self.flat.numel()
         self.early_range = None
+        cuts = {0, n} | set(self._splits)
         if early_range is not None and 0 <= early_range[0] < early_range[1] <= n:
             lo, hi = int(early_range[0]), int(early_range[1])
             self.early_range = (lo, hi)
-            parts = [(0, lo), (lo, hi), (hi, n)]
-        else:
-            parts = [(0, n)]
+            cuts |= {lo, hi}
+        cuts = sorted(cuts)
+        parts = list(zip(cuts, cuts[1:]))
         self.bounds, self._is_early = [], []
         for a, b in parts:
             for s, e in (chunk_bounds(b - a, self._chunk) if b > a else []):
                 self.bounds.append((a + s, a + e))
-                self._is_early.append(self.early_range is not None and (a, b) == self.early_range)
+                self._is_early.append(self.early_range is not None and self.early_range[0] <= a and b <= self.early_range[1])
         # the order in which chunks complete (and the optimizer should consume them): early ones first
         self.order = [k for k, f in enumerate(self._is_early) if f] + [k for k, f in enumerate(self._is_early) if not f]
         self._work = [None] * len(self.bounds)
@@ -130,10 +142,50 @@ class FlatGradientReducer:
         else:
             self.comm[s:e].copy_(self.flat[s:e])
 
+    # -- sharded optimizer step (mode "sharded") ---------------------------------------------------------------
+    def is_sharded(self, k):
+        """Chunk k is reduce-scattered: this rank holds the reduced gradient of `own_slice(k)` only. Shares start on
+        16-byte boundaries of every buffer (the fused Adam kernel moves aligned quads), hence the factor 4."""
+        s, e = self.bounds[k]
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        return self.mode == "sharded" and world > 1 and (e - s) % (4 * world) == 0 and s % 4 == 0
+
+    def own_slice(self, k):
+        s, e = self.bounds[k]
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        n = (e - s) // world
+        return s + rank * n, s + (rank + 1) * n
+
+    def shard(self, k):
+        """The reduced gradient of own_slice(k) (valid after wait(k))."""
+        return self._shards[k]
+
+    def gather(self, k, buffers):
+        """All-gather `own_slice(k)` of every buffer in `buffers` (flat tensors over the whole bucket: the updated
+        parameters, their bf16 copy) into the chunk's slice on every rank, asynchronously; `wait_gathers()` orders the
+        current stream behind them."""
+        s, e = self.bounds[k]
+        lo, hi = self.own_slice(k)
+        for buf in buffers:
+            src = buf[lo:hi].clone()              # (gloo has no in-place form; a 1/world copy of the chunk)
+            self._gather_work.append(dist.all_gather_into_tensor(buf[s:e], src, group=self.group, async_op=True))
+
+    def wait_gathers(self):
+        for w in self._gather_work:
+            w.wait()
+        self._gather_work = []
+
     def _exchange(self, k):
         s, e = self.bounds[k]
         chunk = self.comm[s:e]
         world = dist.get_world_size(self.group)
+        if self.is_sharded(k):
+            share = self._shards.get(k)
+            if share is None or share.numel() != (e - s) // world or share.dtype != chunk.dtype:
+                share = self._shards[k] = torch.empty((e - s) // world, dtype=chunk.dtype, device=chunk.device)
+            self._work[k] = dist.reduce_scatter_tensor(share, chunk, op=dist.ReduceOp.SUM, group=self.group,
+                                                       async_op=True)
+            return
         if self.mode == "rs_ag" and (e - s) % world == 0:
             share = self._shards.get(k)
             if share is None or share.numel() != (e - s) // world:

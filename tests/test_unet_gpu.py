@@ -137,6 +137,63 @@ def test_dwconv7_paths_agree(ops, B, H, W, C):
     assert relerr(out[0][2], out[16][2]) < 2e-6 and relerr(out[0][3], out[16][3]) < 2e-6
 
 
+PIPE_SHAPES = [(2, 48, 48, 32), (3, 24, 24, 128), (2, 12, 12, 512), (1, 20, 27, 32), (2, 9, 8, 64), (1, 14, 21, 96),
+               (5, 16, 16, 32), (1, 96, 96, 32), (2, 48, 32, 128), (3, 8, 8, 32)]
+
+
+@pytest.mark.parametrize("B,H,W,C", PIPE_SHAPES)
+def test_dwconv7_pipelined_kernel_matches_the_first_tiled_kernel(ops, B, H, W, C):
+    """The LDS-DMA double-buffered kernel (sei_dwconv7_fwd_ex seg 66: what seg 0 picks for C % 32 == 0) against the
+    first tiled kernel (seg 65): same accumulation order, so forward and data gradient (flipped taps + scaled
+    residual) are bit-identical; ragged tiles, several tiles / channel groups per workgroup, batch edges."""
+    gen = torch.Generator().manual_seed(3 * B + H + C)
+    x, r = torch.randn((B, H, W, C), generator=gen).cuda(), torch.randn((B, H, W, C), generator=gen).cuda()
+    w, b = (torch.randn((C, 1, 7, 7), generator=gen) * 0.1).cuda(), torch.randn(C, generator=gen).cuda()
+    out = {}
+    for seg in (65, 66, 0):
+        out[seg] = (ops.dwconv7(x, w, b, seg=seg), ops.dwconv7(x, w, None, flip=True, res=r, res_scale=2.0, seg=seg))
+        torch.cuda.synchronize()
+    for seg in (66, 0):
+        assert torch.equal(out[65][0], out[seg][0]) and torch.equal(out[65][1], out[seg][1]), seg
+    again = ops.dwconv7(x, w, b, seg=66)
+    assert torch.equal(again, out[66][0])
+
+
+@pytest.mark.parametrize("out16", [False, True])
+@pytest.mark.parametrize("B,H,W,C", [(2, 48, 48, 32), (3, 24, 24, 128), (1, 20, 27, 32), (2, 9, 8, 128), (5, 16, 16, 32),
+                                     (2, 12, 12, 512), (2, 6, 6, 2048), (1, 14, 21, 64), (1, 96, 96, 32)])
+def test_dwconv7_layernorm_fused_forward(ops, B, H, W, C, out16):
+    """sei_dwconv7_ln_fwd[_ex] (ConvBlock.conv1 -> LayerNorm, convolutional.py:36-39): ONE launch for C = 32 / 128 (a
+    workgroup owns every channel of its pixels), two elsewhere. h1 bit-identical to the depthwise kernel; h2, mean, rstd
+    against the stand-alone LayerNorm kernel on that h1 (another summation order: 2e-6) and against float64."""
+    import _native
+    gen = torch.Generator().manual_seed(B + 2 * H + C)
+    x = (torch.randn((B, H, W, C), generator=gen) * 1.5 + 0.3).cuda()
+    w, b = (torch.randn((C, 1, 7, 7), generator=gen) * 0.1).cuda(), torch.randn(C, generator=gen).cuda()
+    gamma, beta = torch.randn(C, generator=gen).cuda(), torch.randn(C, generator=gen).cuda()
+    assert (_native.lib().sei_dwconv7_ln_fwd_launches(B, H, W, C) == 1) == (C == 32 and H >= 8 and W >= 8)
+    can_fuse = C in (32, 128) and H >= 8 and W >= 8           # (C = 128: on request, it only ties with the two launches)
+    h1, h2, mean, rstd = ops.dwconv7_ln(x, w, b, gamma, beta, out16=out16, fuse=1 if can_fuse else 0)
+    if can_fuse:                                              # the two-launch form of the same entry point agrees
+        g1, g2, gm, gr = ops.dwconv7_ln(x, w, b, gamma, beta, out16=out16, fuse=2)
+        assert torch.equal(g1, h1) and relerr(gm, mean) < 2e-6 and relerr(gr, rstd) < 2e-6
+    ref1 = ops.dwconv7(x, w, b, seg=65 if H >= 8 and W >= 8 else 0)
+    assert torch.equal(h1, ref1)
+    M = B * H * W
+    ref64 = F.layer_norm(ref1.double().cpu().view(M, C), (C,), gamma.double().cpu(), beta.double().cpu(), eps=1e-6)
+    if out16:
+        y, m2, r2 = ops.layer_norm16(ref1.view(M, C), gamma, beta)
+        assert h2.dtype == torch.bfloat16
+        assert float((h2.double().cpu() - ref64).abs().max()) <= 2 ** -8 * float(ref64.abs().max()) + 1e-6
+        # the two kernels round the same f32 value except where their last bits straddle a bf16 tie
+        assert float((h2.float() != y.float()).float().mean()) < 2e-3
+    else:
+        y, m2, r2 = ops.layer_norm(ref1.view(M, C), gamma, beta)
+        assert relerr(h2, y) < 2e-6 and relerr(h2, ref64) < 5e-6
+    assert relerr(mean, m2) < 2e-6 and relerr(rstd, r2) < 2e-6
+    assert relerr(mean, ref1.double().view(M, C).mean(1)) < 1e-5
+
+
 @pytest.mark.parametrize("B,H,W,C", DW_SHAPES[:6])
 def test_dwconv7(ops, B, H, W, C):
     from _native import call
