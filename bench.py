@@ -317,6 +317,30 @@ class Leg:
             return None
         return self.graphed.node_counts[0]
 
+    def eager_twin_step(self):
+        """The captured step's launch set issued eagerly (for rocprofv3 --pmc, which attributes counters per kernel
+        dispatch and cannot see inside a graph replay): stored merged weight gradients, the deep levels' optimizer step in
+        the epilogue of their GEMMs, then the Adam launch for the rest of the bucket -- what `--pmc-twin` times."""
+        from models import _ops
+        fused = self.graphed is not None and bool(self.graphed.fused_views)
+        if fused:
+            _ops.set_fused_adam(*self.graphed.fused_table, owner=self.backbone)
+            self.optimizer.prepare_step()
+        try:
+            if self.graphed is not None and self.graphed.store_weight_grads:
+                self.backbone.zero_grad_flat(store_weight_grads=True)
+            else:
+                self.optimizer.zero_grad()
+            loss = self.loss_fn(x=self.x, y=self.y, model=self.model)
+            loss.backward()
+        finally:
+            if fused:
+                _ops.set_fused_adam(None, None, owner=self.backbone)
+        if self.reducer is not None:
+            self.reducer.reduce_async()
+        self.optimizer.step()
+        return loss
+
     def record_one_step(self):
         """One eager step with every native call logged (streaming families) and every GEMM launch recorded with its
         FLOPs, issued exactly as the timed (graphed) step issues them: merged weight gradients STORE."""
@@ -326,7 +350,7 @@ class Leg:
         _native.record_calls(True)
         fused = self.graphed is not None and bool(self.graphed.fused_views)
         if fused:                              # as the captured step: the bottleneck pair is stepped inside its GEMMs
-            _ops.set_fused_adam(*self.graphed.fused_table)
+            _ops.set_fused_adam(*self.graphed.fused_table, owner=self.backbone)
             self.optimizer.prepare_step()
         try:
             if self.graphed is not None and self.graphed.store_weight_grads:
@@ -337,7 +361,7 @@ class Leg:
             keep.backward(retain_graph=True)   # keeps the saved activations (GEMM operands) alive for the replay
         finally:
             if fused:
-                _ops.set_fused_adam(None, None)
+                _ops.set_fused_adam(None, None, owner=self.backbone)
         if self.reducer is not None:
             self.reducer.reduce_async()
         self.optimizer.step()
@@ -434,7 +458,10 @@ def main():
     ap.add_argument("--grad-comm", choices=["auto", "f32", "bf16"], default="auto",
                     help="dtype of the exchanged gradient bucket (auto = f32, as train.py's --grad_comm_dtype default; bf16 is the "
                          "opt-in compressed exchange of both)")
-    ap.add_argument("--grad-comm-mode", choices=["all_reduce", "rs_ag"], default="all_reduce")
+    ap.add_argument("--grad-comm-mode", choices=["all_reduce", "rs_ag"], default="rs_ag",
+                    help="N > 1: rs_ag = reduce-scatter the gradient chunks, Adam on this rank's 1 / N share, all-gather the "
+                         "updated weights (bf16 copies for the GEMM weights: sharded optimizer step, train.py's default "
+                         "too); all_reduce = every rank steps the whole bucket")
     ap.add_argument("--fuse-optimizer", action=argparse.BooleanOptionalAction, default=True,
                     help="one GPU, bf16, hipGraph: apply Adam to the 1x1-convolution weights of the two deepest levels (98.8 %% "
                          "of the parameters) in the epilogue of the GEMM that produces their gradient")
@@ -444,6 +471,10 @@ def main():
     ap.add_argument("--fuse-min-numel", type=int, default=1 << 24, help="smallest weight that takes its step that way")
     ap.add_argument("--graph", action=argparse.BooleanOptionalAction, default=True,
                     help="replay forward+backward as one hipGraph (the eager launch path otherwise)")
+    ap.add_argument("--pmc-twin", action="store_true",
+                    help="profiling aid: capture as usual, then run the steps as the captured step's EAGER twin (same launch "
+                         "set: stored merged weight gradients, Adam inside the deep weight-gradient GEMMs), so that "
+                         "rocprofv3 --pmc can attribute counters to the kernels of the timed configuration")
     ap.add_argument("--task", choices=["deblurring", "sr"], default="deblurring",
                     help="deblurring = BASELINE configs[1] (the headline); sr = configs[2] (x4 by default), a "
                          "secondary series: pairs (48r x 48r, 48 x 48) as the reference's dataset hands them over")
@@ -473,6 +504,8 @@ def main():
 
     sr = opt.task == "sr"
     leg = Leg(opt, opt.dtype, device, rank, world)
+    if opt.pmc_twin:
+        leg.step = leg.eager_twin_step
     fused_opt = leg.graphed is not None and bool(leg.graphed.fused_views)
     elapsed, loss_value = leg.timed(opt.warmup, opt.steps, fence)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -554,7 +587,9 @@ def main():
                        "optimizer": "Adam (fused, flat bucket" + ("; the deep levels' weights are stepped in the epilogue "
                                                                   "of their weight-gradient GEMMs)" if fused_opt else ")"),
                        "grad_allreduce": None if world == 1 else
-                       f"{str(comm_dtype).replace('torch.', '')}, {opt.grad_comm_mode}",
+                       f"{str(comm_dtype).replace('torch.', '')}, " +
+                       ("reduce-scatter + Adam on 1/N shares + all-gather of the updated weights (sharded step)"
+                        if opt.grad_comm_mode == "rs_ag" else "all_reduce, every rank steps the whole bucket"),
                        "launch": ("hipGraph replay of forward+backward (random draws made eagerly into static buffers)"
                                   + (", early gradient release" if graphed_early else "")) if opt.graph else "eager",
                        "final_loss": loss_value},

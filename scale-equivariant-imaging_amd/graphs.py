@@ -92,7 +92,7 @@ class GraphedLossStep:
             return value.detach()
 
         from models import _ops
-        _ops.weight_grad_views(reset=True)           # record this model's weight-gradient views only
+        _ops.weight_grad_views(reset=True, owner=backbone)           # record this model's weight-gradient views only
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
@@ -123,11 +123,11 @@ class GraphedLossStep:
                 g = prm._sei_grad_view
                 off = (g.data_ptr() - base) // esz
                 if prm.dim() == 4 and prm.shape[2:] == (1, 1) and prm.numel() >= fuse_min_numel and off % 4 == 0 \
-                        and prm.shape[1] % 8 == 0 and g.data_ptr() in _ops.merged_weight_grads():
+                        and prm.shape[1] % 8 == 0 and g.data_ptr() in _ops.merged_weight_grads(backbone):
                     self.fused_views.append(g.view(prm.shape[0], prm.shape[1]))
             if self.fused_views:
                 self.fused_table = optimizer.fuse_weight_updates(self.fused_views)
-                _ops.set_fused_adam(*self.fused_table)
+                _ops.set_fused_adam(*self.fused_table, owner=backbone)
         # Several GPUs with a bf16-compressed exchange: the same weights' gradients go to the exchange buffer as bf16
         # (no float32 copy, no cast pass); the reducer is told which slices not to cast after a replayed step.
         self.direct_views = []
@@ -140,23 +140,23 @@ class GraphedLossStep:
                 g = prm._sei_grad_view
                 off = (g.data_ptr() - grads.data_ptr()) // grads.element_size()
                 if prm.dim() == 4 and prm.shape[2:] == (1, 1) and prm.numel() >= fuse_min_numel and off % 4 == 0 \
-                        and prm.shape[1] % 8 == 0 and g.data_ptr() in _ops.merged_weight_grads():
+                        and prm.shape[1] % 8 == 0 and g.data_ptr() in _ops.merged_weight_grads(backbone):
                     view = g.view(prm.shape[0], prm.shape[1])
                     table[view.data_ptr()] = reducer.comm[off:off + prm.numel()].view(prm.shape[0], prm.shape[1])
                     ranges.append((off, off + prm.numel()))
                     self.direct_views.append(view)
             if table:
                 reducer.set_direct_ranges(ranges)
-                _ops.set_direct_bf16_grads(table)
+                _ops.set_direct_bf16_grads(table, owner=backbone)
         self.graph = torch.cuda.CUDAGraph(keep_graph=True) if count_nodes else torch.cuda.CUDAGraph()
         self.node_counts = None
         try:
             with torch.cuda.graph(self.graph):
                 self.static_loss = fwd_bwd()
-            if self.direct_views and _ops.direct_bf16_launches() != {v.data_ptr() for v in self.direct_views}:
+            if self.direct_views and _ops.direct_bf16_launches(backbone) != {v.data_ptr() for v in self.direct_views}:
                 raise RuntimeError("bf16 gradients into the exchange buffer: not every registered weight was written "
                                    "by the captured step")
-            if self.fused_views and _ops.fused_adam_launches() != {v.data_ptr() for v in self.fused_views}:
+            if self.fused_views and _ops.fused_adam_launches(backbone) != {v.data_ptr() for v in self.fused_views}:
                 raise RuntimeError("fused optimizer step: not every registered weight was updated by the captured step")
             if count_nodes:
                 import _native
@@ -169,15 +169,15 @@ class GraphedLossStep:
                 reducer.set_direct_ranges([])
             raise
         finally:
-            _ops.set_weight_grad_milestone(None, None)
-            _ops.set_fused_adam(None, None)
-            _ops.set_direct_bf16_grads(None)
+            _ops.set_weight_grad_milestone(None, None, owner=backbone)
+            _ops.set_fused_adam(None, None, owner=backbone)
+            _ops.set_direct_bf16_grads(None, owner=backbone)
         self.backbone.zero_grad_flat()
 
     def _plan_early_release(self, _ops):
         base, esz = self.backbone.flat_grads.data_ptr(), self.backbone.flat_grads.element_size()
         total = self.backbone.flat_grads.numel()
-        views = sorted(((n, ptr) for ptr, n in _ops.weight_grad_views().items()
+        views = sorted(((n, ptr) for ptr, n in _ops.weight_grad_views(owner=self.backbone).items()
                         if base <= ptr < base + total * esz), reverse=True)
         if len(views) < 2:
             return None
@@ -189,7 +189,7 @@ class GraphedLossStep:
             return None
         import _native
         event = _native.ExternalEvent()
-        _ops.set_weight_grad_milestone({p0, p1}, event)
+        _ops.set_weight_grad_milestone({p0, p1}, event, owner=self.backbone)
         return (event, int(start), int(stop))
 
     def _draw(self, given=None):

@@ -18,6 +18,7 @@ class FlatParameterBucket:
         self.flat_params = None
         self.flat_grads = None
         self.flat_shadow = None
+        self.flat_shadow_only_start = None
         self._sei_plain_state = {"gen": -1, "version": {}}
         self._sei_zero_ranges = None
         # load_state_dict copies into the parameters: cached bf16 shadows are stale afterwards
@@ -26,8 +27,14 @@ class FlatParameterBucket:
     @staticmethod
     def _goes_last(p):
         """GEMM weights (1x1 convolutions) go last in the bucket, so that everything else -- the part of the
-        gradient bucket that must be zeroed every step in store mode -- is one contiguous head."""
-        return p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1
+        gradient bucket that must be zeroed every step in store mode -- is one contiguous head; and of those, the ones
+        that the bf16 throughput mode reads ONLY through their bf16 copy (both extents multiples of 32: every block
+        that owns such a weight takes the bf16 path, models/_ops.use_bf16_blocks) come last of all: with a sharded
+        optimizer step (optim.FlatAdam under several GPUs) only that copy of them is all-gathered.
+        0 = head, 1 = 1x1 weights read as float32 by some path, 2 = bf16-copy-only weights."""
+        if not (p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1):
+            return 0
+        return 2 if min(p.shape[0], p.shape[1]) % 32 == 0 else 1
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -47,9 +54,14 @@ class FlatParameterBucket:
         # for all of them whatever the sizes before; the padding stays zero in all three buckets
         align = 64
         offsets, total = [], 0
+        self.flat_shadow_only_start = None          # bucket offset where the bf16-copy-only weights begin
         for p in params:
+            if self.flat_shadow_only_start is None and self._goes_last(p) == 2:
+                self.flat_shadow_only_start = total
             offsets.append(total)
             total += (p.numel() + align - 1) // align * align
+        if self.flat_shadow_only_start is None:
+            self.flat_shadow_only_start = total
         flat = torch.zeros(total, dtype=dt, device=dev)
         grads = torch.zeros(total, dtype=dt, device=dev)
         for p, off in zip(params, offsets):
@@ -59,6 +71,7 @@ class FlatParameterBucket:
             p._sei_grad_view = grads[off:off + n].view(p.shape)
             p.grad = None
         self.flat_params, self.flat_grads = flat, grads
+        _ops.register_gradient_range(self, grads)       # backward functions find this model's bookkeeping by address
         # bf16 copy of the whole bucket for the throughput mode (written by the fused Adam kernel)
         self.flat_shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
         # validity of the bf16 bucket is tracked per model: {"gen": generation it was written for,
@@ -89,7 +102,7 @@ class FlatParameterBucket:
         else:
             for off, n in ranges:
                 self.flat_grads[off:off + n].zero_()
-        _ops.begin_step(store=ranges is not None, store_min=getattr(self, "_sei_store_min", 0))
+        _ops.begin_step(store=ranges is not None, store_min=getattr(self, "_sei_store_min", 0), owner=self)
         for p in self.parameters():
             p.grad = p._sei_grad_view
 
@@ -101,7 +114,7 @@ class FlatParameterBucket:
         base, esz = self.flat_grads.data_ptr(), self.flat_grads.element_size()
         total = self.flat_grads.numel()
         self._sei_store_min = int(min_numel)
-        skip = sorted(((ptr - base) // esz, n) for ptr, n in _ops.weight_grad_views().items()
+        skip = sorted(((ptr - base) // esz, n) for ptr, n in _ops.weight_grad_views(owner=self).items()
                       if base <= ptr < base + total * esz and n >= min_numel)
         ranges, pos = [], 0
         for off, n in skip:

@@ -429,21 +429,69 @@ def cast16(x2d, colsum_into_=None):
 # of accumulating, and zero_grad skips those gradients -- valid because the captured step writes every one
 # of them exactly this way on every replay.
 # ---------------------------------------------------------------------------------------------
-_DW = {"uses": 0, "arrivals": {}, "parked": {}, "written": set(), "store": False, "store_min": 0,
-       "flush_queued": False, "merge": True, "seen": {}, "milestone": None, "milestone_done": False,
-       "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set(), "flops_per_row": {}, "taps": {}, "merged_ok": {}}
+def _fresh_state():
+    return {"uses": 0, "arrivals": {}, "parked": {}, "written": set(), "store": False, "store_min": 0,
+            "flush_queued": False, "merge": True, "seen": {}, "milestone": None, "milestone_done": False,
+            "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set(), "flops_per_row": {},
+            "taps": {}, "merged_ok": {}}
 
 
-def note_forward():
-    """A model call that autograd will differentiate (ConvolutionalModel.forward)."""
+class WeightGradState:
+    """The bookkeeping below, PER BACKBONE: model calls of the step, parked pairs, store / fused-Adam / direct-bf16
+    tables. Two models alive in one process (a frozen copy beside the fine-tuned one, two networks trained side by
+    side) each merge and store their own weight gradients. A backbone's state is found from the address of the
+    gradient a backward function writes (`register_gradient_range`: the flat gradient bucket, SwinPack's staging);
+    gradients outside every registered range (kernel-level tests) share the default state."""
+
+    def __init__(self):
+        self.d = _fresh_state()
+
+
+_DEFAULT_STATE = WeightGradState()
+_RANGES = []                      # [(first byte, end byte, weakref to the WeightGradState)], newest last
+
+
+def state_of(owner=None):
+    """The state dict of `owner` (a backbone with a flat bucket; created on first use), or the default one."""
+    if owner is None:
+        return _DEFAULT_STATE.d
+    st = owner.__dict__.get("_sei_dw_state")
+    if st is None:
+        st = WeightGradState()
+        owner.__dict__["_sei_dw_state"] = st
+    return st.d
+
+
+def register_gradient_range(owner, tensor):
+    """Gradients written inside `tensor` (the owner's flat gradient bucket, a staging buffer) belong to `owner`."""
+    import weakref
+    state_of(owner)
+    lo = tensor.data_ptr()
+    _RANGES[:] = [r for r in _RANGES if r[2]() is not None and not (r[0] < lo + tensor.numel() * tensor.element_size()
+                                                                    and lo < r[1])]
+    _RANGES.append((lo, lo + tensor.numel() * tensor.element_size(), weakref.ref(owner.__dict__["_sei_dw_state"])))
+
+
+def _state_for(ptr):
+    for lo, hi, ref in reversed(_RANGES):
+        if lo <= ptr < hi:
+            st = ref()
+            if st is not None:
+                return st.d
+    return _DEFAULT_STATE.d
+
+
+def note_forward(owner=None):
+    """A model call that autograd will differentiate (ConvolutionalModel.forward / SwinIR.forward pass themselves)."""
     if torch.is_grad_enabled():
-        _DW["uses"] += 1
+        state_of(owner)["uses"] += 1
 
 
-def begin_step(store=False, store_min=0):
+def begin_step(store=False, store_min=0, owner=None):
     """Start of a step (zero_grad): nothing parked, no model call counted, no gradient written yet. store: the
     first launch of the step into a weight gradient of at least store_min elements stores (it was not zeroed)."""
-    flush_weight_grads()
+    _DW = state_of(owner)
+    flush_weight_grads(owner)
     _DW["uses"] = 0
     _DW["arrivals"].clear()
     _DW["written"].clear()
@@ -452,13 +500,15 @@ def begin_step(store=False, store_min=0):
     _DW["store_min"] = int(store_min)
 
 
-def set_weight_grad_merging(enabled):
+def set_weight_grad_merging(enabled, owner=None):
+    _DW = state_of(owner)
     previous, _DW["merge"] = _DW["merge"], bool(enabled)
     return previous
 
 
-def weight_grad_views(reset=False):
+def weight_grad_views(reset=False, owner=None):
     """{data_ptr: numel} of every gradient view written through weight_grad16 since the last reset."""
+    _DW = state_of(owner)
     seen = dict(_DW["seen"])
     if reset:
         _DW["seen"].clear()
@@ -468,19 +518,19 @@ def weight_grad_views(reset=False):
     return seen
 
 
-def set_weight_grad_milestone(keys, event):
+def set_weight_grad_milestone(keys, event, owner=None):
     """Record `event` on the current stream right after the LAST of the gradients `keys` (data_ptrs) has been
     launched in a step (GraphedLossStep: an external event inside the captured backward, after which the
     bottleneck block's gradients -- most of the bucket -- are final and their all-reduce may start)."""
-    _DW["milestone"] = (frozenset(keys), event) if keys else None
+    state_of(owner)["milestone"] = (frozenset(keys), event) if keys else None
 
 
-def _launch_weight_grad(grad2d, pairs):
+def _launch_weight_grad(_DW, grad2d, pairs):
     key = grad2d.data_ptr()
     store = _DW["store"] and key not in _DW["written"] and grad2d.numel() >= _DW["store_min"]
     _DW["written"].add(key)
     try:
-        _launch_weight_grad_inner(grad2d, pairs, store)
+        _launch_weight_grad_inner(_DW, grad2d, pairs, store)
     finally:
         ms = _DW["milestone"]
         if ms is not None and key in ms[0] and ms[0] <= _DW["written"] and not _DW["milestone_done"]:
@@ -490,41 +540,43 @@ def _launch_weight_grad(grad2d, pairs):
                 _DW["milestone_done"] = True
 
 
-def set_fused_adam(table, hyper):
+def set_fused_adam(table, hyper, owner=None):
     """Optimizer step inside the weight-gradient GEMM (optim.FlatAdam.fuse_weight_updates): `table` maps the
     data_ptr of a gradient view to the (param, exp_avg, exp_avg_sq, bf16 shadow or None) views of the same shape,
     `hyper` is the device array of the step's six Adam scalars. The step's single, merged, storing launch into such a
     gradient applies the update instead of writing the gradient (sei_gemm_bf16nt_dw2_adam); None switches it off."""
+    _DW = state_of(owner)
     _DW["adam"] = (dict(table), hyper) if table else None
     _DW["adam_launched"] = set()
 
 
-def set_direct_bf16_grads(table):
+def set_direct_bf16_grads(table, owner=None):
     """Several GPUs, bf16-compressed exchange (parallel.FlatGradientReducer): `table` maps the data_ptr of a gradient
     view to the bf16 view of the exchange buffer with the same shape. The step's single, merged, storing launch into
     such a gradient writes bf16 there (sei_gemm_bf16nt_dw2_bf16out) and nothing into the float32 bucket, which the
     reducer then does not cast for those ranges; None switches it off."""
+    _DW = state_of(owner)
     _DW["direct16"] = dict(table) if table else None
     _DW["direct16_launched"] = set()
 
 
-def direct_bf16_launches():
-    return set(_DW["direct16_launched"])
+def direct_bf16_launches(owner=None):
+    return set(state_of(owner)["direct16_launched"])
 
 
-def fused_adam_launches():
+def fused_adam_launches(owner=None):
     """data_ptrs whose update was applied inside a GEMM since set_fused_adam."""
-    return set(_DW["adam_launched"])
+    return set(state_of(owner)["adam_launched"])
 
 
-def merged_weight_grads():
+def merged_weight_grads(owner=None):
     """data_ptrs of the gradients whose last launch carried the step's COMPLETE gradient as one two-segment GEMM (the
     condition for applying the optimizer step, or writing bf16, in that launch: graphs.GraphedLossStep reads this after
     its warm-up steps -- a batch whose pixel counts do not add up to a multiple of 8 rows is served by other launches)."""
-    return {k for k, ok in _DW["merged_ok"].items() if ok}
+    return {k for k, ok in state_of(owner)["merged_ok"].items() if ok}
 
 
-def _launch_weight_grad_inner(grad2d, pairs, store):
+def _launch_weight_grad_inner(_DW, grad2d, pairs, store):
     key = grad2d.data_ptr()
     Np, Kp = grad2d.shape[-2:]
     _DW["merged_ok"][key] = (len(pairs) == 2 and len(pairs) == _DW["uses"]
@@ -585,12 +637,13 @@ def _launch_weight_grad_inner(grad2d, pairs, store):
         store = False
 
 
-def flush_weight_grads():
-    """Issue every parked weight gradient on its own (no partner arrived)."""
+def flush_weight_grads(owner=None, _state=None):
+    """Issue every parked weight gradient of `owner` (default state when None) on its own (no partner arrived)."""
+    _DW = _state if _state is not None else state_of(owner)
     _DW["flush_queued"] = False
     parked, _DW["parked"] = _DW["parked"], {}
     for gy16, x16, grad2d in parked.values():
-        _launch_weight_grad(grad2d, [(gy16, x16)])
+        _launch_weight_grad(_DW, grad2d, [(gy16, x16)])
 
 
 def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None):
@@ -601,6 +654,7 @@ def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None):
     tap_rows[t]] -- the taps of a 3x3 convolution's weight gradient in one launch (sei_gemm_bf16nt_dw2_taps); x16 is
     the un-shifted window of a grid with guard rows on both sides."""
     key = grad2d.data_ptr()
+    _DW = _state_for(key)
     _DW["seen"][key] = grad2d.numel()
     _DW["flops_per_row"][key] = flops_per_row
     if tap_rows is not None:
@@ -611,19 +665,19 @@ def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None):
     _DW["arrivals"][key] = n
     partner = _DW["parked"].pop(key, None)
     if partner is not None:
-        _launch_weight_grad(grad2d, [partner[:2], (gy16, x16)])
-    elif _DW["merge"] and n < _DW["uses"] and _queue_flush():
+        _launch_weight_grad(_DW, grad2d, [partner[:2], (gy16, x16)])
+    elif _DW["merge"] and n < _DW["uses"] and _queue_flush(_DW):
         _DW["parked"][key] = (gy16, x16, grad2d)
     else:
-        _launch_weight_grad(grad2d, [(gy16, x16)])
+        _launch_weight_grad(_DW, grad2d, [(gy16, x16)])
 
 
-def _queue_flush():
+def _queue_flush(_DW):
     """Ask autograd to flush parked pairs when the running backward ends; False outside a backward pass
     (then nothing may be parked: nobody would flush it)."""
     if not _DW["flush_queued"]:
         try:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_weight_grads)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_weight_grads(_state=_DW))
         except RuntimeError:
             return False
         _DW["flush_queued"] = True

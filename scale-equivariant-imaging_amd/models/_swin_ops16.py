@@ -124,6 +124,7 @@ class SwinPack:
         self.wint = torch.zeros(self.wmap.numel(), dtype=torch.bfloat16, device=dev)
         self.bint = torch.zeros(self.bmap.numel(), dtype=torch.float32, device=dev)
         self.gint = torch.zeros(self.gmap.numel(), dtype=torch.float32, device=dev)
+        _ops.register_gradient_range(model, self.gint)  # these staged gradients are part of `model`'s step bookkeeping
         self._flush_queued = False
         self._key = (base, flat.numel())
 
@@ -159,7 +160,7 @@ class SwinPack:
     def flush(self):
         """Staged gradients -> the flat gradient bucket (+=), then clear the staging for the next backward pass."""
         self._flush_queued = False
-        _ops.flush_weight_grads()                        # pairs still parked for a partner that never came
+        _ops.flush_weight_grads(self.model)                        # pairs still parked for a partner that never came
         grads = self.model.flat_grads
         for p in self.model.parameters():                # gradients not attached yet (no zero_grad_flat): attach
             if p.grad is None:

@@ -213,7 +213,7 @@ class ConvolutionalModel(FlatParameterBucket, Module):
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, y):
         y = N.check_tensor(y.contiguous(), "y")        # crops arrive as strided views
-        _ops.note_forward()
+        _ops.note_forward(self)
         div = 2 ** (self.scales - 1)
         pad_h = (div - y.shape[-2] % div) % div
         pad_w = (div - y.shape[-1] % div) % div

@@ -222,7 +222,7 @@ class SwinIR(FlatParameterBucket, nn.Module):
         """x: (B, 3, H, W). drop_masks: "draw" (training: draw them here, eval: none), None, or the list returned by
         draw_drop_masks (injected by tests / a captured step)."""
         x = N.check_tensor(x.contiguous(), "x")
-        _ops.note_forward()
+        _ops.note_forward(self)
         B, _, H, W = x.shape
         ws = self.window_size
         ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws

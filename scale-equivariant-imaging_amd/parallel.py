@@ -170,6 +170,17 @@ class FlatGradientReducer:
             src = buf[lo:hi].clone()              # (gloo has no in-place form; a 1/world copy of the chunk)
             self._gather_work.append(dist.all_gather_into_tensor(buf[s:e], src, group=self.group, async_op=True))
 
+    def gathered_gradient(self):
+        """Collective, tests only: the complete reduced bucket (a copy) after reduce_async in mode "sharded", where
+        each rank holds its shares alone."""
+        self.wait_all()
+        full = self.comm.clone()
+        for k in range(len(self.bounds)):
+            if self.is_sharded(k):
+                s, e = self.bounds[k]
+                dist.all_gather_into_tensor(full[s:e], self._shards[k].clone(), group=self.group)
+        return full
+
     def wait_gathers(self):
         for w in self._gather_work:
             w.wait()

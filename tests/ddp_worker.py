@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--mode", default="all_reduce")
     ap.add_argument("--comm", default="f32")
+    ap.add_argument("--hidden", type=int, default=8, help="32: GEMM weights that the bf16 mode reads through bf16 copies only")
+    ap.add_argument("--shard", type=int, default=1, help="rs_ag: the sharded optimizer step (FlatAdam's default)")
     ap.add_argument("--direct-min", type=int, default=0,
                     help=">0: weight gradients of at least this many elements are stored (store_min_numel=0) and, with "
                          "--comm bf16, written into the exchange buffer as bf16 by their GEMM")
@@ -43,7 +45,7 @@ def main():
     from optim import FlatAdam
 
     _ops.set_compute_dtype(opt.dtype)
-    args = bench.reference_args("cuda", 8, 3)
+    args = bench.reference_args("cuda", opt.hidden, 3)
     torch.manual_seed(0)
     p = physics.get_physics(args, "cuda")
     model = models.get_model(args, p, "cuda").to("cuda")
@@ -54,7 +56,9 @@ def main():
     comm = torch.bfloat16 if opt.comm == "bf16" else torch.float32
     reducer = parallel.FlatGradientReducer(bb.flat_grads, comm_dtype=comm, chunk_mib=1, mode=opt.mode) \
         if world > 1 else None
-    optim = FlatAdam(model, lr=1e-4, reducer=reducer)
+    optim = FlatAdam(model, lr=1e-4, reducer=reducer, shard_step=bool(opt.shard))
+    sharded = reducer is not None and reducer.mode == "sharded"
+    assert sharded == (world > 1 and opt.mode == "rs_ag" and bool(opt.shard))
 
     G, B = opt.global_batch, opt.global_batch // world
     lo = rank * B
@@ -65,7 +69,7 @@ def main():
     kw = dict(store_min_numel=0, fuse_min_numel=opt.direct_min) if opt.direct_min > 0 else dict(direct_bf16_grads=False)
     graphed = GraphedLossStep(lf, model, optim, (B, 3, 48, 48), **kw) if opt.graph else None
     direct = graphed is not None and bool(graphed.direct_views)
-    if opt.direct_min > 0 and opt.comm == "bf16" and world > 1 and opt.dtype == "bf16":
+    if opt.direct_min > 0 and opt.comm == "bf16" and world > 1 and opt.dtype == "bf16" and opt.hidden == 8:
         assert len(graphed.direct_views) == 2, len(graphed.direct_views)
     losses, grads0 = [], None
     for step in range(opt.steps):
@@ -85,15 +89,24 @@ def main():
             val.backward()
         if reducer is not None:
             reducer.reduce_async(direct=direct)
-            reducer.wait_all()
+            if not (sharded and step > 0):
+                reducer.wait_all()
         if step == 0:
-            g = (reducer.comm if reducer is not None else bb.flat_grads).float() / world
+            if sharded:                                 # each rank holds its shares: put the bucket together (test aid)
+                g = reducer.gathered_gradient().float() / world
+            else:
+                g = (reducer.comm if reducer is not None else bb.flat_grads).float() / world
             grads0 = g.cpu().clone()
         optim.step()
         losses.append(float(parallel.all_reduce_mean_scalar(val.detach().clone())))
+    stale = bool(getattr(optim, "_master_stale", False))
+    shadow = bb.flat_shadow.cpu().clone() if opt.dtype == "bf16" else None
+    optim.consolidate()                                 # sharded step: float32 masters + moments of the other shares
     torch.cuda.synchronize()
     os.makedirs(opt.out, exist_ok=True)
-    torch.save({"params": bb.flat_params.cpu(), "grads_step0": grads0, "losses": losses},
+    st = optim.state[bb.flat_params]
+    torch.save({"params": bb.flat_params.cpu(), "grads_step0": grads0, "losses": losses, "stale": stale, "shadow": shadow,
+                "exp_avg": st["exp_avg"].cpu(), "sharded": sharded},
                os.path.join(opt.out, f"rank{rank}.pt"))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -34,16 +34,27 @@ def relerr(a, b):
 
 @pytest.mark.parametrize("extra,tol", [
     (["--dtype", "f32", "--graph", "1", "--mode", "all_reduce"], 2e-5),
+    # rs_ag + FlatAdam = the sharded optimizer step: reduce-scatter, Adam on this rank's shares, all-gather of the weights
     (["--dtype", "f32", "--graph", "0", "--mode", "rs_ag"], 2e-5),
-    (["--dtype", "bf16", "--graph", "1", "--mode", "rs_ag", "--comm", "bf16"], 2e-2),
-    # the bottleneck pair's gradients written into the bf16 exchange buffer by their GEMM (no f32 copy, no cast pass)
+    (["--dtype", "bf16", "--graph", "1", "--mode", "rs_ag", "--comm", "bf16", "--hidden", "32"], 2e-2),
+    # ... with the big weight gradients written into the bf16 exchange buffer by their GEMM (no f32 copy, no cast pass)
+    (["--dtype", "bf16", "--graph", "1", "--mode", "rs_ag", "--comm", "bf16", "--direct-min", "60000"], 2e-2),
     (["--dtype", "bf16", "--graph", "1", "--mode", "all_reduce", "--comm", "bf16", "--direct-min", "60000"], 2e-2)])
 def test_two_ranks_on_one_gpu_match_the_single_process_run(tmp_path, extra, tol):
     """Two ranks x half the batch == one process x the whole batch: the summed, world-averaged gradient of the first
     step equals the single-process gradient (to split-K / atomic-order noise; to bf16 rounding when the exchange
-    is compressed), the replicas stay bit-identical through the optimizer steps, and the per-step losses agree."""
+    is compressed), the replicas stay bit-identical through the optimizer steps, and the per-step losses agree.
+    Sharded step (rs_ag): every rank steps its shares only; the bf16 copies the next forward reads are identical on both
+    ranks after every step, the float32 masters and the moments after `consolidate()`."""
     two = _run(str(tmp_path / "w2"), 2, extra)
     one = _run(str(tmp_path / "w1"), 1, extra)                             # (exchange flags are inert at world 1)
+    assert two[0]["sharded"] == ("rs_ag" in extra) and not one[0]["sharded"]
+    if two[0]["shadow"] is not None:
+        assert torch.equal(two[0]["shadow"], two[1]["shadow"])
+        if two[0]["sharded"]:                  # 1x1 weights with both extents % 32 == 0 (levels 1 and 2 at hidden 8, every
+            assert two[0]["stale"]             # level at hidden 32) travelled as bf16 copies alone: their float32 masters
+                                               # were stale on the other rank until consolidate()
+    assert torch.equal(two[0]["exp_avg"], two[1]["exp_avg"])
     assert torch.equal(two[0]["params"], two[1]["params"])                  # replicas never diverge
     assert torch.equal(two[0]["grads_step0"], two[1]["grads_step0"])
     assert relerr(two[0]["grads_step0"], one[0]["grads_step0"]) < tol

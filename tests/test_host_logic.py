@@ -322,6 +322,109 @@ def test_flat_gradient_reducer_gloo_world2():
         assert loss == pytest.approx(1.5) and nchunks == 4
 
 
+def _sharded_worker(r, w, port, q):
+    """One rank of the sharded optimizer step on CPU tensors over gloo: parallel.FlatGradientReducer in mode "sharded"
+    (what optim.FlatAdam turns "rs_ag" into) + FlatAdam._step_sharded / consolidate with a torch restatement of the
+    Adam kernel as the update function (the product's update is the HIP kernel: no CPU path)."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "scale-equivariant-imaging_amd"))
+    import parallel
+    from models import _ops
+    from models._flat import FlatParameterBucket
+    from optim import FlatAdam
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(w), LOCAL_RANK=str(r))
+    parallel.init_from_env(backend="gloo")
+
+    class Net(FlatParameterBucket, torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(5)
+            mk = lambda *s: torch.nn.Parameter(torch.randn(s, generator=g))
+            self.big = mk(96, 64, 1, 1)            # read through its bf16 copy only (both extents % 32 == 0)
+            self.small = mk(40, 3, 1, 1)           # a 1x1 weight some float32 path reads
+            self.bias = mk(70)
+            self.dw = mk(32, 1, 7, 7)
+            self._init_bucket()
+            self.flatten_parameters()
+
+        def get_backbone(self):
+            return self
+
+    prev = _ops.set_compute_dtype("bf16")
+    net = Net()
+    total = net.flat_params.numel()
+    assert net.flat_shadow_only_start == total - 96 * 64 and net.big.data_ptr() == net.flat_params[total - 6144:].data_ptr()
+    net.flat_shadow = net.flat_params.bfloat16()
+    start = net.flat_params.clone()
+    red = parallel.FlatGradientReducer(net.flat_grads, chunk_mib=1, mode="rs_ag", comm_dtype=torch.float32)
+    red._chunk = 2048                                   # several chunks on either side of the split
+    opt = FlatAdam(net, lr=1e-2, reducer=red)
+    assert red.mode == "sharded" and all(not (s < net.flat_shadow_only_start < e) for s, e in red.bounds)
+    st = opt.state[net.flat_params]
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+    grads = [[torch.randn(total, generator=torch.Generator().manual_seed(10 * step + k)) for k in range(w)]
+             for step in range(2)]
+
+    def adam(p, g, m, v, step):
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        p.addcdiv_(m, (v.sqrt() / (1 - b2 ** step) ** 0.5).add_(eps), value=-lr / (1 - b1 ** step))
+
+    ref_p, ref_m, ref_v = start.clone(), torch.zeros(total), torch.zeros(total)
+    stale_seen = False
+    for step in (1, 2):
+        net.flat_grads.copy_(grads[step - 1][r])
+        red.reduce_async()
+        st["step"] = step
+
+        def update(lo, hi, g, g16):
+            adam(net.flat_params[lo:hi], g.float() / w, st["exp_avg"][lo:hi], st["exp_avg_sq"][lo:hi], step)
+            net.flat_shadow[lo:hi] = net.flat_params[lo:hi].bfloat16()
+
+        opt._step_sharded(update, net.flat_shadow)
+        adam(ref_p, sum(grads[step - 1]) / w, ref_m, ref_v, step)
+        # the bf16 copies are complete on every rank, the head is complete in float32 ...
+        first = net.flat_shadow_only_start
+        assert torch.equal(net.flat_shadow[first:], ref_p[first:].bfloat16())
+        assert torch.equal(net.flat_params[:first], ref_p[:first])
+        # ... and the float32 masters of the OTHER rank's shares of the bf16-copy-only weights are not (by design)
+        stale_seen = stale_seen or not torch.equal(net.flat_params[first:], ref_p[first:])
+    assert stale_seen and opt._master_stale
+    opt.consolidate()
+    ok = (torch.equal(net.flat_params, ref_p) and torch.equal(st["exp_avg"], ref_m) and torch.equal(st["exp_avg_sq"], ref_v)
+          and not opt._master_stale)
+    sd = opt.state_dict()                                # torch.optim.Adam's layout, complete after consolidate()
+    ok = ok and torch.equal(sd["state"][0]["exp_avg"].flatten(), ref_m[total - 6144:]) and len(sd["state"]) == 4
+    full = None
+    net.flat_grads.copy_(grads[0][r])
+    red.reduce_async()
+    full = red.gathered_gradient()
+    ok = ok and torch.equal(full, grads[0][0] + grads[0][1])
+    _ops.set_compute_dtype(prev)
+    q.put((r, bool(ok), len(red.bounds), sum(red.is_sharded(k) for k in range(len(red.bounds)))))
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_step_gloo_world2():
+    """Two ranks, CPU + gloo: reduce-scatter of the gradient chunks, the step on each rank's shares, all-gather of the
+    updated weights (bf16 copies alone for the GEMM weights) == one process stepping the whole bucket on the averaged
+    gradient, bit for bit; `consolidate()` completes the float32 masters and the moments for a checkpoint."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, ok, nchunks, nsharded in res:
+        assert ok and nchunks >= 4 and nsharded >= nchunks - 1, (r, ok, nchunks, nsharded)
+
+
 def test_reducer_chunk_plan_with_an_early_range():
     """Chunks never straddle the early range, cover the bucket exactly once, and the early ones come first in
     the consumption order."""

@@ -973,7 +973,7 @@ def test_merged_and_stored_weight_grads_match_plain_accumulation():
         y = p(x)
         grads = {}
         for mode in ("plain", "merged"):
-            was = _ops.set_weight_grad_merging(mode == "merged")
+            was = _ops.set_weight_grad_merging(mode == "merged", owner=bb)
             try:
                 torch.manual_seed(21)
                 torch.cuda.manual_seed(22)
@@ -987,7 +987,7 @@ def test_merged_and_stored_weight_grads_match_plain_accumulation():
                     assert sum(r[1] == "sei_gemm_bf16nt_dw2" for r in records) > 10      # the merge happened
                 grads[mode] = bb.flat_grads.clone()
             finally:
-                _ops.set_weight_grad_merging(was)
+                _ops.set_weight_grad_merging(was, owner=bb)
         assert torch.isfinite(grads["merged"]).all()
         # identical bf16 products; the f32 sums over up to 221,184 terms run in another order
         assert relerr(grads["merged"], grads["plain"]) < 2e-4
@@ -1006,6 +1006,56 @@ def test_merged_and_stored_weight_grads_match_plain_accumulation():
         assert torch.isfinite(outs[0]).all() and relerr(outs[0], outs[1]) < 1e-4
         # same seeds -> same crop and same draws as the eager runs: stored == accumulated
         assert relerr(outs[0], grads["merged"]) < 2e-4, relerr(outs[0], grads["merged"])
+    finally:
+        _ops.set_compute_dtype(prev)
+
+
+def test_two_models_in_one_process_keep_their_own_step_state():
+    """The weight-gradient bookkeeping of models/_ops.py (model calls of the step, parked pairs, merged launches) is per
+    backbone: two networks whose steps interleave -- forward A, forward B, backward A, backward B, as when a second
+    model is trained or evaluated with gradients beside the first -- each merge their own pairs and end with the
+    gradients they get when stepped alone."""
+    import bench
+    import models
+    import physics
+    from losses import get_loss
+    from models import _ops
+    prev = _ops.set_compute_dtype("bf16")
+    try:
+        args = bench.reference_args("cuda", 32, 3)
+        p = physics.get_physics(args, "cuda")
+        lf = get_loss(args, p)
+        nets = []
+        for seed in (0, 1):
+            torch.manual_seed(seed)
+            nets.append(models.get_model(args, p, "cuda").to("cuda"))
+        bbs = [m.get_backbone() for m in nets]
+        assert _ops.state_of(bbs[0]) is not _ops.state_of(bbs[1])
+        x = torch.rand(4, 3, 256, 256, device="cuda")
+        y = p(x)
+
+        def loss_of(m, seed):
+            torch.manual_seed(seed)
+            torch.cuda.manual_seed(seed)
+            return lf(x=x, y=y, model=m)
+
+        alone = []
+        for m, bb in zip(nets, bbs):
+            bb.zero_grad_flat()
+            loss_of(m, 5).backward()
+            alone.append(bb.flat_grads.clone())
+            assert len(_ops.merged_weight_grads(bb)) > 4          # the step's two model calls merged, per weight
+        for bb in bbs:
+            bb.zero_grad_flat()
+        la, lb = loss_of(nets[0], 5), loss_of(nets[1], 5)
+        assert _ops.state_of(bbs[0])["uses"] == 2 and _ops.state_of(bbs[1])["uses"] == 2
+        la.backward()
+        lb.backward()
+        torch.cuda.synchronize()
+        for bb, ref in zip(bbs, alone):
+            assert relerr(bb.flat_grads, ref) < 2e-4
+            assert not _ops.state_of(bb)["parked"] and len(_ops.merged_weight_grads(bb)) > 4
+        assert _ops.state_of()["uses"] == 0                      # nothing leaked into the default state
     finally:
         _ops.set_compute_dtype(prev)
 

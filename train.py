@@ -89,8 +89,11 @@ def build_parser():
          help="dtype of the all-reduced gradient bucket under torch.distributed.run: f32 (exact sum, default) or "
               "bf16 (half the xGMI bytes; the sum runs in bf16, its rounding grows with the number of ranks; "
               "needs --fused_optimizer)")
-    flag("--grad_comm_mode", choices=["all_reduce", "rs_ag"], default="all_reduce",
-         help="gradient exchange: chunked all-reduce, or reduce-scatter + all-gather of each chunk (parallel.py)")
+    flag("--grad_comm_mode", choices=["all_reduce", "rs_ag"], default="rs_ag",
+         help="gradient exchange under torch.distributed.run: rs_ag = reduce-scatter of every chunk, the fused Adam steps "
+              "this rank's 1 / world share and the UPDATED weights are all-gathered (sharded optimizer step; with another "
+              "optimizer: reduce-scatter + all-gather of the gradients); all_reduce = chunked all-reduce, every rank "
+              "steps the whole bucket (parallel.py, optim.py)")
     flag("--device_cache", default=False, **onoff,
          help="keep every (x, y) training pair in HBM (deterministic measurements) and draw crops on the device "
               "instead of the per-item DataLoader path (datasets/device_cache.py)")
@@ -201,6 +204,13 @@ def main(argv=None):
     def checkpoint_name(epoch):
         return f"{checkpoints_dir}/ckp_{epoch:0{len(str(epochs))}}.pt"
 
+    def consolidate():
+        """Several GPUs with the sharded optimizer step: every rank brings its float32 weights and Adam moments up to
+        date before rank 0 writes them (a collective; a no-op otherwise)."""
+        if hasattr(optimizer, "consolidate"):
+            optimizer.consolidate()
+
+    consolidate()
     if rank == 0:
         save_training_state(epoch=0, model=model, optimizer=optimizer, scheduler=scheduler,
                             state_path=checkpoint_name(0))
@@ -253,6 +263,8 @@ def main(argv=None):
             scheduler.step()
 
         epoch_loss = parallel.all_reduce_mean_scalar(loss_sum / max(steps, 1)).item()
+        if (epoch % checkpoint_interval == 0) or (epoch == epochs - 1):
+            consolidate()
         if rank == 0:
             stamp = datetime.now().strftime("%Y-%m-%d %H:%M:%S")
             print(f"\t{stamp}\t[{epoch + 1:{len(str(int(epochs)))}d}/{epochs}]\tTraining_Loss: {epoch_loss:.2e}")
