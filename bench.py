@@ -55,9 +55,10 @@ def reference_args(device, hidden=32, scales=5, task="deblurring", sr_factor=Non
 def cpu_baseline(batch, hidden, scales, timed_steps=2):
     """The oracle's restatement of the same training step on the host CPU (kind "port"), by the protocol of
     BASELINE.md section 3 / SURVEY 8(d): batch 4, float32, all host cores, 1 warm-up step + >= 2 timed steps."""
+    import oracle
     from oracle import torch_path as tp
     torch.manual_seed(0)
-    threads = torch.get_num_threads()
+    threads = oracle.use_all_usable_cpus()                 # the cgroup's CPU quota, not every logical CPU of the host
     sd = {k: v.requires_grad_(True) for k, v in tp.unet_init_state_dict(hidden, scales).items()}
     opt = torch.optim.Adam(list(sd.values()), lr=1e-4)
     k = tp.blur_kernel(KERNEL)
@@ -84,7 +85,8 @@ def cpu_baseline(batch, hidden, scales, timed_steps=2):
     return {"value": round(batch / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"{timed_steps} timed proposed-loss steps after 1 warm-up ({t1 - t0:.1f} s) of the same U-Net at "
                       f"batch {batch} (crop {CROP}, 3 fwd + 3 bwd + Adam), float32, torch CPU ops in the reference's "
-                      f"order (oracle/torch_path.py), {dt:.1f} s per step"}
+                      f"order (oracle/torch_path.py), {dt:.1f} s per step; {threads} intra-op threads = the CPUs this process may use "
+                      f"(affinity and cgroup quota; the host has {os.cpu_count()} logical CPUs)"}
 
 
 # Algorithmic HBM bytes of one launch of the streaming entry points, from the call's own arguments (DESIGN.md

@@ -18,3 +18,29 @@ Parity pin status: PINNED for every in-tree reference function (goldens G1..G9, 
 outputs). UNPINNED for the deepinv-owned glue (EILoss, GaussianNoise), which is
 restated from its documented behaviour only -- see DESIGN.md.
 """
+
+
+def usable_cpus():
+    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup quota (cpu.max). A GPU box
+    reports 256 logical CPUs but grants 16 (cpu.max = 1600000 100000); torch's default of 128 intra-op threads then
+    oversubscribes them 8-fold and the float64 oracle runs an order of magnitude slower (measured: one small U-Net
+    forward + backward 9.3 s with 128 threads, 0.76 s with 16)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def use_all_usable_cpus():
+    """Size torch's intra-op pool to `usable_cpus()` (the tests and bench.py's cpu_baseline leg call this before the
+    oracle runs); returns the thread count in effect."""
+    import torch
+    n = usable_cpus()
+    if torch.get_num_threads() != n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()

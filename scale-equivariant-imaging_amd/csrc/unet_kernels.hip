@@ -625,18 +625,21 @@ __device__ __forceinline__ float half_wave_sum(float v) {        // over the 32 
     return v;
 }
 
-// forward hidden(32, NHWC) -> CS <= 4 channels: y[p, co] = bias[co] + sum_{t, ci} w[co][ci][t] x[p + t, ci] (+ res)
+// forward hidden(32, NHWC) -> CS <= 4 channels: y[p, co] = bias[co] + sum_{t, ci} w[co][ci][t] x[p + t, ci] (+ res);
+// transposed = 1: the data gradient of a CS -> 32 convolution (w is THAT convolution's (32, CS, 3, 3) weight, read with
+// flipped taps and swapped channel roles): gx[p, c] = sum_{t, co} w[co][c][8 - t] gy[p + t, co]
 template <int CS>
 __global__ __launch_bounds__(C3_THREADS) void conv3x3_c32_to_small_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
     const float *__restrict__ res, float *__restrict__ y, int B, int H, int W, int nchw_out, int nruns_row,
-    int total_runs) {
+    int total_runs, int transposed) {
     const int ci = threadIdx.x & 31, grp = threadIdx.x >> 5;
     float wr[CS][9];
 #pragma unroll
     for (int co = 0; co < CS; ++co)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wr[co][t] = w[((size_t)co * 32 + ci) * 9 + t];
+        for (int t = 0; t < 9; ++t)
+            wr[co][t] = transposed ? w[((size_t)ci * CS + co) * 9 + (8 - t)] : w[((size_t)co * 32 + ci) * 9 + t];
     for (int run = blockIdx.x * (C3_THREADS / 32) + grp; run < total_runs; run += gridDim.x * (C3_THREADS / 32)) {
         const int jr = run % nruns_row, bi = run / nruns_row;
         const int i = bi % H, b = bi / H;
@@ -1354,14 +1357,15 @@ extern "C" int sei_conv3x3_fwd(const float *x, const float *w, const float *bias
     const size_t npix = (size_t)B * H * W;
     const unsigned pgrid = capped_grid(npix, C3_THREADS, 8192);
     hipStream_t s = (hipStream_t)stream;
-    if (Cin == 32 && Cout <= 4 && !nchw_in && !transposed) {      // hidden -> image: lanes = hidden channels
+    if (Cin == 32 && Cout <= 4 && !nchw_in) {      // hidden -> image (or the data gradient of image -> hidden, whose
+        // pixel-per-thread form took 8 ms per launch on the 192 x 192 grids of the x4 network): lanes = hidden channels
         const int nruns_row = (int)sei_ceil_div(W, C3L_RUN);
         const size_t runs = (size_t)B * H * nruns_row;
         SEI_REQUIRE(runs < ((size_t)1 << 31));
         const dim3 grid(capped_grid(runs, C3_THREADS / 32, 65535));
 #define SEI_C3_LANES(CS)                                                                                            \
     hipLaunchKernelGGL(conv3x3_c32_to_small_kernel<CS>, grid, dim3(C3_THREADS), 0, s, x, w, bias, res, y, B, H, W, \
-                       nchw_out ? 1 : 0, nruns_row, (int)runs);                                                     \
+                       nchw_out ? 1 : 0, nruns_row, (int)runs, transposed ? 1 : 0);                                 \
     return sei_launch_status();
         switch (Cout) {
             case 1: SEI_C3_LANES(1)

@@ -18,6 +18,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import oracle
+    oracle.use_all_usable_cpus()       # the CPU oracle on the cgroup's CPUs, not on every logical CPU of the host
 
 
 def pytest_collection_modifyitems(config, items):
