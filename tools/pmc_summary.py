@@ -18,10 +18,31 @@ import re
 import sys
 
 
+WINDOW = None      # "start=<regex>": dispatches from the first kernel matching on; "endmark=<regex>": whole steps, each ENDING
+                   # with a kernel matching (the run's earlier dispatches -- warm-up, capture preparation -- are left out)
+
+
+def _first_dispatch(rows):
+    if not WINDOW:
+        return 0
+    kind, pat = WINDOW.split("=", 1)
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    hits = sorted({int(r["Dispatch_Id"]) for r in rows if re.search(pat, r["Kernel_Name"])})
+    if not hits:
+        return 0
+    if kind == "start":
+        return hits[0]
+    ends = [h for k, h in enumerate(hits) if k + 1 == len(hits) or hits[k + 1] - h > 8]     # last launch of each group
+    period = ends[1] - ends[0] if len(ends) > 1 else ends[0] - ids[0] + 1
+    return ends[0] - period + 1
+
+
 def load(path, counter):
     d = collections.defaultdict(lambda: [0.0, 0, 0.0])
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
+    rows = list(csv.DictReader(open(path)))
+    first = _first_dispatch(rows)
+    for r in rows:
+        if r["Counter_Name"] != counter or int(r["Dispatch_Id"]) < first:
             continue
         k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         k = re.sub(r"\(.*", "", k)
@@ -34,7 +55,9 @@ def load(path, counter):
 def main():
     src, out = sys.argv[1], sys.argv[2]
     title = sys.argv[3] if len(sys.argv) > 3 else "PMC passes of bench.py (bf16, eager launches, 3 steps)"
-    exclude = re.compile(sys.argv[4]) if len(sys.argv) > 4 else None      # kernels kept out of the GEMM family
+    exclude = re.compile(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] else None   # kernels kept out of the GEMM family
+    global WINDOW
+    WINDOW = sys.argv[5] if len(sys.argv) > 5 else None
     F = load(f"{src}/pmc_FETCH_SIZE/pmc_counter_collection.csv", "FETCH_SIZE")
     W = load(f"{src}/pmc_WRITE_SIZE/pmc_counter_collection.csv", "WRITE_SIZE")
     Mb = load(f"{src}/pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_counter_collection.csv", "SQ_VALU_MFMA_BUSY_CYCLES")
