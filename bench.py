@@ -128,7 +128,9 @@ def _stream_bytes(name, a):
         B, H, W, heads = (a[5:9] if bwd else a[3:7])
         width = heads * (32 if bf16 else a[9 if bwd else 7])
         return B * H * W * width * (2 if bf16 else 4) * (8 if bwd else 4)
-    if name == "sei_sepmap2_packed":
+    if name == "sei_sepmap2_bf16_pack":
+        return 0
+    if name in ("sei_sepmap2_packed", "sei_sepmap2_bf16"):
         B, Hi, Wi, Ho, Wo, C = a[2:8]
         return 4 * B * C * (Hi * Wi + Ho * Wo)
     if name == "sei_cast_transpose_bf16":

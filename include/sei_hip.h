@@ -319,6 +319,18 @@ int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo,
 /* The same map with the four matrices packed for the kernel's scalar loads (what the build's host code uses):
  * RW[j][j'][t] = R_t[j'][j] with j' padded to a multiple of 24 (zeros), LH[i][t][i'] = L_t[i'][i] with i' padded
  * to a multiple of 24. Results are bit-identical to sei_sepmap2. */
+/* The same map in the bf16 throughput mode, on the matrix cores (sepmap_mfma.hip): activations rounded to bf16 (x before
+ * the W product, the intermediate between the products), the four matrices as bf16 head + remainder (exact to ~2^-17),
+ * f32 accumulation and output. Eligible shapes only (sei_sepmap2_bf16_eligible: 24 <= Hi, Wi <= 64 with the
+ * intermediate of one image x 16 channels in LDS, C % 16 == 0); SEI_ERR_BAD_ARG otherwise -- the caller takes
+ * sei_sepmap2_packed. `packed`: the matrices in the kernel's LDS image, made once per map by sei_sepmap2_bf16_pack from
+ * L1, L2: (Ho, Hi), R1, R2: (Wo, Wi) float32 row-major into sei_sepmap2_bf16_pack_elems(..) uint16 elements. */
+int sei_sepmap2_bf16(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C, const uint16_t *packed,
+                     void *stream);
+int sei_sepmap2_bf16_pack(const float *L1, const float *R1, const float *L2, const float *R2, uint16_t *packed, int Hi,
+                          int Wi, int Ho, int Wo, void *stream);
+size_t sei_sepmap2_bf16_eligible(int B, int Hi, int Wi, int Ho, int Wo, int C);
+size_t sei_sepmap2_bf16_pack_elems(int Hi, int Wi, int Ho, int Wo);
 int sei_sepmap2_packed(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
                        const float *RW, const float *LH, float *work, size_t work_floats, void *stream);
 

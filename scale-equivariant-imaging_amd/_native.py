@@ -68,6 +68,8 @@ SIGNATURES = {
     "sei_gemm_bf16nt_dw2_taps": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "sei_sepmap2": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P],
     "sei_sepmap2_packed": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P],
+    "sei_sepmap2_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "sei_sepmap2_bf16_pack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sei_colsum_f32": [_P, _P, _Z, _I, _P],
     "sei_colsum_weighted_f32": [_P, _P, _P, _Z, _I, _P],
     "sei_mlp_fused_fwd": [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P],
@@ -100,6 +102,8 @@ SIZE_QUERIES = {
     "sei_dwconv7_bwd_weight_workspace_ex": [_I, _I, _I, _I, _I],
     "sei_ln_bwd_workspace": [_Z, _I],
     "sei_dwconv7_ln_fwd_launches": [_I, _I, _I, _I],
+    "sei_sepmap2_bf16_eligible": [_I, _I, _I, _I, _I, _I],
+    "sei_sepmap2_bf16_pack_elems": [_I, _I, _I, _I],
     "sei_swin_partials_floats": [_I],
 }
 ABI_VERSION = 5       # SEI_ABI_VERSION of include/sei_hip.h this table was written against

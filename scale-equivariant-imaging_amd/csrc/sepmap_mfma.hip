@@ -1,0 +1,269 @@
+// Ideal{Down,Up}sample on the matrix cores (bf16 throughput mode), gfx950.
+// (reference: src/models/convolutional.py:54-92,113-133 -- the FFT "ideal" resamplers, which are exactly the real
+//  separable rank-2 map  y[b,:,:,c] = L1 X R1^T + L2 X R2^T  (models/_mats.py))
+//
+// The f32 kernels (sepmap_*_packed_kernel, unet_kernels.hip) evaluate the two dense products on packed f32 FMAs and
+// are bound by the FMA issue rate (1.36 G FMAs per fine-level call = 35 us at one wave-instruction per 4 cycles).
+// Per image row the W product is a small GEMM  T_t[i] (Wo x C) = R_t (Wo x Wi) . X_i (Wi x C)  and per output column
+// the H product is  Y[:, jo, :] (Ho x C) = [L1 L2] (Ho x 2 Hi) . [T1; T2][:, jo, :] (2 Hi x C): batches of GEMMs with
+// K = 12 ... 48 and N = the channel count, i.e. v_mfma_f32_16x16x32_bf16 work with the CONSTANT matrix as the A operand
+// and 16 channels on the lanes' columns.
+//
+// One workgroup (8 waves) = one image x 16 channels:
+//   pass W: a wave takes image rows i = wave, wave + 8, ...; its B fragments (8 consecutive input columns of one
+//           channel per lane) come straight from global memory (f32 -> bf16 in registers: every element of x is
+//           loaded once), the A fragments (rows of R) from LDS; the result tile has the output column on the
+//           accumulator rows and the channel on the lane, and goes to LDS as bf16 in the layout the next product
+//           reads K-contiguous:  T[t][jo][c][i];
+//   pass H: a wave takes (output column jo, 16-row tile of Ho) pairs: A = rows of [L1 L2] from LDS, B = T[t][jo][c][i..]
+//           (one ds_read_b128 per fragment), f32 results straight to y (64-byte segments: 16 channels).
+// The matrices are split into a bf16 head and a bf16 remainder (two MFMAs per product): the operator itself stays
+// exact to ~2^-17 and only the ACTIVATIONS are rounded to bf16 (x before the W product, T between the products) -- the
+// rounding every GEMM operand of this mode already has. Matrix-core time is negligible (a few hundred MFMAs per
+// workgroup); the kernel streams x once and y once.
+// Eligible: 24 <= Hi, Wi <= 48 (the T image of one workgroup must fit LDS), C % 16 == 0; everything else stays on the
+// f32 kernels (the 3x3 / 6x6 levels cost ~13 us there; larger images -- the x4 network -- need T tiled over jo).
+#include "sei_common.h"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int SMM_THREADS = 512, SMM_WAVES = 8;
+constexpr int SMM_NC = 16;                        // channels per workgroup = the MFMA's N
+constexpr int SMM_PADK = 8;                       // bf16 elements of padding per K-contiguous LDS row (bank spread)
+constexpr int SMM_LDS = 152 * 1024;
+
+__device__ __forceinline__ unsigned short smm_f2bf(float v) {
+    const __bf16 b = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float smm_bf2f(unsigned short u) {
+    return __builtin_bit_cast(float, (unsigned)u << 16);
+}
+
+struct SmmGeom {
+    int B, Hi, Wi, Ho, Wo, C;
+    int HiP, WiP;          // K extents padded to 32
+    int HoT, WoT;          // 16-row tiles of the outputs
+    int ldR, ldL, ldT;     // LDS row strides in elements (K extent + SMM_PADK)
+    int offRlo, offL, offLlo, offT;   // element offsets of the LDS sections (R head at 0)
+};
+
+// The four matrices in the kernel's LDS image (sei_sepmap2_bf16_pack, once per map): bf16 head + remainder, zero-padded
+// to 16-row tiles x (K padded to 32, + SMM_PADK): [R head | R remainder | L head | L remainder], each [t][row][k].
+__global__ __launch_bounds__(256) void sepmap_pack_kernel(const float *__restrict__ L1, const float *__restrict__ R1,
+                                                          const float *__restrict__ L2, const float *__restrict__ R2,
+                                                          unsigned short *__restrict__ out, SmmGeom g) {
+    const int nR = 2 * g.WoT * 16 * g.ldR, nL = 2 * g.HoT * 16 * g.ldL;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nR + nL; e += gridDim.x * 256) {
+        float v = 0.f;
+        int hi_at, lo_at;
+        if (e < nR) {
+            const int k = e % g.ldR, row = (e / g.ldR) % (g.WoT * 16), t = e / (g.ldR * g.WoT * 16);
+            if (row < g.Wo && k < g.Wi) v = (t ? R2 : R1)[(size_t)row * g.Wi + k];
+            hi_at = e;
+            lo_at = g.offRlo + e;
+        } else {
+            const int f = e - nR;
+            const int k = f % g.ldL, row = (f / g.ldL) % (g.HoT * 16), t = f / (g.ldL * g.HoT * 16);
+            if (row < g.Ho && k < g.Hi) v = (t ? L2 : L1)[(size_t)row * g.Hi + k];
+            hi_at = g.offL + f;
+            lo_at = g.offLlo + f;
+        }
+        const unsigned short h = smm_f2bf(v);
+        out[hi_at] = h;
+        out[lo_at] = smm_f2bf(v - smm_bf2f(h));
+    }
+}
+
+__global__ __launch_bounds__(SMM_THREADS, 2) void sepmap_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                   const unsigned short *__restrict__ mats, SmmGeom g,
+                                                                   int items) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[SMM_LDS / 2];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lc = lane & 15, lg = lane >> 4;                  // MFMA column / row-in-tile, and the k group
+    const int ctiles = g.C / SMM_NC;
+
+    // ---- once per workgroup: the packed matrices -> LDS (16-byte copies); T's K padding (i >= Hi) zeroed -- it meets
+    //      zero matrix columns, but uninitialised LDS may hold NaN patterns; pass W never writes there
+    unsigned short *Rh = lds, *Rl = lds + g.offRlo, *Lh = lds + g.offL, *Ll = lds + g.offLlo, *T = lds + g.offT;
+    {
+        const int n16 = g.offT / 8;                             // the matrix sections, in 16-byte pieces
+        for (int e = threadIdx.x; e < n16; e += SMM_THREADS)
+            reinterpret_cast<uint4 *>(lds)[e] = reinterpret_cast<const uint4 *>(mats)[e];
+        const int first = g.Hi / 8 * 8;                         // (columns first .. Hi-1 are rewritten by every pass W)
+        const int pad8 = (g.ldT - first) / 8;                   // 16-byte pieces from there to the end of a T row
+        const int rows = 2 * g.Wo * SMM_NC;
+        for (int e = threadIdx.x; e < rows * pad8; e += SMM_THREADS) {
+            const int k = e % pad8, row = e / pad8;
+            *reinterpret_cast<uint4 *>(T + (size_t)row * g.ldT + first + 8 * k) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    __syncthreads();
+
+    const int ksW = g.WiP / 32, ksH = g.HiP / 32;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int b = item / ctiles, c0 = (item - b * ctiles) * SMM_NC;
+    // ---- pass W: T[t][jo][c][i] = sum_j R_t[jo][j] x[b][i][j][c0 + c] --------------------------------------------
+    const float *xb = x + (size_t)b * g.Hi * g.Wi * g.C + c0 + lc;
+    auto load_row = [&](int i, float (&v)[16]) {               // this lane's 8 (16) input columns of row i, one channel
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = ks * 32 + lg * 8 + jj;
+                v[ks * 8 + jj] = (ks < ksW && j < g.Wi) ? xb[((size_t)i * g.Wi + j) * g.C] : 0.f;
+            }
+    };
+    auto w_row = [&](int i, const float (&v)[16]) {
+        bf16x8 bx[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bx[e >> 3][e & 7] = (__bf16)v[e];
+        for (int t = 0; t < 2; ++t) {
+            for (int jt = 0; jt < g.WoT; ++jt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int arow = (t * g.WoT * 16 + jt * 16 + lc) * g.ldR + lg * 8;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (ks < ksW) {
+                        const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(Rh + arow + ks * 32);
+                        const bf16x8 al = *reinterpret_cast<const bf16x8 *>(Rl + arow + ks * 32);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bx[ks], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bx[ks], acc, 0, 0, 0);
+                    }
+                }
+                // accumulator: row (= jo within the tile) 4 * lg + r, column (= channel) lc
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jo = jt * 16 + 4 * lg + r;
+                    if (jo < g.Wo) T[((size_t)(t * g.Wo + jo) * SMM_NC + lc) * g.ldT + i] = smm_f2bf(acc[r]);
+                }
+            }
+        }
+    };
+    {   // three rows in flight per wave: the loads of rows i + 8 and i + 16 are issued before row i is multiplied
+        float va[16], vb[16], vc[16];
+        int i = wave;
+        if (i < g.Hi) load_row(i, va);
+        if (i + SMM_WAVES < g.Hi) load_row(i + SMM_WAVES, vb);
+        while (i < g.Hi) {
+            if (i + 2 * SMM_WAVES < g.Hi) load_row(i + 2 * SMM_WAVES, vc);
+            w_row(i, va);
+            i += SMM_WAVES;
+            if (i >= g.Hi) break;
+            if (i + 2 * SMM_WAVES < g.Hi) load_row(i + 2 * SMM_WAVES, va);
+            w_row(i, vb);
+            i += SMM_WAVES;
+            if (i >= g.Hi) break;
+            if (i + 2 * SMM_WAVES < g.Hi) load_row(i + 2 * SMM_WAVES, vb);
+            w_row(i, vc);
+            i += SMM_WAVES;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass H: y[b][io][jo][c0 + c] = sum_t sum_i L_t[io][i] T[t][jo][c][i] --------------------------------------
+    // Operand roles swapped against pass W: A = T[t][jo][c][i..] (row = channel), B = L_t[io][i..] (column = io), so the
+    // accumulator holds FOUR CONSECUTIVE CHANNELS of one output pixel per lane: one 16-byte store instead of four
+    // 4-byte ones. Two (jo, io-tile) items per iteration: independent chains, so the LDS reads and MFMAs of one cover
+    // the latencies of the other.
+    float *yb = y + (size_t)b * g.Ho * g.Wo * g.C + c0 + 4 * lg;
+    const int hitems = g.Wo * g.HoT;
+    auto h_item = [&](int it, f32x4 &acc) {
+        const int jo = it / g.HoT, ht = it - jo * g.HoT;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int lrow = (t * g.HoT * 16 + ht * 16 + lc) * g.ldL + lg * 8;
+            const size_t trow = ((size_t)(t * g.Wo + jo) * SMM_NC + lc) * g.ldT + lg * 8;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks < ksH) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(Lh + lrow + ks * 32);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(Ll + lrow + ks * 32);
+                    const bf16x8 at = *reinterpret_cast<const bf16x8 *>(T + trow + ks * 32);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at, bl, acc, 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto h_store = [&](int it, const f32x4 &acc) {
+        const int jo = it / g.HoT, ht = it - jo * g.HoT;
+        const int io = ht * 16 + lc;                              // accumulator: column = io, rows = channels 4 lg .. 4 lg + 3
+        if (io < g.Ho)
+            *reinterpret_cast<float4 *>(yb + ((size_t)io * g.Wo + jo) * g.C) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    };
+    for (int it = wave; it < hitems; it += 2 * SMM_WAVES) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        const int it1 = it + SMM_WAVES;
+        h_item(it, a0);
+        if (it1 < hitems) h_item(it1, a1);
+        h_store(it, a0);
+        if (it1 < hitems) h_store(it1, a1);
+    }
+    __syncthreads();                                            // T is rewritten by the next item's pass W
+    }
+}
+
+inline bool smm_plan(int B, int Hi, int Wi, int Ho, int Wo, int C, SmmGeom &g) {
+    if (B <= 0 || C <= 0 || C % SMM_NC != 0) return false;
+    // (smaller images: too little work per workgroup item, the f32 kernels tie or win -- 64 x 12 x 12 x 512: 48 us there)
+    if (Hi < 24 || Wi < 24 || Hi > 64 || Wi > 64 || Ho < 1 || Wo < 1 || Ho > 128 || Wo > 128) return false;
+    g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.C = C;
+    g.HiP = (Hi + 31) / 32 * 32;
+    g.WiP = (Wi + 31) / 32 * 32;
+    if (g.HiP > 64 || g.WiP > 64) return false;
+    g.HoT = (Ho + 15) / 16;
+    g.WoT = (Wo + 15) / 16;
+    g.ldR = g.WiP + SMM_PADK;
+    g.ldL = g.HiP + SMM_PADK;
+    g.ldT = g.HiP + SMM_PADK;
+    const size_t nR = (size_t)2 * g.WoT * 16 * g.ldR, nL = (size_t)2 * g.HoT * 16 * g.ldL;
+    const size_t nT = (size_t)2 * Wo * SMM_NC * g.ldT;
+    g.offRlo = (int)nR;
+    g.offL = (int)(2 * nR);
+    g.offLlo = (int)(2 * nR + nL);
+    g.offT = (int)(2 * nR + 2 * nL);
+    if ((size_t)B * (C / SMM_NC) >= ((size_t)1 << 31)) return false;
+    return (2 * nR + 2 * nL + nT) * 2 <= (size_t)SMM_LDS;
+}
+
+}  // namespace
+
+// 1 when sei_sepmap2_bf16 serves this shape, else 0 (the caller then takes sei_sepmap2_packed).
+extern "C" size_t sei_sepmap2_bf16_eligible(int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    SmmGeom g;
+    return smm_plan(B, Hi, Wi, Ho, Wo, C, g) ? 1 : 0;
+}
+
+// Elements (uint16) of the packed matrix image of a map (0 when no batch / channel count makes the shape eligible).
+extern "C" size_t sei_sepmap2_bf16_pack_elems(int Hi, int Wi, int Ho, int Wo) {
+    SmmGeom g;
+    return smm_plan(1, Hi, Wi, Ho, Wo, SMM_NC, g) ? (size_t)g.offT : 0;
+}
+
+// L1, L2: (Ho, Hi), R1, R2: (Wo, Wi) float32 row-major -> the kernel's bf16 head + remainder image (once per map).
+extern "C" int sei_sepmap2_bf16_pack(const float *L1, const float *R1, const float *L2, const float *R2, uint16_t *packed,
+                                     int Hi, int Wi, int Ho, int Wo, void *stream) {
+    SEI_REQUIRE(L1 && R1 && L2 && R2 && packed);
+    SmmGeom g;
+    if (!smm_plan(1, Hi, Wi, Ho, Wo, SMM_NC, g)) return SEI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sepmap_pack_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, L1, R1, L2, R2, packed, g);
+    return sei_launch_status();
+}
+
+// y[b,:,:,c] = L1 X R1^T + L2 X R2^T with bf16-rounded activations on the matrix cores (bf16 throughput mode); `packed`
+// from sei_sepmap2_bf16_pack for the same (Hi, Wi, Ho, Wo), 16-byte aligned. SEI_ERR_BAD_ARG when not eligible.
+extern "C" int sei_sepmap2_bf16(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                const uint16_t *packed, void *stream) {
+    SEI_REQUIRE(x && y && packed && x != y && (reinterpret_cast<uintptr_t>(packed) & 15) == 0);
+    SmmGeom g;
+    if (!smm_plan(B, Hi, Wi, Ho, Wo, C, g)) return SEI_ERR_BAD_ARG;
+    const int items = B * (C / SMM_NC);
+    const int grid = items < 256 ? items : 256;                 // one resident workgroup per CU walks its items
+    hipLaunchKernelGGL(sepmap_mfma_kernel, dim3((unsigned)grid), dim3(SMM_THREADS), 0, (hipStream_t)stream, x, y, packed, g,
+                       items);
+    return sei_launch_status();
+}

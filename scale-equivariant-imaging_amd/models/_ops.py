@@ -173,6 +173,38 @@ def sepmap2(x, mats, Ho, Wo):
     return y
 
 
+# SEI_SEPMAP_F32=1 keeps the resamplers of the bf16 mode on the f32 FMA kernels (A/B runs)
+_SEPMAP_MFMA = __import__("os").environ.get("SEI_SEPMAP_F32") != "1"
+
+
+def sepmap2_16(x, mats, Ho, Wo):
+    """sepmap2 in the bf16 throughput mode: on the matrix cores where the shape is eligible (sei_sepmap2_bf16:
+    activations rounded to bf16, matrices as bf16 head + remainder, f32 accumulation), else the f32 kernels."""
+    B, Hi, Wi, C = x.shape
+    if _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_bf16_eligible(B, Hi, Wi, Ho, Wo, C):
+        y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        N.call("sei_sepmap2_bf16", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, _packed16(mats).data_ptr())
+        return y
+    return sepmap2(x, mats, Ho, Wo)
+
+
+_PACKED16 = {}
+
+
+def _packed16(mats):
+    """The map's matrices in sei_sepmap2_bf16's image (bf16 head + remainder), packed once per matrix set."""
+    L1, R1, L2, R2 = mats[:4]
+    key = (L1.data_ptr(), R1.data_ptr(), L2.data_ptr(), R2.data_ptr(), tuple(L1.shape), tuple(R1.shape))
+    hit = _PACKED16.get(key)
+    if hit is None:
+        (Ho, Hi), (Wo, Wi) = L1.shape, R1.shape
+        out = torch.empty(N.lib().sei_sepmap2_bf16_pack_elems(Hi, Wi, Ho, Wo), dtype=torch.int16, device=L1.device)
+        N.call("sei_sepmap2_bf16_pack", L1.data_ptr(), R1.data_ptr(), L2.data_ptr(), R2.data_ptr(), out.data_ptr(), Hi, Wi,
+               Ho, Wo)
+        hit = _PACKED16[key] = (out, L1, R1, L2, R2)          # (keeps the sources alive: the key holds their addresses)
+    return hit[0]
+
+
 def _nhwc(x):
     N.check_tensor(x, "activation")
     if x.dim() != 4:
@@ -809,7 +841,7 @@ class DownsampleFn16(torch.autograd.Function):
         h, mean, rstd = layer_norm(x.view(M, C), gamma, beta)
         fwd, bwd = _mats.resample_matrices("down", H, W, rate, x.device)
         Ho, Wo = fwd[0].shape[0], fwd[1].shape[0]
-        u = sepmap2(h.view(B, H, W, C), fwd, Ho, Wo)
+        u = sepmap2_16(h.view(B, H, W, C), fwd, Ho, Wo)
         Mo = B * Ho * Wo
         s = _mats.constant_response("down", H, W, rate, x.device, B)
         u16 = cast16(u.view(Mo, C))
@@ -832,7 +864,7 @@ class DownsampleFn16(torch.autograd.Function):
         gu = torch.empty((Mo, C), dtype=torch.float32, device=x.device)
         gemm_nt16(go16, shadow(w), Mo, C, Co, EPI_NONE, out32=gu, b_rmajor=True)
         weight_grad16(go16, u16, grad_of(w).view(Co, C))           # after the data gradient: see ConvBlockFn16.backward
-        gh = sepmap2(gu.view(B, Ho, Wo, C), ctx.mats_t, H, W).view(M, C)
+        gh = sepmap2_16(gu.view(B, Ho, Wo, C), ctx.mats_t, H, W).view(M, C)
         gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
         return (gx if ctx.needs_input_grad[0] else None), None, None, None, None, None
 
@@ -845,7 +877,7 @@ class UpsampleFn16(torch.autograd.Function):
         Co = w.shape[0]
         fwd, bwd = _mats.resample_matrices("up", H, W, rate, x.device)
         Ho, Wo = fwd[0].shape[0], fwd[1].shape[0]
-        u = sepmap2(x, fwd, Ho, Wo)
+        u = sepmap2_16(x, fwd, Ho, Wo)
         M = B * Ho * Wo
         h, mean, rstd = layer_norm16(u.view(M, C), gamma, beta)
         w16 = shadow(w)
@@ -876,7 +908,7 @@ class UpsampleFn16(torch.autograd.Function):
         gu = layer_norm_bwd(u.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta))
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = sepmap2(gu.view(B, Ho, Wo, C), ctx.mats_t, *ctx.in_hw)
+            gx = sepmap2_16(gu.view(B, Ho, Wo, C), ctx.mats_t, *ctx.in_hw)
         gskip = go if ctx.needs_input_grad[1] else None
         return gx, gskip, None, None, None, None, None
 

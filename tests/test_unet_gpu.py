@@ -194,6 +194,44 @@ def test_dwconv7_layernorm_fused_forward(ops, B, H, W, C, out16):
     assert relerr(mean, ref1.double().view(M, C).mean(1)) < 1e-5
 
 
+@pytest.mark.parametrize("kind,B,H,W,C", [("down", 3, 48, 48, 32), ("up", 2, 24, 24, 128), ("down", 2, 24, 24, 128),
+                                          ("down", 5, 28, 24, 64), ("up", 1, 24, 24, 48), ("down", 2, 40, 28, 48),
+                                          ("down", 300, 24, 24, 16)])
+def test_resampler_on_the_matrix_cores(ops, kind, B, H, W, C):
+    """sei_sepmap2_bf16 (Ideal{Down,Up}sample as two small-GEMM passes on v_mfma_f32_16x16x32_bf16, bf16 mode) against
+    the f32 kernel and against float64 on the matrices of models/_mats.py: activations are rounded to bf16 (x, and the
+    intermediate between the two products), the matrices are split into head + remainder, so the error is a few bf16
+    roundings of the data; forward and transposed (backward) maps, ragged tiles, non-square images."""
+    import _native
+    from models import _mats
+    rate = 2
+    fwd, bwd = _mats.resample_matrices(kind, H, W, rate, "cuda")
+    gen = torch.Generator().manual_seed(B + H + C)
+    x = torch.randn((B, H, W, C), generator=gen).cuda()
+    Ho, Wo = fwd[0].shape[0], fwd[1].shape[0]
+    assert _native.lib().sei_sepmap2_bf16_eligible(B, H, W, Ho, Wo, C) == 1
+    for mats, xin, ho, wo in ((fwd, x, Ho, Wo), (bwd, torch.randn((B, Ho, Wo, C), generator=gen).cuda(), H, W)):
+        if not _native.lib().sei_sepmap2_bf16_eligible(xin.shape[0], xin.shape[1], xin.shape[2], ho, wo, C):
+            continue                                        # (the transposed 96 -> 48 map of the widest case)
+        y16 = ops.sepmap2_16(xin, mats, ho, wo)
+        y32 = ops.sepmap2(xin, mats, ho, wo)
+        L1, R1, L2, R2 = (m.double().cpu() for m in mats[:4])
+        xd = xin.double().cpu()
+        ref = torch.einsum("pi,bijc,qj->bpqc", L1, xd, R1) + torch.einsum("pi,bijc,qj->bpqc", L2, xd, R2)
+        assert relerr(y32, ref) < 5e-6
+        scale = float(ref.abs().max())
+        err = float((y16.double().cpu() - ref).abs().max()) / scale
+        assert err < 1.5e-2, err                            # max-norm: a few 2^-9 roundings of the largest terms
+        rms = float((y16.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        assert rms < 4e-3, rms
+        # exact on data that bf16 represents: integers through a 0/1 matrix-free check is not available here, so the
+        # run-to-run determinism (no atomics) is asserted instead
+        assert torch.equal(y16, ops.sepmap2_16(xin, mats, ho, wo))
+    assert _native.lib().sei_sepmap2_bf16_eligible(2, 6, 6, 12, 12, 2048) == 0     # small levels stay on the f32 kernels
+    assert _native.lib().sei_sepmap2_bf16_eligible(2, 12, 12, 24, 24, 512) == 0
+    assert _native.lib().sei_sepmap2_bf16_eligible(2, 96, 96, 192, 192, 128) == 0  # the x4 network's fine levels too
+
+
 @pytest.mark.parametrize("B,H,W,C", DW_SHAPES[:6])
 def test_dwconv7(ops, B, H, W, C):
     from _native import call
