@@ -172,7 +172,7 @@ def _stream_bytes(name, a):
 
 _STREAM_FAMILIES = [
     ("adam_vec_kernel (fused Adam over the flat bucket)", ("sei_adam_fused",)),
-    ("gemm_bf16nt_kernel<..., ADAM> (deep-level weight gradients whose epilogue applies the Adam step)",
+    ("gemm_bf16nt_kernel<..., ADAM> (HBM-bound weight gradients whose epilogue applies the Adam step: the bottleneck pair)",
      ("sei_gemm_bf16nt_dw2_adam",)),
     ("dwconv7_* (depthwise 7x7: forward, data and weight gradients)", ("sei_dwconv7_",)),
     ("ln_* (channel LayerNorm forward / backward)", ("sei_ln_",)),
@@ -189,10 +189,22 @@ PMC_TRAFFIC_FILE = "r03_d_unet_pmc_gemm.json"      # the committed PMC pass `roo
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+# A weight-gradient GEMM with the Adam step in its epilogue moves 26 B per output element under 2 (K1 + K2) FLOP: the
+# bottleneck pair (K = 864) sits at 66 FLOP per byte -- HBM-bound, booked with the streaming families --, the level-3
+# launches (K = 3456) at 264 FLOP per byte run at ~600 TFLOP/s and belong to the MFMA family.
+ADAM_GEMM_MFMA_INTENSITY = 150.0
+
+
+def adam_gemm_is_mfma_bound(args):
+    M, Nn, K1, K2 = args[11:15]
+    return 2.0 * M * Nn * (K1 + K2) / _stream_bytes("sei_gemm_bf16nt_dw2_adam", args) > ADAM_GEMM_MFMA_INTENSITY
+
+
 def stream_roofline(log, reps=3):
     """Re-issue the logged streaming launches of one step, family by family, between HIP events."""
     import _native
     out = []
+    log = [(n, a) for n, a in log if not (n == "sei_gemm_bf16nt_dw2_adam" and adam_gemm_is_mfma_bound(a))]
     for label, prefixes in _STREAM_FAMILIES:
         calls = [(n, a) for n, a in log if n.startswith(prefixes) and _stream_bytes(n, a) is not None]
         if not calls:
@@ -376,13 +388,15 @@ class Leg:
 
 
 def gemm_roofline(records, dtype, reps=3):
-    """MFMA-bound family. The weight-gradient GEMMs that carry the optimizer step in their epilogue move 26 bytes per
-    output element under 1.7 kFLOP of matrix work: they are HBM-bound and are booked with the streaming families
-    (stream_roofline), FLOPs and all; re-issuing them here would also step their weights again."""
+    """MFMA-bound family. The bottleneck level's weight-gradient GEMMs that carry the optimizer step in their epilogue
+    move 26 bytes per output element under 1.7 kFLOP of matrix work: they are HBM-bound and are booked with the streaming
+    families (stream_roofline), FLOPs and all; the level-3 ones (K = 3456) are MFMA-bound and are timed here. (Re-issuing
+    any of them steps their weights again: `rooflines` restores the optimizer state afterwards.)"""
     import _native
     total_ms, flops = 0.0, 0.0
-    riding = sum(fl for fl, entry, _ in records if entry == "sei_gemm_bf16nt_dw2_adam")
-    records = [r for r in records if r[1] != "sei_gemm_bf16nt_dw2_adam"]
+    hbm_side = lambda r: r[1] == "sei_gemm_bf16nt_dw2_adam" and not adam_gemm_is_mfma_bound(r[2])
+    riding = sum(fl for fl, entry, a in records if hbm_side((fl, entry, a)))
+    records = [r for r in records if not hbm_side(r)]
     for fl, entry, cargs in records:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         _native.call(entry, *cargs)                 # warm

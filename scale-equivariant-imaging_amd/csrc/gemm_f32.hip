@@ -244,9 +244,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-template <int TM, int TN, bool TA, bool TB>
+template <int TM, int TN, bool TA, bool TB, int WM = 2, int WN = 2>
 int launch(const GemmArgs &g, hipStream_t s) {
-    constexpr int WM = 2, WN = 2;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     dim3 grid((unsigned)sei_ceil_div(g.N, BN), (unsigned)sei_ceil_div(g.M, BM), (unsigned)(g.splitk * g.batch));
     hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, WM, WN, TA, TB>), grid, dim3(WM * WN * 64), 0, s, g);
@@ -259,6 +258,16 @@ int dispatch_layout(const GemmArgs &g, int ta, int tb, hipStream_t s) {
     if (!ta && !tb) return launch<TM, TN, false, false>(g, s);
     if (ta && !tb) return launch<TM, TN, true, false>(g, s);
     return launch<TM, TN, true, true>(g, s);
+}
+
+// 96 x 128 tiles (one row of four waves, three 32 x 32 accumulator tiles each): the bottleneck level's activation
+// matrices have 288 or 576 rows (9 pixels x 32 or 64 crops), which 128-row tiles cover with 25 % / 10 % of their MFMAs
+// on rows that do not exist.
+int dispatch_layout_96(const GemmArgs &g, int ta, int tb, hipStream_t s) {
+    if (!ta && tb) return launch<3, 1, false, true, 1, 4>(g, s);
+    if (!ta && !tb) return launch<3, 1, false, false, 1, 4>(g, s);
+    if (ta && !tb) return launch<3, 1, true, false, 1, 4>(g, s);
+    return launch<3, 1, true, true, 1, 4>(g, s);
 }
 
 inline size_t tiles(int M, int N, int bm, int bn) { return sei_ceil_div(M, bm) * sei_ceil_div(N, bn); }
@@ -304,6 +313,9 @@ extern "C" int sei_gemm_f32_ex(const float *A, const float *B, float *D, int M, 
         }
     }
     hipStream_t s = (hipStream_t)stream;
+    // rows in whole 96-row tiles but not in whole 128-row ones, and enough tiles to fill the chip: no padded rows
+    if (tm == 2 && g.splitk == 1 && M % 96 == 0 && M % 128 != 0 && tiles(M, N, 96, 128) * batch >= want)
+        return dispatch_layout_96(g, transA, transB, s);
     if (tm == 2) return dispatch_layout<2, 2>(g, transA, transB, s);
     if (tn == 2) return dispatch_layout<1, 2>(g, transA, transB, s);
     return dispatch_layout<1, 1>(g, transA, transB, s);

@@ -80,6 +80,23 @@ def test_gemm_epilogues(ops):
     assert relerr(base, acc + R2.double()) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [(288, 24576, 96, 0, 1), (576, 16384, 72, 0, 0), (288, 22528, 40, 1, 0),
+                                         (576, 16400, 64, 1, 1)])
+def test_gemm_96_row_tiles(ops, M, N, K, ta, tb):
+    """The 96 x 128 tile of the f32 GEMM (one row of four waves, three accumulator tiles each): chosen for the bottleneck
+    level's 288- / 576-row matrices when whole 96-row tiles fill the chip; all four layouts, a ragged last column tile,
+    and an epilogue with row-indexed inputs (BIAS_RES on the same launch geometry)."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), generator=gen)
+    Bm = torch.randn((N, K) if tb else (K, N), generator=gen)
+    ref = (A.double().T if ta else A.double()) @ (Bm.double().T if tb else Bm.double())
+    out = ops.gemm(A.cuda(), Bm.cuda(), M, N, K, ta, tb, ops.EPI_NONE)
+    assert relerr(out, ref) < 2e-6
+    bias, R1 = torch.randn(N, generator=gen), torch.randn((M, N), generator=gen)
+    out = ops.gemm(A.cuda(), Bm.cuda(), M, N, K, ta, tb, ops.EPI_BIAS_RES, bias=bias.cuda(), R1=R1.cuda())
+    assert relerr(out, ref + bias.double() + R1.double()) < 2e-6
+
+
 def test_gemm_splitk_weight_gradient_shape(ops):
     # dW[128,32] = dY^T X over 73,728 pixel rows: the split-K + atomics path
     gen = torch.Generator().manual_seed(4)
