@@ -116,7 +116,7 @@ class GraphedLossStep:
             self.early_grads = self._plan_early_release(_ops)
         self.fused_views, self.fused_table = [], None
         if fuse_optimizer and self.store_weight_grads and hasattr(optimizer, "fuse_weight_updates") \
-                and _ops.get_compute_dtype() == "bf16" and getattr(optimizer, "reducer", None) is None:
+                and _ops.get_compute_dtype(backbone) == "bf16" and getattr(optimizer, "reducer", None) is None:
             grads = self.backbone.flat_grads
             base, esz = grads.data_ptr(), grads.element_size()
             for prm in self.backbone.parameters():
@@ -133,7 +133,7 @@ class GraphedLossStep:
         self.direct_views = []
         reducer = getattr(optimizer, "reducer", None)
         if direct_bf16_grads and self.store_weight_grads and reducer is not None and reducer.comm is not reducer.flat \
-                and reducer.comm.dtype == torch.bfloat16 and _ops.get_compute_dtype() == "bf16":
+                and reducer.comm.dtype == torch.bfloat16 and _ops.get_compute_dtype(backbone) == "bf16":
             grads = self.backbone.flat_grads
             table, ranges = {}, []
             for prm in self.backbone.parameters():

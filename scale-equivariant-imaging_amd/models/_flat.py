@@ -19,6 +19,7 @@ class FlatParameterBucket:
         self.flat_grads = None
         self.flat_shadow = None
         self.flat_shadow_only_start = None
+        self.compute_dtype = None                 # "f32" / "bf16": this model's own mode; None = models._ops' process default
         self._sei_plain_state = {"gen": -1, "version": {}}
         self._sei_zero_ranges = None
         # load_state_dict copies into the parameters: cached bf16 shadows are stale afterwards

@@ -38,9 +38,14 @@ _GEMM_ENTRY = {"f32": "sei_gemm_f32_ex", "bf16": "sei_gemm_bf16_ex"}
 _COMPUTE_DTYPE = "f32"
 
 
+_DTYPE_SCOPE = []            # innermost compute_dtype_scope (a model call or a backward function of one) wins
+
+
 def set_compute_dtype(name):
-    """Arithmetic type of the 1x1-convolution GEMMs: "f32" (exact-f32 MFMA; the parity mode) or "bf16"
-    (bf16 MFMA with f32 accumulation; operands stay f32 in HBM). Everything else is f32 either way."""
+    """The PROCESS DEFAULT of the arithmetic type of the 1x1-convolution GEMMs: "f32" (exact-f32 MFMA; the parity mode)
+    or "bf16" (bf16 MFMA with f32 accumulation; operands stay f32 in HBM). Everything else is f32 either way. A backbone
+    may carry its own (`backbone.compute_dtype = "f32" | "bf16"`, None = the default): its forward pass and the backward
+    functions it recorded run under it (`compute_dtype_scope`), so two models of different modes can live in one process."""
     global _COMPUTE_DTYPE
     if name not in _GEMM_ENTRY:
         raise ValueError(f"compute dtype must be one of {sorted(_GEMM_ENTRY)}, got {name!r}")
@@ -48,8 +53,42 @@ def set_compute_dtype(name):
     return previous
 
 
-def get_compute_dtype():
-    return _COMPUTE_DTYPE
+def get_compute_dtype(owner=None):
+    """The mode in effect: `owner`'s own (a backbone), else the innermost scope's, else the process default."""
+    own = getattr(owner, "compute_dtype", None) if owner is not None else None
+    if own is not None:
+        return own
+    return _DTYPE_SCOPE[-1] if _DTYPE_SCOPE else _COMPUTE_DTYPE
+
+
+class compute_dtype_scope:
+    """`with compute_dtype_scope(backbone_or_name):` -- the GEMMs issued inside use that backbone's mode (or the named
+    one); a backbone without its own mode, or None, leaves the mode in effect unchanged."""
+
+    def __init__(self, owner_or_name):
+        name = owner_or_name if isinstance(owner_or_name, str) or owner_or_name is None \
+            else getattr(owner_or_name, "compute_dtype", None)
+        if name is not None and name not in _GEMM_ENTRY:
+            raise ValueError(f"compute dtype must be one of {sorted(_GEMM_ENTRY)}, got {name!r}")
+        self.name = name
+
+    def __enter__(self):
+        if self.name is not None:
+            _DTYPE_SCOPE.append(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if self.name is not None:
+            _DTYPE_SCOPE.pop()
+        return False
+
+
+def _in_forward_mode(fn):
+    """Decorator for the backward of an autograd Function whose forward stored `ctx.dtype = get_compute_dtype()`."""
+    def backward(ctx, *grads):
+        with compute_dtype_scope(getattr(ctx, "dtype", None)):
+            return fn(ctx, *grads)
+    return staticmethod(backward)
 
 
 def profile_gemms(enable):
@@ -69,7 +108,7 @@ def _gemm_call(flops, entry, *args):
 def gemm(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2=None, allow_splitk=True):
     if out is None:
         out = torch.empty((M, Nn), dtype=torch.float32, device=A.device)
-    _gemm_call(2.0 * M * Nn * K, _GEMM_ENTRY[_COMPUTE_DTYPE], A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K,
+    _gemm_call(2.0 * M * Nn * K, _GEMM_ENTRY[get_compute_dtype()], A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K,
                ta, tb, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2), 1, 0, 0, 0, int(allow_splitk))
     return out
 
@@ -220,6 +259,7 @@ def _nhwc(x):
 class ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, gamma, beta, w2, b2, w3, b3, twice):
+        ctx.dtype = get_compute_dtype()
         x = _nhwc(x)
         B, H, W, C = x.shape
         M = B * H * W
@@ -232,7 +272,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.twice = twice
         return out.view(B, H, W, C)
 
-    @staticmethod
+    @_in_forward_mode
     def backward(ctx, go):
         x, h1, mean, rstd, h2, h3, h4 = ctx.saved_tensors
         w1, b1, gamma, beta, w2, b2, w3, b3 = ctx.params
@@ -272,6 +312,7 @@ class DownsampleFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, w, b, rate):
+        ctx.dtype = get_compute_dtype()
         x = _nhwc(x)
         B, H, W, C = x.shape
         M, Co = B * H * W, w.shape[0]
@@ -286,7 +327,7 @@ class DownsampleFn(torch.autograd.Function):
         ctx.params, ctx.mats_t, ctx.hw = (gamma, beta, w, b), bwd, (H, W, Ho, Wo)
         return out.view(B, Ho, Wo, Co)
 
-    @staticmethod
+    @_in_forward_mode
     def backward(ctx, go):
         x, mean, rstd, u, s = ctx.saved_tensors
         gamma, beta, w, b = ctx.params
@@ -308,6 +349,7 @@ class DownsampleFn(torch.autograd.Function):
 class UpsampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, skip, gamma, beta, w, b, rate):
+        ctx.dtype = get_compute_dtype()
         x = _nhwc(x)
         B, H, W, C = x.shape
         Co = w.shape[0]
@@ -327,7 +369,7 @@ class UpsampleFn(torch.autograd.Function):
         ctx.params, ctx.mats_t, ctx.in_hw = (gamma, beta, w, b), bwd, (H, W)
         return out.view(B, Ho, Wo, Co)
 
-    @staticmethod
+    @_in_forward_mode
     def backward(ctx, go):
         u, mean, rstd, h = ctx.saved_tensors
         gamma, beta, w, b = ctx.params
@@ -718,7 +760,7 @@ def _queue_flush(_DW):
 
 def use_bf16_blocks(C):
     """A block takes the bf16-storage path when the mode is bf16 and its GEMMs fit the NT kernel."""
-    return _COMPUTE_DTYPE == "bf16" and C % 32 == 0
+    return get_compute_dtype() == "bf16" and C % 32 == 0
 
 
 # Levels whose ConvBlock MLP runs as the fused kernel. Measured on MI355X at batch 32 (2B pass): C = 32 wins
@@ -743,6 +785,7 @@ class ConvBlockFn16(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, gamma, beta, w2, b2, w3, b3, twice):
+        ctx.dtype = get_compute_dtype()
         x = _nhwc(x)
         B, H, W, C = x.shape
         M = B * H * W
@@ -771,7 +814,7 @@ class ConvBlockFn16(torch.autograd.Function):
         ctx.twice = twice
         return out.view(B, H, W, C)
 
-    @staticmethod
+    @_in_forward_mode
     def backward(ctx, go):
         if ctx.fused:
             return ConvBlockFn16._backward_fused(ctx, go)
@@ -835,6 +878,7 @@ class DownsampleFn16(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, w, b, rate):
+        ctx.dtype = get_compute_dtype()
         x = _nhwc(x)
         B, H, W, C = x.shape
         M, Co = B * H * W, w.shape[0]
@@ -851,7 +895,7 @@ class DownsampleFn16(torch.autograd.Function):
         ctx.params, ctx.mats_t, ctx.hw = (gamma, beta, w, b), bwd, (H, W, Ho, Wo)
         return out.view(B, Ho, Wo, Co)
 
-    @staticmethod
+    @_in_forward_mode
     def backward(ctx, go):
         x, mean, rstd, u16, s = ctx.saved_tensors
         gamma, beta, w, b = ctx.params
@@ -872,6 +916,7 @@ class DownsampleFn16(torch.autograd.Function):
 class UpsampleFn16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, skip, gamma, beta, w, b, rate):
+        ctx.dtype = get_compute_dtype()
         x = _nhwc(x)
         B, H, W, C = x.shape
         Co = w.shape[0]
@@ -893,7 +938,7 @@ class UpsampleFn16(torch.autograd.Function):
         ctx.params, ctx.mats_t, ctx.in_hw = (gamma, beta, w, b), bwd, (H, W)
         return out.view(B, Ho, Wo, Co)
 
-    @staticmethod
+    @_in_forward_mode
     def backward(ctx, go):
         u, mean, rstd, h = ctx.saved_tensors
         gamma, beta, w, b = ctx.params

@@ -86,6 +86,7 @@ class SwinBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, g1, b1, table, wqkv, bqkv, wproj, bproj, g2, b2, w1, bm1, w2, bm2, heads, shift, drop1, drop2):
+        ctx.dtype = _ops.get_compute_dtype()
         N.check_tensor(x, "tokens")
         B, H, W, C = x.shape
         M, Ch = B * H * W, w1.shape[0]
@@ -109,7 +110,7 @@ class SwinBlockFn(torch.autograd.Function):
         ctx.cfg = (heads, shift)
         return out.view(B, H, W, C)
 
-    @staticmethod
+    @_ops._in_forward_mode
     def backward(ctx, go):
         x, mean1, rstd1, h1, qkv, a, x1, mean2, rstd2, h2, f3, f4, drop1, drop2 = ctx.saved_tensors
         g1, b1, table, wqkv, bqkv, wproj, bproj, g2, b2, w1, bm1, w2, bm2 = ctx.params
@@ -159,6 +160,7 @@ class Conv3x3GemmFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, res, act):
+        ctx.dtype = _ops.get_compute_dtype()
         N.check_tensor(x, "conv3x3 input")
         B, H, W, Cin = x.shape
         Cout = weight.shape[0]
@@ -182,7 +184,7 @@ class Conv3x3GemmFn(torch.autograd.Function):
         ctx.params, ctx.cfg = (weight, bias), (B, H, W, Cin, Cout, guard, act)
         return y
 
-    @staticmethod
+    @_ops._in_forward_mode
     def backward(ctx, go):
         xp, wt, y_act = ctx.saved_tensors
         weight, bias = ctx.params

@@ -212,6 +212,10 @@ class ConvolutionalModel(FlatParameterBucket, Module):
 
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, y):
+        with _ops.compute_dtype_scope(self):           # this model's own arithmetic mode, if it carries one
+            return self._forward(y)
+
+    def _forward(self, y):
         y = N.check_tensor(y.contiguous(), "y")        # crops arrive as strided views
         _ops.note_forward(self)
         div = 2 ** (self.scales - 1)

@@ -221,6 +221,10 @@ class SwinIR(FlatParameterBucket, nn.Module):
     def forward(self, x, drop_masks="draw"):
         """x: (B, 3, H, W). drop_masks: "draw" (training: draw them here, eval: none), None, or the list returned by
         draw_drop_masks (injected by tests / a captured step)."""
+        with _ops.compute_dtype_scope(self):             # this model's own arithmetic mode, if it carries one
+            return self._forward(x, drop_masks)
+
+    def _forward(self, x, drop_masks):
         x = N.check_tensor(x.contiguous(), "x")
         _ops.note_forward(self)
         B, _, H, W = x.shape

@@ -59,7 +59,7 @@ class FlatAdam(torch.optim.Optimizer):
         from models import _ops
         flat, grads = self.backbone.flat_params, self.backbone.flat_grads
         st = self.state[flat]
-        shadow = getattr(self.backbone, "flat_shadow", None) if _ops.get_compute_dtype() == "bf16" else None
+        shadow = getattr(self.backbone, "flat_shadow", None) if _ops.get_compute_dtype(self.backbone) == "bf16" else None
         table, ranges = {}, []
         for gv in grad_views:
             off = (gv.data_ptr() - grads.data_ptr()) // grads.element_size()
@@ -126,7 +126,7 @@ class FlatAdam(torch.optim.Optimizer):
         """Chunk starting at `start` holds weights whose only reader in the next forward pass is their bf16 copy."""
         from models import _ops
         first = getattr(self.backbone, "flat_shadow_only_start", None)
-        return (_ops.get_compute_dtype() == "bf16" and getattr(self.backbone, "flat_shadow", None) is not None
+        return (_ops.get_compute_dtype(self.backbone) == "bf16" and getattr(self.backbone, "flat_shadow", None) is not None
                 and first is not None and start >= first)
 
     def _step_sharded(self, update, shadow):
@@ -249,7 +249,7 @@ class FlatAdam(torch.optim.Optimizer):
             grads = self.reducer.comm                     # the (possibly bf16-compressed) reduced bucket
             grads_16 = grads.dtype == torch.bfloat16
         from models import _ops
-        shadow = getattr(self.backbone, "flat_shadow", None) if _ops.get_compute_dtype() == "bf16" else None
+        shadow = getattr(self.backbone, "flat_shadow", None) if _ops.get_compute_dtype(self.backbone) == "bf16" else None
         if self.reducer is not None and self.reducer.mode == "sharded" and world > 1:
             def update(lo, hi, g, g16):
                 N.call("sei_adam_fused", flat[lo:hi].data_ptr(), g.data_ptr(), int(g16), st["exp_avg"][lo:hi].data_ptr(),

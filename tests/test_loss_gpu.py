@@ -1061,6 +1061,18 @@ def test_two_models_in_one_process_keep_their_own_step_state():
             assert relerr(bb.flat_grads, ref) < 2e-4
             assert not _ops.state_of(bb)["parked"] and len(_ops.merged_weight_grads(bb)) > 4
         assert _ops.state_of()["uses"] == 0                      # nothing leaked into the default state
+        # ... and a backbone may carry its own arithmetic mode: an exact-f32 model beside the bf16 one (process default
+        # bf16), interleaved with it, gives the gradients it gives alone in an f32 process
+        bbs[1].compute_dtype = "f32"
+        bbs[1].zero_grad_flat()
+        loss_of(nets[1], 5).backward()
+        mixed = bbs[1].flat_grads.clone()
+        _ops.set_compute_dtype("f32")
+        bbs[1].compute_dtype = None
+        bbs[1].zero_grad_flat()
+        loss_of(nets[1], 5).backward()
+        assert relerr(mixed, bbs[1].flat_grads) < 2e-5            # the same exact-f32 launches (split-K atomics aside)
+        assert relerr(mixed, alone[1]) > 1e-4                     # and not the bf16 result
     finally:
         _ops.set_compute_dtype(prev)
 
