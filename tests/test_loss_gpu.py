@@ -1008,7 +1008,9 @@ def test_merged_and_stored_weight_grads_match_plain_accumulation():
             torch.cuda.manual_seed(22)
             g(x, y)
             outs.append(bb.flat_grads.clone())
-        assert torch.isfinite(outs[0]).all() and relerr(outs[0], outs[1]) < 1e-4
+        # (two replays of one step differ by the order of the split-K float atomics; a last-bit difference that flips a
+        # bf16 rounding downstream -- GEMM operands, and since round 3 the resamplers' -- shows at ~1e-4 of the largest gradient)
+        assert torch.isfinite(outs[0]).all() and relerr(outs[0], outs[1]) < 2e-4
         # same seeds -> same crop and same draws as the eager runs: stored == accumulated
         assert relerr(outs[0], grads["merged"]) < 2e-4, relerr(outs[0], grads["merged"])
     finally:
