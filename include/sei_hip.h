@@ -32,7 +32,7 @@ extern "C" {
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
-#define SEI_ABI_VERSION 5
+#define SEI_ABI_VERSION 6
 int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
@@ -460,6 +460,33 @@ int sei_gemm_bf16nt_dw2_taps(const uint16_t *A1, const uint16_t *A2, int lda, co
 
 int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1, const uint16_t *B2,
                                 int ldb, uint16_t *D16, int M, int N, int K1, int K2, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Token-streaming GEMMs for layer-sized weights (token_gemm.hip; ABI 6): the linear layers of the reference's default
+ * backbone, deepinv's SwinIR as built by src/models/__init__.py:51-74 (qkv / proj / fc1 / fc2 of every block:
+ * nn.Linear forward, its data gradient and its weight gradient in torch's autograd), in the bf16 throughput mode.
+ * One persistent workgroup per CU streams its share of the tokens once; the weight (gradient) stays in registers.
+ *
+ * sei_tokgrad_bf16: D (Mo, Ni; row stride ldd) += Y^T X over K1 + K2 tokens; Y1 / Y2: (K, ldy >= Mo), X1 / X2:
+ * (K, ldx >= Ni) bf16, token-major as the layers store them; the two segments are the step's two model calls (K2 = 0:
+ * one). Float atomics: D must hold the running gradient (or zeros). Eligible (sei_tokgrad_bf16_eligible != 0): Mo and Ni
+ * multiples of 192 with at most eight 192 x 192 blocks, K1 and K2 multiples of 64, ldy and ldx multiples of 8, 16-byte
+ * aligned operands. Same product as sei_gemm_bf16nt_dw2(..., accumulate = 1) up to the float summation order. */
+#define SEI_TOKGRAD_MAX_BLOCKS 8
+typedef struct SeiTokGradBlock {     /* one 192 x 192 block of a weight gradient: D += Y[:, y0:y0+192]^T X[:, x0:x0+192] */
+    const uint16_t *Y1, *Y2;         /* (K1, ldy) / (K2, ldy) bf16; Y2 unused when K2 = 0 */
+    const uint16_t *X1, *X2;         /* (K1, ldx) / (K2, ldx) */
+    int ldy, ldx, y0, x0;            /* multiples of 8; y0 + 192 <= ldy, x0 + 192 <= ldx */
+    float *D;                        /* the block's first element; row stride ldd >= 192 */
+    int ldd;
+} SeiTokGradBlock;
+/* Up to eight blocks in ONE launch over the same K1 + K2 tokens (all four weight gradients of a Swin block = 3 + 1 + 2 + 2
+ * blocks): the CUs are shared out between the blocks, so every workgroup walks nblocks times as many tokens and the
+ * float atomics per output (one partial block per workgroup) shrink by the same factor. */
+int sei_tokgrad_bf16_blocks(const SeiTokGradBlock *blocks, int nblocks, long long K1, long long K2, void *stream);
+int sei_tokgrad_bf16(const uint16_t *Y1, const uint16_t *Y2, int ldy, const uint16_t *X1, const uint16_t *X2, int ldx,
+                     float *D, int ldd, int Mo, int Ni, long long K1, long long K2, void *stream);
+size_t sei_tokgrad_bf16_eligible(int Mo, int Ni, int ldy, int ldx, long long K1, long long K2);
 
 #ifdef __cplusplus
 }

@@ -88,12 +88,20 @@ SIGNATURES = {
     "sei_cast_pad_bf16": [_P, _P, _P, _P, _Z, _I, _I, _P, _Z, _P],
     "sei_pad_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_gemm_bf16nt_conv": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P],
+    "sei_tokgrad_bf16_blocks": [_P, _I, _L, _L, _P],
+    "sei_tokgrad_bf16": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _L, _L, _P],
     "sei_adam_fused": [_P, _P, _I, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P, _P],
     "sei_adam_scalars": [_F, _F, _F, _F, _F, _I, _P, _P],
     "sei_adam_scalars_to_device": [_F, _F, _F, _F, _F, _I, _P, _P],
 }
 
 _lib = None
+
+
+class TokGradBlock(_c.Structure):
+    """SeiTokGradBlock of include/sei_hip.h (one 192 x 192 block of a token-streamed weight gradient)."""
+    _fields_ = [("Y1", _P), ("Y2", _P), ("X1", _P), ("X2", _P), ("ldy", _I), ("ldx", _I), ("y0", _I), ("x0", _I),
+                ("D", _P), ("ldd", _I)]
 
 
 # size queries: return size_t, take no stream
@@ -105,8 +113,9 @@ SIZE_QUERIES = {
     "sei_sepmap2_bf16_eligible": [_I, _I, _I, _I, _I, _I],
     "sei_sepmap2_bf16_pack_elems": [_I, _I, _I, _I],
     "sei_swin_partials_floats": [_I],
+    "sei_tokgrad_bf16_eligible": [_I, _I, _I, _I, _L, _L],
 }
-ABI_VERSION = 5       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
+ABI_VERSION = 6       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 
 
 class NativeLibraryError(RuntimeError):

@@ -599,6 +599,15 @@ def set_weight_grad_milestone(keys, event, owner=None):
     state_of(owner)["milestone"] = (frozenset(keys), event) if keys else None
 
 
+def _check_milestone(_DW, key):
+    ms = _DW["milestone"]
+    if ms is not None and key in ms[0] and ms[0] <= _DW["written"] and not _DW["milestone_done"]:
+        # every gradient of the milestone has had its (single, merged) launch of this step
+        if all(_DW["arrivals"].get(k, 0) >= max(_DW["uses"], 1) for k in ms[0]):
+            ms[1].record()
+            _DW["milestone_done"] = True
+
+
 def _launch_weight_grad(_DW, grad2d, pairs):
     key = grad2d.data_ptr()
     store = _DW["store"] and key not in _DW["written"] and grad2d.numel() >= _DW["store_min"]
@@ -606,12 +615,54 @@ def _launch_weight_grad(_DW, grad2d, pairs):
     try:
         _launch_weight_grad_inner(_DW, grad2d, pairs, store)
     finally:
-        ms = _DW["milestone"]
-        if ms is not None and key in ms[0] and ms[0] <= _DW["written"] and not _DW["milestone_done"]:
-            # every gradient of the milestone has had its (single, merged) launch of this step
-            if all(_DW["arrivals"].get(k, 0) >= max(_DW["uses"], 1) for k in ms[0]):
-                ms[1].record()
-                _DW["milestone_done"] = True
+        _check_milestone(_DW, key)
+
+
+def _launch_weight_grad_group(_DW, segs):
+    """The weight gradients of several layers over the same tokens -- segs: one list of (gy16, x16, grad2d, flops per
+    row) per model call of the step, the layers in the same order -- as ONE token-streamed launch
+    (sei_tokgrad_bf16_blocks: every 192 x 192 block of every gradient on its share of the CUs) when the shapes allow
+    it and every gradient accumulates; one launch per layer otherwise."""
+    first = segs[0]
+    rows = [seg[0][0].shape[0] for seg in segs]
+    blocks, ok = [], len(segs) <= 2 and all(r % 64 == 0 for r in rows)
+    for i, (_, _, grad2d, _) in enumerate(first):
+        key = grad2d.data_ptr()
+        ok = ok and grad2d.dim() == 2 and grad2d.is_contiguous() and grad2d.dtype == torch.float32
+        ok = ok and not (_DW["store"] and key not in _DW["written"] and grad2d.numel() >= _DW["store_min"])
+        ok = ok and not (_DW["adam"] is not None and key in _DW["adam"][0])
+        ok = ok and not (_DW["direct16"] is not None and key in _DW["direct16"]) and key not in _DW["taps"]
+        for s, seg in enumerate(segs):
+            gy, x = seg[i][0], seg[i][1]
+            ok = ok and gy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and gy.is_contiguous() and x.is_contiguous()
+            ok = ok and gy.shape == (rows[s], grad2d.shape[0]) and x.shape == (rows[s], grad2d.shape[1])
+        if ok:
+            ok = N.lib().sei_tokgrad_bf16_eligible(grad2d.shape[0], grad2d.shape[1], grad2d.shape[0], grad2d.shape[1],
+                                                   rows[0], rows[1] if len(rows) == 2 else 0) != 0
+        if not ok:
+            break
+        Mo, Ni = grad2d.shape
+        a, b = segs[0][i], segs[-1][i]
+        for gy in range(Mo // 192):
+            for gx in range(Ni // 192):
+                blocks.append(N.TokGradBlock(a[0].data_ptr(), b[0].data_ptr(), a[1].data_ptr(), b[1].data_ptr(), Mo, Ni,
+                                             192 * gy, 192 * gx, grad2d.data_ptr() + 4 * (192 * gy * Ni + 192 * gx), Ni))
+    if not ok or len(blocks) > 8:
+        for i, (_, _, grad2d, _) in enumerate(first):
+            _launch_weight_grad(_DW, grad2d, [(seg[i][0], seg[i][1]) for seg in segs])
+        return
+    flops = 0.0
+    for _, _, grad2d, fpr in first:
+        key = grad2d.data_ptr()
+        _DW["written"].add(key)
+        _DW["merged_ok"][key] = len(segs) == 2 and len(segs) == _DW["uses"]
+        flops += (fpr or 2.0 * grad2d.shape[0] * grad2d.shape[1]) * sum(rows)
+    arr = (N.TokGradBlock * len(blocks))(*blocks)
+    try:
+        _gemm_call(flops, "sei_tokgrad_bf16_blocks", arr, len(blocks), rows[0], rows[1] if len(rows) == 2 else 0)
+    finally:
+        for _, _, grad2d, _ in first:
+            _check_milestone(_DW, grad2d.data_ptr())
 
 
 def set_fused_adam(table, hyper, owner=None):
@@ -716,8 +767,12 @@ def flush_weight_grads(owner=None, _state=None):
     _DW = _state if _state is not None else state_of(owner)
     _DW["flush_queued"] = False
     parked, _DW["parked"] = _DW["parked"], {}
-    for gy16, x16, grad2d in parked.values():
-        _launch_weight_grad(_DW, grad2d, [(gy16, x16)])
+    for entry in parked.values():
+        if isinstance(entry, list):                    # a parked group (weight_grad16_group)
+            _launch_weight_grad_group(_DW, [entry])
+        else:
+            gy16, x16, grad2d = entry
+            _launch_weight_grad(_DW, grad2d, [(gy16, x16)])
 
 
 def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None):
@@ -744,6 +799,30 @@ def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None):
         _DW["parked"][key] = (gy16, x16, grad2d)
     else:
         _launch_weight_grad(_DW, grad2d, [(gy16, x16)])
+
+
+def weight_grad16_group(items):
+    """weight_grad16 for several layers whose operands cover the SAME tokens (the four linear layers of a Swin block):
+    items = [(gy16, x16, grad2d, flops_per_row)]. Parked and merged across the step's model calls like single pairs; the
+    launch is one token-streamed kernel for all of them (_launch_weight_grad_group)."""
+    items = list(items)
+    head = items[0][2].data_ptr()
+    _DW = _state_for(head)
+    for gy16, x16, grad2d, fpr in items:
+        key = grad2d.data_ptr()
+        _DW["seen"][key] = grad2d.numel()
+        _DW["flops_per_row"][key] = fpr
+        _DW["taps"].pop(key, None)
+        _DW["arrivals"][key] = _DW["arrivals"].get(key, 0) + 1
+    n = _DW["arrivals"][head]
+    gkey = ("group", head)
+    partner = _DW["parked"].pop(gkey, None)
+    if partner is not None:
+        _launch_weight_grad_group(_DW, [partner, items])
+    elif _DW["merge"] and n < _DW["uses"] and _queue_flush(_DW):
+        _DW["parked"][gkey] = items
+    else:
+        _launch_weight_grad_group(_DW, [items])
 
 
 def _queue_flush(_DW):

@@ -16,7 +16,7 @@ import torch
 import _native as N
 from . import _ops
 from ._ops import (EPI_ACCUM, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_NONE, colsum16_into, colsum_into,
-                   gemm_nt16, grad_of, weight_grad16)
+                   gemm_nt16, grad_of, weight_grad16, weight_grad16_group)
 from ._swin_ops import EPI_BIAS_SCALE_RES, LN_EPS, rowscale
 
 CP, HP = 192, 32                # padded embedding width, padded head width
@@ -81,19 +81,24 @@ class SwinPack:
             bq = np.where(rows >= 0, index_of(a.qkv.bias)[np.maximum(rows, 0)], -1)
             wp = index_of(a.proj.weight)                 # (180, 180): columns follow the padded heads
             mp = np.where(head_cols[None, :] >= 0, wp[:, np.maximum(head_cols, 0)], -1)
-            layouts = {"qkv": mq, "proj": pad_rows(mp, CP), "fc1": pad_cols(index_of(mlp.fc1.weight), CP),
-                       "fc2": pad_rows(index_of(mlp.fc2.weight), CP)}
+            hid = mlp.fc1.weight.shape[0]
+            hidp = pad64(hid)                            # the hidden activations are (M, 384) rows: whole 64-column k-tiles
+            layouts = {"qkv": mq, "proj": pad_rows(mp, CP), "fc1": pad_rows(pad_cols(index_of(mlp.fc1.weight), CP), hidp),
+                       "fc2": pad_cols(pad_rows(index_of(mlp.fc2.weight), CP), hidp)}
             # gradient layouts: as the weights, plus -- for the two layers fed by a LayerNorm, whose padded rows carry a
             # column of ones (ln16) -- the bias in column C: dY^T [h | 1] puts the bias gradient there
             grads = dict(layouts)
             grads["qkv"] = mq.copy()
             grads["qkv"][:, C] = bq
             grads["fc1"] = layouts["fc1"].copy()
-            grads["fc1"][:, C] = index_of(mlp.fc1.bias)
+            grads["fc1"][:hid, C] = index_of(mlp.fc1.bias)
             for k, m in layouts.items():
                 add("w", f"{name}.{k}", m)
                 add("g", f"{name}.{k}", grads[k])
             add("b", f"{name}.qkv_bias", bq)
+            b1 = np.full(hidp, -1, dtype=np.int64)
+            b1[:hid] = index_of(mlp.fc1.bias)
+            add("b", f"{name}.fc1_bias", b1)
         for name, conv in model.named_modules():
             if not isinstance(conv, torch.nn.Conv2d):
                 continue
@@ -215,7 +220,7 @@ class SwinBlockFn16(torch.autograd.Function):
         M = B * H * W
         x2 = x.view(M, C)
         wqkv, wproj, w1, w2 = (pack.w(f"{key}.{k}") for k in ("qkv", "proj", "fc1", "fc2"))
-        Ch = w1.shape[0]
+        Ch, Chr = w1.shape[0], bm1.shape[0]              # padded (384) / real (360) hidden width
         dev = x.device
         h1, mean1, rstd1 = ln16(x2, g1, b1)
         qkv = torch.empty((M, 3 * heads * HP), dtype=torch.bfloat16, device=dev)
@@ -232,12 +237,13 @@ class SwinBlockFn16(torch.autograd.Function):
         h2, mean2, rstd2 = ln16(x1, g2, b2)
         f3 = torch.empty((M, Ch), dtype=torch.float32, device=dev)
         f4 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
-        gemm_nt16(h2, w1, M, Ch, CP, EPI_BIAS_GELU, out32=f3, bias=bm1, D2_16=f4, flops=2.0 * M * Ch * C)
+        gemm_nt16(h2, w1, M, Ch, CP, EPI_BIAS_GELU, out32=f3, bias=pack.b(f"{key}.fc1_bias"), D2_16=f4,
+                  flops=2.0 * M * Chr * C)
         out = torch.empty((M, C), dtype=torch.float32, device=dev)
         if drop2 is None:
-            gemm_nt16(f4, w2, M, C, Ch, EPI_BIAS_RES, out32=out, bias=bm2, R1=x1)
+            gemm_nt16(f4, w2, M, C, Ch, EPI_BIAS_RES, out32=out, bias=bm2, R1=x1, flops=2.0 * M * Chr * C)
         else:
-            gemm_nt16(f4, w2, M, C, Ch, EPI_BIAS_SCALE_RES, out32=out, bias=bm2, R1=drop2, R2=x1)
+            gemm_nt16(f4, w2, M, C, Ch, EPI_BIAS_SCALE_RES, out32=out, bias=bm2, R1=drop2, R2=x1, flops=2.0 * M * Chr * C)
         ctx.save_for_backward(x, mean1, rstd1, h1, qkv, a, x1, mean2, rstd2, h2, f3, f4, drop1, drop2)
         ctx.params = (g1, b1, table, bproj, g2, b2, bm1, bm2)
         ctx.cfg = (pack, key, heads, shift)
@@ -252,30 +258,29 @@ class SwinBlockFn16(torch.autograd.Function):
         M = B * H * W
         dev = x.device
         wqkv, wproj, w1, w2 = (pack.w(f"{key}.{k}") for k in ("qkv", "proj", "fc1", "fc2"))
-        Ch = w1.shape[0]
+        Ch, Chr = w1.shape[0], bm1.shape[0]
         go2 = go.contiguous().view(M, C)
         # MLP branch
         gy = cast_pad(go2, drop2, grad_of(bm2))
-        weight_grad16(gy, f4, pack.g(f"{key}.fc2"), flops_per_row=2.0 * Ch * C)
         gf3 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
-        gemm_nt16(gy, w2, M, Ch, CP, EPI_MUL_DGELU, out16=gf3, R1=f3, b_rmajor=True, flops=2.0 * M * Ch * C)
-        weight_grad16(gf3, h2, pack.g(f"{key}.fc1"), flops_per_row=2.0 * Ch * C)      # (+ the bias gradient, column C)
+        gemm_nt16(gy, w2, M, Ch, CP, EPI_MUL_DGELU, out16=gf3, R1=f3, b_rmajor=True, flops=2.0 * M * Chr * C)
         gh2 = torch.empty((M, CP), dtype=torch.float32, device=dev)
-        gemm_nt16(gf3, w1, M, CP, Ch, EPI_NONE, out32=gh2, b_rmajor=True, flops=2.0 * M * Ch * C)
+        gemm_nt16(gf3, w1, M, CP, Ch, EPI_NONE, out32=gh2, b_rmajor=True, flops=2.0 * M * Chr * C)
         gx1 = ln_bwd(x1, g2, mean2, rstd2, gh2, go2, grad_of(g2), grad_of(b2))
         # attention branch
-        gy = cast_pad(gx1, drop1, grad_of(bproj))
-        weight_grad16(gy, a, pack.g(f"{key}.proj"), flops_per_row=2.0 * C * C)
+        gy1 = cast_pad(gx1, drop1, grad_of(bproj))
         ga = torch.empty((M, CP), dtype=torch.bfloat16, device=dev)
-        gemm_nt16(gy, wproj, M, CP, CP, EPI_NONE, out16=ga, b_rmajor=True, flops=2.0 * M * C * C)
+        gemm_nt16(gy1, wproj, M, CP, CP, EPI_NONE, out16=ga, b_rmajor=True, flops=2.0 * M * C * C)
         dqkv = torch.empty_like(qkv)
         scale = float((C // heads) ** -0.5)
         N.call("sei_swin_attn_bwd_bf16", qkv.data_ptr(), table.data_ptr(), ga.data_ptr(), dqkv.data_ptr(),
                grad_of(table).data_ptr(), B, H, W, heads, shift, scale)
-        weight_grad16(dqkv, h1, pack.g(f"{key}.qkv"), flops_per_row=2.0 * 3 * C * C)   # (+ the bias gradient, column C)
         gh1 = torch.empty((M, CP), dtype=torch.float32, device=dev)
         gemm_nt16(dqkv, wqkv, M, CP, 3 * heads * HP, EPI_NONE, out32=gh1, b_rmajor=True, flops=2.0 * M * 3 * C * C)
         gx = ln_bwd(x.view(M, C), g1, mean1, rstd1, gh1, gx1, grad_of(g1), grad_of(b1))
+        # the four weight gradients (+ the qkv / fc1 bias gradients, column C) over the same tokens: one launch
+        weight_grad16_group([(dqkv, h1, pack.g(f"{key}.qkv"), 2.0 * 3 * C * C), (gy1, a, pack.g(f"{key}.proj"), 2.0 * C * C),
+                             (gf3, h2, pack.g(f"{key}.fc1"), 2.0 * Chr * C), (gy, f4, pack.g(f"{key}.fc2"), 2.0 * Chr * C)])
         return (gx.view(B, H, W, C) if ctx.needs_input_grad[0] else None,) + (None,) * 14
 
 

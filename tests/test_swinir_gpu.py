@@ -477,3 +477,39 @@ def test_conv_weight_gradient_taps_in_one_launch():
         dense = torch.einsum("rm,rn->mn", g1.float(), x1[guard + offs[5]:guard + offs[5] + K1].float())
         if not two:
             assert relerr(out[5], dense) < 1e-4
+
+
+@pytest.mark.parametrize("K1,K2", [(4608, 2304), (64, 0), (320, 192), (50 * 64, 0)])
+def test_token_streamed_weight_gradients(K1, K2):
+    """sei_tokgrad_bf16 / sei_tokgrad_bf16_blocks (nn.Linear's weight gradient dY^T X of deepinv's SwinIR blocks, both
+    operands token-major, the step's two model calls as two segments) against the float32 product of the same bf16
+    operands, on top of a running gradient: one launch per weight, and the four weights of a block (3 + 1 + 2 + 2
+    192 x 192 blocks, operands with padding columns beyond the block) in one launch. Token counts from one 64-token
+    k-tile (most workgroups idle) to more k-tiles than workgroups."""
+    import _native as N
+    gen = torch.Generator(device="cuda").manual_seed(K1 + K2)
+    blocks, expect = [], []
+    for Mo, Ni, ldy, ldx in [(576, 192, 576, 192), (192, 192, 200, 192), (384, 192, 384, 256), (192, 384, 192, 384)]:
+        ys = [(0.5 * torch.randn((k, ldy), device="cuda", generator=gen)).bfloat16() for k in (K1, K2) if k]
+        xs = [torch.randn((k, ldx), device="cuda", generator=gen).bfloat16() for k in (K1, K2) if k]
+        base = torch.randn((Mo, Ni), device="cuda", generator=gen)
+        ref = base + sum(y[:, :Mo].float().T @ x[:, :Ni].float() for y, x in zip(ys, xs))
+        d = base.clone()
+        assert N.lib().sei_tokgrad_bf16_eligible(Mo, Ni, ldy, ldx, K1, K2) == (Mo // 192) * (Ni // 192)
+        N.call("sei_tokgrad_bf16", ys[0].data_ptr(), ys[-1].data_ptr(), ldy, xs[0].data_ptr(), xs[-1].data_ptr(), ldx,
+               d.data_ptr(), Ni, Mo, Ni, K1, K2)
+        assert relerr(d, ref) < 2e-5, (Mo, Ni, relerr(d, ref))
+        dg = base.clone()
+        for gy in range(Mo // 192):
+            for gx in range(Ni // 192):
+                blocks.append(N.TokGradBlock(ys[0].data_ptr(), ys[-1].data_ptr(), xs[0].data_ptr(), xs[-1].data_ptr(), ldy, ldx,
+                                             192 * gy, 192 * gx, dg.data_ptr() + 4 * (192 * gy * Ni + 192 * gx), Ni))
+        expect.append((dg, ref, ys, xs))
+    arr = (N.TokGradBlock * len(blocks))(*blocks)
+    N.call("sei_tokgrad_bf16_blocks", arr, len(blocks), K1, K2)
+    for dg, ref, _, _ in expect:
+        assert relerr(dg, ref) < 2e-5, relerr(dg, ref)
+    # shapes the kernel does not take are refused, not mangled
+    assert N.lib().sei_tokgrad_bf16_eligible(180, 192, 192, 192, 64, 0) == 0
+    assert N.lib().sei_tokgrad_bf16_eligible(192, 192, 192, 192, 72, 0) == 0
+    assert N.lib().sei_tokgrad_bf16_eligible(576, 576, 576, 576, 64, 0) == 0
