@@ -488,6 +488,24 @@ int sei_tokgrad_bf16(const uint16_t *Y1, const uint16_t *Y2, int ldy, const uint
                      float *D, int ldd, int Mo, int Ni, long long K1, long long K2, void *stream);
 size_t sei_tokgrad_bf16_eligible(int Mo, int Ni, int ldy, int ldx, long long K1, long long K2);
 
+/* sei_rowgemm_bf16: D (M, N) = epilogue(A W^T): A (M, lda >= K) bf16 rows, W (N, ldw >= K) bf16 -- the layer's matrix as
+ * nn.Linear stores it (forward) or its transpose (data gradient), zero-padded to N in {192, 384, 576} rows and
+ * K in {192, 384, 576} columns -- with the SEI_EPI_* epilogues of sei_gemm_bf16nt:
+ *   SEI_EPI_BIAS            D16 = bf16(acc + bias)                                   (N 576, K 192: qkv)
+ *   SEI_EPI_BIAS_RES        D32 = acc + bias + R1                                     (N 192, K 192 / 384: proj, fc2)
+ *   SEI_EPI_BIAS_SCALE_RES  D32 = R2 + R1[row] (acc + bias)    (stochastic depth)     (the same two)
+ *   SEI_EPI_BIAS_GELU       D32 = acc + bias, D16 = bf16(gelu(D32))                   (N 384, K 192: fc1; nv = N)
+ *   SEI_EPI_MUL_DGELU       D16 = bf16(acc gelu'(R1))                                 (N 384, K 192: fc2's data gradient)
+ *   SEI_EPI_NONE            D16 = bf16(acc) (N 192, K 192)  or  D32 = acc (N 192, K 384 / 576)   (the other data gradients)
+ * nv (a multiple of 4, <= N): valid columns of the float32 output, of bias and of the row-shaped R (ldr >= nv); bf16
+ * outputs always receive all N columns (ld16 >= N; zeros where W's padding rows are zero). M a multiple of 64.
+ * sei_rowgemm_bf16_eligible(M, N, K, epilogue, out16) != 0 says whether a combination is built; the caller takes
+ * sei_gemm_bf16nt otherwise (same results up to the float summation order). */
+int sei_rowgemm_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, float *D32, int ld32, uint16_t *D16,
+                     int ld16, long long M, int N, int K, int nv, int epilogue, const float *bias, const float *R1,
+                     const float *R2, int ldr, void *stream);
+size_t sei_rowgemm_bf16_eligible(long long M, int N, int K, int epilogue, int out16);
+
 #ifdef __cplusplus
 }
 #endif

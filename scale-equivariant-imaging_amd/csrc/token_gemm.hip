@@ -148,6 +148,260 @@ __global__ __launch_bounds__(TG_NT) void tokgrad_kernel(TokGradArgs g) {
             for (int r = 0; r < 4; ++r) atomicAdd(d + (size_t)(16 * i + r) * b.ldd + 16 * j, acc[i][j][r]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// sei_rowgemm_bf16: D (M x N) = epilogue(A (M x K) W^T), W (N x K) the layer's matrix, K = 192 / 384 / 576 and
+// N = 192 / 384 / 576 (zero-padded): nn.Linear forward and data gradient of the Swin blocks.
+//
+// One workgroup per CU, eight waves = 4 (columns) x 2 (halves of K). A wave keeps its 16 NB columns x K / 2 slice of W in
+// registers for the whole launch (36-108 VGPRs) and streams row tiles (TR = 32 or 64 rows, every tile this workgroup
+// owns: b, b + G, ...) through a three-stage LDS ring filled by LDS-DMA two tiles ahead -- A is read from HBM exactly once,
+// W once per workgroup. Per tile: [the tile's residual / GELU' rows into registers, DMA of tile t + 2] MFMAs [one counted
+// vmcnt: tile t + 1 has landed] the K halves are summed in an LDS patch, and all 512 threads walk the patch as row
+// quads: 16-byte auxiliary values (loaded before the MFMAs) and 16- / 8-byte stores on whole rows. Three barriers
+// per tile. Against the tiled kernels (K = 192: 3 k-tiles of loop, then an epilogue nothing overlaps; 1.125-2.25 rounds
+// of 128-row tiles on the chip) the loads of the next tiles and the stores of the last one are always in flight.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RG_NT = 512;
+
+struct RowGemmArgs {
+    const unsigned short *A, *W;
+    int lda, ldw;
+    int tiles;                // M / TR
+    const float *bias;        // nv entries or nullptr
+    const float *R1, *R2;     // BIAS_RES: R1 (+ R2) residual rows; BIAS_SCALE_RES: R1 = one factor per row, R2 = residual rows;
+    int ldr;                  // MUL_DGELU: R1 = the GELU' input rows.  Row stride of the row-shaped one(s)
+    float *D32;
+    unsigned short *D16;      // the result in bf16 (BIAS, NONE, MUL_DGELU) / gelu(result) in bf16 (BIAS_GELU)
+    int ld32, ld16;
+    int nv;                   // valid output columns of D32 / R (a multiple of 4); D16 always gets all 64 NB columns
+};
+
+template <int N>
+__device__ __forceinline__ void rg_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is six bits");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// LDS writes of this wave done, then the barrier (a bare s_barrier does not wait for them; __syncthreads would also
+// wait for every global load and LDS-DMA piece in flight)
+__device__ __forceinline__ void rg_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+__device__ __forceinline__ unsigned rg_pack2(float a, float b) {
+    const __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+// EPI: the SEI_EPI_* code; OUT16: SEI_EPI_NONE / _BIAS write bf16 (else float32)
+template <int KT, int NB, int TR, int EPI, bool OUT16>
+__global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
+    constexpr int NP = 64 * NB;                       // padded output width
+    constexpr int LDP = NP + 4;                       // patch row stride (floats): 4 LDP = 16 mod 64 banks
+    constexpr int STAGE = KT * TR * 128;              // KT images of [TR rows][64 k] bf16
+    constexpr int P = KT * TR / 8;                    // 1-KiB DMA pieces per stage
+    constexpr int EMAX = (P + 7) / 8;
+    constexpr int QR = NP / 4;                        // quads per row
+    constexpr int QPT = TR * QR / RG_NT;              // quads per thread
+    static_assert(TR * QR % RG_NT == 0 && TR % 16 == 0, "whole passes over the patch");
+    constexpr bool HAS_ROWS = EPI == SEI_EPI_BIAS_RES || EPI == SEI_EPI_BIAS_SCALE_RES || EPI == SEI_EPI_MUL_DGELU;
+    constexpr bool HAS_BIAS = EPI == SEI_EPI_BIAS || EPI == SEI_EPI_BIAS_GELU || EPI == SEI_EPI_BIAS_RES ||
+                              EPI == SEI_EPI_BIAS_SCALE_RES;
+    constexpr int UNR = NB == 9 ? 1 : QPT;            // the widest variant (108 + 72 registers of W and accumulators) walks its quads one by one
+    constexpr int NAUX = (HAS_ROWS ? QPT : 0) + (EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 0);   // loads per thread and tile
+    __shared__ __attribute__((aligned(1024))) char smem[3 * STAGE + TR * LDP * 4 + NP * 4];
+    float *patch = reinterpret_cast<float *>(smem + 3 * STAGE);
+    float *lbias = patch + TR * LDP;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wk = wave >> 2;
+    const int l16 = lane & 15, lg = lane >> 4;
+    const int G = gridDim.x, b = blockIdx.x;
+    if (b >= g.tiles) return;
+    const int nt = (g.tiles - b + G - 1) / G;          // tiles b, b + G, ...
+
+    // ---- W slice of this wave: columns 16 NB wn .., k-steps wk KT .. (32 k each), MFMA B-operand layout
+    bf16x8 wf[NB][KT];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s = 0; s < KT; ++s)
+            wf[nb][s] = *reinterpret_cast<const bf16x8 *>(g.W + (size_t)(16 * NB * wn + 16 * nb + l16) * g.ldw +
+                                                          32 * (wk * KT + s) + 8 * lg);
+    if (HAS_BIAS)
+        for (int c = tid; c < NP; c += RG_NT) lbias[c] = c < g.nv ? g.bias[c] : 0.f;
+    // W is in the registers before the ring starts: a use the compiler can see here, so that it does not wait for these
+    // loads -- and with them for every LDS-DMA piece issued since -- in front of the first MFMA of every tile
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s = 0; s < KT; ++s) asm volatile("" : "+v"(wf[nb][s]));
+
+    // ---- DMA pieces of a stage: piece q = image q / (TR / 8), rows 8 (q % (TR / 8)) ..; chunk swizzle (r >> 1) & 7
+    unsigned offa[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        const int q = min(wave + 8 * e, P - 1), im = q / (TR / 8), p = q % (TR / 8);
+        const int r = 8 * p + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        offa[e] = (unsigned)r * (unsigned)g.lda * 2u + 128u * im + 16u * c;
+    }
+    auto issue = [&](int t) {                            // tile t of this workgroup (clamped: see the loop)
+        const int tile = b + min(t, nt - 1) * G;
+        const char *ab = reinterpret_cast<const char *>(g.A + (size_t)tile * TR * g.lda);
+        char *dst = smem + (t % 3) * STAGE;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            if (P % 8 != 0 && e == EMAX - 1 && wave >= P % 8) break;           // wave-uniform
+            __builtin_amdgcn_global_load_lds((glb_void *)(ab + offa[e]), (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
+        }
+    };
+    constexpr int NDMA_LO = P / 8;                       // pieces per wave and stage: waves below P % 8 issue one more
+
+    // ---- the quads of a tile this thread finishes: quad i = (row, 4 columns)
+    // Float32 outputs narrower than the tile (180 of 192 columns): the lanes past the edge redo the row's LAST valid quad --
+    // same inputs, same result, same address -- instead of masking their stores: a branch around a store makes the store
+    // count of the in-order vmcnt unknowable, and the compiler then waits for everything (the ring included) before it
+    constexpr bool F32_ONLY = !(OUT16 || EPI == SEI_EPI_MUL_DGELU || EPI == SEI_EPI_BIAS_GELU);
+    auto quad_row = [&](int i) { return (tid + RG_NT * i) / QR; };
+    auto quad_col = [&](int i) {
+        const int c = 4 * ((tid + RG_NT * i) % QR);
+        return F32_ONLY ? min(c, g.nv - 4) : c;
+    };
+    f32x4 cur[HAS_ROWS ? QPT : 1];
+    float curs[EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 1];
+    auto load_aux = [&](int t, f32x4 (&a)[HAS_ROWS ? QPT : 1], float (&sc)[EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 1]) {
+        if constexpr (HAS_ROWS) {
+            const int tile = b + min(t, nt - 1) * G;
+            const float *rows = EPI == SEI_EPI_BIAS_SCALE_RES ? g.R2 : g.R1;
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                const size_t row = (size_t)tile * TR + quad_row(i);
+                const int qc = quad_col(i);
+                // Loads the compiler does not track (it would wait for them, and with them for every LDS-DMA piece in
+                // flight, with vmcnt(0)): the values are used only behind rg_wait_rows below
+                const float *src = rows + row * g.ldr + (qc < g.nv ? qc : 0);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[i]) : "v"(src) : "memory");
+                if constexpr (EPI == SEI_EPI_BIAS_SCALE_RES) {
+                    const float *ssrc = g.R1 + row;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(sc[i]) : "v"(ssrc) : "memory");
+                }
+            }
+        }
+    };
+
+    // ---- prologue: tile 0 and its auxiliary rows landed, tile 1 in flight
+    issue(0);
+    issue(1);
+    if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NDMA_LO + 1>();
+    else rg_wait_vmcnt<NDMA_LO>();
+    rg_lds_barrier();
+
+    for (int t = 0; t < nt; ++t) {
+        load_aux(t, cur, curs);                           // this tile's residual / GELU' rows: used after the MFMAs
+        __builtin_amdgcn_sched_barrier(0);                // (the order the counted wait below assumes)
+        issue(t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMAs: rows 16 rb .. of the tile x this wave's columns, its half of K
+        const char *st = smem + (t % 3) * STAGE;
+        f32x4 acc[TR / 16][NB];
+#pragma unroll
+        for (int rb = 0; rb < TR / 16; ++rb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KT; ++s) {
+            const int sg = wk * KT + s;                   // wave-uniform
+            const char *img = st + (sg >> 1) * (TR * 128) + l16 * 128 + (((4 * (sg & 1) + lg) ^ (l16 >> 1)) * 16);
+#pragma unroll
+            for (int rb = 0; rb < TR / 16; ++rb) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(img + rb * 16 * 128);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf[nb][s], acc[rb][nb], 0, 0, 0);
+            }
+        }
+        // tile t + 1 (issued one iteration ago) and everything older have landed; what this iteration issued may fly
+        if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NAUX + NDMA_LO + 1>();
+        else rg_wait_vmcnt<NAUX + NDMA_LO>();
+        // ---- the two K halves meet in the patch
+        float *pw = patch + (4 * lg) * LDP + 16 * NB * wn + l16;
+        if (wk == 0) {
+#pragma unroll
+            for (int rb = 0; rb < TR / 16; ++rb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pw[(16 * rb + j) * LDP + 16 * nb] = acc[rb][nb][j];
+        }
+        rg_lds_barrier();
+        if (wk == 1) {
+#pragma unroll
+            for (int rb = 0; rb < TR / 16; ++rb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pw[(16 * rb + j) * LDP + 16 * nb] += acc[rb][nb][j];
+        }
+        rg_lds_barrier();
+        // ---- rows out: the tile's auxiliary rows have landed when only this iteration's DMA pieces are in flight. The wait
+        // first, between scheduling fences, and only then a use of the registers that the compiler can see: a copy it
+        // makes for that use then reads landed data (tied to the wait itself, the copy was placed in front of it)
+        if constexpr (HAS_ROWS) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NDMA_LO + 1>();
+            else rg_wait_vmcnt<NDMA_LO>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                asm volatile("" : "+v"(cur[i]));
+                if constexpr (EPI == SEI_EPI_BIAS_SCALE_RES) asm volatile("" : "+v"(curs[i]));
+            }
+        }
+        const size_t row0 = (size_t)(b + t * G) * TR;
+#pragma unroll UNR
+        for (int i = 0; i < QPT; ++i) {
+            const int qr = quad_row(i), qc = quad_col(i);
+            f32x4 v = *reinterpret_cast<const f32x4 *>(patch + qr * LDP + qc);
+            const size_t row = row0 + qr;
+            const bool ok = qc < g.nv;
+            if constexpr (HAS_BIAS) v += *reinterpret_cast<const f32x4 *>(lbias + qc);
+            if constexpr (EPI == SEI_EPI_BIAS_RES) v += cur[i];
+            if constexpr (EPI == SEI_EPI_BIAS_SCALE_RES) v = cur[i] + curs[i] * v;
+            if constexpr (EPI == SEI_EPI_MUL_DGELU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] * sei_dgelu_bf16out(cur[i][j]) : 0.f;
+            }
+            if constexpr (EPI == SEI_EPI_BIAS_GELU || F32_ONLY)      // (BIAS_GELU: nv = all 64 NB columns, host-checked)
+                *reinterpret_cast<f32x4 *>(g.D32 + row * g.ld32 + qc) = v;
+            if constexpr (EPI == SEI_EPI_BIAS_GELU) {
+                uint2 h;
+                h.x = rg_pack2(sei_gelu_bf16out(v[0]), sei_gelu_bf16out(v[1]));
+                h.y = rg_pack2(sei_gelu_bf16out(v[2]), sei_gelu_bf16out(v[3]));
+                *reinterpret_cast<uint2 *>(g.D16 + row * g.ld16 + qc) = h;
+            } else if constexpr (OUT16 || EPI == SEI_EPI_MUL_DGELU) {
+                uint2 h;
+                h.x = rg_pack2(v[0], v[1]);
+                h.y = rg_pack2(v[2], v[3]);
+                *reinterpret_cast<uint2 *>(g.D16 + row * g.ld16 + qc) = h;
+            }
+        }
+        rg_lds_barrier();                                 // the patch and stage t % 3 are free again
+    }
+    rg_wait_vmcnt<0>();                                   // the clamped stages still in flight
+}
+
+template <int KT, int NB, int TR, int EPI, bool OUT16>
+int rg_launch(const RowGemmArgs &g, int M, hipStream_t s) {
+    RowGemmArgs a = g;
+    a.tiles = M / TR;
+    const int grid = a.tiles < 256 ? a.tiles : 256;
+    hipLaunchKernelGGL((rowgemm_kernel<KT, NB, TR, EPI, OUT16>), dim3((unsigned)grid), dim3(RG_NT), 0, s, a);
+    return sei_launch_status();
+}
+
 bool tg_block_ok(const SeiTokGradBlock &b, long long K2) {
     if (!b.Y1 || !b.X1 || !b.D || (K2 && (!b.Y2 || !b.X2))) return false;
     if (b.ldy % 8 || b.ldx % 8 || b.y0 % 8 || b.x0 % 8 || b.y0 < 0 || b.x0 < 0) return false;
@@ -201,4 +455,58 @@ extern "C" int sei_tokgrad_bf16(const uint16_t *Y1, const uint16_t *Y2, int ldy,
             b.D = D + (size_t)192 * gy * ldd + 192 * gx; b.ldd = ldd;
         }
     return sei_tokgrad_bf16_blocks(blocks, n, K1, K2, stream);
+}
+
+extern "C" size_t sei_rowgemm_bf16_eligible(long long M, int N, int K, int epilogue, int out16) {
+    if (M <= 0 || M % 64 != 0 || M >= (1ll << 31)) return 0;
+    const bool f32out = !out16;
+    switch (epilogue) {
+        case SEI_EPI_BIAS: return (N == 576 && K == 192 && out16) ? 1 : 0;
+        case SEI_EPI_BIAS_RES:
+        case SEI_EPI_BIAS_SCALE_RES: return (N == 192 && (K == 192 || K == 384) && f32out) ? 1 : 0;
+        case SEI_EPI_BIAS_GELU: return (N == 384 && K == 192) ? 1 : 0;
+        case SEI_EPI_MUL_DGELU: return (N == 384 && K == 192 && out16) ? 1 : 0;
+        case SEI_EPI_NONE: return (N == 192 && ((K == 192 && out16) || ((K == 384 || K == 576) && f32out))) ? 1 : 0;
+        default: return 0;
+    }
+}
+
+extern "C" int sei_rowgemm_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, float *D32, int ld32,
+                                uint16_t *D16, int ld16, long long M, int N, int K, int nv, int epilogue,
+                                const float *bias, const float *R1, const float *R2, int ldr, void *stream) {
+    const int out16 = (D16 != nullptr && D32 == nullptr) ? 1 : 0;
+    SEI_REQUIRE(A && W && sei_rowgemm_bf16_eligible(M, N, K, epilogue, out16));
+    SEI_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0);
+    SEI_REQUIRE((((uintptr_t)A | (uintptr_t)W) & 15) == 0);
+    SEI_REQUIRE(nv > 0 && nv <= N && nv % 4 == 0);
+    SEI_REQUIRE((unsigned long long)64 * (size_t)lda * 2 < (1ull << 32));
+    const bool has_bias = epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU || epilogue == SEI_EPI_BIAS_RES ||
+                          epilogue == SEI_EPI_BIAS_SCALE_RES;
+    SEI_REQUIRE(!has_bias || bias);
+    if (D32) SEI_REQUIRE(ld32 >= nv && ld32 % 4 == 0 && ((uintptr_t)D32 & 15) == 0);
+    if (D16) SEI_REQUIRE(ld16 >= N && ld16 % 4 == 0 && ((uintptr_t)D16 & 7) == 0);
+    if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D32 && D16 && nv == N);
+    if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU)
+        SEI_REQUIRE(R1 && !R2 && ldr >= nv && ldr % 4 == 0 && ((uintptr_t)R1 & 15) == 0);
+    if (epilogue == SEI_EPI_BIAS_SCALE_RES) SEI_REQUIRE(R1 && R2 && ldr >= nv && ldr % 4 == 0 && ((uintptr_t)R2 & 15) == 0);
+    RowGemmArgs g;
+    g.A = A; g.W = W; g.lda = lda; g.ldw = ldw; g.tiles = 0; g.bias = bias; g.R1 = R1; g.R2 = R2; g.ldr = ldr;
+    g.D32 = D32; g.D16 = D16; g.ld32 = ld32; g.ld16 = ld16; g.nv = nv;
+    hipStream_t s = (hipStream_t)stream;
+    const int m = (int)M;
+    switch (epilogue) {
+        case SEI_EPI_BIAS: return rg_launch<3, 9, 32, SEI_EPI_BIAS, true>(g, m, s);
+        case SEI_EPI_BIAS_RES:
+            return K == 192 ? rg_launch<3, 3, 64, SEI_EPI_BIAS_RES, false>(g, m, s)
+                            : rg_launch<6, 3, 32, SEI_EPI_BIAS_RES, false>(g, m, s);
+        case SEI_EPI_BIAS_SCALE_RES:
+            return K == 192 ? rg_launch<3, 3, 64, SEI_EPI_BIAS_SCALE_RES, false>(g, m, s)
+                            : rg_launch<6, 3, 32, SEI_EPI_BIAS_SCALE_RES, false>(g, m, s);
+        case SEI_EPI_BIAS_GELU: return rg_launch<3, 6, 32, SEI_EPI_BIAS_GELU, false>(g, m, s);
+        case SEI_EPI_MUL_DGELU: return rg_launch<3, 6, 32, SEI_EPI_MUL_DGELU, true>(g, m, s);
+        default:
+            if (K == 192) return rg_launch<3, 3, 64, SEI_EPI_NONE, true>(g, m, s);
+            if (K == 384) return rg_launch<6, 3, 32, SEI_EPI_NONE, false>(g, m, s);
+            return rg_launch<9, 3, 32, SEI_EPI_NONE, false>(g, m, s);
+    }
 }
