@@ -94,6 +94,7 @@ class SwinPack:
             grads["fc1"][:hid, C] = index_of(mlp.fc1.bias)
             for k, m in layouts.items():
                 add("w", f"{name}.{k}", m)
+                add("w", f"{name}.{k}T", np.ascontiguousarray(m.T))     # the data gradients read the transposes K-contiguous
                 add("g", f"{name}.{k}", grads[k])
             add("b", f"{name}.qkv_bias", bq)
             b1 = np.full(hidp, -1, dtype=np.int64)
@@ -210,6 +211,27 @@ def cast_pad(x2d, rows_scale=None, colsum=None, width=CP):
     return y
 
 
+def linear16(A16, W, Wt, M, epi, nv, out32=None, out16=None, bias=None, R1=None, R2=None, flops=None):
+    """D = epilogue(A16 W^T) for a layer-sized W (N, K): the row-streaming kernel (sei_rowgemm_bf16) where it is built
+    for the shape, the tiled GEMM otherwise. Wt: what the tiled kernel reads instead for a data gradient (the forward
+    matrix (K, N), reduction-major); None for a forward product."""
+    Nn, K = W.shape
+    only16 = out16 is not None and out32 is None
+    if N.lib().sei_rowgemm_bf16_eligible(M, Nn, K, epi, int(only16)):
+        rows = R2 if epi == EPI_BIAS_SCALE_RES else R1
+        _ops._gemm_call(2.0 * M * Nn * K if flops is None else float(flops), "sei_rowgemm_bf16", A16.data_ptr(), A16.shape[1],
+                        W.data_ptr(), K, N.ptr(out32), 0 if out32 is None else out32.shape[1], N.ptr(out16),
+                        0 if out16 is None else out16.shape[1], M, Nn, K, nv, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2),
+                        0 if rows is None else rows.shape[1])
+        return
+    if epi == EPI_BIAS_GELU:
+        gemm_nt16(A16, W, M, nv, K, epi, out32=out32, bias=bias, D2_16=out16, flops=flops)
+    elif Wt is None:
+        gemm_nt16(A16, W, M, nv, K, epi, out32=out32, out16=out16, bias=bias, R1=R1, R2=R2, flops=flops)
+    else:
+        gemm_nt16(A16, Wt, M, nv, K, epi, out32=out32, out16=out16, R1=R1, b_rmajor=True, flops=flops)
+
+
 class SwinBlockFn16(torch.autograd.Function):
     """models._swin_ops.SwinBlockFn in bf16 mode; `pack` / `key` give the block's re-laid-out matrices."""
 
@@ -224,26 +246,24 @@ class SwinBlockFn16(torch.autograd.Function):
         dev = x.device
         h1, mean1, rstd1 = ln16(x2, g1, b1)
         qkv = torch.empty((M, 3 * heads * HP), dtype=torch.bfloat16, device=dev)
-        gemm_nt16(h1, wqkv, M, 3 * heads * HP, CP, EPI_BIAS, out16=qkv, bias=pack.b(f"{key}.qkv_bias"),
-                  flops=2.0 * M * 3 * C * C)
+        linear16(h1, wqkv, None, M, EPI_BIAS, 3 * heads * HP, out16=qkv, bias=pack.b(f"{key}.qkv_bias"), flops=2.0 * M * 3 * C * C)
         a = torch.empty((M, CP), dtype=torch.bfloat16, device=dev)
         scale = float((C // heads) ** -0.5)
         N.call("sei_swin_attn_fwd_bf16", qkv.data_ptr(), table.data_ptr(), a.data_ptr(), B, H, W, heads, shift, scale)
         x1 = torch.empty((M, C), dtype=torch.float32, device=dev)
         if drop1 is None:
-            gemm_nt16(a, wproj, M, C, CP, EPI_BIAS_RES, out32=x1, bias=bproj, R1=x2, flops=2.0 * M * C * C)
+            linear16(a, wproj, None, M, EPI_BIAS_RES, C, out32=x1, bias=bproj, R1=x2, flops=2.0 * M * C * C)
         else:
-            gemm_nt16(a, wproj, M, C, CP, EPI_BIAS_SCALE_RES, out32=x1, bias=bproj, R1=drop1, R2=x2, flops=2.0 * M * C * C)
+            linear16(a, wproj, None, M, EPI_BIAS_SCALE_RES, C, out32=x1, bias=bproj, R1=drop1, R2=x2, flops=2.0 * M * C * C)
         h2, mean2, rstd2 = ln16(x1, g2, b2)
         f3 = torch.empty((M, Ch), dtype=torch.float32, device=dev)
         f4 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
-        gemm_nt16(h2, w1, M, Ch, CP, EPI_BIAS_GELU, out32=f3, bias=pack.b(f"{key}.fc1_bias"), D2_16=f4,
-                  flops=2.0 * M * Chr * C)
+        linear16(h2, w1, None, M, EPI_BIAS_GELU, Ch, out32=f3, out16=f4, bias=pack.b(f"{key}.fc1_bias"), flops=2.0 * M * Chr * C)
         out = torch.empty((M, C), dtype=torch.float32, device=dev)
         if drop2 is None:
-            gemm_nt16(f4, w2, M, C, Ch, EPI_BIAS_RES, out32=out, bias=bm2, R1=x1, flops=2.0 * M * Chr * C)
+            linear16(f4, w2, None, M, EPI_BIAS_RES, C, out32=out, bias=bm2, R1=x1, flops=2.0 * M * Chr * C)
         else:
-            gemm_nt16(f4, w2, M, C, Ch, EPI_BIAS_SCALE_RES, out32=out, bias=bm2, R1=drop2, R2=x1, flops=2.0 * M * Chr * C)
+            linear16(f4, w2, None, M, EPI_BIAS_SCALE_RES, C, out32=out, bias=bm2, R1=drop2, R2=x1, flops=2.0 * M * Chr * C)
         ctx.save_for_backward(x, mean1, rstd1, h1, qkv, a, x1, mean2, rstd2, h2, f3, f4, drop1, drop2)
         ctx.params = (g1, b1, table, bproj, g2, b2, bm1, bm2)
         ctx.cfg = (pack, key, heads, shift)
@@ -263,20 +283,20 @@ class SwinBlockFn16(torch.autograd.Function):
         # MLP branch
         gy = cast_pad(go2, drop2, grad_of(bm2))
         gf3 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
-        gemm_nt16(gy, w2, M, Ch, CP, EPI_MUL_DGELU, out16=gf3, R1=f3, b_rmajor=True, flops=2.0 * M * Chr * C)
+        linear16(gy, pack.w(f"{key}.fc2T"), w2, M, EPI_MUL_DGELU, Ch, out16=gf3, R1=f3, flops=2.0 * M * Chr * C)
         gh2 = torch.empty((M, CP), dtype=torch.float32, device=dev)
-        gemm_nt16(gf3, w1, M, CP, Ch, EPI_NONE, out32=gh2, b_rmajor=True, flops=2.0 * M * Chr * C)
+        linear16(gf3, pack.w(f"{key}.fc1T"), w1, M, EPI_NONE, CP, out32=gh2, flops=2.0 * M * Chr * C)
         gx1 = ln_bwd(x1, g2, mean2, rstd2, gh2, go2, grad_of(g2), grad_of(b2))
         # attention branch
         gy1 = cast_pad(gx1, drop1, grad_of(bproj))
         ga = torch.empty((M, CP), dtype=torch.bfloat16, device=dev)
-        gemm_nt16(gy1, wproj, M, CP, CP, EPI_NONE, out16=ga, b_rmajor=True, flops=2.0 * M * C * C)
+        linear16(gy1, pack.w(f"{key}.projT"), wproj, M, EPI_NONE, CP, out16=ga, flops=2.0 * M * C * C)
         dqkv = torch.empty_like(qkv)
         scale = float((C // heads) ** -0.5)
         N.call("sei_swin_attn_bwd_bf16", qkv.data_ptr(), table.data_ptr(), ga.data_ptr(), dqkv.data_ptr(),
                grad_of(table).data_ptr(), B, H, W, heads, shift, scale)
         gh1 = torch.empty((M, CP), dtype=torch.float32, device=dev)
-        gemm_nt16(dqkv, wqkv, M, CP, 3 * heads * HP, EPI_NONE, out32=gh1, b_rmajor=True, flops=2.0 * M * 3 * C * C)
+        linear16(dqkv, pack.w(f"{key}.qkvT"), wqkv, M, EPI_NONE, CP, out32=gh1, flops=2.0 * M * 3 * C * C)
         gx = ln_bwd(x.view(M, C), g1, mean1, rstd1, gh1, gx1, grad_of(g1), grad_of(b1))
         # the four weight gradients (+ the qkv / fc1 bias gradients, column C) over the same tokens: one launch
         weight_grad16_group([(dqkv, h1, pack.g(f"{key}.qkv"), 2.0 * 3 * C * C), (gy1, a, pack.g(f"{key}.proj"), 2.0 * C * C),
