@@ -152,12 +152,12 @@ __global__ __launch_bounds__(TG_NT) void tokgrad_kernel(TokGradArgs g) {
 // sei_rowgemm_bf16: D (M x N) = epilogue(A (M x K) W^T), W (N x K) the layer's matrix, K = 192 / 384 / 576 and
 // N = 192 / 384 / 576 (zero-padded): nn.Linear forward and data gradient of the Swin blocks.
 //
-// One workgroup per CU, eight waves = 4 (columns) x 2 (halves of K). A wave keeps its 16 NB columns x K / 2 slice of W in
-// registers for the whole launch (36-108 VGPRs) and streams row tiles (TR = 32 or 64 rows, every tile this workgroup
+// One workgroup per CU, eight waves = column groups x row groups (x halves of K for K = 576). A wave keeps its slice of W
+// (its columns x K) in registers for the whole launch (72-144 VGPRs) and streams row tiles (TR = 32 or 64 rows, every tile this workgroup
 // owns: b, b + G, ...) through a three-stage LDS ring filled by LDS-DMA two tiles ahead -- A is read from HBM exactly once,
 // W once per workgroup. Per tile: [the tile's residual / GELU' rows into registers, DMA of tile t + 2] MFMAs [one counted
-// vmcnt: tile t + 1 has landed] the K halves are summed in an LDS patch, and all 512 threads walk the patch as row
-// quads: 16-byte auxiliary values (loaded before the MFMAs) and 16- / 8-byte stores on whole rows. Three barriers
+// vmcnt: tile t + 1 has landed] accumulators into an LDS patch, and all 512 threads walk the patch as row
+// quads: 16-byte auxiliary values (loaded before the MFMAs) and 16- / 8-byte stores on whole rows. Two barriers
 // per tile. Against the tiled kernels (K = 192: 3 k-tiles of loop, then an epilogue nothing overlaps; 1.125-2.25 rounds
 // of 128-row tiles on the chip) the loads of the next tiles and the stores of the last one are always in flight.
 // ---------------------------------------------------------------------------------------------------------------
@@ -195,20 +195,36 @@ __device__ __forceinline__ unsigned rg_pack2(float a, float b) {
 }
 
 // EPI: the SEI_EPI_* code; OUT16: SEI_EPI_NONE / _BIAS write bf16 (else float32)
-template <int KT, int NB, int TR, int EPI, bool OUT16>
+// Wave layout: 8 = WN (column groups) x WR (row groups) x WK (halves of K). WK = 2 only where a wave's slice of W would
+// not fit otherwise (K = 576): the two partial sums then meet in the patch. NBT 16-column blocks are dealt to the WN
+// groups as evenly as they go (36 blocks on 8 groups: five each for the first four, four for the rest).
+template <int KT, int NBT, int TR, int WN, int WR, int EPI, bool OUT16>
 __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
-    constexpr int NP = 64 * NB;                       // padded output width
+    constexpr int WK = 8 / (WN * WR);
+    static_assert(WN * WR * WK == 8 && (WK == 1 || WK == 2), "eight waves");
+    constexpr int NB = (NBT + WN - 1) / WN;           // blocks of the widest column group
+    constexpr int NBX = NBT % WN;                     // groups below NBX hold NB blocks, the others NB - 1 (0: all NB)
+    constexpr int RB = TR / WR / 16;                  // 16-row blocks per wave
+    constexpr int KS = 2 * KT / WK;                   // 32-wide k-steps per wave
+    static_assert(TR % (16 * WR) == 0 && (2 * KT) % WK == 0, "whole blocks per wave");
+    constexpr int NP = 16 * NBT;                      // padded output width
     constexpr int LDP = NP + 4;                       // patch row stride (floats): 4 LDP = 16 mod 64 banks
     constexpr int STAGE = KT * TR * 128;              // KT images of [TR rows][64 k] bf16
     constexpr int P = KT * TR / 8;                    // 1-KiB DMA pieces per stage
     constexpr int EMAX = (P + 7) / 8;
     constexpr int QR = NP / 4;                        // quads per row
-    constexpr int QPT = TR * QR / RG_NT;              // quads per thread
-    static_assert(TR * QR % RG_NT == 0 && TR % 16 == 0, "whole passes over the patch");
+    // what a thread finishes at a time: a quad (float32 outputs: 16-byte stores) or two neighbouring quads (bf16-only
+    // outputs: 16-byte stores of eight values)
+    constexpr int GQ = (OUT16 || EPI == SEI_EPI_MUL_DGELU) ? 2 : 1;
+    constexpr int IR = QR / GQ;                       // items per row
+    constexpr int IPT = (TR * IR + RG_NT - 1) / RG_NT;   // items per thread (the last pass may be partly empty)
+    constexpr bool RAGGED = TR * IR % RG_NT != 0;
+    constexpr int QPT = IPT * GQ;                     // quads per thread
+    static_assert(TR % 16 == 0 && QR % GQ == 0, "whole items");
     constexpr bool HAS_ROWS = EPI == SEI_EPI_BIAS_RES || EPI == SEI_EPI_BIAS_SCALE_RES || EPI == SEI_EPI_MUL_DGELU;
     constexpr bool HAS_BIAS = EPI == SEI_EPI_BIAS || EPI == SEI_EPI_BIAS_GELU || EPI == SEI_EPI_BIAS_RES ||
                               EPI == SEI_EPI_BIAS_SCALE_RES;
-    constexpr int UNR = NB == 9 ? 1 : QPT;            // the widest variant (108 + 72 registers of W and accumulators) walks its quads one by one
+    constexpr int UNR = IPT > 3 ? (GQ == 2 ? 2 : 3) : IPT;   // items in flight per thread in the last pass
     constexpr int NAUX = (HAS_ROWS ? QPT : 0) + (EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 0);   // loads per thread and tile
     __shared__ __attribute__((aligned(1024))) char smem[3 * STAGE + TR * LDP * 4 + NP * 4];
     float *patch = reinterpret_cast<float *>(smem + 3 * STAGE);
@@ -216,20 +232,22 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 3, wk = wave >> 2;
+    const int wn = wave % WN, wr = (wave / WN) % WR, wk = wave / (WN * WR);
+    const int nbw = (NBX == 0 || wn < NBX) ? NB : NB - 1;                          // this wave's blocks ...
+    const int nb0 = (NBX == 0 || wn < NBX) ? NB * wn : NB * NBX + (NB - 1) * (wn - NBX);   // ... from block nb0 on
     const int l16 = lane & 15, lg = lane >> 4;
     const int G = gridDim.x, b = blockIdx.x;
     if (b >= g.tiles) return;
     const int nt = (g.tiles - b + G - 1) / G;          // tiles b, b + G, ...
 
     // ---- W slice of this wave: columns 16 NB wn .., k-steps wk KT .. (32 k each), MFMA B-operand layout
-    bf16x8 wf[NB][KT];
+    bf16x8 wf[NB][KS];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int s = 0; s < KT; ++s)
-            wf[nb][s] = *reinterpret_cast<const bf16x8 *>(g.W + (size_t)(16 * NB * wn + 16 * nb + l16) * g.ldw +
-                                                          32 * (wk * KT + s) + 8 * lg);
+        for (int s = 0; s < KS; ++s)
+            wf[nb][s] = *reinterpret_cast<const bf16x8 *>(g.W + (size_t)(16 * (nb0 + min(nb, nbw - 1)) + l16) * g.ldw +
+                                                          32 * (wk * KS + s) + 8 * lg);
     if (HAS_BIAS)
         for (int c = tid; c < NP; c += RG_NT) lbias[c] = c < g.nv ? g.bias[c] : 0.f;
     // W is in the registers before the ring starts: a use the compiler can see here, so that it does not wait for these
@@ -237,7 +255,7 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int s = 0; s < KT; ++s) asm volatile("" : "+v"(wf[nb][s]));
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[nb][s]));
 
     // ---- DMA pieces of a stage: piece q = image q / (TR / 8), rows 8 (q % (TR / 8)) ..; chunk swizzle (r >> 1) & 7
     unsigned offa[EMAX];
@@ -265,11 +283,12 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     // same inputs, same result, same address -- instead of masking their stores: a branch around a store makes the store
     // count of the in-order vmcnt unknowable, and the compiler then waits for everything (the ring included) before it
     constexpr bool F32_ONLY = !(OUT16 || EPI == SEI_EPI_MUL_DGELU || EPI == SEI_EPI_BIAS_GELU);
-    auto quad_row = [&](int i) { return (tid + RG_NT * i) / QR; };
-    auto quad_col = [&](int i) {
-        const int c = 4 * ((tid + RG_NT * i) % QR);
+    auto quad_row = [&](int q) { return (tid + RG_NT * (q / GQ)) / IR; };        // quad q = quad q % GQ of item q / GQ
+    auto quad_col = [&](int q) {
+        const int c = 4 * (GQ * ((tid + RG_NT * (q / GQ)) % IR) + q % GQ);
         return F32_ONLY ? min(c, g.nv - 4) : c;
     };
+    static_assert(!(HAS_ROWS && RAGGED), "auxiliary rows are loaded for whole passes");
     f32x4 cur[HAS_ROWS ? QPT : 1];
     float curs[EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 1];
     auto load_aux = [&](int t, f32x4 (&a)[HAS_ROWS ? QPT : 1], float (&sc)[EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 1]) {
@@ -304,48 +323,54 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);                // (the order the counted wait below assumes)
         issue(t + 2);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- MFMAs: rows 16 rb .. of the tile x this wave's columns, its half of K
+        // ---- MFMAs: this wave's rows x columns of the tile (its half of K when WK = 2)
         const char *st = smem + (t % 3) * STAGE;
-        f32x4 acc[TR / 16][NB];
+        f32x4 acc[RB][NB];
 #pragma unroll
-        for (int rb = 0; rb < TR / 16; ++rb)
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < KT; ++s) {
-            const int sg = wk * KT + s;                   // wave-uniform
-            const char *img = st + (sg >> 1) * (TR * 128) + l16 * 128 + (((4 * (sg & 1) + lg) ^ (l16 >> 1)) * 16);
+        for (int s = 0; s < KS; ++s) {
+            const int sg = wk * KS + s;                   // wave-uniform
+            const char *img = st + (sg >> 1) * (TR * 128) + (wr * RB * 16 + l16) * 128 + (((4 * (sg & 1) + lg) ^ (l16 >> 1)) * 16);
 #pragma unroll
-            for (int rb = 0; rb < TR / 16; ++rb) {
+            for (int rb = 0; rb < RB; ++rb) {
                 const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(img + rb * 16 * 128);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (NBX != 0 && nb == NB - 1 && nbw < NB) break;         // wave-uniform: this group has NB - 1 blocks
                     acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf[nb][s], acc[rb][nb], 0, 0, 0);
+                }
             }
         }
         // tile t + 1 (issued one iteration ago) and everything older have landed; what this iteration issued may fly
         if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NAUX + NDMA_LO + 1>();
         else rg_wait_vmcnt<NAUX + NDMA_LO>();
-        // ---- the two K halves meet in the patch
-        float *pw = patch + (4 * lg) * LDP + 16 * NB * wn + l16;
+        // ---- accumulators into the patch (WK = 2: the second half of K adds to the first)
+        float *pw = patch + (wr * RB * 16 + 4 * lg) * LDP + 16 * nb0 + l16;
         if (wk == 0) {
 #pragma unroll
-            for (int rb = 0; rb < TR / 16; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (NBX != 0 && nb == NB - 1 && nbw < NB) break;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) pw[(16 * rb + j) * LDP + 16 * nb] = acc[rb][nb][j];
+                }
         }
         rg_lds_barrier();
-        if (wk == 1) {
+        if constexpr (WK == 2) {
+            if (wk == 1) {
 #pragma unroll
-            for (int rb = 0; rb < TR / 16; ++rb)
+                for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pw[(16 * rb + j) * LDP + 16 * nb] += acc[rb][nb][j];
+                        for (int j = 0; j < 4; ++j) pw[(16 * rb + j) * LDP + 16 * nb] += acc[rb][nb][j];
+            }
+            rg_lds_barrier();
         }
-        rg_lds_barrier();
         // ---- rows out: the tile's auxiliary rows have landed when only this iteration's DMA pieces are in flight. The wait
         // first, between scheduling fences, and only then a use of the registers that the compiler can see: a copy it
         // makes for that use then reads landed data (tied to the wait itself, the copy was placed in front of it)
@@ -362,30 +387,39 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
         }
         const size_t row0 = (size_t)(b + t * G) * TR;
 #pragma unroll UNR
-        for (int i = 0; i < QPT; ++i) {
-            const int qr = quad_row(i), qc = quad_col(i);
-            f32x4 v = *reinterpret_cast<const f32x4 *>(patch + qr * LDP + qc);
-            const size_t row = row0 + qr;
-            const bool ok = qc < g.nv;
-            if constexpr (HAS_BIAS) v += *reinterpret_cast<const f32x4 *>(lbias + qc);
-            if constexpr (EPI == SEI_EPI_BIAS_RES) v += cur[i];
-            if constexpr (EPI == SEI_EPI_BIAS_SCALE_RES) v = cur[i] + curs[i] * v;
-            if constexpr (EPI == SEI_EPI_MUL_DGELU) {
+        for (int it = 0; it < IPT; ++it) {
+            if (RAGGED && it == IPT - 1 && tid + RG_NT * it >= TR * IR) break;      // wave-uniform (whole waves past the end)
+            f32x4 v[GQ];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] * sei_dgelu_bf16out(cur[i][j]) : 0.f;
+            for (int gq = 0; gq < GQ; ++gq) {
+                const int i = it * GQ + gq;
+                const int qr = quad_row(i), qc = quad_col(i);
+                v[gq] = *reinterpret_cast<const f32x4 *>(patch + qr * LDP + qc);
+                if constexpr (HAS_BIAS) v[gq] += *reinterpret_cast<const f32x4 *>(lbias + qc);
+                if constexpr (EPI == SEI_EPI_BIAS_RES) v[gq] += cur[i];
+                if constexpr (EPI == SEI_EPI_BIAS_SCALE_RES) v[gq] = cur[i] + curs[i] * v[gq];
+                if constexpr (EPI == SEI_EPI_MUL_DGELU) {
+                    const bool ok = qc < g.nv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[gq][j] = ok ? v[gq][j] * sei_dgelu_bf16out(cur[i][j]) : 0.f;
+                }
             }
-            if constexpr (EPI == SEI_EPI_BIAS_GELU || F32_ONLY)      // (BIAS_GELU: nv = all 64 NB columns, host-checked)
-                *reinterpret_cast<f32x4 *>(g.D32 + row * g.ld32 + qc) = v;
+            const int qr = quad_row(it * GQ), qc = quad_col(it * GQ);
+            const size_t row = row0 + qr;
+            if constexpr (EPI == SEI_EPI_BIAS_GELU || F32_ONLY)      // (BIAS_GELU: nv = all the columns, host-checked)
+                *reinterpret_cast<f32x4 *>(g.D32 + row * g.ld32 + qc) = v[0];
             if constexpr (EPI == SEI_EPI_BIAS_GELU) {
                 uint2 h;
-                h.x = rg_pack2(sei_gelu_bf16out(v[0]), sei_gelu_bf16out(v[1]));
-                h.y = rg_pack2(sei_gelu_bf16out(v[2]), sei_gelu_bf16out(v[3]));
+                h.x = rg_pack2(sei_gelu_bf16out(v[0][0]), sei_gelu_bf16out(v[0][1]));
+                h.y = rg_pack2(sei_gelu_bf16out(v[0][2]), sei_gelu_bf16out(v[0][3]));
                 *reinterpret_cast<uint2 *>(g.D16 + row * g.ld16 + qc) = h;
-            } else if constexpr (OUT16 || EPI == SEI_EPI_MUL_DGELU) {
-                uint2 h;
-                h.x = rg_pack2(v[0], v[1]);
-                h.y = rg_pack2(v[2], v[3]);
-                *reinterpret_cast<uint2 *>(g.D16 + row * g.ld16 + qc) = h;
+            } else if constexpr (GQ == 2) {
+                uint4 h;
+                h.x = rg_pack2(v[0][0], v[0][1]);
+                h.y = rg_pack2(v[0][2], v[0][3]);
+                h.z = rg_pack2(v[GQ - 1][0], v[GQ - 1][1]);
+                h.w = rg_pack2(v[GQ - 1][2], v[GQ - 1][3]);
+                *reinterpret_cast<uint4 *>(g.D16 + row * g.ld16 + qc) = h;
             }
         }
         rg_lds_barrier();                                 // the patch and stage t % 3 are free again
@@ -393,12 +427,12 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     rg_wait_vmcnt<0>();                                   // the clamped stages still in flight
 }
 
-template <int KT, int NB, int TR, int EPI, bool OUT16>
+template <int KT, int NBT, int TR, int WN, int WR, int EPI, bool OUT16>
 int rg_launch(const RowGemmArgs &g, int M, hipStream_t s) {
     RowGemmArgs a = g;
     a.tiles = M / TR;
     const int grid = a.tiles < 256 ? a.tiles : 256;
-    hipLaunchKernelGGL((rowgemm_kernel<KT, NB, TR, EPI, OUT16>), dim3((unsigned)grid), dim3(RG_NT), 0, s, a);
+    hipLaunchKernelGGL((rowgemm_kernel<KT, NBT, TR, WN, WR, EPI, OUT16>), dim3((unsigned)grid), dim3(RG_NT), 0, s, a);
     return sei_launch_status();
 }
 
@@ -484,7 +518,7 @@ extern "C" int sei_rowgemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
                           epilogue == SEI_EPI_BIAS_SCALE_RES;
     SEI_REQUIRE(!has_bias || bias);
     if (D32) SEI_REQUIRE(ld32 >= nv && ld32 % 4 == 0 && ((uintptr_t)D32 & 15) == 0);
-    if (D16) SEI_REQUIRE(ld16 >= N && ld16 % 4 == 0 && ((uintptr_t)D16 & 7) == 0);
+    if (D16) SEI_REQUIRE(ld16 >= N && ld16 % 8 == 0 && ((uintptr_t)D16 & 15) == 0);
     if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D32 && D16 && nv == N);
     if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU)
         SEI_REQUIRE(R1 && !R2 && ldr >= nv && ldr % 4 == 0 && ((uintptr_t)R1 & 15) == 0);
@@ -494,19 +528,20 @@ extern "C" int sei_rowgemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
     g.D32 = D32; g.D16 = D16; g.ld32 = ld32; g.ld16 = ld16; g.nv = nv;
     hipStream_t s = (hipStream_t)stream;
     const int m = (int)M;
+    // <k-tiles, 16-column blocks, rows per tile, column groups, row groups>
     switch (epilogue) {
-        case SEI_EPI_BIAS: return rg_launch<3, 9, 32, SEI_EPI_BIAS, true>(g, m, s);
+        case SEI_EPI_BIAS: return rg_launch<3, 36, 32, 8, 1, SEI_EPI_BIAS, true>(g, m, s);
         case SEI_EPI_BIAS_RES:
-            return K == 192 ? rg_launch<3, 3, 64, SEI_EPI_BIAS_RES, false>(g, m, s)
-                            : rg_launch<6, 3, 32, SEI_EPI_BIAS_RES, false>(g, m, s);
+            return K == 192 ? rg_launch<3, 12, 64, 4, 2, SEI_EPI_BIAS_RES, false>(g, m, s)
+                            : rg_launch<6, 12, 32, 4, 2, SEI_EPI_BIAS_RES, false>(g, m, s);
         case SEI_EPI_BIAS_SCALE_RES:
-            return K == 192 ? rg_launch<3, 3, 64, SEI_EPI_BIAS_SCALE_RES, false>(g, m, s)
-                            : rg_launch<6, 3, 32, SEI_EPI_BIAS_SCALE_RES, false>(g, m, s);
-        case SEI_EPI_BIAS_GELU: return rg_launch<3, 6, 32, SEI_EPI_BIAS_GELU, false>(g, m, s);
-        case SEI_EPI_MUL_DGELU: return rg_launch<3, 6, 32, SEI_EPI_MUL_DGELU, true>(g, m, s);
+            return K == 192 ? rg_launch<3, 12, 64, 4, 2, SEI_EPI_BIAS_SCALE_RES, false>(g, m, s)
+                            : rg_launch<6, 12, 32, 4, 2, SEI_EPI_BIAS_SCALE_RES, false>(g, m, s);
+        case SEI_EPI_BIAS_GELU: return rg_launch<3, 24, 32, 8, 1, SEI_EPI_BIAS_GELU, false>(g, m, s);
+        case SEI_EPI_MUL_DGELU: return rg_launch<3, 24, 32, 8, 1, SEI_EPI_MUL_DGELU, true>(g, m, s);
         default:
-            if (K == 192) return rg_launch<3, 3, 64, SEI_EPI_NONE, true>(g, m, s);
-            if (K == 384) return rg_launch<6, 3, 32, SEI_EPI_NONE, false>(g, m, s);
-            return rg_launch<9, 3, 32, SEI_EPI_NONE, false>(g, m, s);
+            if (K == 192) return rg_launch<3, 12, 64, 4, 2, SEI_EPI_NONE, true>(g, m, s);
+            if (K == 384) return rg_launch<6, 12, 32, 4, 2, SEI_EPI_NONE, false>(g, m, s);
+            return rg_launch<9, 12, 32, 4, 1, SEI_EPI_NONE, false>(g, m, s);
     }
 }

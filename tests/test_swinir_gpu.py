@@ -513,3 +513,79 @@ def test_token_streamed_weight_gradients(K1, K2):
     assert N.lib().sei_tokgrad_bf16_eligible(180, 192, 192, 192, 64, 0) == 0
     assert N.lib().sei_tokgrad_bf16_eligible(192, 192, 192, 192, 72, 0) == 0
     assert N.lib().sei_tokgrad_bf16_eligible(576, 576, 576, 576, 64, 0) == 0
+
+
+_ROWGEMM_CASES = [("qkv", 576, 192, 576, 1, True), ("proj", 192, 192, 180, 3, False), ("proj_drop", 192, 192, 180, 7, False),
+                  ("fc1", 384, 192, 384, 2, False), ("fc2", 192, 384, 180, 3, False), ("fc2_drop", 192, 384, 180, 7, False),
+                  ("fc2_dgrad", 384, 192, 384, 4, True), ("fc1_dgrad", 192, 384, 192, 0, False),
+                  ("proj_dgrad", 192, 192, 192, 0, True), ("qkv_dgrad", 192, 576, 192, 0, False)]
+
+
+@pytest.mark.parametrize("M", [64, 4608, 256 * 64 + 128])
+@pytest.mark.parametrize("name,Nn,K,nv,epi,only16", _ROWGEMM_CASES, ids=[c[0] for c in _ROWGEMM_CASES])
+def test_row_streaming_linear_layers(M, name, Nn, K, nv, epi, only16):
+    """sei_rowgemm_bf16 (nn.Linear forward and data gradient of deepinv's SwinIR blocks with the layer's matrix held in
+    registers) against float64 on the same bf16 operands, every epilogue the blocks use: float32 outputs to 2e-6 of the
+    largest value, bf16 outputs to one rounding; padding columns of bf16 outputs are exact zeros; the float32 output is
+    not touched past its nv columns. One tile, fewer tiles than workgroups, more tiles than workgroups (ragged shares).
+    The tiled kernel (sei_gemm_bf16nt) on the same inputs agrees to the float summation order."""
+    import _native as N
+    gen = torch.Generator(device="cuda").manual_seed(M + Nn + K + epi)
+    a = torch.randn((M, K), device="cuda", generator=gen).bfloat16()
+    w = (0.1 * torch.randn((Nn, K), device="cuda", generator=gen)).bfloat16()
+    w[nv:] = 0
+    bias = torch.randn(nv, device="cuda", generator=gen)
+    rows = torch.randn((M, nv), device="cuda", generator=gen)
+    drop = (torch.rand(M, device="cuda", generator=gen) > 0.2).float() / 0.8
+    assert N.lib().sei_rowgemm_bf16_eligible(M, Nn, K, epi, int(only16)) == 1
+    ld32 = nv + 4                                          # a guard column block: must stay untouched
+    d32 = None if only16 else torch.full((M, ld32), 7.0, device="cuda")
+    d16 = torch.full((M, Nn), 7.0, device="cuda").bfloat16() if (only16 or epi == 2) else None
+    R1 = drop if epi == 7 else (rows if epi in (3, 4) else None)
+    R2 = rows if epi == 7 else None
+    N.call("sei_rowgemm_bf16", a.data_ptr(), K, w.data_ptr(), K, N.ptr(d32), ld32, N.ptr(d16), Nn, M, Nn, K, nv, epi,
+           bias.data_ptr() if epi in (1, 2, 3, 7) else None, N.ptr(R1), N.ptr(R2), nv)
+    acc = a.double() @ w.double().T
+    if epi in (1, 2, 3, 7):
+        acc[:, :nv] += bias.double()
+    if epi == 3:
+        ref = acc[:, :nv] + rows.double()
+    elif epi == 7:
+        ref = rows.double() + drop.double()[:, None] * acc[:, :nv]
+    elif epi == 4:
+        x = rows.double()
+        ref = acc[:, :nv] * (0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * np.pi) ** 0.5)
+    else:
+        ref = acc[:, :nv]
+    scale = float(ref.abs().max())
+    if d32 is not None:
+        assert float((d32[:, :nv].double() - ref).abs().max()) < 2e-6 * scale
+        assert bool((d32[:, nv:] == 7.0).all())
+    if d16 is not None:
+        r16 = torch.nn.functional.gelu(ref) if epi == 2 else ref
+        assert float((d16[:, :nv].double() - r16).abs().max()) < 2.0 ** -8 * max(float(r16.abs().max()), 1.0)
+        if nv < Nn:
+            assert bool((d16[:, nv:] == 0).all())
+    if epi != 2 and not (only16 and nv != Nn):             # the tiled kernel on the same inputs
+        o32 = None if only16 else torch.zeros((M, nv), device="cuda")
+        o16 = torch.zeros((M, nv), device="cuda").bfloat16() if only16 else None
+        N.call("sei_gemm_bf16nt", a.data_ptr(), K, 0, w.data_ptr(), K, 0, N.ptr(o32), N.ptr(o16), M, nv, K, epi,
+               bias.data_ptr() if epi in (1, 3, 7) else None, N.ptr(R1), N.ptr(R2), None)
+        if o32 is not None:
+            assert float((d32[:, :nv] - o32).abs().max()) < 2e-6 * scale
+        else:
+            assert float((d16[:, :nv].float() - o16.float()).abs().max()) <= 2.0 ** -7 * max(scale, 1.0)
+
+
+def test_row_streaming_kernel_refuses_other_shapes():
+    import _native as N
+    elig = N.lib().sei_rowgemm_bf16_eligible
+    assert elig(4608, 576, 192, 1, 1) == 1
+    assert elig(4600, 576, 192, 1, 1) == 0                 # rows: whole 64-row tiles only
+    assert elig(4608, 540, 192, 1, 1) == 0 and elig(4608, 576, 180, 1, 1) == 0
+    assert elig(4608, 576, 192, 1, 0) == 0                 # qkv is built for bf16 output only
+    assert elig(4608, 192, 576, 3, 0) == 0                 # no residual epilogue at K = 576
+    a = torch.zeros((64, 192), device="cuda").bfloat16()
+    with pytest.raises(N.NativeLibraryError):
+        N.call("sei_rowgemm_bf16", a.data_ptr(), 192, a.data_ptr(), 192, None, 0, a.data_ptr(), 576, 64, 576, 192, 576, 1,
+               None, None, None, 0)                        # SEI_EPI_BIAS without a bias
