@@ -506,6 +506,23 @@ int sei_rowgemm_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, flo
                      const float *R2, int ldr, void *stream);
 size_t sei_rowgemm_bf16_eligible(long long M, int N, int K, int epilogue, int out16);
 
+/* The data gradient of a linear layer that follows a LayerNorm, with the LayerNorm's backward in the epilogue (the
+ * product never leaves the chip): gh = A W^T (A: (M, lda >= K) bf16; W: (192, ldw >= K) bf16, rows >= C zero; K 384 or
+ * 576), then torch's native_layer_norm_backward over the C channels of every row plus the residual gradient:
+ *   gx = rstd (gh gamma - mean_c(gh gamma) - xhat mean_c(gh gamma xhat)) + res,   xhat = (x - mean) rstd;
+ *   ggamma += sum_rows gh xhat,  gbeta += sum_rows gh;
+ * and, when y16 is given (K = 384 only), the operand of the next weight / data gradient in the same pass:
+ *   y16 (M, ldy >= 192; zeros past C) = bf16(gx row_scale[row]),  colsum += sum_rows gx row_scale[row].
+ * x, res, gx: (M, C) float32 rows; mean, rstd, row_scale: M floats. work: sei_rowgemm_lnbwd_work_floats(C) floats (per-
+ * workgroup column sums, folded by a second launch). Replaces sei_gemm_bf16nt + sei_ln_bwd_pad (+ sei_cast_pad_bf16):
+ * deepinv SwinIR's norm1 / norm2 in front of qkv / fc1 (reference construction: src/models/__init__.py:51-74). */
+int sei_rowgemm_lnbwd_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, long long M, int K, const float *x,
+                           const float *gamma, const float *mean, const float *rstd, const float *res, float *gx, int C,
+                           float *ggamma, float *gbeta, const float *row_scale, uint16_t *y16, int ldy, float *colsum,
+                           float *work, size_t work_floats, void *stream);
+size_t sei_rowgemm_lnbwd_bf16_eligible(long long M, int K, int C);
+size_t sei_rowgemm_lnbwd_work_floats(int C);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,3 +100,6 @@ bool sei_dwconv7_ln_fused_eligible(const float *x, const float *w, int B, int H,
 int sei_dwconv7_ln_fused_launch(const float *x, const float *w, const float *bias, const float *gamma,
                                 const float *beta, float *h1, void *h2, int out16, float *mean, float *rstd, int B, int H,
                                 int W, int C, float eps, hipStream_t s);
+
+// swin_bf16_kernels.hip: out[c] += sum over groups of part[group][..][c] (internal linkage between translation units)
+int sei_fold_partials3(const float *part, int groups, int C, float *a, float *b, float *c3, hipStream_t s);

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_pad_kernel(const float *__restrict
 // workgroup, four slices of 256-512 DEPENDENT loads each -- 64 us per fold, 12 % of the SwinIR step.)
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float *__restrict__ part, int groups, int ncol,
                                                              int split, float *__restrict__ out_a,
-                                                             float *__restrict__ out_b) {
+                                                             float *__restrict__ out_b, float *__restrict__ out_c = nullptr) {
     __shared__ float red[16][16];
     const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + el;
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float *__restr
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += red[k][el];
         if (c < split) out_a[c] += s;
-        else out_b[c - split] += s;
+        else if (c < 2 * split) out_b[c - split] += s;
+        else if (out_c) out_c[c - 2 * split] += s;          // (three sums per row: token_gemm.hip's LayerNorm epilogue)
     }
 }
 
@@ -266,6 +267,14 @@ extern "C" int sei_ln_fwd_bf16_pad(const float *x, const float *gamma, const flo
                 ((uintptr_t)y & 7) == 0);
     hipLaunchKernelGGL(ln_fwd_bf16_pad_kernel, dim3(stream_grid(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
                        beta, y, mean, rstd, rows, C, ldy, eps, ones_col);
+    return sei_launch_status();
+}
+
+// [groups][3][C] partial sums -> a[c] += .., b[c] += .., c3[c] += .. (c3 may be null: the third sum is dropped)
+int sei_fold_partials3(const float *part, int groups, int C, float *a, float *b, float *c3, hipStream_t s) {
+    const int ncol = 3 * C;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)sei_ceil_div(ncol, 16)), dim3(256), 0, s, part, groups, ncol, C, a,
+                       b, c3);
     return sei_launch_status();
 }
 

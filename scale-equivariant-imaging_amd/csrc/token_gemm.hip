@@ -174,7 +174,14 @@ struct RowGemmArgs {
     unsigned short *D16;      // the result in bf16 (BIAS, NONE, MUL_DGELU) / gelu(result) in bf16 (BIAS_GELU)
     int ld32, ld16;
     int nv;                   // valid output columns of D32 / R (a multiple of 4); D16 always gets all 64 NB columns
+    // RG_EPI_LNBWD (the product is the gradient with respect to a LayerNorm's output): the norm's input rows (R1, ldr),
+    // its statistics and weight, the residual gradient rows (R2, ldr); D32 = the gradient with respect to the input;
+    // optionally D16 = bf16(D32 * scale[row]) in 192-column rows; part: [workgroup][3][nv] column sums
+    const float *mean, *rstd, *gamma, *scale;
+    float *part;
 };
+
+constexpr int RG_EPI_LNBWD = 100;     // internal epilogue code (sei_rowgemm_lnbwd_bf16)
 
 template <int N>
 __device__ __forceinline__ void rg_wait_vmcnt() {
@@ -215,7 +222,9 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     constexpr int QR = NP / 4;                        // quads per row
     // what a thread finishes at a time: a quad (float32 outputs: 16-byte stores) or two neighbouring quads (bf16-only
     // outputs: 16-byte stores of eight values)
-    constexpr int GQ = (OUT16 || EPI == SEI_EPI_MUL_DGELU) ? 2 : 1;
+    constexpr bool LNB = EPI == RG_EPI_LNBWD;         // OUT16 then says: also write the scaled bf16 copy
+    static_assert(!LNB || (NBT == 12 && TR == 32), "the LayerNorm epilogue owns 32 rows x 192 columns: 16 lanes per row");
+    constexpr int GQ = (!LNB && (OUT16 || EPI == SEI_EPI_MUL_DGELU)) ? 2 : 1;
     constexpr int IR = QR / GQ;                       // items per row
     constexpr int IPT = (TR * IR + RG_NT - 1) / RG_NT;   // items per thread (the last pass may be partly empty)
     constexpr bool RAGGED = TR * IR % RG_NT != 0;
@@ -225,7 +234,8 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     constexpr bool HAS_BIAS = EPI == SEI_EPI_BIAS || EPI == SEI_EPI_BIAS_GELU || EPI == SEI_EPI_BIAS_RES ||
                               EPI == SEI_EPI_BIAS_SCALE_RES;
     constexpr int UNR = IPT > 3 ? (GQ == 2 ? 2 : 3) : IPT;   // items in flight per thread in the last pass
-    constexpr int NAUX = (HAS_ROWS ? QPT : 0) + (EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 0);   // loads per thread and tile
+    constexpr int NAUX = LNB ? 8 + (OUT16 ? 1 : 0)
+                             : (HAS_ROWS ? QPT : 0) + (EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 0);   // loads per thread and tile
     __shared__ __attribute__((aligned(1024))) char smem[3 * STAGE + TR * LDP * 4 + NP * 4];
     float *patch = reinterpret_cast<float *>(smem + 3 * STAGE);
     float *lbias = patch + TR * LDP;
@@ -311,6 +321,37 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
         }
     };
 
+    // ---- LayerNorm backward in the epilogue: thread = (row tid / 16, lane el of 16), quads el, el + 16, el + 32 of the row
+    const int er = tid >> 4, el = tid & 15;
+    const int nvq = g.nv >> 2;
+    f32x4 lx[LNB ? 3 : 1], lr[LNB ? 3 : 1], ag[LNB ? 3 : 1], ab[LNB ? 3 : 1], ac[LNB ? 3 : 1];
+    float lmu = 0.f, lrs = 0.f, lsc = 1.f;
+    if constexpr (LNB) {
+        for (int c = tid; c < NP; c += RG_NT) lbias[c] = c < g.nv ? g.gamma[c] : 0.f;     // the norm's weight, read per tile
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ag[k] = ab[k] = ac[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto load_ln = [&](int t) {
+        if constexpr (LNB) {
+            const int tile = b + min(t, nt - 1) * G;
+            const size_t row = (size_t)tile * TR + er;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int c = 4 * min(el + 16 * k, nvq - 1);
+                const float *xs = g.R1 + row * g.ldr + c, *rs = g.R2 + row * g.ldr + c;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lx[k]) : "v"(xs) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lr[k]) : "v"(rs) : "memory");
+            }
+            const float *ms = g.mean + row, *ss = g.rstd + row;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(lmu) : "v"(ms) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(lrs) : "v"(ss) : "memory");
+            if constexpr (OUT16) {
+                const float *cs = g.scale + row;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(lsc) : "v"(cs) : "memory");
+            }
+        }
+    };
+
     // ---- prologue: tile 0 and its auxiliary rows landed, tile 1 in flight
     issue(0);
     issue(1);
@@ -320,6 +361,7 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
 
     for (int t = 0; t < nt; ++t) {
         load_aux(t, cur, curs);                           // this tile's residual / GELU' rows: used after the MFMAs
+        load_ln(t);
         __builtin_amdgcn_sched_barrier(0);                // (the order the counted wait below assumes)
         issue(t + 2);
         __builtin_amdgcn_sched_barrier(0);
@@ -386,8 +428,70 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
             }
         }
         const size_t row0 = (size_t)(b + t * G) * TR;
+        if constexpr (LNB) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NDMA_LO + 1>();
+            else rg_wait_vmcnt<NDMA_LO>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                asm volatile("" : "+v"(lx[k]));
+                asm volatile("" : "+v"(lr[k]));
+            }
+            asm volatile("" : "+v"(lmu));
+            asm volatile("" : "+v"(lrs));
+            if constexpr (OUT16) asm volatile("" : "+v"(lsc));
+            // gx = rstd (t - mean_c(t) - xhat mean_c(t xhat)) + residual, t = g gamma (torch's native_layer_norm_backward)
+            f32x4 gh[3], xh[3], tq[3];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const bool valid = el + 16 * k < nvq;
+                gh[k] = *reinterpret_cast<const f32x4 *>(patch + er * LDP + 4 * (el + 16 * k));
+                const f32x4 gm = *reinterpret_cast<const f32x4 *>(lbias + 4 * (el + 16 * k));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[k][j] = (lx[k][j] - lmu) * lrs;
+                    tq[k][j] = gh[k][j] * gm[j];
+                }
+                if (valid) {
+                    s1 += (tq[k][0] + tq[k][1]) + (tq[k][2] + tq[k][3]);
+                    s2 += (tq[k][0] * xh[k][0] + tq[k][1] * xh[k][1]) + (tq[k][2] * xh[k][2] + tq[k][3] * xh[k][3]);
+                    ag[k] += gh[k] * xh[k];
+                    ab[k] += gh[k];
+                }
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                s1 += __shfl_xor(s1, off, 16);
+                s2 += __shfl_xor(s2, off, 16);
+            }
+            const float invC = 1.0f / (float)g.nv;
+            s1 *= invC;
+            s2 *= invC;
+            const size_t row = row0 + er;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int qk = el + 16 * k;
+                const bool valid = qk < nvq;
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = lrs * (tq[k][j] - s1 - xh[k][j] * s2) + lr[k][j];
+                if (valid) *reinterpret_cast<f32x4 *>(g.D32 + row * g.ld32 + 4 * qk) = o;
+                if constexpr (OUT16) {
+                    f32x4 ys;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ys[j] = valid ? o[j] * lsc : 0.f;
+                    ac[k] += ys;
+                    uint2 h;
+                    h.x = rg_pack2(ys[0], ys[1]);
+                    h.y = rg_pack2(ys[2], ys[3]);
+                    *reinterpret_cast<uint2 *>(g.D16 + row * g.ld16 + 4 * qk) = h;
+                }
+            }
+        }
 #pragma unroll UNR
-        for (int it = 0; it < IPT; ++it) {
+        for (int it = 0; it < (LNB ? 0 : IPT); ++it) {
             if (RAGGED && it == IPT - 1 && tid + RG_NT * it >= TR * IR) break;      // wave-uniform (whole waves past the end)
             f32x4 v[GQ];
 #pragma unroll
@@ -425,6 +529,26 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
         rg_lds_barrier();                                 // the patch and stage t % 3 are free again
     }
     rg_wait_vmcnt<0>();                                   // the clamped stages still in flight
+    if constexpr (LNB) {
+        // column sums of this workgroup: [3][32 rows][48 quads] through the (now idle) ring, then 3 x 48 threads add up
+        // the 32 rows in a fixed order; [workgroup][3][nv] partials, folded by sei_fold_partials3
+        static_assert(3 * STAGE >= 3 * 32 * 48 * 16, "the ring holds the partial sums");
+        __builtin_amdgcn_s_barrier();
+        f32x4 *red = reinterpret_cast<f32x4 *>(smem);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            red[(0 * 32 + er) * 48 + el + 16 * k] = ag[k];
+            red[(1 * 32 + er) * 48 + el + 16 * k] = ab[k];
+            red[(2 * 32 + er) * 48 + el + 16 * k] = ac[k];
+        }
+        __syncthreads();
+        if (tid < 144) {
+            const int sel = tid / 48, qk = tid - sel * 48;
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 32; ++r) a += red[(sel * 32 + r) * 48 + qk];
+            if (qk < nvq) *reinterpret_cast<f32x4 *>(g.part + ((size_t)b * 3 + sel) * g.nv + 4 * qk) = a;
+        }
+    }
 }
 
 template <int KT, int NBT, int TR, int WN, int WR, int EPI, bool OUT16>
@@ -544,4 +668,37 @@ extern "C" int sei_rowgemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
             if (K == 384) return rg_launch<6, 12, 32, 4, 2, SEI_EPI_NONE, false>(g, m, s);
             return rg_launch<9, 12, 32, 4, 1, SEI_EPI_NONE, false>(g, m, s);
     }
+}
+
+extern "C" size_t sei_rowgemm_lnbwd_bf16_eligible(long long M, int K, int C) {
+    return (M > 0 && M % 64 == 0 && M < (1ll << 31) && (K == 384 || K == 576) && C > 0 && C % 4 == 0 && C <= 192) ? 1 : 0;
+}
+
+extern "C" size_t sei_rowgemm_lnbwd_work_floats(int C) { return C > 0 ? (size_t)256 * 3 * (size_t)C : 0; }
+
+extern "C" int sei_rowgemm_lnbwd_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, long long M, int K, const float *x,
+                                      const float *gamma, const float *mean, const float *rstd, const float *res, float *gx,
+                                      int C, float *ggamma, float *gbeta, const float *row_scale, uint16_t *y16, int ldy,
+                                      float *colsum, float *work, size_t work_floats, void *stream) {
+    SEI_REQUIRE(A && W && x && gamma && mean && rstd && res && gx && ggamma && gbeta && work);
+    SEI_REQUIRE(sei_rowgemm_lnbwd_bf16_eligible(M, K, C) && work_floats >= sei_rowgemm_lnbwd_work_floats(C));
+    SEI_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0);
+    SEI_REQUIRE((unsigned long long)64 * (size_t)lda * 2 < (1ull << 32));
+    SEI_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)res | (uintptr_t)gx | (uintptr_t)work) & 15) == 0);
+    SEI_REQUIRE((y16 != nullptr) == (row_scale != nullptr) && (y16 != nullptr) == (colsum != nullptr));
+    SEI_REQUIRE(!y16 || K == 384);            // (the bf16 copy next to K = 576 does not fit the register file: not built)
+    if (y16) SEI_REQUIRE(ldy >= 192 && ldy % 4 == 0 && ((uintptr_t)y16 & 7) == 0);
+    RowGemmArgs g;
+    g.A = A; g.W = W; g.lda = lda; g.ldw = ldw; g.tiles = 0; g.bias = nullptr; g.R1 = x; g.R2 = res; g.ldr = C;
+    g.D32 = gx; g.D16 = y16; g.ld32 = C; g.ld16 = ldy; g.nv = C;
+    g.mean = mean; g.rstd = rstd; g.gamma = gamma; g.scale = row_scale; g.part = work;
+    hipStream_t s = (hipStream_t)stream;
+    const int m = (int)M, groups = m / 32 < 256 ? m / 32 : 256;
+    int rc;
+    if (K == 384)
+        rc = y16 ? rg_launch<6, 12, 32, 4, 1, RG_EPI_LNBWD, true>(g, m, s) : rg_launch<6, 12, 32, 4, 1, RG_EPI_LNBWD, false>(g, m, s);
+    else
+        rc = rg_launch<9, 12, 32, 4, 1, RG_EPI_LNBWD, false>(g, m, s);
+    if (rc != 0) return rc;
+    return sei_fold_partials3(work, groups, C, ggamma, gbeta, y16 ? colsum : nullptr, s);
 }

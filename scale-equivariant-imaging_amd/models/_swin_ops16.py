@@ -232,6 +232,29 @@ def linear16(A16, W, Wt, M, epi, nv, out32=None, out16=None, bias=None, R1=None,
         gemm_nt16(A16, Wt, M, nv, K, epi, out32=out32, out16=out16, R1=R1, b_rmajor=True, flops=flops)
 
 
+def linear_lnbwd16(A16, W, Wt, M, x2d, gamma, mean, rstd, res, ggamma, gbeta, row_scale=None, colsum=None):
+    """gx = LayerNorm backward of gh = A16 W^T (the data gradient of the linear layer behind the norm) + res, the norm's
+    weight / bias gradients accumulated, and -- with row_scale / colsum -- gy16 = bf16(gx * row_scale) in padded rows with
+    its column sums added to colsum: one launch where the fused kernel is built (sei_rowgemm_lnbwd_bf16), GEMM +
+    sei_ln_bwd_pad + sei_cast_pad_bf16 otherwise. Returns (gx, gy16 or None)."""
+    Nn, K = W.shape
+    C = x2d.shape[1]
+    want16 = colsum is not None
+    if (Nn == CP and N.lib().sei_rowgemm_lnbwd_bf16_eligible(M, K, C) and (not want16 or (K == 384 and row_scale is not None))):
+        gx = torch.empty_like(x2d)
+        gy16 = torch.empty((M, CP), dtype=torch.bfloat16, device=x2d.device) if want16 else None
+        work = torch.empty(N.lib().sei_rowgemm_lnbwd_work_floats(C), dtype=torch.float32, device=x2d.device)
+        _ops._gemm_call(2.0 * M * C * K, "sei_rowgemm_lnbwd_bf16", A16.data_ptr(), A16.shape[1], W.data_ptr(), K, M, K,
+                        x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), res.data_ptr(), gx.data_ptr(), C,
+                        ggamma.data_ptr(), gbeta.data_ptr(), N.ptr(row_scale) if want16 else None, N.ptr(gy16), CP,
+                        N.ptr(colsum) if want16 else None, work.data_ptr(), work.numel())
+        return gx, gy16
+    gh = torch.empty((M, CP), dtype=torch.float32, device=x2d.device)
+    linear16(A16, W, Wt, M, EPI_NONE, CP, out32=gh, flops=2.0 * M * C * K)
+    gx = ln_bwd(x2d, gamma, mean, rstd, gh, res, ggamma, gbeta)
+    return gx, (cast_pad(gx, row_scale, colsum) if want16 else None)
+
+
 class SwinBlockFn16(torch.autograd.Function):
     """models._swin_ops.SwinBlockFn in bf16 mode; `pack` / `key` give the block's re-laid-out matrices."""
 
@@ -284,20 +307,18 @@ class SwinBlockFn16(torch.autograd.Function):
         gy = cast_pad(go2, drop2, grad_of(bm2))
         gf3 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
         linear16(gy, pack.w(f"{key}.fc2T"), w2, M, EPI_MUL_DGELU, Ch, out16=gf3, R1=f3, flops=2.0 * M * Chr * C)
-        gh2 = torch.empty((M, CP), dtype=torch.float32, device=dev)
-        linear16(gf3, pack.w(f"{key}.fc1T"), w1, M, EPI_NONE, CP, out32=gh2, flops=2.0 * M * Chr * C)
-        gx1 = ln_bwd(x1, g2, mean2, rstd2, gh2, go2, grad_of(g2), grad_of(b2))
-        # attention branch
-        gy1 = cast_pad(gx1, drop1, grad_of(bproj))
+        # fc1's data gradient, norm2's backward (+ the block's incoming gradient), and the cast / stochastic-depth scale /
+        # bias column sums that open the attention branch
+        gx1, gy1 = linear_lnbwd16(gf3, pack.w(f"{key}.fc1T"), w1, M, x1, g2, mean2, rstd2, go2, grad_of(g2), grad_of(b2),
+                                  drop1, grad_of(bproj))
         ga = torch.empty((M, CP), dtype=torch.bfloat16, device=dev)
         linear16(gy1, pack.w(f"{key}.projT"), wproj, M, EPI_NONE, CP, out16=ga, flops=2.0 * M * C * C)
         dqkv = torch.empty_like(qkv)
         scale = float((C // heads) ** -0.5)
         N.call("sei_swin_attn_bwd_bf16", qkv.data_ptr(), table.data_ptr(), ga.data_ptr(), dqkv.data_ptr(),
                grad_of(table).data_ptr(), B, H, W, heads, shift, scale)
-        gh1 = torch.empty((M, CP), dtype=torch.float32, device=dev)
-        linear16(dqkv, pack.w(f"{key}.qkvT"), wqkv, M, EPI_NONE, CP, out32=gh1, flops=2.0 * M * 3 * C * C)
-        gx = ln_bwd(x.view(M, C), g1, mean1, rstd1, gh1, gx1, grad_of(g1), grad_of(b1))
+        gx, _ = linear_lnbwd16(dqkv, pack.w(f"{key}.qkvT"), wqkv, M, x.view(M, C), g1, mean1, rstd1, gx1, grad_of(g1),
+                               grad_of(b1))
         # the four weight gradients (+ the qkv / fc1 bias gradients, column C) over the same tokens: one launch
         weight_grad16_group([(dqkv, h1, pack.g(f"{key}.qkv"), 2.0 * 3 * C * C), (gy1, a, pack.g(f"{key}.proj"), 2.0 * C * C),
                              (gf3, h2, pack.g(f"{key}.fc1"), 2.0 * Chr * C), (gy, f4, pack.g(f"{key}.fc2"), 2.0 * Chr * C)])

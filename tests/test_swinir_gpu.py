@@ -589,3 +589,51 @@ def test_row_streaming_kernel_refuses_other_shapes():
     with pytest.raises(N.NativeLibraryError):
         N.call("sei_rowgemm_bf16", a.data_ptr(), 192, a.data_ptr(), 192, None, 0, a.data_ptr(), 576, 64, 576, 192, 576, 1,
                None, None, None, 0)                        # SEI_EPI_BIAS without a bias
+
+
+@pytest.mark.parametrize("M,K,cast", [(64, 384, True), (4608, 384, True), (4608, 384, False), (4608, 576, False),
+                                      (300 * 64, 576, False), (300 * 64, 384, True)])
+def test_layernorm_backward_inside_the_data_gradient(M, K, cast):
+    """sei_rowgemm_lnbwd_bf16: nn.Linear's data gradient + nn.LayerNorm's backward + the residual gradient (+ the bf16
+    cast / stochastic-depth scale / column sums that feed the next weight gradient) in one launch, against float64
+    autograd of the same composition on the same bf16 operands."""
+    import _native as N
+    C, CP = 180, 192
+    gen = torch.Generator(device="cuda").manual_seed(M + K + int(cast))
+    a = torch.randn((M, K), device="cuda", generator=gen).bfloat16()
+    w = (0.1 * torch.randn((CP, K), device="cuda", generator=gen)).bfloat16()
+    w[C:] = 0
+    x = torch.randn((M, C), device="cuda", generator=gen) * 2 + 0.3
+    gamma = torch.randn(C, device="cuda", generator=gen)
+    res = torch.randn((M, C), device="cuda", generator=gen)
+    drop = (torch.rand(M, device="cuda", generator=gen) > 0.2).float() / 0.8
+    mean = x.mean(1)
+    rstd = (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    gg0, gb0, cs0 = (torch.randn(C, device="cuda", generator=gen) for _ in range(3))
+    gg, gb, cs = gg0.clone(), gb0.clone(), cs0.clone()
+    gx = torch.full((M, C), 7.0, device="cuda")
+    y16 = torch.full((M, CP), 7.0, device="cuda").bfloat16() if cast else None
+    work = torch.empty(N.lib().sei_rowgemm_lnbwd_work_floats(C), device="cuda")
+    assert N.lib().sei_rowgemm_lnbwd_bf16_eligible(M, K, C) == 1
+    N.call("sei_rowgemm_lnbwd_bf16", a.data_ptr(), K, w.data_ptr(), K, M, K, x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+           rstd.data_ptr(), res.data_ptr(), gx.data_ptr(), C, gg.data_ptr(), gb.data_ptr(), drop.data_ptr() if cast else None,
+           N.ptr(y16), CP, cs.data_ptr() if cast else None, work.data_ptr(), work.numel())
+    # float64 reference through autograd: y = LayerNorm(x) (weight gamma), loss = sum(y * gh) -> dx, dgamma; dbeta = sum gh
+    gh = (a.double() @ w.double().T)[:, :C]
+    xd = x.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xd, (C,), gd, torch.zeros(C, device="cuda", dtype=torch.float64), 1e-5)
+    dx, dg = torch.autograd.grad((y * gh).sum(), (xd, gd))
+    ref = dx + res.double()
+    assert float((gx.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert float((gg.double() - gg0.double() - dg).abs().max()) < 2e-5 * float(dg.abs().max())
+    assert float((gb.double() - gb0.double() - gh.sum(0)).abs().max()) < 2e-5 * float(gh.sum(0).abs().max()) + 1e-4
+    if cast:
+        ys = ref * drop.double()[:, None]
+        assert float((y16[:, :C].double() - ys).abs().max()) < 2.0 ** -8 * float(ys.abs().max())
+        assert bool((y16[:, C:] == 0).all())
+        assert float((cs.double() - cs0.double() - ys.sum(0)).abs().max()) < 2e-5 * float(ys.abs().sum(0).max())
+    with pytest.raises(N.NativeLibraryError):              # the bf16 copy exists next to K = 384 only
+        N.call("sei_rowgemm_lnbwd_bf16", a.data_ptr(), K, w.data_ptr(), K, M, 576, x.data_ptr(), gamma.data_ptr(),
+               mean.data_ptr(), rstd.data_ptr(), res.data_ptr(), gx.data_ptr(), C, gg.data_ptr(), gb.data_ptr(),
+               drop.data_ptr(), work.data_ptr(), CP, cs.data_ptr(), work.data_ptr(), work.numel())
