@@ -154,6 +154,17 @@ def _stream_bytes(name, a):
     if name == "sei_gemm_bf16nt_dw2_adam":                # param / exp_avg / exp_avg_sq in and out, shadow out, operands
         M, Nn, K1, K2 = a[11:15]
         return M * Nn * (24 + (2 if a[9] else 0)) + 2 * (K1 + K2) * (M + Nn)
+    if name == "sei_rowgemm_bf16":                        # A rows in; float32 (nv columns) and / or bf16 (N columns) rows out;
+        M, Nn, K, nv, epi = a[8:13]                       # residual / GELU' rows in
+        return M * (2 * K + (4 * nv if a[4] else 0) + (2 * Nn if a[6] else 0) + (4 * nv if epi in (3, 4, 7) else 0)
+                    + (4 if epi == 7 else 0))
+    if name == "sei_rowgemm_lnbwd_bf16":                  # A rows, x and residual rows in; gx (and the bf16 copy) out
+        M, K, C = a[4], a[5], a[12]
+        return M * (2 * K + 12 * C + 8 + ((2 * a[17] + 4) if a[16] else 0))
+    if name == "sei_tokgrad_bf16_blocks":                 # every distinct 192-column operand slice once
+        blocks, n, K1, K2 = a[0], a[1], a[2], a[3]
+        slices = {(blocks[i].Y1, blocks[i].y0) for i in range(n)} | {(blocks[i].X1, blocks[i].x0) for i in range(n)}
+        return 2 * 192 * (K1 + K2) * len(slices)
     if name == "sei_blur_sep_circ":
         return 8 * a[6] * a[7] * a[8]
     if name in ("sei_scale_resample_fwd", "sei_scale_resample_bwd"):
@@ -174,6 +185,9 @@ _STREAM_FAMILIES = [
     ("adam_vec_kernel (fused Adam over the flat bucket)", ("sei_adam_fused",)),
     ("gemm_bf16nt_kernel<..., ADAM> (HBM-bound weight gradients whose epilogue applies the Adam step: the bottleneck pair)",
      ("sei_gemm_bf16nt_dw2_adam",)),
+    ("rowgemm_* / tokgrad_* (token-streaming GEMMs of layer-sized weights: the Swin blocks' linear layers forward, data "
+     "gradient (+ LayerNorm backward) and weight gradient; HBM-bound at K = 192-576, also booked in the MFMA family)",
+     ("sei_rowgemm_", "sei_tokgrad_")),
     ("dwconv7_* (depthwise 7x7: forward, data and weight gradients)", ("sei_dwconv7_",)),
     ("ln_* (channel LayerNorm forward / backward)", ("sei_ln_",)),
     ("sepmap_* (ideal resamplers)", ("sei_sepmap2",)),
@@ -417,6 +431,10 @@ def gemm_roofline(records, dtype, reps=3):
     names = sorted({entry for _, entry, _ in records})
     if names == ["sei_gemm_bf16_ex"]:
         kernels = "gemm_bf16_kernel<*> (register-staged bf16 MFMA, f32 operands in HBM)"
+    elif any(n.startswith(("sei_rowgemm_", "sei_tokgrad_")) for n in names):
+        kernels = ("rowgemm_kernel<*> / tokgrad_kernel (token-streaming GEMMs of the Swin blocks' linear layers: K = 192-576, "
+                   "HBM-bound -- see the same family in roofline_hbm) + gemm_bf16nt_kernel<*> (3x3 convolutions as implicit "
+                   "GEMMs, their tap-batched weight gradients)")
     elif dtype == "bf16":
         kernels = ("gemm_bf16pq_kernel<*> (quadrant schedule, deep levels) + gemm_bf16nt_kernel<*> (128x128 loop, "
                    "everything else) + gemm_bf16_kernel<*> (K<64 layers)")
