@@ -426,9 +426,13 @@ inline int check(int B, int H, int W, int heads, int shift) {
     return SEI_OK;
 }
 
-inline int group_count(int nwin) {
-    int groups = (nwin + WAVES - 1) / WAVES;
-    return groups > 128 ? 128 : groups;                   // x heads workgroups; each loops over its windows
+// groups x heads workgroups, each looping over its windows. Two workgroups fit a CU (80 KB of LDS each): 512 resident.
+// 128 groups x 6 heads = 768 ran as one full round and a half-empty one; 85 x 6 = 510 are all resident and walk
+// more windows each.
+inline int group_count(int nwin, int heads) {
+    const int groups = (nwin + WAVES - 1) / WAVES;
+    const int cap = 512 / heads > 0 ? 512 / heads : 1;
+    return groups > cap ? cap : groups;
 }
 
 }  // namespace
@@ -439,7 +443,7 @@ extern "C" int sei_swin_attn_fwd_bf16(const uint16_t *qkv, const float *table, u
     SEI_REQUIRE((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0);
     if (int rc = check(B, H, W, heads, shift)) return rc;
     MGeom g{H, W, H / WS, W / WS, shift, heads, B * (H / WS) * (W / WS)};
-    const int groups = group_count(g.nwin);
+    const int groups = group_count(g.nwin, heads);
     if (shift)
         hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel<true>, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
                            (hipStream_t)stream, qkv, table, out, g, scale, groups);
@@ -456,7 +460,7 @@ extern "C" int sei_swin_attn_bwd_bf16(const uint16_t *qkv, const float *table, c
     SEI_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv) & 15) == 0);
     if (int rc = check(B, H, W, heads, shift)) return rc;
     MGeom g{H, W, H / WS, W / WS, shift, heads, B * (H / WS) * (W / WS)};
-    const int groups = group_count(g.nwin);
+    const int groups = group_count(g.nwin, heads);
     if (shift)
         hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel<true>, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
                            (hipStream_t)stream, qkv, table, dout, dqkv, dtable, g, scale, groups);

@@ -62,7 +62,7 @@ def main():
     W = load(f"{src}/pmc_WRITE_SIZE/pmc_counter_collection.csv", "WRITE_SIZE")
     Mb = load(f"{src}/pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_counter_collection.csv", "SQ_VALU_MFMA_BUSY_CYCLES")
     G = load(f"{src}/pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_counter_collection.csv", "GRBM_GUI_ACTIVE")
-    gem = [k for k in F if ("gemm_" in k or "mlp_fwd" in k or "mlp_bwd" in k) and not (exclude and exclude.search(k))]
+    gem = [k for k in F if ("gemm_" in k or "tokgrad" in k or "mlp_fwd" in k or "mlp_bwd" in k) and not (exclude and exclude.search(k))]
     n = sum(F[k][1] for k in gem)
     fetch = sum(F[k][0] for k in gem) * 1024 * 2          # KiB -> B, x2 (gfx950 wide-stream correction)
     write = sum(W[k][0] for k in gem if k in W) * 1024
