@@ -35,6 +35,8 @@ def _copy_nested(dst, src):
     """dst <- src over matching dicts / sequences of tensors (None entries must match)."""
     if isinstance(dst, torch.Tensor):
         dst.copy_(src.reshape(dst.shape))
+    elif hasattr(dst, "buffer") and hasattr(src, "buffer") and dst.buffer.shape == src.buffer.shape:
+        dst.buffer.copy_(src.buffer)                   # models.swinir.DropMasks: every mask of a model call in one copy
     elif isinstance(dst, dict):
         for key, value in dst.items():
             _copy_nested(value, src[key])

@@ -37,6 +37,8 @@ def _concat_masks(first, second):
     """Two B-sized mask sets -> one for the pass of 2B images that runs both calls at once."""
     if first is None or second is None:
         return first if second is None else second
+    if hasattr(first, "buffer") and hasattr(second, "buffer"):          # models.swinir.DropMasks: one concatenation
+        return first.rebuilt_on(torch.cat([first.buffer, second.buffer], dim=1))
     return [None if a is None else tuple(torch.cat([u, v]) for u, v in zip(a, b)) for a, b in zip(first, second)]
 
 

@@ -51,6 +51,31 @@ class WindowAttention(nn.Module):
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
 
 
+class DropMasks(list):
+    """The stochastic-depth factors of one model call: a list with one (attention branch, MLP branch) pair of per-sample
+    vectors per block (None for a block that draws nothing), all of them rows of `buffer` (2 x drawing blocks, batch)."""
+
+    def __init__(self, buffer):
+        super().__init__()
+        self.buffer = buffer
+
+    def rebuilt_on(self, buffer):
+        """The same structure over another buffer of the same row count (concatenated batches, a static copy)."""
+        out, j = DropMasks(buffer), 0
+        for m in self:
+            if m is None:
+                out.append(None)
+            else:
+                out.append((buffer[j], buffer[j + 1]))
+                j += 2
+        return out
+
+    def rows(self, tokens_per_image):
+        """Per-ROW factors (what the GEMM epilogues take), all blocks expanded by one launch."""
+        wide = self.buffer.to(torch.float32).repeat_interleave(tokens_per_image, dim=1)
+        return [None if m is None else (m[0], m[1]) for m in self.rebuilt_on(wide)]
+
+
 class SwinTransformerBlock(nn.Module):
     def __init__(self, dim, input_resolution, num_heads, window_size, shift_size, mlp_ratio, drop_path):
         super().__init__()
@@ -200,13 +225,24 @@ class SwinIR(FlatParameterBucket, nn.Module):
         if not self.training:
             return None
         device = device if device is not None else self.conv_first.weight.device
-        masks = []
-        for blk in self.blocks():
-            keep = 1.0 - blk.drop_path_rate
+        blocks = list(self.blocks())
+        # the same draws as before (one bernoulli_ + div_ per DropPath call, in call order), into the rows of ONE buffer:
+        # a captured step then refreshes its masks with one copy and expands them to rows with one launch
+        keeps = [1.0 - b.drop_path_rate for b in blocks if b.drop_path_rate != 0.0 for _ in range(2)]
+        masks = DropMasks(torch.empty((len(keeps), batch), device=device))
+        j = 0
+        for blk in blocks:
             if blk.drop_path_rate == 0.0:
                 masks.append(None)
             else:
-                masks.append(tuple(torch.empty(batch, device=device).bernoulli_(keep).div_(keep) for _ in range(2)))
+                masks.append(tuple(masks.buffer[j + i].bernoulli_(keeps[j + i]) for i in range(2)))
+                j += 2
+        if keeps:                                        # x / keep for every row at once (the same IEEE division as div_)
+            cache = self.__dict__.setdefault("_keep_columns", {})
+            col = cache.get((device, len(keeps)))
+            if col is None:
+                col = cache[(device, len(keeps))] = torch.tensor(keeps, dtype=torch.float32, device=device)[:, None]
+            masks.buffer.div_(col)
         return masks
 
     def _last(self, t, res, pack):
@@ -251,10 +287,13 @@ class SwinIR(FlatParameterBucket, nn.Module):
         if self.patch_embed.norm is not None:
             t = S.LayerNormFn.apply(t, self.patch_embed.norm.weight, self.patch_embed.norm.bias)
         k = 0
+        row_masks = drop_masks.rows(Hp * Wp) if isinstance(drop_masks, DropMasks) else None
         for layer in self.layers:
             n = len(layer.residual_group.blocks)
             drops = [None] * n
-            if drop_masks is not None:
+            if row_masks is not None:
+                drops = row_masks[k:k + n]
+            elif drop_masks is not None:
                 drops = [None if m is None else tuple(v.to(torch.float32).repeat_interleave(Hp * Wp) for v in m)
                          for m in drop_masks[k:k + n]]
             t = layer(t, drops, pack)
