@@ -494,7 +494,7 @@ size_t sei_tokgrad_bf16_eligible(int Mo, int Ni, int ldy, int ldx, long long K1,
  *   SEI_EPI_BIAS            D16 = bf16(acc + bias)                                   (N 576, K 192: qkv)
  *   SEI_EPI_BIAS_RES        D32 = acc + bias + R1                                     (N 192, K 192 / 384: proj, fc2)
  *   SEI_EPI_BIAS_SCALE_RES  D32 = R2 + R1[row] (acc + bias)    (stochastic depth)     (the same two)
- *   SEI_EPI_BIAS_GELU       D32 = acc + bias, D16 = bf16(gelu(D32))                   (N 384, K 192: fc1; nv = N)
+ *   SEI_EPI_BIAS_GELU       D32 = acc + bias (optional: may be NULL), D16 = bf16(gelu(acc + bias))   (N 384, K 192: fc1; nv = N)
  *   SEI_EPI_MUL_DGELU       D16 = bf16(acc gelu'(R1))                                 (N 384, K 192: fc2's data gradient)
  *   SEI_EPI_NONE            D16 = bf16(acc) (N 192, K 192)  or  D32 = acc (N 192, K 384 / 576)   (the other data gradients)
  * nv (a multiple of 4, <= N): valid columns of the float32 output, of bias and of the row-shaped R (ldr >= nv); bf16
@@ -522,6 +522,18 @@ int sei_rowgemm_lnbwd_bf16(const uint16_t *A, int lda, const uint16_t *W, int ld
                            float *work, size_t work_floats, void *stream);
 size_t sei_rowgemm_lnbwd_bf16_eligible(long long M, int K, int C);
 size_t sei_rowgemm_lnbwd_work_floats(int C);
+
+/* fc2's data gradient through GELU with the GELU' input RECOMPUTED instead of stored: D16 (M, ld16 >= N) =
+ * bf16((A W^T) * gelu'(A2 W2^T + bias2)), A = the gradient rows (M, lda >= K), W = fc2's matrix transposed (N, K);
+ * A2 = fc1's input rows (M, lda2 >= K), W2 = fc1's matrix (N, K), bias2 its bias (nv entries) -- the second product is
+ * the forward pass's pre-activation, bit for bit (same MFMA order as sei_rowgemm_bf16 with SEI_EPI_BIAS_GELU), so the
+ * forward pass need not write it (D32 = NULL there) nor this pass read it: 1536 of the 2688 bytes per token of either
+ * kernel. N = 384, K = 192 (deepinv SwinIR's Mlp: nn.Linear(180, 360) -> nn.GELU -> nn.Linear(360, 180), zero-padded).
+ * Same result as sei_rowgemm_bf16(SEI_EPI_MUL_DGELU) on the stored pre-activation. */
+int sei_rowgemm_dgelu_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, const uint16_t *A2, int lda2,
+                           const uint16_t *W2, int ldw2, const float *bias2, int nv, uint16_t *D16, int ld16, long long M,
+                           int N, int K, void *stream);
+size_t sei_rowgemm_dgelu_bf16_eligible(long long M, int N, int K);
 
 #ifdef __cplusplus
 }

@@ -179,9 +179,14 @@ struct RowGemmArgs {
     // optionally D16 = bf16(D32 * scale[row]) in 192-column rows; part: [workgroup][3][nv] column sums
     const float *mean, *rstd, *gamma, *scale;
     float *part;
+    // RG_EPI_DGELU2 (D16 = bf16((A W^T) gelu'(A2 W2^T + bias))): the second product's operands -- the GELU' input is
+    // RECOMPUTED from the layer's input rows instead of being stored by the forward pass and read back
+    const unsigned short *A2, *W2;
+    int lda2, ldw2;
 };
 
-constexpr int RG_EPI_LNBWD = 100;     // internal epilogue code (sei_rowgemm_lnbwd_bf16)
+constexpr int RG_EPI_LNBWD = 100;     // internal epilogue codes (sei_rowgemm_lnbwd_bf16, sei_rowgemm_dgelu_bf16)
+constexpr int RG_EPI_DGELU2 = 101;
 
 template <int N>
 __device__ __forceinline__ void rg_wait_vmcnt() {
@@ -216,7 +221,9 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     static_assert(TR % (16 * WR) == 0 && (2 * KT) % WK == 0, "whole blocks per wave");
     constexpr int NP = 16 * NBT;                      // padded output width
     constexpr int LDP = NP + 4;                       // patch row stride (floats): 4 LDP = 16 mod 64 banks
-    constexpr int STAGE = KT * TR * 128;              // KT images of [TR rows][64 k] bf16
+    constexpr bool TWO = EPI == RG_EPI_DGELU2;        // two products over the same rows: A W^T and A2 W2^T
+    constexpr int OPS = TWO ? 2 : 1;
+    constexpr int STAGE = OPS * KT * TR * 128;        // KT images of [TR rows][64 k] bf16 per operand
     constexpr int P = KT * TR / 8;                    // 1-KiB DMA pieces per stage
     constexpr int EMAX = (P + 7) / 8;
     constexpr int QR = NP / 4;                        // quads per row
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     // outputs: 16-byte stores of eight values)
     constexpr bool LNB = EPI == RG_EPI_LNBWD;         // OUT16 then says: also write the scaled bf16 copy
     static_assert(!LNB || (NBT == 12 && TR == 32), "the LayerNorm epilogue owns 32 rows x 192 columns: 16 lanes per row");
-    constexpr int GQ = (!LNB && (OUT16 || EPI == SEI_EPI_MUL_DGELU)) ? 2 : 1;
+    constexpr int GQ = (!LNB && (OUT16 || EPI == SEI_EPI_MUL_DGELU || TWO)) ? 2 : 1;
     constexpr int IR = QR / GQ;                       // items per row
     constexpr int IPT = (TR * IR + RG_NT - 1) / RG_NT;   // items per thread (the last pass may be partly empty)
     constexpr bool RAGGED = TR * IR % RG_NT != 0;
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     static_assert(TR % 16 == 0 && QR % GQ == 0, "whole items");
     constexpr bool HAS_ROWS = EPI == SEI_EPI_BIAS_RES || EPI == SEI_EPI_BIAS_SCALE_RES || EPI == SEI_EPI_MUL_DGELU;
     constexpr bool HAS_BIAS = EPI == SEI_EPI_BIAS || EPI == SEI_EPI_BIAS_GELU || EPI == SEI_EPI_BIAS_RES ||
-                              EPI == SEI_EPI_BIAS_SCALE_RES;
+                              EPI == SEI_EPI_BIAS_SCALE_RES;       // (added to rows in the last pass; TWO: see below)
     constexpr int UNR = IPT > 3 ? (GQ == 2 ? 2 : 3) : IPT;   // items in flight per thread in the last pass
     constexpr int NAUX = LNB ? 8 + (OUT16 ? 1 : 0)
                              : (HAS_ROWS ? QPT : 0) + (EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 0);   // loads per thread and tile
@@ -258,6 +265,25 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
         for (int s = 0; s < KS; ++s)
             wf[nb][s] = *reinterpret_cast<const bf16x8 *>(g.W + (size_t)(16 * (nb0 + min(nb, nbw - 1)) + l16) * g.ldw +
                                                           32 * (wk * KS + s) + 8 * lg);
+    bf16x8 wf2[TWO ? NB : 1][TWO ? KS : 1];
+    float bias2[TWO ? NB : 1];
+    if constexpr (TWO) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                wf2[nb][s] = *reinterpret_cast<const bf16x8 *>(g.W2 + (size_t)(16 * (nb0 + min(nb, nbw - 1)) + l16) * g.ldw2 +
+                                                               32 * (wk * KS + s) + 8 * lg);
+            const int c = 16 * (nb0 + min(nb, nbw - 1)) + l16;
+            bias2[nb] = c < g.nv ? g.bias[c] : 0.f;        // the accumulator's column is the lane's for every row
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            asm volatile("" : "+v"(bias2[nb]));
+#pragma unroll
+            for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf2[nb][s]));
+        }
+    }
     if (HAS_BIAS)
         for (int c = tid; c < NP; c += RG_NT) lbias[c] = c < g.nv ? g.bias[c] : 0.f;
     // W is in the registers before the ring starts: a use the compiler can see here, so that it does not wait for these
@@ -276,6 +302,16 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         offa[e] = (unsigned)r * (unsigned)g.lda * 2u + 128u * im + 16u * c;
     }
+    unsigned offa2[TWO ? EMAX : 1];
+    if constexpr (TWO) {
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            const int q = min(wave + 8 * e, P - 1), im = q / (TR / 8), p = q % (TR / 8);
+            const int r = 8 * p + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            offa2[e] = (unsigned)r * (unsigned)g.lda2 * 2u + 128u * im + 16u * c;
+        }
+    }
     auto issue = [&](int t) {                            // tile t of this workgroup (clamped: see the loop)
         const int tile = b + min(t, nt - 1) * G;
         const char *ab = reinterpret_cast<const char *>(g.A + (size_t)tile * TR * g.lda);
@@ -285,14 +321,24 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
             if (P % 8 != 0 && e == EMAX - 1 && wave >= P % 8) break;           // wave-uniform
             __builtin_amdgcn_global_load_lds((glb_void *)(ab + offa[e]), (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
         }
+        if constexpr (TWO) {
+            const char *a2 = reinterpret_cast<const char *>(g.A2 + (size_t)tile * TR * g.lda2);
+#pragma unroll
+            for (int e = 0; e < EMAX; ++e) {
+                if (P % 8 != 0 && e == EMAX - 1 && wave >= P % 8) break;
+                __builtin_amdgcn_global_load_lds((glb_void *)(a2 + offa2[e]),
+                                                 (lds_void *)(dst + KT * TR * 128 + (wave + 8 * e) * 1024), 16, 0, 0);
+            }
+        }
     };
-    constexpr int NDMA_LO = P / 8;                       // pieces per wave and stage: waves below P % 8 issue one more
+    constexpr int NDMA_LO = OPS * (P / 8);               // pieces per wave and stage: waves below P % 8 issue OPS more
+    constexpr int NDMA_HI = OPS * (P / 8 + 1);
 
     // ---- the quads of a tile this thread finishes: quad i = (row, 4 columns)
     // Float32 outputs narrower than the tile (180 of 192 columns): the lanes past the edge redo the row's LAST valid quad --
     // same inputs, same result, same address -- instead of masking their stores: a branch around a store makes the store
     // count of the in-order vmcnt unknowable, and the compiler then waits for everything (the ring included) before it
-    constexpr bool F32_ONLY = !(OUT16 || EPI == SEI_EPI_MUL_DGELU || EPI == SEI_EPI_BIAS_GELU);
+    constexpr bool F32_ONLY = !(OUT16 || EPI == SEI_EPI_MUL_DGELU || EPI == SEI_EPI_BIAS_GELU || TWO);
     auto quad_row = [&](int q) { return (tid + RG_NT * (q / GQ)) / IR; };        // quad q = quad q % GQ of item q / GQ
     auto quad_col = [&](int q) {
         const int c = 4 * (GQ * ((tid + RG_NT * (q / GQ)) % IR) + q % GQ);
@@ -355,7 +401,7 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     // ---- prologue: tile 0 and its auxiliary rows landed, tile 1 in flight
     issue(0);
     issue(1);
-    if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NDMA_LO + 1>();
+    if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NDMA_HI>();
     else rg_wait_vmcnt<NDMA_LO>();
     rg_lds_barrier();
 
@@ -386,8 +432,38 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
                 }
             }
         }
+        if constexpr (TWO) {
+            // the GELU' input of these very elements, recomputed: acc2 = A2 W2^T in the same accumulator layout (same MFMA
+            // order as the forward kernel: the same float32 values it fed to GELU), then acc <- acc * gelu'(acc2 + bias)
+            f32x4 acc2[RB][NB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc2[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int sg = wk * KS + s;
+                const char *img = st + KT * TR * 128 + (sg >> 1) * (TR * 128) + (wr * RB * 16 + l16) * 128 +
+                                  (((4 * (sg & 1) + lg) ^ (l16 >> 1)) * 16);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(img + rb * 16 * 128);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        if (NBX != 0 && nb == NB - 1 && nbw < NB) break;
+                        acc2[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf2[nb][s], acc2[rb][nb], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[rb][nb][j] *= sei_dgelu_bf16out(acc2[rb][nb][j] + bias2[nb]);
+        }
         // tile t + 1 (issued one iteration ago) and everything older have landed; what this iteration issued may fly
-        if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NAUX + NDMA_LO + 1>();
+        if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NAUX + NDMA_HI>();
         else rg_wait_vmcnt<NAUX + NDMA_LO>();
         // ---- accumulators into the patch (WK = 2: the second half of K adds to the first)
         float *pw = patch + (wr * RB * 16 + 4 * lg) * LDP + 16 * nb0 + l16;
@@ -418,7 +494,7 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
         // makes for that use then reads landed data (tied to the wait itself, the copy was placed in front of it)
         if constexpr (HAS_ROWS) {
             __builtin_amdgcn_sched_barrier(0);
-            if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NDMA_LO + 1>();
+            if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NDMA_HI>();
             else rg_wait_vmcnt<NDMA_LO>();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -430,7 +506,7 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
         const size_t row0 = (size_t)(b + t * G) * TR;
         if constexpr (LNB) {
             __builtin_amdgcn_sched_barrier(0);
-            if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NDMA_LO + 1>();
+            if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NDMA_HI>();
             else rg_wait_vmcnt<NDMA_LO>();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -510,8 +586,10 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
             }
             const int qr = quad_row(it * GQ), qc = quad_col(it * GQ);
             const size_t row = row0 + qr;
-            if constexpr (EPI == SEI_EPI_BIAS_GELU || F32_ONLY)      // (BIAS_GELU: nv = all the columns, host-checked)
-                *reinterpret_cast<f32x4 *>(g.D32 + row * g.ld32 + qc) = v[0];
+            if constexpr (F32_ONLY) *reinterpret_cast<f32x4 *>(g.D32 + row * g.ld32 + qc) = v[0];
+            if constexpr (EPI == SEI_EPI_BIAS_GELU) {                // (nv = all the columns, host-checked; the float32
+                if (g.D32) *reinterpret_cast<f32x4 *>(g.D32 + row * g.ld32 + qc) = v[0];   // pre-activation is optional:
+            }                                                        // uniform branch, no aux loads in this variant)
             if constexpr (EPI == SEI_EPI_BIAS_GELU) {
                 uint2 h;
                 h.x = rg_pack2(sei_gelu_bf16out(v[0][0]), sei_gelu_bf16out(v[0][1]));
@@ -622,7 +700,7 @@ extern "C" size_t sei_rowgemm_bf16_eligible(long long M, int N, int K, int epilo
         case SEI_EPI_BIAS: return (N == 576 && K == 192 && out16) ? 1 : 0;
         case SEI_EPI_BIAS_RES:
         case SEI_EPI_BIAS_SCALE_RES: return (N == 192 && (K == 192 || K == 384) && f32out) ? 1 : 0;
-        case SEI_EPI_BIAS_GELU: return (N == 384 && K == 192) ? 1 : 0;
+        case SEI_EPI_BIAS_GELU: return (N == 384 && K == 192) ? 1 : 0;      // float32 pre-activation and / or bf16 gelu
         case SEI_EPI_MUL_DGELU: return (N == 384 && K == 192 && out16) ? 1 : 0;
         case SEI_EPI_NONE: return (N == 192 && ((K == 192 && out16) || ((K == 384 || K == 576) && f32out))) ? 1 : 0;
         default: return 0;
@@ -643,7 +721,7 @@ extern "C" int sei_rowgemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
     SEI_REQUIRE(!has_bias || bias);
     if (D32) SEI_REQUIRE(ld32 >= nv && ld32 % 4 == 0 && ((uintptr_t)D32 & 15) == 0);
     if (D16) SEI_REQUIRE(ld16 >= N && ld16 % 8 == 0 && ((uintptr_t)D16 & 15) == 0);
-    if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D32 && D16 && nv == N);
+    if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D16 && nv == N);     // D32 (the float32 pre-activation) is optional
     if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU)
         SEI_REQUIRE(R1 && !R2 && ldr >= nv && ldr % 4 == 0 && ((uintptr_t)R1 & 15) == 0);
     if (epilogue == SEI_EPI_BIAS_SCALE_RES) SEI_REQUIRE(R1 && R2 && ldr >= nv && ldr % 4 == 0 && ((uintptr_t)R2 & 15) == 0);
@@ -701,4 +779,22 @@ extern "C" int sei_rowgemm_lnbwd_bf16(const uint16_t *A, int lda, const uint16_t
         rc = rg_launch<9, 12, 32, 4, 1, RG_EPI_LNBWD, false>(g, m, s);
     if (rc != 0) return rc;
     return sei_fold_partials3(work, groups, C, ggamma, gbeta, y16 ? colsum : nullptr, s);
+}
+
+extern "C" size_t sei_rowgemm_dgelu_bf16_eligible(long long M, int N, int K) {
+    return (M > 0 && M % 64 == 0 && M < (1ll << 31) && N == 384 && K == 192) ? 1 : 0;
+}
+
+extern "C" int sei_rowgemm_dgelu_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, const uint16_t *A2, int lda2,
+                                      const uint16_t *W2, int ldw2, const float *bias2, int nv, uint16_t *D16, int ld16,
+                                      long long M, int N, int K, void *stream) {
+    SEI_REQUIRE(A && W && A2 && W2 && bias2 && D16 && sei_rowgemm_dgelu_bf16_eligible(M, N, K));
+    SEI_REQUIRE(lda >= K && ldw >= K && lda2 >= K && ldw2 >= K && lda % 8 == 0 && ldw % 8 == 0 && lda2 % 8 == 0 && ldw2 % 8 == 0);
+    SEI_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)A2 | (uintptr_t)W2 | (uintptr_t)D16) & 15) == 0);
+    SEI_REQUIRE(nv > 0 && nv <= N && ld16 >= N && ld16 % 8 == 0);
+    SEI_REQUIRE((unsigned long long)64 * (size_t)lda * 2 < (1ull << 32) && (unsigned long long)64 * (size_t)lda2 * 2 < (1ull << 32));
+    RowGemmArgs g = {};
+    g.A = A; g.W = W; g.lda = lda; g.ldw = ldw; g.A2 = A2; g.W2 = W2; g.lda2 = lda2; g.ldw2 = ldw2;
+    g.bias = bias2; g.D16 = D16; g.ld16 = ld16; g.nv = nv;
+    return rg_launch<3, 24, 32, 8, 1, RG_EPI_DGELU2, true>(g, (int)M, (hipStream_t)stream);
 }

@@ -279,9 +279,17 @@ class SwinBlockFn16(torch.autograd.Function):
         else:
             linear16(a, wproj, None, M, EPI_BIAS_SCALE_RES, C, out32=x1, bias=bproj, R1=drop1, R2=x2, flops=2.0 * M * C * C)
         h2, mean2, rstd2 = ln16(x1, g2, b2)
-        f3 = torch.empty((M, Ch), dtype=torch.float32, device=dev)
+        # the float32 pre-activation is stored only where the backward cannot recompute it (sei_rowgemm_dgelu_bf16)
+        recompute = bool(N.lib().sei_rowgemm_dgelu_bf16_eligible(M, Ch, CP)) and \
+            bool(N.lib().sei_rowgemm_bf16_eligible(M, Ch, CP, EPI_BIAS_GELU, 0))
+        f3 = None if recompute else torch.empty((M, Ch), dtype=torch.float32, device=dev)
         f4 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
-        linear16(h2, w1, None, M, EPI_BIAS_GELU, Ch, out32=f3, out16=f4, bias=pack.b(f"{key}.fc1_bias"), flops=2.0 * M * Chr * C)
+        if recompute:
+            _ops._gemm_call(2.0 * M * Chr * C, "sei_rowgemm_bf16", h2.data_ptr(), CP, w1.data_ptr(), CP, None, 0, f4.data_ptr(),
+                            Ch, M, Ch, CP, Ch, EPI_BIAS_GELU, pack.b(f"{key}.fc1_bias").data_ptr(), None, None, 0)
+        else:
+            linear16(h2, w1, None, M, EPI_BIAS_GELU, Ch, out32=f3, out16=f4, bias=pack.b(f"{key}.fc1_bias"),
+                     flops=2.0 * M * Chr * C)
         out = torch.empty((M, C), dtype=torch.float32, device=dev)
         if drop2 is None:
             linear16(f4, w2, None, M, EPI_BIAS_RES, C, out32=out, bias=bm2, R1=x1, flops=2.0 * M * Chr * C)
@@ -306,7 +314,12 @@ class SwinBlockFn16(torch.autograd.Function):
         # MLP branch
         gy = cast_pad(go2, drop2, grad_of(bm2))
         gf3 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
-        linear16(gy, pack.w(f"{key}.fc2T"), w2, M, EPI_MUL_DGELU, Ch, out16=gf3, R1=f3, flops=2.0 * M * Chr * C)
+        if f3 is None:                                   # GELU' of the recomputed pre-activation h2 W1^T + b1
+            _ops._gemm_call(4.0 * M * Chr * C, "sei_rowgemm_dgelu_bf16", gy.data_ptr(), CP, pack.w(f"{key}.fc2T").data_ptr(), CP,
+                            h2.data_ptr(), CP, w1.data_ptr(), CP, pack.b(f"{key}.fc1_bias").data_ptr(), Ch, gf3.data_ptr(), Ch,
+                            M, Ch, CP)
+        else:
+            linear16(gy, pack.w(f"{key}.fc2T"), w2, M, EPI_MUL_DGELU, Ch, out16=gf3, R1=f3, flops=2.0 * M * Chr * C)
         # fc1's data gradient, norm2's backward (+ the block's incoming gradient), and the cast / stochastic-depth scale /
         # bias column sums that open the attention branch
         gx1, gy1 = linear_lnbwd16(gf3, pack.w(f"{key}.fc1T"), w1, M, x1, g2, mean2, rstd2, go2, grad_of(g2), grad_of(b2),

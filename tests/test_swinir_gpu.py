@@ -637,3 +637,39 @@ def test_layernorm_backward_inside_the_data_gradient(M, K, cast):
         N.call("sei_rowgemm_lnbwd_bf16", a.data_ptr(), K, w.data_ptr(), K, M, 576, x.data_ptr(), gamma.data_ptr(),
                mean.data_ptr(), rstd.data_ptr(), res.data_ptr(), gx.data_ptr(), C, gg.data_ptr(), gb.data_ptr(),
                drop.data_ptr(), work.data_ptr(), CP, cs.data_ptr(), work.data_ptr(), work.numel())
+
+
+@pytest.mark.parametrize("M", [64, 4608, 256 * 64 + 192])
+def test_gelu_gradient_with_the_recomputed_preactivation(M):
+    """sei_rowgemm_dgelu_bf16 recomputes fc1's pre-activation from fc1's input instead of reading the stored one: the same
+    bits as sei_rowgemm_bf16(SEI_EPI_MUL_DGELU) fed with the float32 pre-activation the forward kernel writes, and the
+    forward kernel's bf16 gelu output does not depend on whether that float32 output is requested."""
+    import _native as N
+    Nn, K, nv = 384, 192, 360
+    gen = torch.Generator(device="cuda").manual_seed(M)
+    h2 = torch.randn((M, K), device="cuda", generator=gen).bfloat16()
+    w1 = (0.1 * torch.randn((Nn, K), device="cuda", generator=gen)).bfloat16()
+    w1[nv:] = 0
+    b1 = torch.zeros(Nn, device="cuda")
+    b1[:nv] = torch.randn(nv, device="cuda", generator=gen)
+    gy = torch.randn((M, K), device="cuda", generator=gen).bfloat16()
+    w2t = (0.1 * torch.randn((Nn, K), device="cuda", generator=gen)).bfloat16()
+    w2t[nv:] = 0
+    f3 = torch.empty((M, Nn), device="cuda")
+    f4, f4b = (torch.empty((M, Nn), device="cuda").bfloat16() for _ in range(2))
+    N.call("sei_rowgemm_bf16", h2.data_ptr(), K, w1.data_ptr(), K, f3.data_ptr(), Nn, f4.data_ptr(), Nn, M, Nn, K, Nn, 2,
+           b1.data_ptr(), None, None, 0)
+    N.call("sei_rowgemm_bf16", h2.data_ptr(), K, w1.data_ptr(), K, None, 0, f4b.data_ptr(), Nn, M, Nn, K, Nn, 2,
+           b1.data_ptr(), None, None, 0)
+    assert torch.equal(f4, f4b)
+    stored, recomputed = (torch.full((M, Nn), 7.0, device="cuda").bfloat16() for _ in range(2))
+    N.call("sei_rowgemm_bf16", gy.data_ptr(), K, w2t.data_ptr(), K, None, 0, stored.data_ptr(), Nn, M, Nn, K, Nn, 4, None,
+           f3.data_ptr(), None, Nn)
+    assert N.lib().sei_rowgemm_dgelu_bf16_eligible(M, Nn, K) == 1
+    N.call("sei_rowgemm_dgelu_bf16", gy.data_ptr(), K, w2t.data_ptr(), K, h2.data_ptr(), K, w1.data_ptr(), K, b1.data_ptr(), Nn,
+           recomputed.data_ptr(), Nn, M, Nn, K)
+    assert torch.equal(stored, recomputed)
+    x = (h2.double() @ w1.double().T + b1.double())
+    ref = (gy.double() @ w2t.double().T) * (0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * np.pi) ** 0.5)
+    assert float((recomputed.double() - ref).abs().max()) < 2.0 ** -7 * float(ref.abs().max())
+    assert bool((recomputed[:, nv:] == 0).all())
