@@ -535,6 +535,18 @@ int sei_rowgemm_dgelu_bf16(const uint16_t *A, int lda, const uint16_t *W, int ld
                            int N, int K, void *stream);
 size_t sei_rowgemm_dgelu_bf16_eligible(long long M, int N, int K);
 
+/* A residual linear layer followed by a LayerNorm, in one launch: out (M, C) = res + [row_scale[row]] (A W^T + bias)
+ * (SEI_EPI_BIAS_RES, or SEI_EPI_BIAS_SCALE_RES when row_scale is given: timm's DropPath) and, since a workgroup holds
+ * whole rows of out, nn.LayerNorm(C, eps) of them: h16 (M, ldh >= 192) = bf16((out - mean) rstd gamma + beta), padding
+ * columns zero except column C = 1.0 when ones_col (see sei_ln_fwd_bf16_pad), mean / rstd (M floats each) for the
+ * backward. A (M, lda >= K) bf16, W (192, ldw >= K) bf16 with zero rows past C, K 192 or 384: deepinv SwinIR's
+ * proj -> norm2 and fc2 -> the next block's norm1. Same values as sei_rowgemm_bf16 + sei_ln_fwd_bf16_pad (the LayerNorm
+ * sums run over 16 lanes instead of 64: last-bit differences in mean / rstd). */
+int sei_rowgemm_ln_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, long long M, int K, int C, const float *bias,
+                        const float *row_scale, const float *res, float *out, const float *gamma, const float *beta,
+                        float eps, int ones_col, uint16_t *h16, int ldh, float *mean, float *rstd, void *stream);
+size_t sei_rowgemm_ln_bf16_eligible(long long M, int K, int C);
+
 #ifdef __cplusplus
 }
 #endif

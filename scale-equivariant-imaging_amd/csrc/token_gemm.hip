@@ -183,10 +183,18 @@ struct RowGemmArgs {
     // RECOMPUTED from the layer's input rows instead of being stored by the forward pass and read back
     const unsigned short *A2, *W2;
     int lda2, ldw2;
+    // RG_EPI_*_LN: the LayerNorm that follows the residual sum (weight gamma, bias beta2, eps): D16 = its output in bf16
+    // rows (ones_col: 1.0 in padding column nv), mean / rstd written through mean_out / rstd_out
+    const float *beta2;
+    float *mean_out, *rstd_out;
+    float eps;
+    int ones_col;
 };
 
-constexpr int RG_EPI_LNBWD = 100;     // internal epilogue codes (sei_rowgemm_lnbwd_bf16, sei_rowgemm_dgelu_bf16)
-constexpr int RG_EPI_DGELU2 = 101;
+constexpr int RG_EPI_LNBWD = 100;     // internal epilogue codes (sei_rowgemm_lnbwd_bf16, sei_rowgemm_dgelu_bf16,
+constexpr int RG_EPI_DGELU2 = 101;    // sei_rowgemm_ln_bf16: SEI_EPI_BIAS_RES / _BIAS_SCALE_RES followed by a LayerNorm)
+constexpr int RG_EPI_RES_LN = 102;
+constexpr int RG_EPI_SCALE_RES_LN = 103;
 
 template <int N>
 __device__ __forceinline__ void rg_wait_vmcnt() {
@@ -230,8 +238,10 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     // what a thread finishes at a time: a quad (float32 outputs: 16-byte stores) or two neighbouring quads (bf16-only
     // outputs: 16-byte stores of eight values)
     constexpr bool LNB = EPI == RG_EPI_LNBWD;         // OUT16 then says: also write the scaled bf16 copy
-    static_assert(!LNB || (NBT == 12 && TR == 32), "the LayerNorm epilogue owns 32 rows x 192 columns: 16 lanes per row");
-    constexpr int GQ = (!LNB && (OUT16 || EPI == SEI_EPI_MUL_DGELU || TWO)) ? 2 : 1;
+    constexpr bool LNF = EPI == RG_EPI_RES_LN || EPI == RG_EPI_SCALE_RES_LN;
+    constexpr bool LNX = LNB || LNF;                  // epilogues that reduce over the channels of a row
+    static_assert(!LNX || (NBT == 12 && TR == 32), "the LayerNorm epilogues own 32 rows x 192 columns: 16 lanes per row");
+    constexpr int GQ = (!LNX && (OUT16 || EPI == SEI_EPI_MUL_DGELU || TWO)) ? 2 : 1;
     constexpr int IR = QR / GQ;                       // items per row
     constexpr int IPT = (TR * IR + RG_NT - 1) / RG_NT;   // items per thread (the last pass may be partly empty)
     constexpr bool RAGGED = TR * IR % RG_NT != 0;
@@ -239,13 +249,14 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     static_assert(TR % 16 == 0 && QR % GQ == 0, "whole items");
     constexpr bool HAS_ROWS = EPI == SEI_EPI_BIAS_RES || EPI == SEI_EPI_BIAS_SCALE_RES || EPI == SEI_EPI_MUL_DGELU;
     constexpr bool HAS_BIAS = EPI == SEI_EPI_BIAS || EPI == SEI_EPI_BIAS_GELU || EPI == SEI_EPI_BIAS_RES ||
-                              EPI == SEI_EPI_BIAS_SCALE_RES;       // (added to rows in the last pass; TWO: see below)
+                              EPI == SEI_EPI_BIAS_SCALE_RES || LNF;   // (added to rows in the last pass; TWO: see below)
     constexpr int UNR = IPT > 3 ? (GQ == 2 ? 2 : 3) : IPT;   // items in flight per thread in the last pass
-    constexpr int NAUX = LNB ? 8 + (OUT16 ? 1 : 0)
+    constexpr int NAUX = LNF ? 3 + (EPI == RG_EPI_SCALE_RES_LN ? 1 : 0) : LNB ? 8 + (OUT16 ? 1 : 0)
                              : (HAS_ROWS ? QPT : 0) + (EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 0);   // loads per thread and tile
-    __shared__ __attribute__((aligned(1024))) char smem[3 * STAGE + TR * LDP * 4 + NP * 4];
+    __shared__ __attribute__((aligned(1024))) char smem[3 * STAGE + TR * LDP * 4 + (LNF ? 3 : 1) * NP * 4];
     float *patch = reinterpret_cast<float *>(smem + 3 * STAGE);
     float *lbias = patch + TR * LDP;
+    float *lgam = lbias + NP, *lbet = lgam + NP;       // (LNF only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -370,14 +381,34 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     // ---- LayerNorm backward in the epilogue: thread = (row tid / 16, lane el of 16), quads el, el + 16, el + 32 of the row
     const int er = tid >> 4, el = tid & 15;
     const int nvq = g.nv >> 2;
-    f32x4 lx[LNB ? 3 : 1], lr[LNB ? 3 : 1], ag[LNB ? 3 : 1], ab[LNB ? 3 : 1], ac[LNB ? 3 : 1];
+    f32x4 lx[LNX ? 3 : 1], lr[LNB ? 3 : 1], ag[LNB ? 3 : 1], ab[LNB ? 3 : 1], ac[LNB ? 3 : 1];
     float lmu = 0.f, lrs = 0.f, lsc = 1.f;
+    if constexpr (LNF) {
+        for (int c = tid; c < NP; c += RG_NT) {
+            lgam[c] = c < g.nv ? g.gamma[c] : 0.f;
+            lbet[c] = c < g.nv ? g.beta2[c] : 0.f;
+        }
+    }
     if constexpr (LNB) {
         for (int c = tid; c < NP; c += RG_NT) lbias[c] = c < g.nv ? g.gamma[c] : 0.f;     // the norm's weight, read per tile
 #pragma unroll
         for (int k = 0; k < 3; ++k) ag[k] = ab[k] = ac[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     auto load_ln = [&](int t) {
+        if constexpr (LNF) {                             // the residual rows (and the row's stochastic-depth factor)
+            const int tile = b + min(t, nt - 1) * G;
+            const size_t row = (size_t)tile * TR + er;
+            const float *rows = EPI == RG_EPI_SCALE_RES_LN ? g.R2 : g.R1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float *xs = rows + row * g.ldr + 4 * min(el + 16 * k, nvq - 1);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lx[k]) : "v"(xs) : "memory");
+            }
+            if constexpr (EPI == RG_EPI_SCALE_RES_LN) {
+                const float *cs = g.R1 + row;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(lsc) : "v"(cs) : "memory");
+            }
+        }
         if constexpr (LNB) {
             const int tile = b + min(t, nt - 1) * G;
             const size_t row = (size_t)tile * TR + er;
@@ -504,6 +535,65 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
             }
         }
         const size_t row0 = (size_t)(b + t * G) * TR;
+        if constexpr (LNF) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NDMA_HI>();
+            else rg_wait_vmcnt<NDMA_LO>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(lx[k]));
+            if constexpr (EPI == RG_EPI_SCALE_RES_LN) asm volatile("" : "+v"(lsc));
+            // v = residual + [factor] (acc + bias): the block's new token row; then nn.LayerNorm over its nv channels
+            // (mean, then the variance of the centred values, as sei_ln_fwd_bf16_pad)
+            const size_t row = row0 + er;
+            f32x4 v[3];
+            float s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int qk = el + 16 * k;
+                const bool valid = qk < nvq;
+                v[k] = *reinterpret_cast<const f32x4 *>(patch + er * LDP + 4 * qk) + *reinterpret_cast<const f32x4 *>(lbias + 4 * qk);
+                if constexpr (EPI == RG_EPI_SCALE_RES_LN) v[k] = lx[k] + lsc * v[k];
+                else v[k] += lx[k];
+                if (valid) {
+                    *reinterpret_cast<f32x4 *>(g.D32 + row * g.ld32 + 4 * qk) = v[k];
+                    s1 += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+                }
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) s1 += __shfl_xor(s1, off, 16);
+            const float invC = 1.0f / (float)g.nv, mu = s1 * invC;
+            float s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[k][j] -= mu;
+                if (el + 16 * k < nvq) s2 += (v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3]);
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) s2 += __shfl_xor(s2, off, 16);
+            const float rs = rsqrtf(s2 * invC + g.eps);
+            if (el == 0) {
+                g.mean_out[row] = mu;
+                g.rstd_out[row] = rs;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int qk = el + 16 * k;
+                const f32x4 gm = *reinterpret_cast<const f32x4 *>(lgam + 4 * qk), bt = *reinterpret_cast<const f32x4 *>(lbet + 4 * qk);
+                f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (qk < nvq) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = v[k][j] * rs * gm[j] + bt[j];
+                } else if (qk == nvq && g.ones_col) {
+                    y[0] = 1.0f;
+                }
+                uint2 h;
+                h.x = rg_pack2(y[0], y[1]);
+                h.y = rg_pack2(y[2], y[3]);
+                *reinterpret_cast<uint2 *>(g.D16 + row * g.ld16 + 4 * qk) = h;
+            }
+        }
         if constexpr (LNB) {
             __builtin_amdgcn_sched_barrier(0);
             if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NDMA_HI>();
@@ -567,7 +657,7 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
             }
         }
 #pragma unroll UNR
-        for (int it = 0; it < (LNB ? 0 : IPT); ++it) {
+        for (int it = 0; it < (LNX ? 0 : IPT); ++it) {
             if (RAGGED && it == IPT - 1 && tid + RG_NT * it >= TR * IR) break;      // wave-uniform (whole waves past the end)
             f32x4 v[GQ];
 #pragma unroll
@@ -797,4 +887,31 @@ extern "C" int sei_rowgemm_dgelu_bf16(const uint16_t *A, int lda, const uint16_t
     g.A = A; g.W = W; g.lda = lda; g.ldw = ldw; g.A2 = A2; g.W2 = W2; g.lda2 = lda2; g.ldw2 = ldw2;
     g.bias = bias2; g.D16 = D16; g.ld16 = ld16; g.nv = nv;
     return rg_launch<3, 24, 32, 8, 1, RG_EPI_DGELU2, true>(g, (int)M, (hipStream_t)stream);
+}
+
+extern "C" size_t sei_rowgemm_ln_bf16_eligible(long long M, int K, int C) {
+    return (M > 0 && M % 64 == 0 && M < (1ll << 31) && (K == 192 || K == 384) && C > 0 && C % 4 == 0 && C < 192) ? 1 : 0;
+}
+
+extern "C" int sei_rowgemm_ln_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, long long M, int K, int C,
+                                   const float *bias, const float *row_scale, const float *res, float *out, const float *gamma,
+                                   const float *beta, float eps, int ones_col, uint16_t *h16, int ldh, float *mean,
+                                   float *rstd, void *stream) {
+    SEI_REQUIRE(A && W && bias && res && out && gamma && beta && h16 && mean && rstd && sei_rowgemm_ln_bf16_eligible(M, K, C));
+    SEI_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0);
+    SEI_REQUIRE((unsigned long long)64 * (size_t)lda * 2 < (1ull << 32));
+    SEI_REQUIRE((((uintptr_t)res | (uintptr_t)out) & 15) == 0 && ((uintptr_t)h16 & 7) == 0 && ldh >= 192 && ldh % 4 == 0);
+    RowGemmArgs g = {};
+    g.A = A; g.W = W; g.lda = lda; g.ldw = ldw; g.bias = bias; g.ldr = C; g.D32 = out; g.ld32 = C; g.D16 = h16; g.ld16 = ldh;
+    g.nv = C; g.gamma = gamma; g.beta2 = beta; g.mean_out = mean; g.rstd_out = rstd; g.eps = eps; g.ones_col = ones_col;
+    hipStream_t s = (hipStream_t)stream;
+    const int m = (int)M;
+    if (row_scale) {
+        g.R1 = row_scale; g.R2 = res;
+        return K == 192 ? rg_launch<3, 12, 32, 4, 2, RG_EPI_SCALE_RES_LN, false>(g, m, s)
+                        : rg_launch<6, 12, 32, 4, 2, RG_EPI_SCALE_RES_LN, false>(g, m, s);
+    }
+    g.R1 = res; g.R2 = nullptr;
+    return K == 192 ? rg_launch<3, 12, 32, 4, 2, RG_EPI_RES_LN, false>(g, m, s)
+                    : rg_launch<6, 12, 32, 4, 2, RG_EPI_RES_LN, false>(g, m, s);
 }

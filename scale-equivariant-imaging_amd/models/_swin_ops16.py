@@ -255,11 +255,32 @@ def linear_lnbwd16(A16, W, Wt, M, x2d, gamma, mean, rstd, res, ggamma, gbeta, ro
     return gx, (cast_pad(gx, row_scale, colsum) if want16 else None)
 
 
+def linear_res_ln16(A16, W, M, bias, drop, res, gamma, beta, flops):
+    """out = res + [drop] (A16 W^T + bias) and the LayerNorm (gamma, beta) of out as padded bf16 rows with its statistics:
+    one launch (sei_rowgemm_ln_bf16) where built, else None (the caller runs the layer and the norm separately)."""
+    K = W.shape[1]
+    C = res.shape[1]
+    if not N.lib().sei_rowgemm_ln_bf16_eligible(M, K, C):
+        return None
+    dev = res.device
+    out = torch.empty((M, C), dtype=torch.float32, device=dev)
+    h = torch.empty((M, CP), dtype=torch.bfloat16, device=dev)
+    mean = torch.empty(M, dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    _ops._gemm_call(flops, "sei_rowgemm_ln_bf16", A16.data_ptr(), A16.shape[1], W.data_ptr(), K, M, K, C, bias.data_ptr(),
+                    N.ptr(drop), res.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), LN_EPS, 1, h.data_ptr(), CP,
+                    mean.data_ptr(), rstd.data_ptr())
+    return out, h, mean, rstd
+
+
 class SwinBlockFn16(torch.autograd.Function):
     """models._swin_ops.SwinBlockFn in bf16 mode; `pack` / `key` give the block's re-laid-out matrices."""
 
     @staticmethod
-    def forward(ctx, x, g1, b1, table, bproj, g2, b2, bm1, bm2, pack, key, heads, shift, drop1, drop2):
+    def forward(ctx, x, g1, b1, table, bproj, g2, b2, bm1, bm2, pack, key, heads, shift, drop1, drop2, pre=None, nxt=None):
+        """pre: (h1, mean1, rstd1) = this block's norm1 already applied to x by the layer that produced x (the previous
+        block's fc2 launch); nxt: (weight, bias) of the NEXT block's norm1 -- the block then returns (out, h, mean, rstd)
+        with that norm applied to its output (None entries where the fused launch is not built for the shape)."""
         N.check_tensor(x, "tokens")
         B, H, W, C = x.shape
         M = B * H * W
@@ -267,18 +288,22 @@ class SwinBlockFn16(torch.autograd.Function):
         wqkv, wproj, w1, w2 = (pack.w(f"{key}.{k}") for k in ("qkv", "proj", "fc1", "fc2"))
         Ch, Chr = w1.shape[0], bm1.shape[0]              # padded (384) / real (360) hidden width
         dev = x.device
-        h1, mean1, rstd1 = ln16(x2, g1, b1)
+        h1, mean1, rstd1 = pre if pre is not None else ln16(x2, g1, b1)
         qkv = torch.empty((M, 3 * heads * HP), dtype=torch.bfloat16, device=dev)
         linear16(h1, wqkv, None, M, EPI_BIAS, 3 * heads * HP, out16=qkv, bias=pack.b(f"{key}.qkv_bias"), flops=2.0 * M * 3 * C * C)
         a = torch.empty((M, CP), dtype=torch.bfloat16, device=dev)
         scale = float((C // heads) ** -0.5)
         N.call("sei_swin_attn_fwd_bf16", qkv.data_ptr(), table.data_ptr(), a.data_ptr(), B, H, W, heads, shift, scale)
-        x1 = torch.empty((M, C), dtype=torch.float32, device=dev)
-        if drop1 is None:
-            linear16(a, wproj, None, M, EPI_BIAS_RES, C, out32=x1, bias=bproj, R1=x2, flops=2.0 * M * C * C)
+        fused = linear_res_ln16(a, wproj, M, bproj, drop1, x2, g2, b2, 2.0 * M * C * C)    # proj, residual, norm2
+        if fused is not None:
+            x1, h2, mean2, rstd2 = fused
         else:
-            linear16(a, wproj, None, M, EPI_BIAS_SCALE_RES, C, out32=x1, bias=bproj, R1=drop1, R2=x2, flops=2.0 * M * C * C)
-        h2, mean2, rstd2 = ln16(x1, g2, b2)
+            x1 = torch.empty((M, C), dtype=torch.float32, device=dev)
+            if drop1 is None:
+                linear16(a, wproj, None, M, EPI_BIAS_RES, C, out32=x1, bias=bproj, R1=x2, flops=2.0 * M * C * C)
+            else:
+                linear16(a, wproj, None, M, EPI_BIAS_SCALE_RES, C, out32=x1, bias=bproj, R1=drop1, R2=x2, flops=2.0 * M * C * C)
+            h2, mean2, rstd2 = ln16(x1, g2, b2)
         # the float32 pre-activation is stored only where the backward cannot recompute it (sei_rowgemm_dgelu_bf16)
         recompute = bool(N.lib().sei_rowgemm_dgelu_bf16_eligible(M, Ch, CP)) and \
             bool(N.lib().sei_rowgemm_bf16_eligible(M, Ch, CP, EPI_BIAS_GELU, 0))
@@ -290,18 +315,29 @@ class SwinBlockFn16(torch.autograd.Function):
         else:
             linear16(h2, w1, None, M, EPI_BIAS_GELU, Ch, out32=f3, out16=f4, bias=pack.b(f"{key}.fc1_bias"),
                      flops=2.0 * M * Chr * C)
-        out = torch.empty((M, C), dtype=torch.float32, device=dev)
-        if drop2 is None:
-            linear16(f4, w2, None, M, EPI_BIAS_RES, C, out32=out, bias=bm2, R1=x1, flops=2.0 * M * Chr * C)
+        fused = linear_res_ln16(f4, w2, M, bm2, drop2, x1, nxt[0], nxt[1], 2.0 * M * Chr * C) if nxt is not None else None
+        if fused is not None:                            # fc2, residual, the next block's norm1
+            out, hn, mean_n, rstd_n = fused
         else:
-            linear16(f4, w2, None, M, EPI_BIAS_SCALE_RES, C, out32=out, bias=bm2, R1=drop2, R2=x1, flops=2.0 * M * Chr * C)
+            hn = mean_n = rstd_n = None
+            out = torch.empty((M, C), dtype=torch.float32, device=dev)
+            if drop2 is None:
+                linear16(f4, w2, None, M, EPI_BIAS_RES, C, out32=out, bias=bm2, R1=x1, flops=2.0 * M * Chr * C)
+            else:
+                linear16(f4, w2, None, M, EPI_BIAS_SCALE_RES, C, out32=out, bias=bm2, R1=drop2, R2=x1, flops=2.0 * M * Chr * C)
         ctx.save_for_backward(x, mean1, rstd1, h1, qkv, a, x1, mean2, rstd2, h2, f3, f4, drop1, drop2)
         ctx.params = (g1, b1, table, bproj, g2, b2, bm1, bm2)
         ctx.cfg = (pack, key, heads, shift)
-        return out.view(B, H, W, C)
+        ctx.extra_outputs = nxt is not None
+        if nxt is None:
+            return out.view(B, H, W, C)
+        if hn is None:                                   # not fused: the next block's norm in its own launch, here
+            hn, mean_n, rstd_n = ln16(out, nxt[0], nxt[1])
+        ctx.mark_non_differentiable(hn, mean_n, rstd_n)  # their gradient flows through `out` in the next block's backward
+        return out.view(B, H, W, C), hn, mean_n, rstd_n
 
     @staticmethod
-    def backward(ctx, go):
+    def backward(ctx, go, *unused):
         x, mean1, rstd1, h1, qkv, a, x1, mean2, rstd2, h2, f3, f4, drop1, drop2 = ctx.saved_tensors
         g1, b1, table, bproj, g2, b2, bm1, bm2 = ctx.params
         pack, key, heads, shift = ctx.cfg
@@ -335,7 +371,7 @@ class SwinBlockFn16(torch.autograd.Function):
         # the four weight gradients (+ the qkv / fc1 bias gradients, column C) over the same tokens: one launch
         weight_grad16_group([(dqkv, h1, pack.g(f"{key}.qkv"), 2.0 * 3 * C * C), (gy1, a, pack.g(f"{key}.proj"), 2.0 * C * C),
                              (gf3, h2, pack.g(f"{key}.fc1"), 2.0 * Chr * C), (gy, f4, pack.g(f"{key}.fc2"), 2.0 * Chr * C)])
-        return (gx.view(B, H, W, C) if ctx.needs_input_grad[0] else None,) + (None,) * 14
+        return (gx.view(B, H, W, C) if ctx.needs_input_grad[0] else None,) + (None,) * 16
 
 
 _TAPS = [(ky, kx) for ky in range(3) for kx in range(3)]

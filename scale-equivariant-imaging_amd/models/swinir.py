@@ -104,14 +104,16 @@ class SwinTransformerBlock(nn.Module):
         m = mw.unsqueeze(1) - mw.unsqueeze(2)
         return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
 
-    def forward(self, x, drop=None, pack=None):
-        """x: (B, H, W, C) tokens; drop: (rows_attn, rows_mlp) per-row stochastic-depth factors or None."""
+    def forward(self, x, drop=None, pack=None, pre=None, nxt=None):
+        """x: (B, H, W, C) tokens; drop: (rows_attn, rows_mlp) per-row stochastic-depth factors or None. bf16 mode only:
+        pre = this block's norm1 output / statistics already formed by the previous block, nxt = the next block's norm1
+        (weight, bias) to apply to this block's output -- the return value is then (out, h, mean, rstd)."""
         a, m = self.attn, self.mlp
         d1, d2 = drop if drop is not None else (None, None)
         if pack is not None:                            # throughput mode: bf16 GEMM layouts from the pack
             return S16.SwinBlockFn16.apply(x, self.norm1.weight, self.norm1.bias, a.relative_position_bias_table,
                                            a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.bias, m.fc2.bias,
-                                           pack, self._sei_key, self.num_heads, self.shift_size, d1, d2)
+                                           pack, self._sei_key, self.num_heads, self.shift_size, d1, d2, pre, nxt)
         return S.SwinBlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.relative_position_bias_table,
                                    a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, self.norm2.weight,
                                    self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
@@ -143,8 +145,15 @@ class RSTB(nn.Module):
 
     def forward(self, x, drops, pack=None):
         res = x
-        for blk, drop in zip(self.residual_group.blocks, drops):
-            x = blk(x, drop, pack)
+        blocks = list(self.residual_group.blocks)
+        pre = None
+        for i, (blk, drop) in enumerate(zip(blocks, drops)):
+            if pack is not None and i + 1 < len(blocks):
+                # bf16 mode: a block's last launch also applies the NEXT block's norm1 to the rows it has just formed
+                nxt = (blocks[i + 1].norm1.weight, blocks[i + 1].norm1.bias)
+                x, *pre = blk(x, drop, pack, pre, nxt)
+            else:
+                x, pre = blk(x, drop, pack, pre), None
         return conv3x3(self.conv, x, res, 0, pack)
 
 

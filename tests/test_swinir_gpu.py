@@ -673,3 +673,40 @@ def test_gelu_gradient_with_the_recomputed_preactivation(M):
     ref = (gy.double() @ w2t.double().T) * (0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * np.pi) ** 0.5)
     assert float((recomputed.double() - ref).abs().max()) < 2.0 ** -7 * float(ref.abs().max())
     assert bool((recomputed[:, nv:] == 0).all())
+
+
+@pytest.mark.parametrize("M,K,drop", [(64, 192, True), (4608, 192, False), (4608, 384, True), (300 * 64, 384, False),
+                                      (300 * 64, 192, True)])
+def test_residual_linear_layer_with_the_layernorm_behind_it(M, K, drop):
+    """sei_rowgemm_ln_bf16 (proj -> norm2, fc2 -> the next block's norm1 of deepinv's SwinIR) against the two launches it
+    replaces: the residual rows agree with sei_rowgemm_bf16 bit for bit, mean / rstd / the bf16 LayerNorm rows with
+    sei_ln_fwd_bf16_pad to the last bits (sums over 16 lanes instead of 64), and both with float64."""
+    import _native as N
+    C, CP = 180, 192
+    gen = torch.Generator(device="cuda").manual_seed(M + K)
+    a = torch.randn((M, K), device="cuda", generator=gen).bfloat16()
+    w = (0.1 * torch.randn((CP, K), device="cuda", generator=gen)).bfloat16()
+    w[C:] = 0
+    bias, gamma, beta = (torch.randn(C, device="cuda", generator=gen) for _ in range(3))
+    res = torch.randn((M, C), device="cuda", generator=gen) * 2 + 0.5
+    scale = (torch.rand(M, device="cuda", generator=gen) > 0.2).float() / 0.8 if drop else None
+    out = torch.full((M, C), 7.0, device="cuda")
+    h = torch.full((M, CP), 7.0, device="cuda").bfloat16()
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    assert N.lib().sei_rowgemm_ln_bf16_eligible(M, K, C) == 1
+    N.call("sei_rowgemm_ln_bf16", a.data_ptr(), K, w.data_ptr(), K, M, K, C, bias.data_ptr(), N.ptr(scale), res.data_ptr(),
+           out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 1, h.data_ptr(), CP, mean.data_ptr(), rstd.data_ptr())
+    out2 = torch.empty((M, C), device="cuda")
+    N.call("sei_rowgemm_bf16", a.data_ptr(), K, w.data_ptr(), K, out2.data_ptr(), C, None, 0, M, CP, K, C, 7 if drop else 3,
+           bias.data_ptr(), scale.data_ptr() if drop else res.data_ptr(), res.data_ptr() if drop else None, C)
+    assert torch.equal(out, out2)
+    h2 = torch.empty((M, CP), device="cuda").bfloat16()
+    mean2, rstd2 = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    N.call("sei_ln_fwd_bf16_pad", out2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), h2.data_ptr(), mean2.data_ptr(),
+           rstd2.data_ptr(), M, C, CP, 1e-5, 1)
+    assert float((mean - mean2).abs().max()) < 1e-6 * float(mean2.abs().max())
+    assert float((rstd - rstd2).abs().max()) < 2e-6 * float(rstd2.abs().max())
+    assert float((h.float() - h2.float()).abs().max()) <= 2.0 ** -7 * float(h2.float().abs().max())
+    assert bool((h[:, C] == 1).all()) and bool((h[:, C + 1:] == 0).all())
+    ref = torch.nn.functional.layer_norm(out.double(), (C,), gamma.double(), beta.double(), 1e-5)
+    assert float((h[:, :C].double() - ref).abs().max()) < 2.0 ** -7 * float(ref.abs().max())
