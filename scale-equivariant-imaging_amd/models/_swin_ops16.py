@@ -334,6 +334,7 @@ class SwinBlockFn16(torch.autograd.Function):
         if hn is None:                                   # not fused: the next block's norm in its own launch, here
             hn, mean_n, rstd_n = ln16(out, nxt[0], nxt[1])
         ctx.mark_non_differentiable(hn, mean_n, rstd_n)  # their gradient flows through `out` in the next block's backward
+        ctx.set_materialize_grads(False)                 # (no zero tensors made for them in the backward pass)
         return out.view(B, H, W, C), hn, mean_n, rstd_n
 
     @staticmethod
