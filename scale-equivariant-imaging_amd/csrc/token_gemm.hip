@@ -242,6 +242,11 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     constexpr bool LNX = LNB || LNF;                  // epilogues that reduce over the channels of a row
     static_assert(!LNX || (NBT == 12 && TR == 32), "the LayerNorm epilogues own 32 rows x 192 columns: 16 lanes per row");
     constexpr int GQ = (!LNX && (OUT16 || EPI == SEI_EPI_MUL_DGELU || TWO)) ? 2 : 1;
+    // bf16-only outputs without auxiliary rows: bias and rounding happen in the accumulator layout and the patch holds bf16
+    // (half the LDS bytes; the last pass is one 16-byte LDS read and one 16-byte store per eight values, no arithmetic)
+    constexpr bool P16 = ((EPI == SEI_EPI_BIAS || EPI == SEI_EPI_NONE) && OUT16) || TWO;
+    constexpr int LDP16 = NP + 8;                     // bf16 patch row stride: 4 rows = 64 B apart mod 256
+    static_assert(!P16 || WK == 1, "the bf16 patch has nothing to add up");
     constexpr int IR = QR / GQ;                       // items per row
     constexpr int IPT = (TR * IR + RG_NT - 1) / RG_NT;   // items per thread (the last pass may be partly empty)
     constexpr bool RAGGED = TR * IR % RG_NT != 0;
@@ -304,6 +309,16 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[nb][s]));
 
+    float biasr[(P16 && EPI == SEI_EPI_BIAS) ? NB : 1];
+    if constexpr (P16 && EPI == SEI_EPI_BIAS) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int c = 16 * (nb0 + min(nb, nbw - 1)) + l16;
+            biasr[nb] = c < g.nv ? g.bias[c] : 0.f;        // the accumulator's column is the lane's for every row
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(biasr[nb]));
+    }
     // ---- DMA pieces of a stage: piece q = image q / (TR / 8), rows 8 (q % (TR / 8)) ..; chunk swizzle (r >> 1) & 7
     unsigned offa[EMAX];
 #pragma unroll
@@ -497,8 +512,24 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
         if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NAUX + NDMA_HI>();
         else rg_wait_vmcnt<NAUX + NDMA_LO>();
         // ---- accumulators into the patch (WK = 2: the second half of K adds to the first)
+        if constexpr (P16) {
+            unsigned short *pw16 = reinterpret_cast<unsigned short *>(patch) + (wr * RB * 16 + 4 * lg) * LDP16 + 16 * nb0 + l16;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (NBX != 0 && nb == NB - 1 && nbw < NB) break;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[rb][nb][j];
+                        if constexpr (EPI == SEI_EPI_BIAS) v += biasr[nb];
+                        const __bf16 h = (__bf16)v;
+                        pw16[(16 * rb + j) * LDP16 + 16 * nb] = __builtin_bit_cast(unsigned short, h);
+                    }
+                }
+        }
         float *pw = patch + (wr * RB * 16 + 4 * lg) * LDP + 16 * nb0 + l16;
-        if (wk == 0) {
+        if (!P16 && wk == 0) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -656,8 +687,17 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
                 }
             }
         }
+        if constexpr (P16) {
+#pragma unroll
+            for (int it = 0; it < IPT; ++it) {
+                if (RAGGED && it == IPT - 1 && tid + RG_NT * it >= TR * IR) break;      // wave-uniform
+                const int idx = tid + RG_NT * it, qr = idx / IR, qc = 8 * (idx % IR);
+                const uint4 h = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned short *>(patch) + qr * LDP16 + qc);
+                *reinterpret_cast<uint4 *>(g.D16 + (row0 + qr) * g.ld16 + qc) = h;
+            }
+        }
 #pragma unroll UNR
-        for (int it = 0; it < (LNX ? 0 : IPT); ++it) {
+        for (int it = 0; it < ((LNX || P16) ? 0 : IPT); ++it) {
             if (RAGGED && it == IPT - 1 && tid + RG_NT * it >= TR * IR) break;      // wave-uniform (whole waves past the end)
             f32x4 v[GQ];
 #pragma unroll
