@@ -420,6 +420,13 @@ int sei_pad_nhwc_bf16(const float *x, uint16_t *xp, int B, int H, int W, int C, 
  * tap's row shift. Rows r of the border are computed too (discard them: sei_unpad_nhwc). */
 int sei_gemm_bf16nt_conv(const uint16_t *Ap, int cin_pad, const int *row_off9, const uint16_t *B, int ldb,
                          float *D32, uint16_t *D16, int M, int N, int epilogue, const float *bias, void *stream);
+/* The same convolution with sei_unpad_nhwc in its epilogue: y (Bimg, H, W, N) float32 = [LeakyReLU 0.01 when act = 1]
+ * (conv + bias) [+ res], Ap the zero-bordered (H + 2) x (W + 2) grids of Bimg images; the border pixels are computed and
+ * dropped by the row-patch epilogue, the (grid rows, N) intermediate is never written. N % 4 == 0; res (same layout as
+ * y) requires bias. Reference: nn.Conv2d(3x3, padding 1) (+ residual / LeakyReLU) of deepinv's SwinIR (RSTB.conv,
+ * conv_after_body, the upsampler), forward and -- with the transposed tap-major weights -- data gradient. */
+int sei_gemm_bf16nt_conv_unpad(const uint16_t *Ap, int cin_pad, const int *row_off9, const uint16_t *B, int ldb, float *y,
+                               const float *res, int Bimg, int H, int W, int N, const float *bias, int act, void *stream);
 
 int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, float *exp_avg, float *exp_avg_sq,
                    size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,

@@ -75,6 +75,10 @@ struct NtArgs {
     int batch;
     int batch_row[9];
     long long batch_ld;
+    // sei_gemm_bf16nt_conv_unpad (row-patch epilogue only): the M rows are the pixels of a zero-bordered (H + 2) x (W + 2)
+    // grid per image; only interior rows are written, to row (b H + y - 1) W + x - 1 of D32 / R1 (the NHWC tensors),
+    // with LeakyReLU(0.01) before the residual when unpad_act. unpad_W = 0: rows as they are.
+    int unpad_H, unpad_W, unpad_act;
 };
 
 typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
     // thread then owns quads of a row: residual / GELU' inputs arrive as 16-byte loads on contiguous row segments, float32
     // results leave as 16-byte and bf16 results as 8-byte stores. The element-wise epilogue below issues one 4- or 2-byte
     // access per value and lane and is bound by that instruction count wherever K is short.
-    if constexpr (ROWEPI == 4 && patch_fits<TM, TN, WM, WN, NSTAGE>()) {
+    if constexpr ((ROWEPI == 4 || ROWEPI == 5) && patch_fits<TM, TN, WM, WN, NSTAGE>()) {     // 5: + the unpad row remap
         constexpr int ROWS_WM = 32 * TM;
         constexpr int LDS_ROWS = (NSTAGE * STAGE) / (BN * 4);
         constexpr int GW = LDS_ROWS >= WM * ROWS_WM ? WM : (LDS_ROWS >= 2 * ROWS_WM && WM >= 2 ? 2 : 1);
@@ -574,8 +578,15 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
                 for (int u = 0; u < U; ++u) {
                     const int idx = base + u * NT;
                     const int r = idx / QPR, c4 = idx - r * QPR;
-                    const int row = m0 + pass * RP + r, col = n0 + 4 * c4;
+                    int row = m0 + pass * RP + r;
+                    const int col = n0 + 4 * c4;
                     ok[u] = idx < TOTAL && row < M && col < N;                  // N % 4 == 0: a quad is all in or all out
+                    if constexpr (ROWEPI == 5) {                                // padded-grid pixel -> NHWC row, border rows dropped
+                        const int Wp = g.unpad_W + 2, HWp = (g.unpad_H + 2) * Wp;
+                        const int b = row / HWp, rem = row - b * HWp, yy = rem / Wp, xx = rem - yy * Wp;
+                        ok[u] = ok[u] && yy >= 1 && yy <= g.unpad_H && xx >= 1 && xx <= g.unpad_W;
+                        row = (b * g.unpad_H + yy - 1) * g.unpad_W + xx - 1;
+                    }
                     off[u] = ok[u] ? (size_t)row * N + col : 0;
                     rowi[u] = ok[u] ? row : 0;
                     v[u] = *reinterpret_cast<const float4 *>(patch + (idx < TOTAL ? r * BN + 4 * c4 : 0));
@@ -613,6 +624,10 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
                         o.x = fmaf(o.x, sc, r2[u].x); o.y = fmaf(o.y, sc, r2[u].y);
                         o.z = fmaf(o.z, sc, r2[u].z); o.w = fmaf(o.w, sc, r2[u].w);
                     } else {
+                        if (ROWEPI == 5 && g.unpad_act) {
+                            o.x = o.x > 0.f ? o.x : 0.01f * o.x; o.y = o.y > 0.f ? o.y : 0.01f * o.y;
+                            o.z = o.z > 0.f ? o.z : 0.01f * o.z; o.w = o.w > 0.f ? o.w : 0.01f * o.w;
+                        }
                         o.x += r1[u].x + r2[u].x; o.y += r1[u].y + r2[u].y;
                         o.z += r1[u].z + r2[u].z; o.w += r1[u].w + r2[u].w;
                     }
@@ -715,8 +730,8 @@ int launch_nt(NtArgs &g, hipStream_t s) {
     }
     g.splitk = 1;
     g.k_per_split = g.K;
-    const bool splittable = g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
-                            g.epilogue == SEI_EPI_BIAS_RES || g.epilogue == SEI_EPI_ACCUM;
+    const bool splittable = (g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
+                             g.epilogue == SEI_EPI_BIAS_RES || g.epilogue == SEI_EPI_ACCUM) && !g.unpad_W;
     if ((ROWEPI == 0 || ROWEPI == 3) && splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
         // Wave-quantisation-aware split: a launch takes ceil(tiles*sk / slots) rounds of workgroups, each
         // round costing (k-tiles per split + a fixed prologue/epilogue/atomics overhead); pick the cheapest sk.
@@ -757,11 +772,19 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         const bool r1_rows = g.epilogue == SEI_EPI_BIAS_ROWSCALE || g.epilogue == SEI_EPI_BIAS_SCALE_RES;
         if (g.splitk == 1 && g.N % 4 == 0 && al(g.D32, 15) && al(g.D16, 7) && al(g.D2_16, 7) && (r1_rows || al(g.R1, 15)) &&
             al(g.R2, 15) && !g.force_band) {
+            if constexpr (!ARM && !BRM && NSTAGE == 2) {             // (the convolutions' two tile shapes)
+                if (g.unpad_W) {
+                    hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE, 5>), dim3((unsigned)per_split),
+                                       dim3(NT), 0, s, g);
+                    return sei_launch_status();
+                }
+            }
             hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE, 4>), dim3((unsigned)per_split), dim3(NT),
                                0, s, g);
             return sei_launch_status();
         }
     }
+    if (g.unpad_W) return SEI_ERR_BAD_ARG;                  // the row remap lives in the row-patch epilogue only
     hipLaunchKernelGGL((gemm_bf16nt_kernel<TM, TN, WM, WN, ARM, BRM, NSTAGE, ROWEPI>),
                        dim3((unsigned)(per_split * g.splitk * nbatch)),
                        dim3(NT), 0, s, g);
@@ -843,7 +866,7 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
     if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D2_16);
     if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU) SEI_REQUIRE(R1);
     if (epilogue == SEI_EPI_ACCUM) SEI_REQUIRE(D32 && !D16);
-    NtArgs g;
+    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
     g.A2 = A; g.B2 = B; g.k_seg = K;                       // one reduction segment
@@ -983,7 +1006,7 @@ extern "C" int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, in
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
-    NtArgs g;
+    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
@@ -1022,7 +1045,7 @@ extern "C" int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, 
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
     SEI_REQUIRE((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
                 ((uintptr_t)param_bf16 & 7) == 0);              // the epilogue moves whole quads
-    NtArgs g;
+    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = param; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = SEI_EPI_NONE;
@@ -1042,7 +1065,7 @@ extern "C" int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0 && ((uintptr_t)D16 & 7) == 0);
-    NtArgs g;
+    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = nullptr; g.D16 = D16; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = SEI_EPI_NONE;
@@ -1063,7 +1086,7 @@ extern "C" int sei_gemm_bf16nt_dw2_taps(const uint16_t *A1, const uint16_t *A2, 
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
-    NtArgs g;
+    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
@@ -1093,7 +1116,7 @@ extern "C" int sei_gemm_bf16nt_conv(const uint16_t *Ap, int cin_pad, const int *
     SEI_REQUIRE(ldb >= 9 * cin_pad && ldb % 8 == 0 && (((uintptr_t)Ap | (uintptr_t)B) & 15) == 0);
     SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS);
     if (epilogue == SEI_EPI_BIAS) SEI_REQUIRE(bias);
-    NtArgs g;
+    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.batch = 1;
     g.A = Ap; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = 9 * cin_pad; g.lda = cin_pad; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
@@ -1103,5 +1126,31 @@ extern "C" int sei_gemm_bf16nt_conv(const uint16_t *Ap, int cin_pad, const int *
     for (int t = 0; t < 9; ++t) g.conv_off[t] = row_off9[t];
     hipStream_t s = (hipStream_t)stream;
     if (N > 128 && N <= 192) return launch_nt<1, 3, 4, 2>(g, s);               // 128 x 192: one column tile
+    return launch_nt<2, 1, 2, 4>(g, s);
+}
+
+// The same convolution with sei_unpad_nhwc in its epilogue: y (Bimg, H, W, N) = [LeakyReLU](conv + bias) [+ res], the
+// border rows of the grid are computed and dropped, the (R, N) intermediate never exists.
+extern "C" int sei_gemm_bf16nt_conv_unpad(const uint16_t *Ap, int cin_pad, const int *row_off9, const uint16_t *B, int ldb,
+                                          float *y, const float *res, int Bimg, int H, int W, int N, const float *bias,
+                                          int act, void *stream) {
+    SEI_REQUIRE(Ap && row_off9 && B && y && Bimg > 0 && H > 0 && W > 0 && N > 0 && N % 4 == 0 && cin_pad > 0 && cin_pad % BK == 0);
+    SEI_REQUIRE(ldb >= 9 * cin_pad && ldb % 8 == 0 && (((uintptr_t)Ap | (uintptr_t)B) & 15) == 0);
+    SEI_REQUIRE((((uintptr_t)y | (uintptr_t)res) & 15) == 0 && (act == 0 || act == 1));
+    SEI_REQUIRE((size_t)Bimg * (H + 2) * (W + 2) < ((size_t)1 << 31));
+    NtArgs g;
+    g.batch = 1;
+    g.A = Ap; g.B = B; g.D32 = y; g.D16 = nullptr; g.M = Bimg * (H + 2) * (W + 2); g.N = N; g.K = 9 * cin_pad;
+    g.lda = cin_pad; g.ldb = ldb;
+    g.epilogue = res ? SEI_EPI_BIAS_RES : (bias ? SEI_EPI_BIAS : SEI_EPI_NONE);
+    g.bias = bias; g.R1 = res; g.R2 = nullptr; g.D2_16 = nullptr;
+    if (res && !bias) return SEI_ERR_BAD_ARG;               // (every residual convolution of the backbones has a bias)
+    g.A2 = Ap; g.B2 = B; g.k_seg = g.K;
+    g.force_tile = 0; g.force_band = 0;
+    g.conv_cin = cin_pad;
+    for (int t = 0; t < 9; ++t) g.conv_off[t] = row_off9[t];
+    g.unpad_H = H; g.unpad_W = W; g.unpad_act = act;
+    hipStream_t s = (hipStream_t)stream;
+    if (N > 128 && N <= 192) return launch_nt<1, 3, 4, 2>(g, s);
     return launch_nt<2, 1, 2, 4>(g, s);
 }

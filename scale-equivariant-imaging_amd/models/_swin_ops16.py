@@ -387,11 +387,6 @@ def _tap_offsets(Wp, sign):
     return _OFFSETS[key]
 
 
-def _conv_gemm(ap, cin_pad, offsets, wmat, out32, rows, n_out, epi, bias, flops):
-    _ops._gemm_call(flops, "sei_gemm_bf16nt_conv", ap.data_ptr(), cin_pad, offsets,
-                    wmat.data_ptr(), wmat.shape[1], out32.data_ptr(), None, rows, n_out, epi, N.ptr(bias))
-
-
 class Conv3x3GemmFn16(torch.autograd.Function):
     """models._swin_ops.Conv3x3GemmFn in bf16 mode: ONE implicit GEMM per convolution on the zero-bordered bf16 grid
     (k-tiles = 64-channel slices of one tap, read from the same array at that tap's row shift), the same for the
@@ -412,13 +407,13 @@ class Conv3x3GemmFn16(torch.autograd.Function):
         guard = Wp + 9                                   # tap shifts (<= Wp + 1) + rounding the row count up to 8
         xp = torch.empty((R + 2 * guard, cinp), dtype=torch.bfloat16, device=x.device)
         N.call("sei_pad_nhwc_bf16", x.data_ptr(), xp.data_ptr(), B, H, W, Cin, cinp, guard)
-        outp = torch.empty((R, Cout), dtype=torch.float32, device=x.device)
-        _conv_gemm(xp[guard:], cinp, _tap_offsets(Wp, 1), wf, outp, R, Cout, EPI_BIAS, bias,
-                   2.0 * B * H * W * weight.shape[0] * 9 * weight.shape[1])
         y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
         if res is not None:
             N.check_tensor(res, "conv3x3 residual")
-        N.call("sei_unpad_nhwc", outp.data_ptr(), N.ptr(res), y.data_ptr(), B, H, W, Cout, int(act))
+        # one implicit GEMM whose epilogue drops the border pixels, applies the activation and adds the residual
+        _ops._gemm_call(2.0 * B * H * W * weight.shape[0] * 9 * weight.shape[1], "sei_gemm_bf16nt_conv_unpad",
+                        xp[guard:].data_ptr(), cinp, _tap_offsets(Wp, 1), wf.data_ptr(), wf.shape[1], y.data_ptr(), N.ptr(res),
+                        B, H, W, Cout, bias.data_ptr(), int(act))
         ctx.save_for_backward(xp, y if act else None)
         ctx.params, ctx.cfg = (weight, bias), (B, H, W, Cin, Cout, guard, act, pack, key)
         return y
@@ -443,10 +438,9 @@ class Conv3x3GemmFn16(torch.autograd.Function):
                       flops_per_row=2.0 * M * weight.shape[0] * 9 * weight.shape[1] / R8, tap_rows=_tap_offsets(Wp, 1))
         gx = None
         if ctx.needs_input_grad[0]:
-            dxp = torch.empty((R, Cin), dtype=torch.float32, device=go.device)
-            _conv_gemm(gop[guard:], coutp, _tap_offsets(Wp, -1), pack.w(f"{key}.bwd"), dxp, R, Cin, EPI_NONE, None,
-                       2.0 * M * weight.shape[0] * 9 * weight.shape[1])
             gx = torch.empty((B, H, W, Cin), dtype=torch.float32, device=go.device)
-            N.call("sei_unpad_nhwc", dxp.data_ptr(), None, gx.data_ptr(), B, H, W, Cin, 0)
+            wb = pack.w(f"{key}.bwd")
+            _ops._gemm_call(2.0 * M * weight.shape[0] * 9 * weight.shape[1], "sei_gemm_bf16nt_conv_unpad", gop[guard:].data_ptr(),
+                            coutp, _tap_offsets(Wp, -1), wb.data_ptr(), wb.shape[1], gx.data_ptr(), None, B, H, W, Cin, None, 0)
         gres = go if ctx.needs_input_grad[3] else None
         return gx, None, None, gres, None, None, None

@@ -710,3 +710,38 @@ def test_residual_linear_layer_with_the_layernorm_behind_it(M, K, drop):
     assert bool((h[:, C] == 1).all()) and bool((h[:, C + 1:] == 0).all())
     ref = torch.nn.functional.layer_norm(out.double(), (C,), gamma.double(), beta.double(), 1e-5)
     assert float((h[:, :C].double() - ref).abs().max()) < 2.0 ** -7 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,with_res", [(2, 16, 24, 192, 180, 0, True), (3, 48, 48, 192, 180, 0, False),
+                                                          (1, 24, 16, 64, 4, 0, False), (2, 16, 16, 192, 64, 1, False),
+                                                          (2, 8, 8, 192, 180, 1, True)])
+def test_conv_gemm_with_the_unpad_epilogue(B, H, W, Cin, Cout, act, with_res):
+    """sei_gemm_bf16nt_conv_unpad == sei_gemm_bf16nt_conv followed by sei_unpad_nhwc (border pixels dropped, LeakyReLU,
+    residual) to the float summation order, and the dense convolution of the same bf16 operands."""
+    import ctypes
+    import _native as N
+    gen = torch.Generator(device="cuda").manual_seed(B * H + W + Cout)
+    Wp, R = W + 2, B * (H + 2) * (W + 2)
+    guard = Wp + 9
+    x = torch.randn((B, H, W, Cin), device="cuda", generator=gen)
+    xp = torch.empty((R + 2 * guard, Cin), device="cuda").bfloat16()
+    N.call("sei_pad_nhwc_bf16", x.data_ptr(), xp.data_ptr(), B, H, W, Cin, Cin, guard)
+    w = (0.05 * torch.randn((Cout, 9 * Cin), device="cuda", generator=gen)).bfloat16()
+    bias = torch.randn(Cout, device="cuda", generator=gen)
+    res = torch.randn((B, H, W, Cout), device="cuda", generator=gen) if with_res else None
+    offs = (ctypes.c_int * 9)(*[(ky - 1) * Wp + (kx - 1) for ky in range(3) for kx in range(3)])
+    outp = torch.empty((R, Cout), device="cuda")
+    N.call("sei_gemm_bf16nt_conv", xp[guard:].data_ptr(), Cin, offs, w.data_ptr(), 9 * Cin, outp.data_ptr(), None, R, Cout, 1,
+           bias.data_ptr())
+    ref = torch.empty((B, H, W, Cout), device="cuda")
+    N.call("sei_unpad_nhwc", outp.data_ptr(), N.ptr(res), ref.data_ptr(), B, H, W, Cout, act)
+    y = torch.full((B, H, W, Cout), 7.0, device="cuda")
+    N.call("sei_gemm_bf16nt_conv_unpad", xp[guard:].data_ptr(), Cin, offs, w.data_ptr(), 9 * Cin, y.data_ptr(), N.ptr(res), B, H,
+           W, Cout, bias.data_ptr(), act)
+    assert relerr(y, ref) < 2e-6                           # (the unfused GEMM may split K on small grids: another summation order)
+    dense = torch.nn.functional.conv2d(x.bfloat16().float().permute(0, 3, 1, 2),
+                                       w.float().view(Cout, 9, Cin).permute(0, 2, 1).reshape(Cout, Cin, 3, 3), bias, padding=1)
+    if act:
+        dense = torch.nn.functional.leaky_relu(dense, 0.01)
+    dense = dense.permute(0, 2, 3, 1) + (res if with_res else 0)
+    assert relerr(y, dense) < 1e-4
