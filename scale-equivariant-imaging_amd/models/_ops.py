@@ -6,6 +6,8 @@ straight into `param.grad` (a view of the model's flat gradient bucket when the 
 flattened), which is what lets the kernels fuse "grad += ..." and keeps one contiguous buffer for the
 fused Adam step and the RCCL all-reduce. `optimizer.zero_grad()` (either flavour) is honoured.
 """
+import os
+
 import torch
 
 import _native as N
@@ -599,6 +601,12 @@ def set_weight_grad_milestone(keys, event, owner=None):
     state_of(owner)["milestone"] = (frozenset(keys), event) if keys else None
 
 
+# The token-streaming kernels of token_gemm.hip (Swin blocks) against the tiled GEMMs they replace: on unless
+# SEI_SWIN_TILED=1 (tests flip the flag to run the same step on both paths; shapes the streaming kernels do not take --
+# token counts that are not multiples of 64 -- use the tiled ones anyway).
+TOKEN_STREAMING = os.environ.get("SEI_SWIN_TILED") != "1"
+
+
 def _check_milestone(_DW, key):
     ms = _DW["milestone"]
     if ms is not None and key in ms[0] and ms[0] <= _DW["written"] and not _DW["milestone_done"]:
@@ -625,7 +633,7 @@ def _launch_weight_grad_group(_DW, segs):
     it and every gradient accumulates; one launch per layer otherwise."""
     first = segs[0]
     rows = [seg[0][0].shape[0] for seg in segs]
-    blocks, ok = [], len(segs) <= 2 and all(r % 64 == 0 for r in rows)
+    blocks, ok = [], TOKEN_STREAMING and len(segs) <= 2 and all(r % 64 == 0 for r in rows)
     for i, (_, _, grad2d, _) in enumerate(first):
         key = grad2d.data_ptr()
         ok = ok and grad2d.dim() == 2 and grad2d.is_contiguous() and grad2d.dtype == torch.float32

@@ -217,7 +217,7 @@ def linear16(A16, W, Wt, M, epi, nv, out32=None, out16=None, bias=None, R1=None,
     matrix (K, N), reduction-major); None for a forward product."""
     Nn, K = W.shape
     only16 = out16 is not None and out32 is None
-    if N.lib().sei_rowgemm_bf16_eligible(M, Nn, K, epi, int(only16)):
+    if _ops.TOKEN_STREAMING and N.lib().sei_rowgemm_bf16_eligible(M, Nn, K, epi, int(only16)):
         rows = R2 if epi == EPI_BIAS_SCALE_RES else R1
         _ops._gemm_call(2.0 * M * Nn * K if flops is None else float(flops), "sei_rowgemm_bf16", A16.data_ptr(), A16.shape[1],
                         W.data_ptr(), K, N.ptr(out32), 0 if out32 is None else out32.shape[1], N.ptr(out16),
@@ -240,7 +240,8 @@ def linear_lnbwd16(A16, W, Wt, M, x2d, gamma, mean, rstd, res, ggamma, gbeta, ro
     Nn, K = W.shape
     C = x2d.shape[1]
     want16 = colsum is not None
-    if (Nn == CP and N.lib().sei_rowgemm_lnbwd_bf16_eligible(M, K, C) and (not want16 or (K == 384 and row_scale is not None))):
+    if (_ops.TOKEN_STREAMING and Nn == CP and N.lib().sei_rowgemm_lnbwd_bf16_eligible(M, K, C)
+            and (not want16 or (K == 384 and row_scale is not None))):
         gx = torch.empty_like(x2d)
         gy16 = torch.empty((M, CP), dtype=torch.bfloat16, device=x2d.device) if want16 else None
         work = torch.empty(N.lib().sei_rowgemm_lnbwd_work_floats(C), dtype=torch.float32, device=x2d.device)
@@ -260,7 +261,7 @@ def linear_res_ln16(A16, W, M, bias, drop, res, gamma, beta, flops):
     one launch (sei_rowgemm_ln_bf16) where built, else None (the caller runs the layer and the norm separately)."""
     K = W.shape[1]
     C = res.shape[1]
-    if not N.lib().sei_rowgemm_ln_bf16_eligible(M, K, C):
+    if not (_ops.TOKEN_STREAMING and N.lib().sei_rowgemm_ln_bf16_eligible(M, K, C)):
         return None
     dev = res.device
     out = torch.empty((M, C), dtype=torch.float32, device=dev)
@@ -305,7 +306,7 @@ class SwinBlockFn16(torch.autograd.Function):
                 linear16(a, wproj, None, M, EPI_BIAS_SCALE_RES, C, out32=x1, bias=bproj, R1=drop1, R2=x2, flops=2.0 * M * C * C)
             h2, mean2, rstd2 = ln16(x1, g2, b2)
         # the float32 pre-activation is stored only where the backward cannot recompute it (sei_rowgemm_dgelu_bf16)
-        recompute = bool(N.lib().sei_rowgemm_dgelu_bf16_eligible(M, Ch, CP)) and \
+        recompute = _ops.TOKEN_STREAMING and bool(N.lib().sei_rowgemm_dgelu_bf16_eligible(M, Ch, CP)) and \
             bool(N.lib().sei_rowgemm_bf16_eligible(M, Ch, CP, EPI_BIAS_GELU, 0))
         f3 = None if recompute else torch.empty((M, Ch), dtype=torch.float32, device=dev)
         f4 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
