@@ -158,6 +158,9 @@ def _stream_bytes(name, a):
         M, Nn, K, nv, epi = a[8:13]                       # residual / GELU' rows in
         return M * (2 * K + (4 * nv if a[4] else 0) + (2 * Nn if a[6] else 0) + (4 * nv if epi in (3, 4, 7) else 0)
                     + (4 if epi == 7 else 0))
+    if name == "sei_rowgemm_gelu_bf16":                   # A rows in, bf16 rows out
+        M, Nn, K = a[8:11]
+        return M * (2 * K + 2 * Nn)
     if name == "sei_rowgemm_ln_bf16":                     # A rows and residual rows in; new token rows, their LayerNorm (bf16) out
         M, K, C = a[4:7]
         return M * (2 * K + 8 * C + 2 * a[16] + 8 + (4 if a[8] else 0))

@@ -518,8 +518,10 @@ size_t sei_rowgemm_bf16_eligible(long long M, int N, int K, int epilogue, int ou
  * 576), then torch's native_layer_norm_backward over the C channels of every row plus the residual gradient:
  *   gx = rstd (gh gamma - mean_c(gh gamma) - xhat mean_c(gh gamma xhat)) + res,   xhat = (x - mean) rstd;
  *   ggamma += sum_rows gh xhat,  gbeta += sum_rows gh;
- * and, when y16 is given (K = 384 only), the operand of the next weight / data gradient in the same pass:
- *   y16 (M, ldy >= 192; zeros past C) = bf16(gx row_scale[row]),  colsum += sum_rows gx row_scale[row].
+ * and, when y16 is given, the operand of the next weight / data gradient in the same pass:
+ *   y16 (M, ldy >= 192; zeros past C) = bf16(gx row_scale[row]),  colsum += sum_rows gx row_scale[row]
+ * (colsum: K = 384 only and optional -- at K = 576 no registers are left for the third column sum; the bias gradient it
+ * would be then comes out of the weight gradient through sei_rowgemm_gelu_bf16's ones column).
  * x, res, gx: (M, C) float32 rows; mean, rstd, row_scale: M floats. work: sei_rowgemm_lnbwd_work_floats(C) floats (per-
  * workgroup column sums, folded by a second launch). Replaces sei_gemm_bf16nt + sei_ln_bwd_pad (+ sei_cast_pad_bf16):
  * deepinv SwinIR's norm1 / norm2 in front of qkv / fc1 (reference construction: src/models/__init__.py:51-74). */
@@ -553,6 +555,13 @@ int sei_rowgemm_ln_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, 
                         const float *row_scale, const float *res, float *out, const float *gamma, const float *beta,
                         float eps, int ones_col, uint16_t *h16, int ldh, float *mean, float *rstd, void *stream);
 size_t sei_rowgemm_ln_bf16_eligible(long long M, int K, int C);
+
+/* fc1's forward alone (bf16 gelu output only, the float32 pre-activation is recomputed by sei_rowgemm_dgelu_bf16), with
+ * column one_at of D16 written as 1.0 (-1: none): the weight gradient of the layer behind, D16^T-contracted over the tokens,
+ * then carries that layer's BIAS gradient in column one_at (the qkv / fc1 trick of sei_ln_fwd_bf16_pad's ones_col, for
+ * fc2). bias: all N entries (zeros in the padding). Same values as sei_rowgemm_bf16(SEI_EPI_BIAS_GELU, D32 = NULL). */
+int sei_rowgemm_gelu_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, const float *bias, int nv, uint16_t *D16,
+                          int ld16, long long M, int N, int K, int one_at, void *stream);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,7 @@ SIGNATURES = {
     "sei_rowgemm_lnbwd_bf16": [_P, _I, _P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _Z, _P],
     "sei_rowgemm_dgelu_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _I, _P],
     "sei_rowgemm_ln_bf16": [_P, _I, _P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _F, _I, _P, _I, _P, _P, _P],
+    "sei_rowgemm_gelu_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _I, _I, _P],
     "sei_tokgrad_bf16_blocks": [_P, _I, _L, _L, _P],
     "sei_tokgrad_bf16": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _L, _L, _P],
     "sei_adam_fused": [_P, _P, _I, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P, _P],

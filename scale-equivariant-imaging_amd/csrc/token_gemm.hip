@@ -189,6 +189,7 @@ struct RowGemmArgs {
     float *mean_out, *rstd_out;
     float eps;
     int ones_col;
+    int gelu_one_at;          // SEI_EPI_BIAS_GELU: this column of D16 is written as 1.0 (-1: none)
 };
 
 constexpr int RG_EPI_LNBWD = 100;     // internal epilogue codes (sei_rowgemm_lnbwd_bf16, sei_rowgemm_dgelu_bf16,
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
                     f32x4 ys;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ys[j] = valid ? o[j] * lsc : 0.f;
-                    ac[k] += ys;
+                    if constexpr (KT != 9) ac[k] += ys;              // (K = 576: no registers left for the third column sum)
                     uint2 h;
                     h.x = rg_pack2(ys[0], ys[1]);
                     h.y = rg_pack2(ys[2], ys[3]);
@@ -721,9 +722,12 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
                 if (g.D32) *reinterpret_cast<f32x4 *>(g.D32 + row * g.ld32 + qc) = v[0];   // pre-activation is optional:
             }                                                        // uniform branch, no aux loads in this variant)
             if constexpr (EPI == SEI_EPI_BIAS_GELU) {
+                float ge[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ge[j] = qc + j == g.gelu_one_at ? 1.0f : sei_gelu_bf16out(v[0][j]);
                 uint2 h;
-                h.x = rg_pack2(sei_gelu_bf16out(v[0][0]), sei_gelu_bf16out(v[0][1]));
-                h.y = rg_pack2(sei_gelu_bf16out(v[0][2]), sei_gelu_bf16out(v[0][3]));
+                h.x = rg_pack2(ge[0], ge[1]);
+                h.y = rg_pack2(ge[2], ge[3]);
                 *reinterpret_cast<uint2 *>(g.D16 + row * g.ld16 + qc) = h;
             } else if constexpr (GQ == 2) {
                 uint4 h;
@@ -857,7 +861,7 @@ extern "C" int sei_rowgemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
     if (epilogue == SEI_EPI_BIAS_SCALE_RES) SEI_REQUIRE(R1 && R2 && ldr >= nv && ldr % 4 == 0 && ((uintptr_t)R2 & 15) == 0);
     RowGemmArgs g;
     g.A = A; g.W = W; g.lda = lda; g.ldw = ldw; g.tiles = 0; g.bias = bias; g.R1 = R1; g.R2 = R2; g.ldr = ldr;
-    g.D32 = D32; g.D16 = D16; g.ld32 = ld32; g.ld16 = ld16; g.nv = nv;
+    g.D32 = D32; g.D16 = D16; g.ld32 = ld32; g.ld16 = ld16; g.nv = nv; g.gelu_one_at = -1;
     hipStream_t s = (hipStream_t)stream;
     const int m = (int)M;
     // <k-tiles, 16-column blocks, rows per tile, column groups, row groups>
@@ -893,8 +897,8 @@ extern "C" int sei_rowgemm_lnbwd_bf16(const uint16_t *A, int lda, const uint16_t
     SEI_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0);
     SEI_REQUIRE((unsigned long long)64 * (size_t)lda * 2 < (1ull << 32));
     SEI_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)res | (uintptr_t)gx | (uintptr_t)work) & 15) == 0);
-    SEI_REQUIRE((y16 != nullptr) == (row_scale != nullptr) && (y16 != nullptr) == (colsum != nullptr));
-    SEI_REQUIRE(!y16 || K == 384);            // (the bf16 copy next to K = 576 does not fit the register file: not built)
+    SEI_REQUIRE((y16 != nullptr) == (row_scale != nullptr) && (!colsum || y16));
+    SEI_REQUIRE(!colsum || K == 384);         // (K = 576: the bf16 copy without its column sums -- no registers left for them)
     if (y16) SEI_REQUIRE(ldy >= 192 && ldy % 4 == 0 && ((uintptr_t)y16 & 7) == 0);
     RowGemmArgs g;
     g.A = A; g.W = W; g.lda = lda; g.ldw = ldw; g.tiles = 0; g.bias = nullptr; g.R1 = x; g.R2 = res; g.ldr = C;
@@ -906,9 +910,9 @@ extern "C" int sei_rowgemm_lnbwd_bf16(const uint16_t *A, int lda, const uint16_t
     if (K == 384)
         rc = y16 ? rg_launch<6, 12, 32, 4, 1, RG_EPI_LNBWD, true>(g, m, s) : rg_launch<6, 12, 32, 4, 1, RG_EPI_LNBWD, false>(g, m, s);
     else
-        rc = rg_launch<9, 12, 32, 4, 1, RG_EPI_LNBWD, false>(g, m, s);
+        rc = y16 ? rg_launch<9, 12, 32, 4, 1, RG_EPI_LNBWD, true>(g, m, s) : rg_launch<9, 12, 32, 4, 1, RG_EPI_LNBWD, false>(g, m, s);
     if (rc != 0) return rc;
-    return sei_fold_partials3(work, groups, C, ggamma, gbeta, y16 ? colsum : nullptr, s);
+    return sei_fold_partials3(work, groups, C, ggamma, gbeta, colsum, s);
 }
 
 extern "C" size_t sei_rowgemm_dgelu_bf16_eligible(long long M, int N, int K) {
@@ -954,4 +958,15 @@ extern "C" int sei_rowgemm_ln_bf16(const uint16_t *A, int lda, const uint16_t *W
     g.R1 = res; g.R2 = nullptr;
     return K == 192 ? rg_launch<3, 12, 32, 4, 2, RG_EPI_RES_LN, false>(g, m, s)
                     : rg_launch<6, 12, 32, 4, 2, RG_EPI_RES_LN, false>(g, m, s);
+}
+
+extern "C" int sei_rowgemm_gelu_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, const float *bias, int nv,
+                                     uint16_t *D16, int ld16, long long M, int N, int K, int one_at, void *stream) {
+    SEI_REQUIRE(A && W && bias && D16 && sei_rowgemm_bf16_eligible(M, N, K, SEI_EPI_BIAS_GELU, 0));
+    SEI_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0);
+    SEI_REQUIRE(nv == N && ld16 >= N && ld16 % 8 == 0 && ((uintptr_t)D16 & 15) == 0);       // bias: all N entries (zeros in the pad)
+    SEI_REQUIRE((unsigned long long)64 * (size_t)lda * 2 < (1ull << 32) && one_at >= -1 && one_at < N);
+    RowGemmArgs g = {};
+    g.A = A; g.W = W; g.lda = lda; g.ldw = ldw; g.bias = bias; g.D16 = D16; g.ld16 = ld16; g.nv = nv; g.gelu_one_at = one_at;
+    return rg_launch<3, 24, 32, 8, 1, SEI_EPI_BIAS_GELU, false>(g, (int)M, (hipStream_t)stream);
 }

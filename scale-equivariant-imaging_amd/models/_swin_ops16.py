@@ -92,6 +92,9 @@ class SwinPack:
             grads["qkv"][:, C] = bq
             grads["fc1"] = layouts["fc1"].copy()
             grads["fc1"][:hid, C] = index_of(mlp.fc1.bias)
+            # fc2: the gelu output's first padding column holds 1.0 where fc1 ran on sei_rowgemm_gelu_bf16 (0.0 otherwise)
+            grads["fc2"] = layouts["fc2"].copy()
+            grads["fc2"][:C, hid] = index_of(mlp.fc2.bias)
             for k, m in layouts.items():
                 add("w", f"{name}.{k}", m)
                 add("w", f"{name}.{k}T", np.ascontiguousarray(m.T))     # the data gradients read the transposes K-contiguous
@@ -232,23 +235,23 @@ def linear16(A16, W, Wt, M, epi, nv, out32=None, out16=None, bias=None, R1=None,
         gemm_nt16(A16, Wt, M, nv, K, epi, out32=out32, out16=out16, R1=R1, b_rmajor=True, flops=flops)
 
 
-def linear_lnbwd16(A16, W, Wt, M, x2d, gamma, mean, rstd, res, ggamma, gbeta, row_scale=None, colsum=None):
+def linear_lnbwd16(A16, W, Wt, M, x2d, gamma, mean, rstd, res, ggamma, gbeta, row_scale=None, colsum=None, cast=None):
     """gx = LayerNorm backward of gh = A16 W^T (the data gradient of the linear layer behind the norm) + res, the norm's
     weight / bias gradients accumulated, and -- with row_scale / colsum -- gy16 = bf16(gx * row_scale) in padded rows with
     its column sums added to colsum: one launch where the fused kernel is built (sei_rowgemm_lnbwd_bf16), GEMM +
     sei_ln_bwd_pad + sei_cast_pad_bf16 otherwise. Returns (gx, gy16 or None)."""
     Nn, K = W.shape
     C = x2d.shape[1]
-    want16 = colsum is not None
+    want16 = colsum is not None or bool(cast)            # cast: the scaled bf16 copy without column sums (any K)
     if (_ops.TOKEN_STREAMING and Nn == CP and N.lib().sei_rowgemm_lnbwd_bf16_eligible(M, K, C)
-            and (not want16 or (K == 384 and row_scale is not None))):
+            and (not want16 or row_scale is not None) and (colsum is None or K == 384)):
         gx = torch.empty_like(x2d)
         gy16 = torch.empty((M, CP), dtype=torch.bfloat16, device=x2d.device) if want16 else None
         work = torch.empty(N.lib().sei_rowgemm_lnbwd_work_floats(C), dtype=torch.float32, device=x2d.device)
         _ops._gemm_call(2.0 * M * C * K, "sei_rowgemm_lnbwd_bf16", A16.data_ptr(), A16.shape[1], W.data_ptr(), K, M, K,
                         x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), res.data_ptr(), gx.data_ptr(), C,
                         ggamma.data_ptr(), gbeta.data_ptr(), N.ptr(row_scale) if want16 else None, N.ptr(gy16), CP,
-                        N.ptr(colsum) if want16 else None, work.data_ptr(), work.numel())
+                        N.ptr(colsum), work.data_ptr(), work.numel())
         return gx, gy16
     gh = torch.empty((M, CP), dtype=torch.float32, device=x2d.device)
     linear16(A16, W, Wt, M, EPI_NONE, CP, out32=gh, flops=2.0 * M * C * K)
@@ -278,10 +281,13 @@ class SwinBlockFn16(torch.autograd.Function):
     """models._swin_ops.SwinBlockFn in bf16 mode; `pack` / `key` give the block's re-laid-out matrices."""
 
     @staticmethod
-    def forward(ctx, x, g1, b1, table, bproj, g2, b2, bm1, bm2, pack, key, heads, shift, drop1, drop2, pre=None, nxt=None):
+    def forward(ctx, x, g1, b1, table, bproj, g2, b2, bm1, bm2, pack, key, heads, shift, drop1, drop2, pre=None, nxt=None,
+                prev_scale=None):
         """pre: (h1, mean1, rstd1) = this block's norm1 already applied to x by the layer that produced x (the previous
         block's fc2 launch); nxt: (weight, bias) of the NEXT block's norm1 -- the block then returns (out, h, mean, rstd)
-        with that norm applied to its output (None entries where the fused launch is not built for the shape)."""
+        with that norm applied to its output (None entries where the fused launch is not built for the shape). prev_scale:
+        the per-row stochastic-depth factors of the PREVIOUS block's MLP branch (the block whose output x is): this block's
+        norm1 backward then also leaves bf16(gx * prev_scale) -- what the previous block's backward would cast first."""
         N.check_tensor(x, "tokens")
         B, H, W, C = x.shape
         M = B * H * W
@@ -310,9 +316,9 @@ class SwinBlockFn16(torch.autograd.Function):
             bool(N.lib().sei_rowgemm_bf16_eligible(M, Ch, CP, EPI_BIAS_GELU, 0))
         f3 = None if recompute else torch.empty((M, Ch), dtype=torch.float32, device=dev)
         f4 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
-        if recompute:
-            _ops._gemm_call(2.0 * M * Chr * C, "sei_rowgemm_bf16", h2.data_ptr(), CP, w1.data_ptr(), CP, None, 0, f4.data_ptr(),
-                            Ch, M, Ch, CP, Ch, EPI_BIAS_GELU, pack.b(f"{key}.fc1_bias").data_ptr(), None, None, 0)
+        if recompute:                                    # column Chr of f4 = 1.0: fc2's bias gradient rides in its weight gradient
+            _ops._gemm_call(2.0 * M * Chr * C, "sei_rowgemm_gelu_bf16", h2.data_ptr(), CP, w1.data_ptr(), CP,
+                            pack.b(f"{key}.fc1_bias").data_ptr(), Ch, f4.data_ptr(), Ch, M, Ch, CP, Chr)
         else:
             linear16(h2, w1, None, M, EPI_BIAS_GELU, Ch, out32=f3, out16=f4, bias=pack.b(f"{key}.fc1_bias"),
                      flops=2.0 * M * Chr * C)
@@ -330,6 +336,8 @@ class SwinBlockFn16(torch.autograd.Function):
         ctx.params = (g1, b1, table, bproj, g2, b2, bm1, bm2)
         ctx.cfg = (pack, key, heads, shift)
         ctx.extra_outputs = nxt is not None
+        ctx.ones = recompute                             # f4 carries the ones column
+        ctx.prev_scale = prev_scale if recompute else None      # (same token count, same mode: the previous block does too)
         if nxt is None:
             return out.view(B, H, W, C)
         if hn is None:                                   # not fused: the next block's norm in its own launch, here
@@ -349,8 +357,12 @@ class SwinBlockFn16(torch.autograd.Function):
         wqkv, wproj, w1, w2 = (pack.w(f"{key}.{k}") for k in ("qkv", "proj", "fc1", "fc2"))
         Ch, Chr = w1.shape[0], bm1.shape[0]
         go2 = go.contiguous().view(M, C)
-        # MLP branch
-        gy = cast_pad(go2, drop2, grad_of(bm2))
+        # MLP branch. The bf16 operand gy = bf16(go * drop2): already formed by the next block's norm1 backward (below,
+        # handed over on the gradient tensor itself), else cast here; fc2's bias gradient = its column sums, or -- with the
+        # ones column in f4 -- column Chr of fc2's weight gradient
+        gy = getattr(go, "_sei_cast16", None) if ctx.ones else None
+        if gy is None:
+            gy = cast_pad(go2, drop2, None if ctx.ones else grad_of(bm2))
         gf3 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
         if f3 is None:                                   # GELU' of the recomputed pre-activation h2 W1^T + b1
             _ops._gemm_call(4.0 * M * Chr * C, "sei_rowgemm_dgelu_bf16", gy.data_ptr(), CP, pack.w(f"{key}.fc2T").data_ptr(), CP,
@@ -368,12 +380,17 @@ class SwinBlockFn16(torch.autograd.Function):
         scale = float((C // heads) ** -0.5)
         N.call("sei_swin_attn_bwd_bf16", qkv.data_ptr(), table.data_ptr(), ga.data_ptr(), dqkv.data_ptr(),
                grad_of(table).data_ptr(), B, H, W, heads, shift, scale)
-        gx, _ = linear_lnbwd16(dqkv, pack.w(f"{key}.qkvT"), wqkv, M, x.view(M, C), g1, mean1, rstd1, gx1, grad_of(g1),
-                               grad_of(b1))
+        gx, gy_prev = linear_lnbwd16(dqkv, pack.w(f"{key}.qkvT"), wqkv, M, x.view(M, C), g1, mean1, rstd1, gx1, grad_of(g1),
+                                     grad_of(b1), row_scale=ctx.prev_scale, cast=ctx.prev_scale is not None)
         # the four weight gradients (+ the qkv / fc1 bias gradients, column C) over the same tokens: one launch
         weight_grad16_group([(dqkv, h1, pack.g(f"{key}.qkv"), 2.0 * 3 * C * C), (gy1, a, pack.g(f"{key}.proj"), 2.0 * C * C),
                              (gf3, h2, pack.g(f"{key}.fc1"), 2.0 * Chr * C), (gy, f4, pack.g(f"{key}.fc2"), 2.0 * Chr * C)])
-        return (gx.view(B, H, W, C) if ctx.needs_input_grad[0] else None,) + (None,) * 16
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 18
+        gxv = gx.view(B, H, W, C)
+        if gy_prev is not None:
+            gxv._sei_cast16 = gy_prev                    # for the previous block's backward (same tensor object arrives there)
+        return (gxv,) + (None,) * 17
 
 
 _TAPS = [(ky, kx) for ky in range(3) for kx in range(3)]

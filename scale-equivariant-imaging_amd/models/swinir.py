@@ -104,7 +104,7 @@ class SwinTransformerBlock(nn.Module):
         m = mw.unsqueeze(1) - mw.unsqueeze(2)
         return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
 
-    def forward(self, x, drop=None, pack=None, pre=None, nxt=None):
+    def forward(self, x, drop=None, pack=None, pre=None, nxt=None, prev_scale=None):
         """x: (B, H, W, C) tokens; drop: (rows_attn, rows_mlp) per-row stochastic-depth factors or None. bf16 mode only:
         pre = this block's norm1 output / statistics already formed by the previous block, nxt = the next block's norm1
         (weight, bias) to apply to this block's output -- the return value is then (out, h, mean, rstd)."""
@@ -113,7 +113,8 @@ class SwinTransformerBlock(nn.Module):
         if pack is not None:                            # throughput mode: bf16 GEMM layouts from the pack
             return S16.SwinBlockFn16.apply(x, self.norm1.weight, self.norm1.bias, a.relative_position_bias_table,
                                            a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.bias, m.fc2.bias,
-                                           pack, self._sei_key, self.num_heads, self.shift_size, d1, d2, pre, nxt)
+                                           pack, self._sei_key, self.num_heads, self.shift_size, d1, d2, pre, nxt,
+                                           prev_scale)
         return S.SwinBlockFn.apply(x, self.norm1.weight, self.norm1.bias, a.relative_position_bias_table,
                                    a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, self.norm2.weight,
                                    self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
@@ -146,14 +147,19 @@ class RSTB(nn.Module):
     def forward(self, x, drops, pack=None):
         res = x
         blocks = list(self.residual_group.blocks)
-        pre = None
+        pre = prev_scale = None
         for i, (blk, drop) in enumerate(zip(blocks, drops)):
-            if pack is not None and i + 1 < len(blocks):
-                # bf16 mode: a block's last launch also applies the NEXT block's norm1 to the rows it has just formed
+            if pack is None:
+                x = blk(x, drop, pack)
+                continue
+            # bf16 mode: a block's last launch also applies the NEXT block's norm1 to the rows it has just formed, and
+            # its norm1 backward leaves the bf16 operand the PREVIOUS block's backward starts from (prev_scale)
+            if i + 1 < len(blocks):
                 nxt = (blocks[i + 1].norm1.weight, blocks[i + 1].norm1.bias)
-                x, *pre = blk(x, drop, pack, pre, nxt)
+                x, *pre = blk(x, drop, pack, pre, nxt, prev_scale)
             else:
-                x, pre = blk(x, drop, pack, pre), None
+                x, pre = blk(x, drop, pack, pre, None, prev_scale), None
+            prev_scale = drop[1] if drop is not None else None
         return conv3x3(self.conv, x, res, 0, pack)
 
 
