@@ -14,6 +14,11 @@
 //                      reads, 83 B of LDS per clock against 188 for the 64 x 32 wave tiles of the 128 x 128 loop,
 //                      which that loop's 520 TFLOP/s were bound by) and a contiguous range of tokens; blocks of the
 //                      same token range sit on the same XCD, so X crosses the fabric once. Float atomics at the end.
+//   sei_rowgemm_bf16   D = epilogue(A W^T), the layer's matrix in registers, row tiles streamed (described further down)
+//     .._ln_bf16       + the LayerNorm BEHIND a residual layer in that layer's epilogue (proj -> norm2, fc2 -> next norm1)
+//     .._lnbwd_bf16    + LayerNorm BACKWARD (+ residual gradient, bf16 copy, column sums) behind a data gradient
+//     .._dgelu_bf16    fc2's data gradient with the GELU' input recomputed by a second product in registers
+//     .._gelu_bf16     fc1's forward, bf16 output only, with a ones column that carries fc2's bias gradient
 #include "sei_common.h"
 
 namespace {
