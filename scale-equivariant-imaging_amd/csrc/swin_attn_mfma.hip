@@ -429,9 +429,9 @@ inline int check(int B, int H, int W, int heads, int shift) {
 // groups x heads workgroups, each looping over its windows. Two workgroups fit a CU (80 KB of LDS each): 512 resident.
 // 128 groups x 6 heads = 768 ran as one full round and a half-empty one; 85 x 6 = 510 are all resident and walk
 // more windows each.
-inline int group_count(int nwin, int heads) {
+inline int group_count(int nwin, int heads, int resident = 512) {
     const int groups = (nwin + WAVES - 1) / WAVES;
-    const int cap = 512 / heads > 0 ? 512 / heads : 1;
+    const int cap = resident / heads > 0 ? resident / heads : 1;
     return groups > cap ? cap : groups;
 }
 
@@ -460,7 +460,7 @@ extern "C" int sei_swin_attn_bwd_bf16(const uint16_t *qkv, const float *table, c
     SEI_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv) & 15) == 0);
     if (int rc = check(B, H, W, heads, shift)) return rc;
     MGeom g{H, W, H / WS, W / WS, shift, heads, B * (H / WS) * (W / WS)};
-    const int groups = group_count(g.nwin, heads);
+    const int groups = group_count(g.nwin, heads, 256);        // 494 registers: ONE workgroup per CU
     if (shift)
         hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel<true>, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
                            (hipStream_t)stream, qkv, table, dout, dqkv, dtable, g, scale, groups);
