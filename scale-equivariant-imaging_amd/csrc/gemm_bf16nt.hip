@@ -1054,7 +1054,8 @@ extern "C" int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, 
     g.batch = 1;
     g.force_tile = 0; g.force_band = 0;
     g.adam_p = param; g.adam_m = exp_avg; g.adam_v = exp_avg_sq; g.adam_p16 = param_bf16; g.adam_h = hyper;
-    if (K1 + K2 <= 1024) return launch_nt<2, 1, 2, 4, true, true, 1, 1>(g, (hipStream_t)stream);
+    // (always the double-buffered loop: with the Adam epilogue's 112 registers only two workgroups fit a CU, which is what
+    // the one-stage loop was meant to beat with three; measured at K = 864: 1416-1421 us against 1426-1459)
     return launch_nt<2, 1, 2, 4, true, true, 2, 1>(g, (hipStream_t)stream);
 }
 
