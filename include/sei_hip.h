@@ -32,7 +32,7 @@ extern "C" {
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
-#define SEI_ABI_VERSION 6
+#define SEI_ABI_VERSION 7
 int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
@@ -180,6 +180,8 @@ int sei_dwconv7_fwd(const float *x, const float *w, const float *bias, const flo
 /* `work` holds per-workgroup partial sums (two-stage reduction, no atomics); it must have at least
  * sei_dwconv7_bwd_weight_workspace(B,H,W,C) floats. */
 size_t sei_dwconv7_bwd_weight_workspace(int B, int H, int W, int C);
+/* gw = gbias = NULL: the fold is left to sei_fold_many (kind SEI_FOLD_DWCONV7) -- the partial sums stay in `work`,
+ * [workspace / (50 C)][50][C] floats. */
 int sei_dwconv7_bwd_weight(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
                            int W, int C, float *work, size_t work_floats, void *stream);
 /* The same three with the caller's explicit kernel choice: seg = 0 chooses by shape (LDS-tiled, whole-image or
@@ -215,9 +217,37 @@ int sei_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, 
  * it needs sei_ln_bwd_workspace(rows, C) floats (0 for shapes served by the scalar kernels, which
  * accumulate with float atomics: C not 4*2^k below 512, or not a multiple of 4 above). */
 size_t sei_ln_bwd_workspace(size_t rows, int C);
+/* ggamma = gbeta = NULL: the fold is left to sei_fold_many -- the partial sums stay in `work`, [sei_ln_bwd_part_count]
+ * [2 C] floats from float sei_ln_bwd_part_offset on (allowed where the count is > 0: not for the atomics shapes). */
+size_t sei_ln_bwd_part_offset(size_t rows, int C);
+size_t sei_ln_bwd_part_count(size_t rows, int C);
 int sei_ln_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
                const float *gy, float *gx, float *ggamma, float *gbeta, size_t rows, int C,
                float *work, size_t work_floats, void *stream);
+
+/* The second stage of MANY two-stage reductions in one launch: the LayerNorm parameter gradients and depthwise weight
+ * gradients of a whole backward pass (reference: the autograd of src/models/convolutional.py:21-39 accumulates each of
+ * them into its parameter's .grad; here a reducing kernel leaves per-workgroup partial sums and a fold adds them up in a
+ * fixed order). A job is ONE destination and the partial-sum arrays of up to three launches that add to it (the model
+ * calls of a step that share the parameter), folded one after the other exactly as their own fold launches would have:
+ * bit-identical, in 1 launch instead of ~50 (U-Net step) / ~146 (SwinIR step).
+ *   SEI_FOLD_SPLIT:   part[s]: [groups[s]][ncol]; entry e adds to a[e] (e < split), b[e - split] (e < 2 split) or
+ *                     c[e - 2 split] (c may be NULL: dropped) -- sei_ln_bwd (ncol = 2 C, split = C),
+ *                     sei_rowgemm_lnbwd_bf16 (ncol = 3 C), a plain column sum (ncol = split);
+ *   SEI_FOLD_DWCONV7: part[s]: [groups[s]][50][split = C]; entry (t, c) adds to a[c * 49 + t] for t < 49 and to b[c]
+ *                     (b may be NULL) for t = 49 -- sei_dwconv7_bwd_weight.
+ * Destinations of different jobs must differ (checked). The partial sums must stay untouched until this launch. */
+#define SEI_FOLD_SPLIT 0
+#define SEI_FOLD_DWCONV7 1
+#define SEI_FOLD_MAX_JOBS 40
+typedef struct SeiFoldJob {
+    float *a, *b, *c;
+    int ncol, split, kind, nseg;
+    const float *part[3];
+    int groups[3];
+    int reserved;
+} SeiFoldJob;
+int sei_fold_many(const SeiFoldJob *jobs, int njobs, void *stream);
 
 #define SEI_EPI_NONE 0
 #define SEI_EPI_BIAS 1            /* D = acc + bias[n]                                        */
@@ -523,7 +553,8 @@ size_t sei_rowgemm_bf16_eligible(long long M, int N, int K, int epilogue, int ou
  * (colsum: K = 384 only and optional -- at K = 576 no registers are left for the third column sum; the bias gradient it
  * would be then comes out of the weight gradient through sei_rowgemm_gelu_bf16's ones column).
  * x, res, gx: (M, C) float32 rows; mean, rstd, row_scale: M floats. work: sei_rowgemm_lnbwd_work_floats(C) floats (per-
- * workgroup column sums, folded by a second launch). Replaces sei_gemm_bf16nt + sei_ln_bwd_pad (+ sei_cast_pad_bf16):
+ * workgroup column sums, folded by a second launch; ggamma = gbeta = NULL leaves that fold to sei_fold_many: the sums
+ * stay in `work`, [min(M / 32, 256)][3][C] = for ggamma | gbeta | colsum). Replaces sei_gemm_bf16nt + sei_ln_bwd_pad (+ sei_cast_pad_bf16):
  * deepinv SwinIR's norm1 / norm2 in front of qkv / fc1 (reference construction: src/models/__init__.py:51-74). */
 int sei_rowgemm_lnbwd_bf16(const uint16_t *A, int lda, const uint16_t *W, int ldw, long long M, int K, const float *x,
                            const float *gamma, const float *mean, const float *rstd, const float *res, float *gx, int C,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "sei_colsum_bf16": [_P, _P, _Z, _I, _P],
     "sei_cast_transpose_bf16": [_P, _I, _P, _P, _I, _I, _I, _P, _P],
     "sei_gemm_bf16nt": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "sei_fold_many": [_P, _I, _P],
     "sei_gemm_bf16nt_dw2": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "sei_gemm_bf16nt_ex": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     "sei_gemm_bf16nt_dw2_ex": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -110,6 +111,15 @@ class TokGradBlock(_c.Structure):
                 ("D", _P), ("ldd", _I)]
 
 
+class FoldJob(_c.Structure):
+    """SeiFoldJob of include/sei_hip.h (one destination of sei_fold_many with the partial sums of up to three launches)."""
+    _fields_ = [("a", _P), ("b", _P), ("c", _P), ("ncol", _I), ("split", _I), ("kind", _I), ("nseg", _I),
+                ("part", _P * 3), ("groups", _I * 3), ("reserved", _I)]
+
+
+FOLD_SPLIT, FOLD_DWCONV7, FOLD_MAX_JOBS = 0, 1, 40
+
+
 # size queries: return size_t, take no stream
 SIZE_QUERIES = {
     "sei_dwconv7_bwd_weight_workspace": [_I, _I, _I, _I],
@@ -123,10 +133,12 @@ SIZE_QUERIES = {
     "sei_rowgemm_bf16_eligible": [_L, _I, _I, _I, _I],
     "sei_rowgemm_lnbwd_bf16_eligible": [_L, _I, _I],
     "sei_rowgemm_lnbwd_work_floats": [_I],
+    "sei_ln_bwd_part_offset": [_Z, _I],
+    "sei_ln_bwd_part_count": [_Z, _I],
     "sei_rowgemm_dgelu_bf16_eligible": [_L, _I, _I],
     "sei_rowgemm_ln_bf16_eligible": [_L, _I, _I],
 }
-ABI_VERSION = 6       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
+ABI_VERSION = 7       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 
 
 class NativeLibraryError(RuntimeError):

@@ -551,7 +551,8 @@ extern "C" size_t sei_dwconv7_bwd_weight_workspace(int B, int H, int W, int C) {
 
 extern "C" int sei_dwconv7_bwd_weight_ex(const float *x, const float *gy, float *gw, float *gbias, int B, int H,
                                          int W, int C, float *work, size_t work_floats, int seg, void *stream) {
-    SEI_REQUIRE(x && gy && gw && work && B > 0 && H > 0 && W > 0 && C > 0 && seg >= 0 && seg <= 64);
+    // gw = NULL: the partial sums ([parts][50][C], parts = workspace / (50 C)) stay in `work` for sei_fold_many
+    SEI_REQUIRE(x && gy && work && B > 0 && H > 0 && W > 0 && C > 0 && seg >= 0 && seg <= 64 && (gw || !gbias));
     const DwWgradPlan p = dw_wgrad_plan(B, H, W, C, seg);
     SEI_REQUIRE(work_floats >= p.nparts * 50 * (size_t)C);
     hipStream_t s = (hipStream_t)stream;
@@ -576,7 +577,8 @@ extern "C" int sei_dwconv7_bwd_weight_ex(const float *x, const float *gy, float 
                            gy, work, B, H, W, C, 0, p.Cc, p.nseg, (int)p.total, p.seg);
     }
     // stage 2: fold the partials into the running gradient
-    hipLaunchKernelGGL(dwconv7_wgrad_finish_kernel, dim3((unsigned)sei_ceil_div((size_t)50 * C, FIN_E)),
+    if (gw)
+        hipLaunchKernelGGL(dwconv7_wgrad_finish_kernel, dim3((unsigned)sei_ceil_div((size_t)50 * C, FIN_E)),
                        dim3(FIN_E * FIN_S), 0, s,
                        (const float *)work, (int)p.nparts, C, gw, gbias);
     return sei_launch_status();

@@ -897,7 +897,8 @@ extern "C" int sei_rowgemm_lnbwd_bf16(const uint16_t *A, int lda, const uint16_t
                                       const float *gamma, const float *mean, const float *rstd, const float *res, float *gx,
                                       int C, float *ggamma, float *gbeta, const float *row_scale, uint16_t *y16, int ldy,
                                       float *colsum, float *work, size_t work_floats, void *stream) {
-    SEI_REQUIRE(A && W && x && gamma && mean && rstd && res && gx && ggamma && gbeta && work);
+    // ggamma = gbeta = NULL: the partial sums ([min(M / 32, 256)][3][C]) stay in `work` for sei_fold_many
+    SEI_REQUIRE(A && W && x && gamma && mean && rstd && res && gx && work && (ggamma != nullptr) == (gbeta != nullptr));
     SEI_REQUIRE(sei_rowgemm_lnbwd_bf16_eligible(M, K, C) && work_floats >= sei_rowgemm_lnbwd_work_floats(C));
     SEI_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && (((uintptr_t)A | (uintptr_t)W) & 15) == 0);
     SEI_REQUIRE((unsigned long long)64 * (size_t)lda * 2 < (1ull << 32));
@@ -916,7 +917,7 @@ extern "C" int sei_rowgemm_lnbwd_bf16(const uint16_t *A, int lda, const uint16_t
         rc = y16 ? rg_launch<6, 12, 32, 4, 1, RG_EPI_LNBWD, true>(g, m, s) : rg_launch<6, 12, 32, 4, 1, RG_EPI_LNBWD, false>(g, m, s);
     else
         rc = y16 ? rg_launch<9, 12, 32, 4, 1, RG_EPI_LNBWD, true>(g, m, s) : rg_launch<9, 12, 32, 4, 1, RG_EPI_LNBWD, false>(g, m, s);
-    if (rc != 0) return rc;
+    if (rc != 0 || !ggamma) return rc;
     return sei_fold_partials3(work, groups, C, ggamma, gbeta, colsum, s);
 }
 

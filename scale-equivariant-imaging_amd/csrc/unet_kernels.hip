@@ -369,6 +369,67 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_cols_kernel(
     *reinterpret_cast<float4 *>(out + C + c) = db;
 }
 
+// sei_fold_many: the folds of MANY reducing kernels in one launch (the LayerNorm / depthwise weight gradients of a whole
+// backward pass: 34 + 18 launches of ~5 us per U-Net step, ~146 per SwinIR step). A job is one destination with up to
+// three partial-sum arrays (the model calls of the step that share the parameter), folded one after the other into the
+// running value exactly as the separate launches did: same slices, same order, bit-identical. A workgroup owns 16
+// consecutive entries of one job and finds it by walking the job table in the kernel arguments.
+struct FoldManyArgs {
+    SeiFoldJob job[SEI_FOLD_MAX_JOBS];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void fold_many_kernel(FoldManyArgs g) {
+    __shared__ float red[16][16];
+    int j = 0, first = 0;
+    for (; j < g.njobs; ++j) {                                  // (uniform: scalar loads from the argument block)
+        const int wgs = (g.job[j].ncol + 15) >> 4;
+        if ((int)blockIdx.x < first + wgs) break;
+        first += wgs;
+    }
+    if (j >= g.njobs) return;
+    const SeiFoldJob &J = g.job[j];
+    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int e = ((int)blockIdx.x - first) * 16 + el;
+    const int ncol = J.ncol;
+    float total = 0.f;
+    for (int sg = 0; sg < J.nseg; ++sg) {
+        const float *part = J.part[sg];
+        const int groups = J.groups[sg];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (e < ncol) {
+            int p = slice;
+            for (; p + 48 < groups; p += 64) {
+                s0 += part[(size_t)p * ncol + e];
+                s1 += part[(size_t)(p + 16) * ncol + e];
+                s2 += part[(size_t)(p + 32) * ncol + e];
+                s3 += part[(size_t)(p + 48) * ncol + e];
+            }
+            for (; p < groups; p += 16) s0 += part[(size_t)p * ncol + e];
+        }
+        __syncthreads();                                         // (the last segment's read of red)
+        red[slice][el] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (slice == 0 && e < ncol) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += red[k][el];
+            // the running value takes the segments one by one, as the separate launches added them
+            float *dst;
+            if (J.kind == SEI_FOLD_DWCONV7) {                    // e = t C + c -> gw[c][t], t < 49; bias gradient behind
+                const int t = e / J.split, c = e - t * J.split;
+                dst = t < 49 ? J.a + (size_t)c * 49 + t : (J.b ? J.b + c : nullptr);
+            } else {                                             // a | b | c, `split` entries each (c may be absent)
+                dst = e < J.split ? J.a + e : e < 2 * J.split ? J.b + (e - J.split) : (J.c ? J.c + (e - 2 * J.split) : nullptr);
+            }
+            if (dst) {
+                if (sg == 0) total = *dst;
+                total += s;
+                if (sg == J.nseg - 1) *dst = total;
+            }
+        }
+    }
+}
+
 // fold: ggamma[c] += sum_p part[p][c]; gbeta[c] += sum_p part[p][C + c]   (16 entries x 16 slices per workgroup)
 __global__ __launch_bounds__(256) void ln_bwd_fold_kernel(const float *__restrict__ part, int nparts, int C,
                                                           float *__restrict__ ggamma,
@@ -1293,10 +1354,25 @@ extern "C" size_t sei_ln_bwd_workspace(size_t rows, int C) {
     return p.stats_floats + p.nparts * 2 * (size_t)C;
 }
 
+// Where the partial sums of sei_ln_bwd lie in its workspace ([parts][2 C] floats from this offset on), and how many
+// there are (0: this shape adds with atomics and leaves nothing to fold).
+extern "C" size_t sei_ln_bwd_part_offset(size_t rows, int C) {
+    if (rows == 0 || C <= 0) return 0;
+    return ln_bwd_plan(rows, C).stats_floats;
+}
+extern "C" size_t sei_ln_bwd_part_count(size_t rows, int C) {
+    if (rows == 0 || C <= 0) return 0;
+    const LnBwdPlan p = ln_bwd_plan(rows, C);
+    return p.kind != 0 ? p.nparts : 0;
+}
+
 extern "C" int sei_ln_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
                           const float *gy, float *gx, float *ggamma, float *gbeta, size_t rows, int C,
                           float *work, size_t work_floats, void *stream) {
-    SEI_REQUIRE(x && gamma && mean && rstd && gy && gx && ggamma && gbeta && rows > 0 && C > 0);
+    SEI_REQUIRE(x && gamma && mean && rstd && gy && gx && rows > 0 && C > 0);
+    // ggamma = gbeta = NULL: the partial sums stay in `work` for sei_fold_many (shapes with sei_ln_bwd_part_count > 0)
+    SEI_REQUIRE((ggamma != nullptr) == (gbeta != nullptr));
+    SEI_REQUIRE(ggamma || sei_ln_bwd_part_count(rows, C) > 0);
     if (C > LN_WIDE_EPT * LN_THREADS) return SEI_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
     const LnBwdPlan p = ln_bwd_plan(rows, C);
@@ -1327,8 +1403,9 @@ extern "C" int sei_ln_bwd(const float *x, const float *gamma, const float *mean,
             hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3(p.col_blocks, p.chunks), dim3(LN_THREADS), 0, s, x, gamma,
                                mean, rstd, gy, (const float2 *)stats, gx, part, rows, C, p.rows_per_chunk);
         }
-        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((unsigned)sei_ceil_div((size_t)2 * C, 16)), dim3(256), 0, s,
-                           (const float *)part, (int)p.nparts, C, ggamma, gbeta);
+        if (ggamma)
+            hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((unsigned)sei_ceil_div((size_t)2 * C, 16)), dim3(256), 0, s,
+                               (const float *)part, (int)p.nparts, C, ggamma, gbeta);
         return sei_launch_status();
     }
     // legacy shapes (C not a multiple of 4, or not 4 * 2^k below 512): scalar lanes, float atomics
@@ -1613,5 +1690,27 @@ extern "C" int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, 
         else SEI_ADAM(adam_kernel, float, rest, done);
     }
 #undef SEI_ADAM
+    return sei_launch_status();
+}
+
+
+extern "C" int sei_fold_many(const SeiFoldJob *jobs, int njobs, void *stream) {
+    SEI_REQUIRE(jobs && njobs > 0 && njobs <= SEI_FOLD_MAX_JOBS);
+    FoldManyArgs g;
+    size_t wgs = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const SeiFoldJob &J = jobs[j];
+        SEI_REQUIRE(J.a && J.ncol > 0 && J.split > 0 && J.nseg >= 1 && J.nseg <= 3);
+        SEI_REQUIRE(J.kind == SEI_FOLD_SPLIT || J.kind == SEI_FOLD_DWCONV7);
+        if (J.kind == SEI_FOLD_DWCONV7) SEI_REQUIRE(J.ncol == 50 * J.split);
+        else SEI_REQUIRE(J.ncol <= 3 * J.split && (J.ncol <= J.split || J.b));
+        for (int sg = 0; sg < J.nseg; ++sg) SEI_REQUIRE(J.part[sg] && J.groups[sg] > 0);
+        for (int k = 0; k < j; ++k) SEI_REQUIRE(jobs[k].a != J.a);      // one job per destination: no two workgroups add to one address
+        g.job[j] = J;
+        wgs += sei_ceil_div((size_t)J.ncol, 16);
+    }
+    g.njobs = njobs;
+    SEI_REQUIRE(wgs < ((size_t)1 << 31));
+    hipLaunchKernelGGL(fold_many_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, g);
     return sei_launch_status();
 }

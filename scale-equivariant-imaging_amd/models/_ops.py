@@ -149,8 +149,12 @@ def layer_norm_bwd(x2d, gamma, mean, rstd, gy, ggamma, gbeta):
     gx = torch.empty_like(x2d)
     need = N.lib().sei_ln_bwd_workspace(rows, C)
     work = torch.empty(max(need, 1), dtype=torch.float32, device=x2d.device)
+    parts = N.lib().sei_ln_bwd_part_count(rows, C)
+    deferred = parts > 0 and defer_fold(ggamma, gbeta, None, 2 * C, C, N.FOLD_SPLIT, work,
+                                        N.lib().sei_ln_bwd_part_offset(rows, C), parts)
     N.call("sei_ln_bwd", x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gy.data_ptr(),
-           gx.data_ptr(), ggamma.data_ptr(), gbeta.data_ptr(), rows, C, work.data_ptr(), need)
+           gx.data_ptr(), None if deferred else ggamma.data_ptr(), None if deferred else gbeta.data_ptr(), rows, C,
+           work.data_ptr(), need)
     return gx
 
 
@@ -198,8 +202,9 @@ def dwconv7_weight_grad(x, gy, gw, gb, seg=0):
     B, H, W, C = x.shape
     need = N.lib().sei_dwconv7_bwd_weight_workspace_ex(B, H, W, C, int(seg))
     work = torch.empty(need, dtype=torch.float32, device=x.device)
-    N.call("sei_dwconv7_bwd_weight_ex", x.data_ptr(), gy.data_ptr(), gw.data_ptr(), N.ptr(gb), B, H, W, C,
-           work.data_ptr(), need, int(seg))
+    deferred = need > 0 and defer_fold(gw, gb, None, 50 * C, C, N.FOLD_DWCONV7, work, 0, need // (50 * C))
+    N.call("sei_dwconv7_bwd_weight_ex", x.data_ptr(), gy.data_ptr(), None if deferred else gw.data_ptr(),
+           None if deferred else N.ptr(gb), B, H, W, C, work.data_ptr(), need, int(seg))
 
 
 def sepmap2(x, mats, Ho, Wo):
@@ -509,7 +514,7 @@ def _fresh_state():
     return {"uses": 0, "arrivals": {}, "parked": {}, "written": set(), "store": False, "store_min": 0,
             "flush_queued": False, "merge": True, "seen": {}, "milestone": None, "milestone_done": False,
             "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set(), "flops_per_row": {},
-            "taps": {}, "merged_ok": {}}
+            "taps": {}, "merged_ok": {}, "folds": {}}
 
 
 class WeightGradState:
@@ -781,6 +786,7 @@ def flush_weight_grads(owner=None, _state=None):
         else:
             gy16, x16, grad2d = entry
             _launch_weight_grad(_DW, grad2d, [(gy16, x16)])
+    flush_folds(_DW)
 
 
 def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None):
@@ -831,6 +837,54 @@ def weight_grad16_group(items):
         _DW["parked"][gkey] = items
     else:
         _launch_weight_grad_group(_DW, [items])
+
+
+# ---------------------------------------------------------------------------------------------
+# Deferred folds. The reducing kernels of a backward pass (LayerNorm parameter gradients, depthwise weight gradients,
+# the LayerNorm epilogue of SwinIR's data-gradient GEMMs) leave per-workgroup partial sums; instead of one ~5-us fold
+# launch behind each of them (52 per U-Net step, ~146 per SwinIR step) the partial sums are kept alive and ONE
+# sei_fold_many launch per <= 40 destinations adds them up when the backward pass ends (the engine callback that also
+# flushes parked weight gradients) -- same slices, same order, launches of one destination one after the other:
+# bit-identical gradients. Outside a backward pass (kernel-level tests calling the helpers directly) nothing is
+# deferred. SEI_NO_DEFERRED_FOLDS=1 restores the fold per launch.
+# ---------------------------------------------------------------------------------------------
+DEFERRED_FOLDS = __import__("os").environ.get("SEI_NO_DEFERRED_FOLDS") != "1"
+
+
+def defer_fold(a, b, c, ncol, split, kind, work, offset, groups):
+    """Register `work[offset:]` ([groups][ncol] partial sums, kept alive here) to be folded into a (| b | c) when the
+    running backward pass ends. False: not deferred (switched off / no backward pass running) -- the caller folds."""
+    if not DEFERRED_FOLDS:
+        return False
+    _DW = _state_for(a.data_ptr())
+    if not _queue_flush(_DW):
+        return False
+    key = a.data_ptr()
+    meta = (N.ptr(b), N.ptr(c), int(ncol), int(split), int(kind))
+    job = _DW["folds"].get(key)
+    if job is not None and (job["meta"] != meta or len(job["segs"]) == 3):
+        flush_folds(_DW)
+        job = None
+    if job is None:
+        if len(_DW["folds"]) == N.FOLD_MAX_JOBS:
+            flush_folds(_DW)
+        job = _DW["folds"][key] = {"meta": meta, "segs": []}       # (flush_folds starts a new table)
+    job["segs"].append((work, work.data_ptr() + 4 * int(offset), int(groups)))
+    return True
+
+
+def flush_folds(_DW):
+    jobs, _DW["folds"] = _DW["folds"], {}
+    if not jobs:
+        return
+    arr = (N.FoldJob * len(jobs))()
+    for j, (a_ptr, job) in zip(arr, jobs.items()):
+        b_ptr, c_ptr, ncol, split, kind = job["meta"]
+        j.a, j.b, j.c, j.ncol, j.split, j.kind, j.nseg = a_ptr, b_ptr, c_ptr, ncol, split, kind, len(job["segs"])
+        for k, (_, ptr, groups) in enumerate(job["segs"]):
+            j.part[k] = ptr
+            j.groups[k] = groups
+    N.call("sei_fold_many", arr, len(jobs))           # (the partial-sum tensors in `jobs` live until here)
 
 
 def _queue_flush(_DW):

@@ -248,10 +248,11 @@ def linear_lnbwd16(A16, W, Wt, M, x2d, gamma, mean, rstd, res, ggamma, gbeta, ro
         gx = torch.empty_like(x2d)
         gy16 = torch.empty((M, CP), dtype=torch.bfloat16, device=x2d.device) if want16 else None
         work = torch.empty(N.lib().sei_rowgemm_lnbwd_work_floats(C), dtype=torch.float32, device=x2d.device)
+        deferred = _ops.defer_fold(ggamma, gbeta, colsum, 3 * C, C, N.FOLD_SPLIT, work, 0, min(M // 32, 256))
         _ops._gemm_call(2.0 * M * C * K, "sei_rowgemm_lnbwd_bf16", A16.data_ptr(), A16.shape[1], W.data_ptr(), K, M, K,
                         x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), res.data_ptr(), gx.data_ptr(), C,
-                        ggamma.data_ptr(), gbeta.data_ptr(), N.ptr(row_scale) if want16 else None, N.ptr(gy16), CP,
-                        N.ptr(colsum), work.data_ptr(), work.numel())
+                        None if deferred else ggamma.data_ptr(), None if deferred else gbeta.data_ptr(),
+                        N.ptr(row_scale) if want16 else None, N.ptr(gy16), CP, N.ptr(colsum), work.data_ptr(), work.numel())
         return gx, gy16
     gh = torch.empty((M, CP), dtype=torch.float32, device=x2d.device)
     linear16(A16, W, Wt, M, EPI_NONE, CP, out32=gh, flops=2.0 * M * C * K)

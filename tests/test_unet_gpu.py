@@ -921,3 +921,114 @@ def test_weight_gradient_gemm_with_bf16_output():
             assert torch.equal(out, grad.bfloat16())
         else:
             assert relerr(out.float(), grad) < 1e-2 and bool(torch.isfinite(out.float()).all())
+
+
+# ------------------------------------------------------------------ deferred folds (sei_fold_many)
+def test_fold_many_matches_the_separate_folds(ops):
+    """One sei_fold_many launch against the fold each reducing kernel runs on its own: LayerNorm partial sums (narrow
+    and wide shapes), depthwise weight-gradient partial sums, a three-way split with a dropped third output, and a
+    destination fed by two launches (the two model calls of a step): bit-identical."""
+    import _native as N
+    torch.manual_seed(3)
+    jobs, keep, expect = [], [], []
+
+    def ln_case(rows_list, C):
+        gamma = torch.randn(C, device="cuda")
+        gg_ref, gb_ref = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+        gg, gb = gg_ref.clone(), gb_ref.clone()
+        segs = []
+        for rows in rows_list:
+            x = torch.randn((rows, C), device="cuda"); gy = torch.randn((rows, C), device="cuda")
+            mean = x.mean(1).contiguous(); rstd = (x.var(1, unbiased=False) + 1e-6).rsqrt().contiguous()
+            need = N.lib().sei_ln_bwd_workspace(rows, C)
+            parts, off = N.lib().sei_ln_bwd_part_count(rows, C), N.lib().sei_ln_bwd_part_offset(rows, C)
+            assert parts > 0
+            gx_ref, gx = torch.empty_like(x), torch.empty_like(x)
+            w_ref = torch.empty(need, device="cuda"); w = torch.empty(need, device="cuda")
+            N.call("sei_ln_bwd", x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gy.data_ptr(),
+                   gx_ref.data_ptr(), gg_ref.data_ptr(), gb_ref.data_ptr(), rows, C, w_ref.data_ptr(), need)
+            N.call("sei_ln_bwd", x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gy.data_ptr(),
+                   gx.data_ptr(), None, None, rows, C, w.data_ptr(), need)
+            assert torch.equal(gx, gx_ref)
+            segs.append((w, w.data_ptr() + 4 * off, parts))
+        jobs.append((gg, gb, None, 2 * C, C, N.FOLD_SPLIT, segs))
+        expect.extend([(gg, gg_ref), (gb, gb_ref)])
+
+    def dw_case(shapes, C):
+        gw_ref, gbias_ref = torch.randn((C, 49), device="cuda"), torch.randn(C, device="cuda")
+        gw, gbias = gw_ref.clone(), gbias_ref.clone()
+        segs = []
+        for (B, H, W) in shapes:
+            x = torch.randn((B, H, W, C), device="cuda"); gy = torch.randn((B, H, W, C), device="cuda")
+            need = N.lib().sei_dwconv7_bwd_weight_workspace(B, H, W, C)
+            w_ref = torch.empty(need, device="cuda"); w = torch.empty(need, device="cuda")
+            N.call("sei_dwconv7_bwd_weight", x.data_ptr(), gy.data_ptr(), gw_ref.data_ptr(), gbias_ref.data_ptr(), B, H, W, C,
+                   w_ref.data_ptr(), need)
+            N.call("sei_dwconv7_bwd_weight", x.data_ptr(), gy.data_ptr(), None, None, B, H, W, C, w.data_ptr(), need)
+            segs.append((w, w.data_ptr(), need // (50 * C)))
+        jobs.append((gw, gbias, None, 50 * C, C, N.FOLD_DWCONV7, segs))
+        expect.extend([(gw, gw_ref), (gbias, gbias_ref)])
+
+    ln_case([500], 32); ln_case([1152, 2304], 2048); ln_case([300, 77, 129], 512); ln_case([9], 8192)
+    dw_case([(2, 48, 48), (4, 48, 48)], 32); dw_case([(3, 6, 6)], 512); dw_case([(2, 3, 3), (1, 3, 3)], 8192)
+    # three sums per group, the third one dropped / kept
+    for keep_c in (False, True):
+        C, groups = 180, 256
+        part = torch.randn((groups, 3, C), device="cuda")
+        outs = [torch.randn(C, device="cuda") for _ in range(3)]
+        refs = [o + part[:, k].double().sum(0).float() for k, o in enumerate(outs)]
+        jobs.append((outs[0], outs[1], outs[2] if keep_c else None, 3 * C, C, N.FOLD_SPLIT, [(part, part.data_ptr(), groups)]))
+        keep.append((outs, refs, keep_c))
+    arr = (N.FoldJob * len(jobs))()
+    for j, (a, b, c, ncol, split, kind, segs) in zip(arr, jobs):
+        j.a, j.b, j.c, j.ncol, j.split, j.kind, j.nseg = a.data_ptr(), N.ptr(b), N.ptr(c), ncol, split, kind, len(segs)
+        for k, (_, ptr, groups) in enumerate(segs):
+            j.part[k] = ptr
+            j.groups[k] = groups
+    untouched = keep[0][0][2].clone()
+    N.call("sei_fold_many", arr, len(jobs))
+    torch.cuda.synchronize()
+    for got, ref in expect:
+        assert torch.equal(got, ref)
+    for outs, refs, keep_c in keep:
+        for k in range(3 if keep_c else 2):
+            assert relerr(outs[k], refs[k]) < 1e-5
+    assert torch.equal(keep[0][0][2], untouched)
+    # two jobs with one destination are refused (two workgroups would add to the same address)
+    dup = (N.FoldJob * 2)()
+    dup[0] = arr[0]; dup[1] = arr[0]
+    with pytest.raises(N.NativeLibraryError):
+        N.call("sei_fold_many", dup, 2)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_deferred_folds_leave_the_gradients_bit_identical(ops, mode):
+    """A backward pass of the U-Net with the folds of its reducing kernels deferred to one launch at its end against the
+    fold per launch; two model calls per step, so shared parameters are fed by two launches. The folds themselves are
+    bit-identical (the test above); whole passes differ by the float atomics of the split-K GEMMs upstream, run to run
+    as much as mode to mode, hence a tolerance here."""
+    import _native as N
+    from models.convolutional import ConvolutionalModel
+    torch.manual_seed(0)
+    m = ConvolutionalModel(in_channels=3, upsampling_rate=1, residual=True, inner_residual=True, num_conv_blocks=1,
+                           hidden_channels=32, inout_convs=True, scales=3).cuda()
+    y = torch.rand((2, 3, 24, 24), device="cuda"); y2 = torch.rand((1, 3, 24, 24), device="cuda")
+    ct = torch.randn((2, 3, 24, 24), device="cuda"); ct2 = torch.randn((1, 3, 24, 24), device="cuda")
+    prev = ops.set_compute_dtype(mode)
+    grads, folds = {}, {}
+    try:
+        for deferred in (False, True):
+            ops.DEFERRED_FOLDS = deferred
+            ops.set_weight_grad_merging(False, owner=m)      # (merged launches change the summation order of nothing here,
+            m.zero_grad_flat()                               #  but keep the two passes independent of the parking logic)
+            N.record_calls(True)
+            ((m(y) * ct).sum() + (m(y2) * ct2).sum()).backward()
+            log = N.record_calls(False)
+            folds[deferred] = sum(1 for name, _ in log if name == "sei_fold_many")
+            grads[deferred] = m.flat_grads.clone()
+    finally:
+        ops.DEFERRED_FOLDS = True
+        ops.set_weight_grad_merging(True, owner=m)
+        ops.set_compute_dtype(prev)
+    assert folds[False] == 0 and 1 <= folds[True] <= 2
+    assert relerr(grads[True], grads[False]) < (1e-5 if mode == "f32" else 2e-3)
