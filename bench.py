@@ -118,7 +118,7 @@ def _stream_bytes(name, a):
     if name in ("sei_pad_nhwc", "sei_unpad_nhwc"):
         B, H, W, C = (a[2:6] if name == "sei_pad_nhwc" else a[3:7])
         return 8 * B * H * W * C
-    if name == "sei_pad_nhwc_bf16":
+    if name in ("sei_pad_nhwc_bf16", "sei_pad_nhwc_bf16_ones"):
         B, H, W, C, Cp = a[2:7]
         return B * H * W * (4 * C + 2 * Cp)
     if name == "sei_rowscale":

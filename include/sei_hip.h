@@ -443,6 +443,13 @@ int sei_cast_pad_bf16(const float *x, const float *row_scale, uint16_t *y, float
                       int ldy, float *work, size_t work_floats, void *stream);
 /* sei_pad_nhwc with bf16 output and the channel count padded from C to Cp (zeros). */
 int sei_pad_nhwc_bf16(const float *x, uint16_t *xp, int B, int H, int W, int C, int Cp, int guard_rows, void *stream);
+/* The same with channel C (the first padding channel, Cp > C) set to 1.0 in every row when ones_col: as the input grid
+ * of a 3x3 convolution it meets zero weight columns in the forward product, and in the weight gradient
+ * (sei_gemm_bf16nt_dw2_taps: D[t][n][c] = sum_rows gy[r][n] x[r + shift_t][c]) column C of every tap then holds
+ * sum_rows gy[r][n] -- the convolution's BIAS gradient (nn.Conv2d.bias; reference construction
+ * src/models/__init__.py:51-74), without a column-sum pass over gy. */
+int sei_pad_nhwc_bf16_ones(const float *x, uint16_t *xp, int B, int H, int W, int C, int Cp, int guard_rows, int ones_col,
+                           void *stream);
 /* 3x3 convolution (stride 1, zero padding 1) as ONE implicit GEMM on that grid: D[r, n] = sum over taps t and
  * channels c of Ap[r + row_off9[t], c] * B[n, t * cin_pad + c] (+ bias[n]); Ap points at row 0 of the padded grid
  * (behind the guard rows), cin_pad % 64 == 0, B (N, 9 * cin_pad) bf16 tap-major. The im2col matrix exists only as

@@ -88,6 +88,7 @@ SIGNATURES = {
     "sei_ln_bwd_pad": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P, _Z, _P],
     "sei_cast_pad_bf16": [_P, _P, _P, _P, _Z, _I, _I, _P, _Z, _P],
     "sei_pad_nhwc_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sei_pad_nhwc_bf16_ones": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "sei_gemm_bf16nt_conv": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P],
     "sei_gemm_bf16nt_conv_unpad": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _P],
     "sei_rowgemm_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _I, _P],

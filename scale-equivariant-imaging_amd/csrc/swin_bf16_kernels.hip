@@ -222,8 +222,10 @@ __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float *__restr
     }
 }
 
+// ones_col: channel C (the first padding channel) holds 1.0 in EVERY row -- the weight gradient's reduction over the grid
+// then leaves the column sums of the other operand there (the bias gradient: see sei_pad_nhwc_bf16_ones)
 __global__ __launch_bounds__(256) void pad_nhwc_bf16_kernel(const float *__restrict__ src, unsigned short *__restrict__ dst,
-                                                             int B, int H, int W, int C, int Cp, int guard) {
+                                                             int B, int H, int W, int C, int Cp, int guard, int ones_col) {
     const int Hp = H + 2, Wp = W + 2;
     const size_t rows = (size_t)B * Hp * Wp + 2 * (size_t)guard;
     const int c4 = Cp / 4;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void pad_nhwc_bf16_kernel(const float *__restr
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const size_t r = e / c4;
         const int c = (int)(e - r * c4);
-        ushort4 o = make_ushort4(0, 0, 0, 0);
+        ushort4 o = make_ushort4(ones_col && 4 * c == C ? (unsigned short)0x3f80 : (unsigned short)0, 0, 0, 0);
         if (4 * c < C && r >= (size_t)guard && r < rows - guard) {
             const size_t p = r - guard;
             const int x = (int)(p % Wp), y = (int)((p / Wp) % Hp);
@@ -314,12 +316,17 @@ extern "C" int sei_cast_pad_bf16(const float *x, const float *row_scale, uint16_
     return sei_launch_status();
 }
 
-extern "C" int sei_pad_nhwc_bf16(const float *x, uint16_t *xp, int B, int H, int W, int C, int Cp, int guard_rows,
+extern "C" int sei_pad_nhwc_bf16_ones(const float *x, uint16_t *xp, int B, int H, int W, int C, int Cp, int guard_rows, int ones_col,
                                  void *stream) {
-    SEI_REQUIRE(x && xp && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && Cp >= C && Cp % 4 == 0 && guard_rows >= 0);
+    SEI_REQUIRE((!ones_col || Cp > C) && x && xp && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && Cp >= C && Cp % 4 == 0 && guard_rows >= 0);
     SEI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)xp & 7) == 0);
     const size_t items = ((size_t)B * (H + 2) * (W + 2) + 2 * (size_t)guard_rows) * (Cp / 4);
     hipLaunchKernelGGL(pad_nhwc_bf16_kernel, dim3(stream_grid(items, 256)), dim3(256), 0, (hipStream_t)stream, x, xp, B,
-                       H, W, C, Cp, guard_rows);
+                       H, W, C, Cp, guard_rows, ones_col);
     return sei_launch_status();
+}
+
+extern "C" int sei_pad_nhwc_bf16(const float *x, uint16_t *xp, int B, int H, int W, int C, int Cp, int guard_rows,
+                                 void *stream) {
+    return sei_pad_nhwc_bf16_ones(x, xp, B, H, W, C, Cp, guard_rows, 0, stream);
 }

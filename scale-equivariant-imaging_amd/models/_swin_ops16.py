@@ -37,6 +37,7 @@ class SwinPack:
         base, esz = flat.data_ptr(), flat.element_size()
         wmaps, gmaps, bmaps = [], [], []
         self._w, self._g, self._b = {}, {}, {}
+        self.bias_in_taps = set()                       # convolutions whose bias gradient is a column of their weight gradient
         cursor = {"w": 0, "g": 0, "b": 0}
 
         def index_of(p):                                # flat-bucket index of every element of p, shaped like p
@@ -116,6 +117,11 @@ class SwinPack:
             bwd[:Cin, :, :Cout] = w.reshape(Cout, Cin, 9).transpose(1, 2, 0)
             grd = np.full((9, coutp, cinp), -1, dtype=np.int64)
             grd[:, :Cout, :Cin] = w.reshape(Cout, Cin, 9).transpose(2, 0, 1)
+            if cin4 < cinp and conv.bias is not None and Cout % 4 == 0:
+                # a column of ones in the padded input grid (channel cin4: sei_pad_nhwc_bf16_ones) puts the bias gradient
+                # into that column of every tap's weight gradient; the centre tap's copy is routed to the bias
+                grd[4, :Cout, cin4] = index_of(conv.bias)
+                self.bias_in_taps.add(name)
             add("w", f"{name}.fwd", fwd.reshape(cout4, 9 * cinp))
             add("w", f"{name}.bwd", bwd.reshape(cin4, 9 * coutp))
             add("g", f"{name}.taps", grd)
@@ -425,7 +431,8 @@ class Conv3x3GemmFn16(torch.autograd.Function):
         Wp, R = W + 2, B * (H + 2) * (W + 2)
         guard = Wp + 9                                   # tap shifts (<= Wp + 1) + rounding the row count up to 8
         xp = torch.empty((R + 2 * guard, cinp), dtype=torch.bfloat16, device=x.device)
-        N.call("sei_pad_nhwc_bf16", x.data_ptr(), xp.data_ptr(), B, H, W, Cin, cinp, guard)
+        ones = key in pack.bias_in_taps                 # the bias gradient rides in the weight gradient (SwinPack)
+        N.call("sei_pad_nhwc_bf16_ones", x.data_ptr(), xp.data_ptr(), B, H, W, Cin, cinp, guard, int(ones))
         y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
         if res is not None:
             N.check_tensor(res, "conv3x3 residual")
@@ -449,7 +456,8 @@ class Conv3x3GemmFn16(torch.autograd.Function):
         gpre = go.view(M, Cout)
         if act:
             gpre = rowscale(gpre, None, leaky_gate=y_act.view(M, Cout))
-        colsum_into(grad_of(bias) if Cout == weight.shape[0] else pack.g(f"{key}.bias4"), gpre)
+        if key not in pack.bias_in_taps:
+            colsum_into(grad_of(bias) if Cout == weight.shape[0] else pack.g(f"{key}.bias4"), gpre)
         gop = torch.empty((R + 2 * guard, coutp), dtype=torch.bfloat16, device=go.device)
         N.call("sei_pad_nhwc_bf16", gpre.data_ptr(), gop.data_ptr(), B, H, W, Cout, coutp, guard)
         taps = pack.g(f"{key}.taps")                     # (9, coutp, cinp): one launch for the nine taps

@@ -817,3 +817,36 @@ class N_call_log:
     def __exit__(self, *exc):
         self._n._CALL_LOG = self._prev
         return False
+
+
+def test_conv_bias_gradient_in_a_ones_column_of_the_input_grid():
+    """sei_pad_nhwc_bf16_ones: channel C of the padded grid is 1.0 in every row (zeros elsewhere in the padding, the
+    pixels as sei_pad_nhwc_bf16 writes them), and the tap-batched weight gradient of a convolution on that grid then
+    holds the column sums of the output gradient -- the bias gradient -- in column C of every tap."""
+    import ctypes
+    import _native as N
+    B, H, W, Cin, Cout, cinp, coutp = 2, 16, 24, 180, 180, 192, 192
+    Wp, R = W + 2, B * (H + 2) * (W + 2)
+    guard, R8 = Wp + 9, (R + 7) // 8 * 8
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((B, H, W, Cin), device="cuda", generator=gen)
+    gy = torch.randn((B, H, W, Cout), device="cuda", generator=gen)
+    xp0 = torch.empty((R + 2 * guard, cinp), device="cuda", dtype=torch.bfloat16)
+    xp1 = torch.empty_like(xp0)
+    gop = torch.empty((R + 2 * guard, coutp), device="cuda", dtype=torch.bfloat16)
+    N.call("sei_pad_nhwc_bf16", x.data_ptr(), xp0.data_ptr(), B, H, W, Cin, cinp, guard)
+    N.call("sei_pad_nhwc_bf16_ones", x.data_ptr(), xp1.data_ptr(), B, H, W, Cin, cinp, guard, 1)
+    N.call("sei_pad_nhwc_bf16", gy.data_ptr(), gop.data_ptr(), B, H, W, Cout, coutp, guard)
+    assert torch.equal(xp1[:, :Cin], xp0[:, :Cin]) and torch.equal(xp1[:, Cin + 1:], xp0[:, Cin + 1:])
+    assert bool((xp1[:, Cin].float() == 1.0).all()) and bool((xp0[:, Cin].float() == 0.0).all())
+    with pytest.raises(N.NativeLibraryError):             # no padding channel to put the ones in
+        N.call("sei_pad_nhwc_bf16_ones", x.data_ptr(), xp1.data_ptr(), B, H, W, Cin, Cin, guard, 1)
+    offs = (ctypes.c_int * 9)(*[(ky - 1) * Wp + (kx - 1) for ky in range(3) for kx in range(3)])
+    taps = torch.zeros((9, coutp, cinp), device="cuda")
+    g, xg = gop[guard:guard + R8], xp1[guard:guard + R8]
+    N.call("sei_gemm_bf16nt_dw2_taps", g.data_ptr(), g.data_ptr(), coutp, xg.data_ptr(), xg.data_ptr(), cinp, taps.data_ptr(),
+           coutp, cinp, R8, 0, 1, 9, ctypes.cast(offs, ctypes.c_void_p), coutp * cinp)
+    want = gy.bfloat16().double().sum((0, 1, 2))          # what the GEMM sums: the bf16-rounded gradient
+    for t in range(9):
+        assert relerr(taps[t, :Cout, Cin], want) < 1e-5
+    assert relerr(taps[4, :Cout, Cin], gy.double().sum((0, 1, 2))) < 3e-3      # against the float32 column sums it replaces
