@@ -89,6 +89,44 @@ def cpu_baseline(batch, hidden, scales, timed_steps=2):
                       f"(affinity and cgroup quota; the host has {os.cpu_count()} logical CPUs)"}
 
 
+def cpu_baseline_swinir(batch, sr_factor=2, timed_steps=1):
+    """The CPU figure beside `secondary.swinir_sr2` (SURVEY 8(d) config (1) asks for the reference's DEFAULT arguments,
+    i.e. the SwinIR backbone, src/settings.py:50): the oracle's restatement of the same proposed-loss step (sr x2, training
+    mode with stochastic depth, 3 forward + 3 backward passes + torch.optim.Adam) on the host cores. A bounded sample: one
+    warm-up step + `timed_steps` timed steps at batch `batch` (a step is ~2 TFLOP of float32 work). PARITY UNPINNED like
+    the oracle it times."""
+    import oracle
+    from oracle import swinir_path as sp, torch_path as tp
+    torch.manual_seed(0)
+    threads = oracle.use_all_usable_cpus()
+    sd = {k: v.requires_grad_(True) for k, v in sp.swinir_init_state_dict(upscale=sr_factor).items()
+          if v.dtype.is_floating_point}
+    opt = torch.optim.Adam(list(sd.values()), lr=2e-4)
+    A = lambda v: tp.downsample_aa(v, sr_factor)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand((batch, 3, CROP * sr_factor, CROP * sr_factor), generator=g)
+    y = tp.add_noise(A(x), NOISE / 255)
+    model = lambda v: sp.swinir_forward(sd, v, upscale=sr_factor, drop_masks=sp.draw_drop_masks(v.shape[0]))
+
+    def step():
+        opt.zero_grad()
+        rate, center = tp.sample_scale_params(batch)
+        loss, _ = tp.proposed_loss(y, A, model, NOISE / 255, margin=0, rate=rate, center=center)
+        loss.backward()
+        opt.step()
+
+    t0 = time.perf_counter()
+    step()
+    t1 = time.perf_counter()
+    for _ in range(timed_steps):
+        step()
+    dt = (time.perf_counter() - t1) / timed_steps
+    return {"value": round(batch / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{timed_steps} timed proposed-loss step(s) after 1 warm-up ({t1 - t0:.1f} s) of the SwinIR backbone "
+                      f"(embed 180, 6 x 6 blocks) at batch {batch}, sr x{sr_factor}, pairs {CROP * sr_factor} / {CROP}, float32, "
+                      f"torch CPU ops (oracle/swinir_path.py, PARITY UNPINNED), {dt:.1f} s per step; {threads} intra-op threads"}
+
+
 # Algorithmic HBM bytes of one launch of the streaming entry points, from the call's own arguments (DESIGN.md
 # section 4: every operand read once, every result written once; f32 = 4 B, bf16 = 2 B).
 def _stream_bytes(name, a):
@@ -253,6 +291,41 @@ def stream_roofline(log, reps=3):
     return out
 
 
+def dist1_child(opt, timeout=420):
+    """`secondary.dist1`: configs[3]'s PER-RANK step on this one GPU -- the same workload with the whole N > 1 machinery live
+    on RCCL at world size 1 (SEI_FORCE_EXCHANGE=1: process group, reduce-scatter of every gradient chunk, Adam on the
+    share, all-gather of the updated weights, early release from inside the graph), hence stored float32 gradients and no
+    optimizer step inside the GEMMs. Run as a CHILD process (a fresh interpreter whose environment selects the backend
+    before its first GPU call; this process never re-execs), its JSON line embedded here."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, SEI_FORCE_EXCHANGE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "10", "--warmup", "3", "--batch",
+           str(opt.batch), "--no-secondary", "--no-cpu-baseline", "--grad-comm", opt.grad_comm, "--grad-comm-mode",
+           opt.grad_comm_mode]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"child exited {r.returncode}", "stderr_tail": r.stderr[-600:]}
+        child = json.loads(line[-1])
+    except Exception as exc:                                  # the headline line must survive a failing rehearsal
+        return {"error": f"{type(exc).__name__}: {exc}"[:600]}
+    keep = {k: child.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "roofline_hbm",
+                                      "graph_kernel_nodes_per_step")}
+    keep["workload"] = ("BASELINE configs[3], one rank of it: configs[1]'s step with the gradient exchange LIVE on RCCL at "
+                        "world size 1 (reduce_scatter_tensor / all_gather_into_tensor through ProcessGroupNCCL, sharded "
+                        "FlatAdam, early release; stored f32 gradients, Adam not fused into the GEMMs): the per-rank "
+                        "compute + plumbing cost of the 8-GPU step, without the wire time")
+    keep["grad_allreduce"] = child["config"].get("grad_allreduce")
+    keep["launch"] = child["config"].get("launch")
+    return keep
+
+
 class Leg:
     """One configured training job on this rank: model, loss, optimizer, resident synthetic pairs, step()."""
 
@@ -276,13 +349,13 @@ class Leg:
         model.train()
         self.backbone = backbone = model.get_backbone()
         self.nparams = sum(p.numel() for p in backbone.parameters())
-        if world > 1:
-            parallel.broadcast_parameters(backbone.flat_params)
+        exchanging = parallel.exchange_active()              # several ranks, or SEI_FORCE_EXCHANGE=1 (secondary.dist1)
+        parallel.broadcast_parameters(backbone.flat_params)
         self.loss_fn = loss_fn = get_loss(args, physics)
         # "auto" = f32, train.py's own default (--grad_comm_dtype f32): the bf16-compressed exchange is opt-in in both
         self.comm_dtype = torch.bfloat16 if opt.grad_comm == "bf16" else torch.float32
         self.reducer = reducer = parallel.FlatGradientReducer(backbone.flat_grads, comm_dtype=self.comm_dtype,
-                                                              mode=opt.grad_comm_mode) if world > 1 else None
+                                                              mode=opt.grad_comm_mode) if exchanging else None
         self.optimizer = optimizer = FlatAdam(model, lr=1e-4, betas=(0.9, 0.999), reducer=reducer)
 
         # synthetic 256x256 pairs, resident in HBM before the timed region
@@ -292,8 +365,9 @@ class Leg:
         torch.manual_seed(4321 + rank)
         torch.cuda.manual_seed(4321 + rank)
         self.y = y = physics(x)
+        self.physics = physics
 
-        def eager_step():
+        def eager_step(x=x, y=y):
             optimizer.zero_grad()
             loss = loss_fn(x=x, y=y, model=model)
             loss.backward()
@@ -302,28 +376,43 @@ class Leg:
             optimizer.step()
             return loss
 
-        self.step, self.graphed, self.early_event = eager_step, None, None
+        self.step, self.step_on, self.graphed, self.early_event = eager_step, eager_step, None, None
         if opt.graph:
             from graphs import GraphedLossStep
             ys = 256 if opt.full256 else CROP
             early = reducer is not None and os.environ.get("SEI_NO_EARLY_RELEASE") != "1"
             self.graphed = graphed = GraphedLossStep(loss_fn, model, optimizer, (opt.batch, 3, ys, ys),
                                                      early_release=early,
-                                                     fuse_optimizer=world == 1 and opt.fuse_optimizer,
+                                                     fuse_optimizer=reducer is None and opt.fuse_optimizer,
                                                      fuse_min_numel=opt.fuse_min_numel,
                                                      direct_bf16_grads=opt.direct_bf16_grads, count_nodes=True)
             if early and graphed.early_grads is not None:        # the bottleneck block's gradients leave early
                 self.early_event = graphed.early_grads[0]
                 reducer.set_early_range(graphed.early_grads[1:])
 
-            def step():
+            def step(x=x, y=y):
                 loss = graphed(x, y)
                 if reducer is not None:
                     reducer.reduce_async(early=self.early_event, direct=bool(graphed.direct_views))
                 optimizer.step()
                 return loss
 
-            self.step = step
+            self.step = self.step_on = step
+
+    def feed_from_device_cache(self, pairs):
+        """Every step takes the next batch of an endless epoch loop over datasets.device_cache.DeviceResidentPairs (the
+        reference's per-item dataset path, src/datasets/__init__.py:67-90, produced once and kept in HBM)."""
+        from datasets import SyntheticPairs
+        from datasets.device_cache import DeviceResidentPairs
+        cache = DeviceResidentPairs(SyntheticPairs(self.physics, self.x.device, length=pairs), self.physics, crop_size=256)
+        inner, batch = self.step_on, self.opt.batch
+
+        def epochs():
+            while True:
+                yield from cache.batches(batch, shuffle=True, drop_last=True)
+
+        stream = epochs()
+        self.step = lambda: inner(*next(stream))
 
     def timed(self, warmup, steps, fence):
         for _ in range(warmup):
@@ -572,45 +661,60 @@ def main():
     graph_nodes = leg.graph_nodes()
 
     nparams, side, comm_dtype = leg.nparams, leg.side, leg.comm_dtype
+    exchanging = leg.reducer is not None
     graphed_early = leg.early_event is not None
     secondary = None
-    if opt.secondary and world == 1 and opt.dtype == "bf16" and not opt.full256 and opt.arch == "unet" and not sr:
+    if opt.secondary and world == 1 and not exchanging and opt.dtype == "bf16" and not opt.full256 \
+            and opt.arch == "unet" and not sr:
         del leg                                             # frees the bf16 job's buckets before the next one
         torch.cuda.empty_cache()
         secondary = {}
-        leg32 = Leg(opt, "f32", device, rank, world)
-        el32, loss32 = leg32.timed(2, 5, fence)
-        secondary["f32"] = {"value": round(opt.batch * 5 / el32, 2), "unit": "images/s", "steps": 5, "warmup": 2,
-                            "ms_per_step": round(1e3 * el32 / 5, 2), "dtype": "f32",
-                            "note": "same workload and launch path with exact-f32 MFMA GEMMs: the reference's own "
-                                    "arithmetic, the mode every parity claim is made in", "final_loss": loss32}
-        del leg32
-        torch.cuda.empty_cache()
-        # BASELINE configs[2] and configs[4] on the same line: short runs (2 warm-up + 5 timed steps) of the same
-        # launch path, each with its own roofline objects
-        for key, over, what in (
-                ("sr4", dict(task="sr", sr_factor=4, arch="unet"),
-                 "BASELINE configs[2]: super-resolution x4 noise=5, proposed loss, pairs 192x192 / 48x48, the same "
-                 "ConvolutionalModel with its x4 pre-upsampler (the network runs at 192x192: 16x the pixels of configs[1])"),
-                ("swinir_sr2", dict(task="sr", sr_factor=2, arch="swinir"),
-                 "BASELINE configs[4] on one GPU: SwinIR backbone (embed 180, 6 x 6 blocks, window 8: deepinv.models.SwinIR "
-                 "as src/models/__init__.py:51-74, training mode with stochastic depth), sr x2, proposed loss, pairs 96x96 / "
-                 "48x48; PARITY UNPINNED (deepinv / timm absent: oracle/swinir_path.py restates the published network)")):
+
+        def short_run(key, over, dtype, warmup, steps, what, feed=None):
+            """One more configured job on the same launch path: `warmup` + `steps` steps, its own roofline objects."""
             o2 = argparse.Namespace(**vars(opt))
             for k_, v_ in over.items():
                 setattr(o2, k_, v_)
-            leg2 = Leg(o2, "bf16", device, rank, world)
-            el2, loss2 = leg2.timed(2, 5, fence)
-            ms2 = 1e3 * el2 / 5
-            entry = {"value": round(opt.batch * 5 / el2, 2), "unit": "images/s", "steps": 5, "warmup": 2,
-                     "ms_per_step": round(ms2, 2), "dtype": "bf16", "workload": what, "parameters": leg2.nparams,
-                     "batch": opt.batch, "final_loss": loss2}
+            leg2 = Leg(o2, dtype, device, rank, world)
+            if feed is not None:
+                feed(leg2)
+            el2, loss2 = leg2.timed(warmup, steps, fence)
+            ms2 = 1e3 * el2 / steps
+            entry = {"value": round(o2.batch * steps / el2, 2), "unit": "images/s", "steps": steps, "warmup": warmup,
+                     "ms_per_step": round(ms2, 2), "dtype": dtype, "workload": what, "parameters": leg2.nparams,
+                     "batch": o2.batch, "final_loss": loss2}
             if opt.profile_gemms:
-                entry["roofline"], entry["roofline_hbm"] = rooflines(leg2, "bf16", ms2)
+                entry["roofline"], entry["roofline_hbm"] = rooflines(leg2, dtype, ms2)
             entry["graph_kernel_nodes_per_step"] = leg2.graph_nodes()
             secondary[key] = entry
             del leg2
             torch.cuda.empty_cache()
+
+        # the reference's own arithmetic, first-class: 5 warm-up + 20 timed steps, roofline against the f32 MFMA peak
+        short_run("f32", {}, "f32", 5, 20,
+                  "BASELINE configs[1] with exact-f32 MFMA GEMMs (v_mfma_f32_32x32x2_f32): the reference's own arithmetic, "
+                  "the mode every 1e-4 parity claim is made in; same launch path (hipGraph replay, flat-bucket Adam)")
+        # SURVEY 8(d)'s other two series of configs[1]: the reference's default batch, and the un-cropped pairs
+        short_run("b8", {"batch": 8}, "bf16", 2, 5,
+                  "BASELINE configs[1] at the reference's default batch 8 (demo/train.py:53)")
+        short_run("full256", {"batch": 16, "full256": True}, "bf16", 1, 3,
+                  "SURVEY 8(d) series 'full-256': --no-Loss__crop_training_pairs (src/losses/__init__.py:203-205), the "
+                  "network sees the whole 256x256 pair (28x the pixels of the default 48-crop), batch 16")
+        # BASELINE configs[2] and configs[4] on the same line
+        short_run("sr4", dict(task="sr", sr_factor=4, arch="unet"), "bf16", 2, 5,
+                  "BASELINE configs[2]: super-resolution x4 noise=5, proposed loss, pairs 192x192 / 48x48, the same "
+                  "ConvolutionalModel with its x4 pre-upsampler (the network runs at 192x192: 16x the pixels of configs[1])")
+        short_run("swinir_sr2", dict(task="sr", sr_factor=2, arch="swinir"), "bf16", 2, 5,
+                  "BASELINE configs[4] on one GPU: SwinIR backbone (embed 180, 6 x 6 blocks, window 8: deepinv.models.SwinIR "
+                  "as src/models/__init__.py:51-74, training mode with stochastic depth), sr x2, proposed loss, pairs 96x96 / "
+                  "48x48; PARITY UNPINNED (deepinv / timm absent: oracle/swinir_path.py restates the published network)")
+        # N1: the headline step fed by the GPU-resident pair cache (train.py --device_cache): every step draws its pairs'
+        # 256-crops from HBM-resident (x, y) and Loss.forward crops 48 out of them, instead of replaying one resident batch
+        short_run("device_cache", {}, "bf16", 3, 20,
+                  "BASELINE configs[1] with every step's batch gathered from the GPU-resident pair cache "
+                  "(datasets/device_cache.py, 256 synthetic pairs = 8 batches per epoch; src/datasets/__init__.py:67-90)",
+                  feed=lambda lg: lg.feed_from_device_cache(256))
+        secondary["dist1"] = dist1_child(opt)
 
     if rank == 0:
         images = opt.batch * world * opt.steps
@@ -636,7 +740,7 @@ def main():
                        "parallelism": f"dp{world}",
                        "optimizer": "Adam (fused, flat bucket" + ("; the deep levels' weights are stepped in the epilogue "
                                                                   "of their weight-gradient GEMMs)" if fused_opt else ")"),
-                       "grad_allreduce": None if world == 1 else
+                       "grad_allreduce": None if not exchanging else
                        f"{str(comm_dtype).replace('torch.', '')}, " +
                        ("reduce-scatter + Adam on 1/N shares + all-gather of the updated weights (sharded step)"
                         if opt.grad_comm_mode == "rs_ag" else "all_reduce, every rank steps the whole bucket"),
@@ -651,8 +755,10 @@ def main():
             out["secondary"] = secondary
         if opt.cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(opt.cpu_batch, opt.hidden, opt.scales, opt.cpu_steps)
+            if secondary is not None and "swinir_sr2" in secondary:
+                out["cpu_baseline_swinir"] = cpu_baseline_swinir(opt.cpu_batch)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -20,22 +20,29 @@ class FlatParameterBucket:
         self.flat_shadow = None
         self.flat_shadow_only_start = None
         self.compute_dtype = None                 # "f32" / "bf16": this model's own mode; None = models._ops' process default
-        self._sei_plain_state = {"gen": -1, "version": {}}
+        self._sei_plain_state = _ops._new_plain_state()
         self._sei_zero_ranges = None
-        # load_state_dict copies into the parameters: cached bf16 shadows are stale afterwards
-        self.register_load_state_dict_post_hook(lambda module, incompatible: _ops.weights_updated())
+        # load_state_dict copies into the parameters: THIS model's cached bf16 shadows are stale afterwards (and every
+        # float32 master is what the file said: nothing of a sharded optimizer step's staleness survives a load)
+        self.register_load_state_dict_post_hook(FlatParameterBucket._after_load)
+
+    @staticmethod
+    def _after_load(module, incompatible):
+        _ops.set_stale_masters(module, None)
+        _ops.weights_updated(module)
 
     @staticmethod
     def _goes_last(p):
         """GEMM weights (1x1 convolutions) go last in the bucket, so that everything else -- the part of the
         gradient bucket that must be zeroed every step in store mode -- is one contiguous head; and of those, the ones
         that the bf16 throughput mode reads ONLY through their bf16 copy (both extents multiples of 32: every block
-        that owns such a weight takes the bf16 path, models/_ops.use_bf16_blocks) come last of all: with a sharded
-        optimizer step (optim.FlatAdam under several GPUs) only that copy of them is all-gathered.
+        that owns such a weight takes the bf16 path -- the gate is the block's INPUT channel count,
+        models/_ops.use_bf16_blocks: shape[1] for conv2 / Upsample / Downsample, shape[0] for conv3, hence both) come last
+        of all: with a sharded optimizer step (optim.FlatAdam under several GPUs) only that copy of them is all-gathered.
         0 = head, 1 = 1x1 weights read as float32 by some path, 2 = bf16-copy-only weights."""
         if not (p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1):
             return 0
-        return 2 if min(p.shape[0], p.shape[1]) % 32 == 0 else 1
+        return 2 if p.shape[0] % 32 == 0 and p.shape[1] % 32 == 0 else 1
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -77,8 +84,10 @@ class FlatParameterBucket:
         self.flat_shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
         # validity of the bf16 bucket is tracked per model: {"gen": generation it was written for,
         # "version": torch version counter of each parameter at that time}
-        self._sei_plain_state = {"gen": -1, "version": {}}
+        self._sei_plain_state = _ops._new_plain_state()
         self._sei_zero_ranges = None
+        for p, off in zip(params, offsets):
+            p._sei_bucket_offset = off
         if self.flat_shadow is not None:
             for p, off in zip(params, offsets):
                 p._sei_shadow_view = self.flat_shadow[off:off + p.numel()]

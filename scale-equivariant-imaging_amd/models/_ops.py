@@ -402,49 +402,90 @@ class UpsampleFn(torch.autograd.Function):
 # register-staged kernel on the bf16 tensors and accumulate into the f32 gradient bucket. Everything
 # else (depthwise conv, LayerNorm statistics and backward, resamplers, residuals, Adam) stays f32.
 # =============================================================================================
-_SHADOW_GENERATION = 0      # bumped whenever parameters change behind torch's back (fused Adam kernel)
+_GLOBAL_GENERATION = 0      # bumped by weights_updated() without a model: every model's cached bf16 copies are suspect
+
+
+def _new_plain_state():
+    """Validity of a model's bf16 bucket (`flat_shadow`), tracked PER MODEL: "wgen" = this model's weight generation
+    (bumped whenever its parameters change behind torch's version counters: its own optimizer kernel, its own
+    load_state_dict), "gen" = the (global, own) generation pair the bf16 bucket was last written for, "version" = torch's
+    version counter of each parameter at that time, "stale" = (start, stop) of the bucket whose float32 masters are OUT OF
+    DATE on this rank (sharded optimizer step: only the bf16 copies of other ranks' shares were gathered) or None."""
+    return {"gen": None, "wgen": 0, "version": {}, "stale": None}
+
+
+def _generation(plain):
+    return (_GLOBAL_GENERATION, plain["wgen"] if plain is not None else 0)
 
 
 def weights_updated(backbone=None, plain_shadow_written=False):
-    """Parameters changed outside torch's version counters. `plain_shadow_written`: the optimizer kernel
-    also refreshed `backbone.flat_shadow` (the bf16 copy of every parameter), so only the transposed
-    shadows of that model need rebuilding."""
-    global _SHADOW_GENERATION
-    _SHADOW_GENERATION += 1
-    if plain_shadow_written and backbone is not None:
-        backbone._sei_plain_state["gen"] = _SHADOW_GENERATION
+    """Parameters changed outside torch's version counters. With a `backbone` only THAT model's cached bf16 copies are
+    invalidated (another model's optimizer step or load_state_dict must not make this one recast its weights: under a
+    sharded optimizer step the float32 masters of other ranks' shares are stale and a recast would overwrite good bf16
+    weights with old values); without one, every model's. `plain_shadow_written`: the optimizer kernel also refreshed
+    `backbone.flat_shadow` (the bf16 copy of every parameter), so that copy is current for the new generation."""
+    global _GLOBAL_GENERATION
+    if backbone is None:
+        _GLOBAL_GENERATION += 1
+        return
+    plain = backbone._sei_plain_state
+    plain["wgen"] += 1
+    if plain_shadow_written:
+        plain["gen"] = _generation(plain)
 
 
 def plain_shadow_is_current(backbone):
-    return backbone._sei_plain_state["gen"] == _SHADOW_GENERATION
+    return backbone._sei_plain_state["gen"] == _generation(backbone._sei_plain_state)
+
+
+def set_stale_masters(backbone, span):
+    """optim.FlatAdam (sharded step): float32 parameters inside bucket range `span` are stale on this rank until
+    `consolidate()`; None clears it. While set, nothing may rebuild bf16 copies of that range from the masters."""
+    backbone._sei_plain_state["stale"] = None if span is None else (int(span[0]), int(span[1]))
+
+
+def _stale_error():
+    return RuntimeError("the float32 weights of other ranks' shares are out of date on this rank (sharded optimizer step: "
+                        "only their bf16 copies were all-gathered) and something asked for bf16 copies to be rebuilt from "
+                        "them; call optimizer.consolidate() on every rank before changing or re-reading the weights")
 
 
 def refresh_plain_shadow(backbone):
     """Cast the whole flat parameter bucket to its bf16 copy (what the fused Adam does as a side output)."""
     if getattr(backbone, "flat_shadow", None) is None:
         return
+    if backbone._sei_plain_state["stale"] is not None:
+        raise _stale_error()
     N.call("sei_cast_bf16", backbone.flat_params.data_ptr(), backbone.flat_shadow.data_ptr(),
            backbone.flat_params.numel())
-    weights_updated(backbone, plain_shadow_written=True)
+    plain = backbone._sei_plain_state
+    plain["gen"] = _generation(plain)
 
 
 def shadow(p):
     """bf16 copy w16 (R,C) of a 1x1-conv weight p (R,C,1,1): a view of the owning model's flat bf16 bucket,
     which the fused Adam kernel rewrites every step; cast here only when that copy is not current.
     (No transposed copy exists: the data-gradient GEMM reads w16 reduction-major.)"""
-    key = (_SHADOW_GENERATION, p._version, p.data_ptr())
+    plain = getattr(p, "_sei_plain_state", None)
+    key = (_generation(plain), p._version, p.data_ptr())
     st = getattr(p, "_sei_shadow", None)
     if st is None or st[0] != key:
         R, C = p.shape[0], p.shape[1]
         flat16 = getattr(p, "_sei_shadow_view", None)
-        plain = getattr(p, "_sei_plain_state", None)
         if st is not None and st[1].device == p.device:
             w16 = st[1]
         else:
             w16 = flat16.view(R, C) if flat16 is not None else torch.empty((R, C), dtype=torch.bfloat16, device=p.device)
-        plain_current = (flat16 is not None and plain is not None and plain["gen"] == _SHADOW_GENERATION
+        # the bucket copy is current when it was written for this generation and torch has not changed p since it was
+        # last looked at here
+        plain_current = (flat16 is not None and plain is not None and plain["gen"] == key[0]
                          and plain["version"].get(id(p)) == p._version)
         if not plain_current:
+            stale = plain["stale"] if plain is not None else None
+            if stale is not None:
+                off = getattr(p, "_sei_bucket_offset", None)
+                if off is None or (off < stale[1] and stale[0] < off + p.numel()):
+                    raise _stale_error()
             N.call("sei_cast_bf16", p.data_ptr(), w16.data_ptr(), p.numel())
         if plain is not None:
             plain["version"][id(p)] = p._version

@@ -367,7 +367,10 @@ class SwinBlockFn16(torch.autograd.Function):
         # MLP branch. The bf16 operand gy = bf16(go * drop2): already formed by the next block's norm1 backward (below,
         # handed over on the gradient tensor itself), else cast here; fc2's bias gradient = its column sums, or -- with the
         # ones column in f4 -- column Chr of fc2's weight gradient
-        gy = getattr(go, "_sei_cast16", None) if ctx.ones else None
+        # (accepted only while `go` is still the very tensor, unmodified, that the next block's backward returned: a second
+        # consumer of the block output or an in-place hook makes autograd accumulate into / rewrite it)
+        tag = getattr(go, "_sei_cast16", None) if ctx.ones else None
+        gy = tag[0] if tag is not None and tag[1] == go.data_ptr() and tag[2] == go._version else None
         if gy is None:
             gy = cast_pad(go2, drop2, None if ctx.ones else grad_of(bm2))
         gf3 = torch.empty((M, Ch), dtype=torch.bfloat16, device=dev)
@@ -396,7 +399,8 @@ class SwinBlockFn16(torch.autograd.Function):
             return (None,) * 18
         gxv = gx.view(B, H, W, C)
         if gy_prev is not None:
-            gxv._sei_cast16 = gy_prev                    # for the previous block's backward (same tensor object arrives there)
+            # for the previous block's backward (the same tensor object arrives there), with what identifies its contents
+            gxv._sei_cast16 = (gy_prev, gxv.data_ptr(), gxv._version)
         return (gxv,) + (None,) * 17
 
 

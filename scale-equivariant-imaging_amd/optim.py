@@ -25,7 +25,6 @@ class FlatAdam(torch.optim.Optimizer):
             raise ValueError("FlatAdam needs a model whose parameters live in one flat bucket")
         self.backbone = backbone
         self.reducer = reducer
-        self._master_stale = False        # sharded step, bf16 mode: float32 weights of other ranks' shares are out of date
         if reducer is not None and reducer.mode == "rs_ag" and shard_step:
             reducer.mode = "sharded"
             start = getattr(backbone, "flat_shadow_only_start", None)
@@ -41,6 +40,12 @@ class FlatAdam(torch.optim.Optimizer):
         self._prepared_for = None
         self._eager_grads = False
         self._hyper_dev = None
+
+    @property
+    def _master_stale(self):
+        """Sharded step, bf16 mode: the float32 weights of other ranks' shares are out of date on this rank (kept on the
+        backbone, where models/_ops refuses to rebuild bf16 copies from them until `consolidate()`)."""
+        return self.backbone._sei_plain_state["stale"] is not None
 
     def zero_grad(self, set_to_none=True):
         self.backbone.zero_grad_flat()
@@ -136,8 +141,10 @@ class FlatAdam(torch.optim.Optimizer):
         parameter on the wire instead of 4, the float32 masters of other ranks' shares go stale until `consolidate`),
         the float32 weights (and their bf16 copy) for everything else. A chunk that cannot be cut into aligned shares
         was all-reduced; every rank steps the whole of it."""
+        from models import _ops
         red = self.reducer
         flat = self.backbone.flat_params
+        stale = self.backbone._sei_plain_state["stale"]
         for k in red.order:
             s, e = red.bounds[k]
             red.wait(k)
@@ -149,10 +156,14 @@ class FlatAdam(torch.optim.Optimizer):
             update(lo, hi, share, share.dtype == torch.bfloat16)
             if self._shadow_only(s):
                 red.gather(k, [shadow])
-                self._master_stale = True
+                stale = (s, e) if stale is None else (min(stale[0], s), max(stale[1], e))
             else:
                 red.gather(k, [flat] + ([shadow] if shadow is not None else []))
         red.wait_gathers()
+        _ops.set_stale_masters(self.backbone, stale)
+        # this rank's moments and masters are current for the shares of THIS plan only (parallel.FlatGradientReducer)
+        red.lock_plan("a sharded optimizer step has been taken: call optimizer.consolidate() (moments included) on every "
+                      "rank before changing the chunk plan")
 
     def consolidate(self, moments=True):
         """Collective (every rank calls it): bring the float32 weights -- and, for a checkpoint, both Adam moments -- of
@@ -165,14 +176,16 @@ class FlatAdam(torch.optim.Optimizer):
         st = self.state[self.backbone.flat_params]
         bufs = ([self.backbone.flat_params] if self._master_stale else []) + \
             ([st["exp_avg"], st["exp_avg_sq"]] if moments and st["step"] > 0 else [])
-        if not bufs:
-            return
-        for k in range(len(red.bounds)):
-            if red.is_sharded(k):
-                stale = self._shadow_only(red.bounds[k][0])
-                red.gather(k, [b for b in bufs if b is not self.backbone.flat_params or stale])
-        red.wait_gathers()
-        self._master_stale = False
+        if bufs:
+            for k in range(len(red.bounds)):
+                if red.is_sharded(k):
+                    stale = self._shadow_only(red.bounds[k][0])
+                    red.gather(k, [b for b in bufs if b is not self.backbone.flat_params or stale])
+            red.wait_gathers()
+        from models import _ops
+        _ops.set_stale_masters(self.backbone, None)
+        if moments:
+            red.unlock_plan()             # every rank holds complete masters and moments: any chunk plan may follow
 
     def state_dict(self):
         """torch.optim.Adam's layout: state[i] = {step, exp_avg, exp_avg_sq} for parameter i of
@@ -242,15 +255,17 @@ class FlatAdam(torch.optim.Optimizer):
         world = 1
         bounds = self._step_bounds(flat.numel(), whole)
         grads_16 = False
+        exchanging = False
         if self.reducer is not None:
-            from parallel import world_size
+            from parallel import exchange_active, world_size
             world = world_size()
+            exchanging = exchange_active()
             bounds = self.reducer.bounds
             grads = self.reducer.comm                     # the (possibly bf16-compressed) reduced bucket
             grads_16 = grads.dtype == torch.bfloat16
         from models import _ops
         shadow = getattr(self.backbone, "flat_shadow", None) if _ops.get_compute_dtype(self.backbone) == "bf16" else None
-        if self.reducer is not None and self.reducer.mode == "sharded" and world > 1:
+        if self.reducer is not None and self.reducer.mode == "sharded" and exchanging:
             def update(lo, hi, g, g16):
                 N.call("sei_adam_fused", flat[lo:hi].data_ptr(), g.data_ptr(), int(g16), st["exp_avg"][lo:hi].data_ptr(),
                        st["exp_avg_sq"][lo:hi].data_ptr(), hi - lo, float(group["lr"]), float(b1), float(b2),

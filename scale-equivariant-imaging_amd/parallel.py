@@ -19,12 +19,25 @@ import torch
 import torch.distributed as dist
 
 
+def force_exchange():
+    """SEI_FORCE_EXCHANGE=1: build and run the whole N > 1 machinery -- process group, FlatGradientReducer, sharded
+    FlatAdam, early release -- at WORLD_SIZE = 1 too, with none of the single-process short cuts, so that
+    `reduce_scatter_tensor` / `all_gather_into_tensor` / the side-stream waits really go through the backend (RCCL on a GPU
+    box: the one-GPU rehearsal of the 8-GPU step; tests/dist1_worker.py, bench.py's `secondary.dist1`)."""
+    return os.environ.get("SEI_FORCE_EXCHANGE") == "1"
+
+
+def exchange_active():
+    """True when gradient collectives are to be issued: several ranks, or one rank with SEI_FORCE_EXCHANGE=1."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or force_exchange())
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torch.distributed.run)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_exchange()) and not dist.is_initialized():
         if backend is None:
             # SEI_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL refuses that)
             backend = os.environ.get("SEI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -84,6 +97,8 @@ class FlatGradientReducer:
         self._direct_now = False
         self._splits = []             # extra positions no chunk may straddle (set_splits)
         self._gather_work = []
+        self._plan_lock = None        # why the chunk plan may not change any more (lock_plan), or None
+        self._warned_fallback = False
         self.set_early_range(early_range)
 
     def set_direct_ranges(self, ranges):
@@ -101,22 +116,53 @@ class FlatGradientReducer:
         self._splits = sorted({int(p) for p in positions if 0 < int(p) < n})
         self.set_early_range(self.early_range)
 
+    def lock_plan(self, reason):
+        """optim.FlatAdam after a sharded step: which slice of the bucket this rank owns follows from the chunk plan, and
+        its Adam moments / float32 masters are current for exactly those slices -- a re-plan would silently hand ranks
+        slices with stale state. Until unlock_plan() (FlatAdam.consolidate(moments=True)) a CHANGED plan is refused."""
+        self._plan_lock = str(reason)
+
+    def unlock_plan(self):
+        self._plan_lock = None
+
+    def _share_quantum(self):
+        """Shares of a reduce-scattered chunk start on 16-byte boundaries of every buffer: chunk lengths that are multiples
+        of 4 x world cut into aligned shares."""
+        if self.mode in ("sharded", "rs_ag") and dist.is_initialized():
+            return 4 * dist.get_world_size(self.group)
+        return 1
+
     def set_early_range(self, early_range):
         """(Re)plan the chunks; see __init__. Call before the first reduce_async of a step."""
         n = self.flat.numel()
-        self.early_range = None
+        new_early = None
         cuts = {0, n} | set(self._splits)
         if early_range is not None and 0 <= early_range[0] < early_range[1] <= n:
             lo, hi = int(early_range[0]), int(early_range[1])
-            self.early_range = (lo, hi)
+            new_early = (lo, hi)
             cuts |= {lo, hi}
         cuts = sorted(cuts)
         parts = list(zip(cuts, cuts[1:]))
-        self.bounds, self._is_early = [], []
+        # in the reduce-scatter modes every chunk is a whole number of aligned shares (world sizes such as 3, 5, 6, 7
+        # do not divide the power-of-two default): full chunks are rounded down, a part's tail is cut into its largest
+        # such piece + a remainder of fewer than 4 x world elements that is all-reduced
+        q = self._share_quantum()
+        chunk = max(q, self._chunk // q * q)
+        bounds, is_early = [], []
         for a, b in parts:
-            for s, e in (chunk_bounds(b - a, self._chunk) if b > a else []):
-                self.bounds.append((a + s, a + e))
-                self._is_early.append(self.early_range is not None and self.early_range[0] <= a and b <= self.early_range[1])
+            pieces = []
+            for s, e in (chunk_bounds(b - a, chunk) if b > a else []):
+                main = (e - s) // q * q
+                if q > 1 and 0 < main < e - s:
+                    pieces += [(s, s + main), (s + main, e)]
+                else:
+                    pieces.append((s, e))
+            for s, e in pieces:
+                bounds.append((a + s, a + e))
+                is_early.append(new_early is not None and new_early[0] <= a and b <= new_early[1])
+        if self._plan_lock is not None and bounds != getattr(self, "bounds", None):
+            raise RuntimeError(f"FlatGradientReducer: the chunk plan may not change now ({self._plan_lock})")
+        self.early_range, self.bounds, self._is_early = new_early, bounds, is_early
         # the order in which chunks complete (and the optimizer should consume them): early ones first
         self.order = [k for k, f in enumerate(self._is_early) if f] + [k for k, f in enumerate(self._is_early) if not f]
         self._work = [None] * len(self.bounds)
@@ -148,7 +194,7 @@ class FlatGradientReducer:
         16-byte boundaries of every buffer (the fused Adam kernel moves aligned quads), hence the factor 4."""
         s, e = self.bounds[k]
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        return self.mode == "sharded" and world > 1 and (e - s) % (4 * world) == 0 and s % 4 == 0
+        return self.mode == "sharded" and exchange_active() and (e - s) % (4 * world) == 0 and s % 4 == 0
 
     def own_slice(self, k):
         s, e = self.bounds[k]
@@ -197,6 +243,11 @@ class FlatGradientReducer:
             self._work[k] = dist.reduce_scatter_tensor(share, chunk, op=dist.ReduceOp.SUM, group=self.group,
                                                        async_op=True)
             return
+        if self.mode == "sharded" and not self._warned_fallback and e - s >= 4 * world:
+            self._warned_fallback = True
+            import warnings
+            warnings.warn(f"FlatGradientReducer: chunk [{s}, {e}) cannot be cut into {world} aligned shares; it is "
+                          "all-reduced and every rank steps the whole of it")
         if self.mode == "rs_ag" and (e - s) % world == 0:
             share = self._shards.get(k)
             if share is None or share.numel() != (e - s) // world:
@@ -216,7 +267,7 @@ class FlatGradientReducer:
         wrote `direct_ranges` into the exchange buffer itself."""
         self._direct_now = bool(direct) and bool(self.direct_ranges)
         self._work = [None] * len(self.bounds)
-        single = world_size() == 1
+        single = not exchange_active()
         if early is not None and self.early_range is not None and self._side is not None:
             lo, hi = self.early_range
             with torch.cuda.stream(self._side):
@@ -255,13 +306,13 @@ class FlatGradientReducer:
 
 def broadcast_parameters(flat_params, src=0):
     """Make every replica start from rank `src`'s weights."""
-    if world_size() > 1:
+    if exchange_active():
         dist.broadcast(flat_params, src=src)
 
 
 def all_reduce_mean_scalar(t):
     """Average a scalar tensor over ranks (epoch-level loss logging; not on the per-step path)."""
-    if world_size() > 1:
+    if exchange_active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         t /= world_size()
     return t

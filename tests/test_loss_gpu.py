@@ -415,13 +415,17 @@ def test_sr4_composite_step_vs_oracle(net):
     assert worst < 1e-4, worst
 
 
-def test_sr4_bf16_graphed_step_vs_oracle():
+@pytest.mark.parametrize("crop,B,oracle_dtype", [(16, 2, torch.float64), (48, 1, torch.float32)])
+def test_sr4_bf16_graphed_step_vs_oracle(crop, B, oracle_dtype):
     """BASELINE configs[2] as it is benchmarked (`bench.py --task sr`, bf16): the default 645 M-parameter network with its
     x4 pre-upsampler, x4 antialiased downsampling physics, SURE margin 0, paired crop, bf16 GEMMs, hipGraph replay with
     merged + stored weight gradients -- against the FLOAT64 oracle on the same weights, crop (16: the network runs at
     64x64) and injected draws: restored images within 0.01 dB PSNR-Y, loss within bf16 rounding, gradient cosines.
     (The float64 oracle of this 645 M-parameter network is ~1 minute of host time on the box's 16 CPUs; the float32
-    twin of this step is test_sr4_composite_step_vs_oracle.)"""
+    twin of this step is test_sr4_composite_step_vs_oracle.)
+    Second case: THE SIZE THAT IS TIMED -- crop 48, the network on a 192 x 192 grid (the dispatch branches of that size:
+    lane-per-channel 3 -> 32 data gradient, the 24-output resampler maps, the large-grid depthwise kernels, weight
+    gradients over 36,864-pixel reductions) -- one pair, against the float32 oracle (~3 TFLOP of host work)."""
     import bench
     import metrics
     import models
@@ -432,13 +436,13 @@ def test_sr4_bf16_graphed_step_vs_oracle():
     from optim import FlatAdam
     prev = _ops.set_compute_dtype("bf16")
     try:
-        crop, B = 16, 2
+        od = oracle_dtype
         args = ref_args(task="sr", sr_factor=4, kernel=None, Loss__crop_size=crop, ConvolutionalModel__hidden_channels=32,
                         ConvolutionalModel__scales=5)
         p = physics.get_physics(args, "cuda")
         torch.manual_seed(0)
         model = models.get_model(args, p, "cuda")
-        sd = {k: v.detach().double().requires_grad_(True) for k, v in model.get_weights().items()}
+        sd = {k: v.detach().to(od).clone().requires_grad_(True) for k, v in model.get_weights().items()}
         model.to("cuda")
         bb = model.get_backbone()
         lf = get_loss(args, p)
@@ -450,7 +454,7 @@ def test_sr4_bf16_graphed_step_vs_oracle():
         y = tp.downsample_aa(x, 4) + 5 / 255 * torch.randn((B, 3, crop, crop), generator=gen)
         b = torch.randn((B, 3, crop, crop), generator=gen)
         noise = torch.randn((B, 3, crop, crop), generator=gen)
-        rate, center = torch.tensor([0.5, 0.75]), torch.tensor([[-0.4, 0.1], [0.7, -0.6]])
+        rate, center = torch.tensor([0.5, 0.75])[:B], torch.tensor([[-0.4, 0.1], [0.7, -0.6]])[:B]
         graphed = GraphedLossStep(lf, model, opt, (B, 3, crop, crop))
         assert graphed.store_weight_grads
         draws = {"b": b.cuda(), "rate": rate.cuda(), "center": center.cuda(), "noise": noise.cuda()}
@@ -463,21 +467,21 @@ def test_sr4_bf16_graphed_step_vs_oracle():
         torch.manual_seed(9)
         xc, yc = tp.crop_pair(x, y, crop, 4)
         assert torch.equal(graphed.static_y.cpu(), yc.contiguous())
-        ref, aux = tp.proposed_loss(yc.contiguous().double(), lambda v: tp.downsample_aa(v, 4),
+        ref, aux = tp.proposed_loss(yc.contiguous().to(od), lambda v: tp.downsample_aa(v, 4),
                                     lambda v: tp.unet_forward(sd, v, scales=5, upsampling_rate=4), 5 / 255, margin=0,
-                                    rate=rate.double(), center=center.double().view(B, 1, 1, 2), b=b.double(),
-                                    n=noise.double())
+                                    rate=rate.to(od), center=center.to(od).view(B, 1, 1, 2), b=b.to(od),
+                                    n=noise.to(od))
         ref.backward()
         assert aux["x_net"].shape == (B, 3, 4 * crop, 4 * crop) == x_net.shape
         for i in range(B):
-            d = abs(float(metrics.psnr_fn(x_net[i], xc[i])) - float(tp.psnr_y(aux["x_net"][i].detach(), xc[i].double())))
+            d = abs(float(metrics.psnr_fn(x_net[i], xc[i])) - float(tp.psnr_y(aux["x_net"][i].detach().double(), xc[i].double())))
             assert d < 0.01, d
         assert relerr(x_net, aux["x_net"]) < 2e-2
         assert abs(loss - float(ref)) < 2e-2 * abs(float(ref)), (loss, float(ref))
         assert torch.isfinite(bb.flat_grads).all()
         worst_big, worst_small = 1.0, 1.0
         for name, prm in bb.named_parameters():
-            g, r = prm.grad.double().flatten().cpu(), sd[name].grad.flatten()
+            g, r = prm.grad.double().flatten().cpu(), sd[name].grad.double().flatten()
             cos = float(g @ r / (g.norm() * r.norm()))
             if prm.dim() == 4 and prm.shape[-1] == 1 and prm.numel() >= 4096:
                 worst_big = min(worst_big, cos)
@@ -485,7 +489,7 @@ def test_sr4_bf16_graphed_step_vs_oracle():
                 worst_small = min(worst_small, cos)
             assert cos > 0.99, (name, cos)
         assert worst_big > 0.999, worst_big
-        print(f"SR x4 bf16 graphed step vs f64 oracle: loss {loss:.6f} vs {float(ref):.6f}; gradient cosine >= "
+        print(f"SR x4 bf16 graphed step (crop {crop}, B {B}) vs {str(od)[6:]} oracle: loss {loss:.6f} vs {float(ref):.6f}; gradient cosine >= "
               f"{worst_big:.5f} (1x1 weights), >= {worst_small:.5f} (others)")
     finally:
         _ops.set_compute_dtype(prev)

@@ -122,8 +122,7 @@ def main(argv=None):
     if args.weights is not None:
         model.load_weights(get_weights(args.weights, args.device))
     backbone = model.get_backbone()
-    if world > 1:
-        parallel.broadcast_parameters(backbone.flat_params)
+    parallel.broadcast_parameters(backbone.flat_params)       # (no-op without a gradient exchange)
     torch.manual_seed(seed)
     torch.cuda.manual_seed(seed)                      # decorrelated b / noise / rates / centres per rank
 
@@ -165,7 +164,7 @@ def main(argv=None):
         raise ValueError("--grad_comm_dtype bf16 needs the fused Adam (it reads the bf16 bucket directly)")
     comm_dtype = torch.bfloat16 if args.grad_comm_dtype == "bf16" else torch.float32
     reducer = parallel.FlatGradientReducer(backbone.flat_grads, comm_dtype=comm_dtype,
-                                           mode=args.grad_comm_mode) if world > 1 else None
+                                           mode=args.grad_comm_mode) if parallel.exchange_active() else None
     if optimizer_kind == "Adam" and args.fused_optimizer:
         optimizer = FlatAdam(model, lr=lr, betas=(0.9, args.optimizer_beta2), reducer=reducer)
     elif optimizer_kind == "Adam":
@@ -235,9 +234,13 @@ def main(argv=None):
                     graphed = GraphedLossStep(loss, model, optimizer,
                                               (args.batch_size, y.shape[1], args.Loss__crop_size, args.Loss__crop_size),
                                               early_release=early,
-                                              fuse_optimizer=world == 1 and args.fuse_optimizer_step)
+                                              fuse_optimizer=reducer is None and args.fuse_optimizer_step)
                     if early and graphed.early_grads is not None:
                         early_event = graphed.early_grads[0]
+                        # (a capture after sharded optimizer steps -- the first batches were short -- changes which
+                        # slices a rank owns: complete every rank's masters and moments first; a collective, reached by
+                        # all ranks at the same step since their shards are equal-length)
+                        consolidate()
                         reducer.set_early_range(graphed.early_grads[1:])
                 training_loss = graphed(x, y)
                 used_graph = True
