@@ -32,7 +32,7 @@ extern "C" {
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
-#define SEI_ABI_VERSION 7
+#define SEI_ABI_VERSION 8
 int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
@@ -531,6 +531,26 @@ int sei_tokgrad_bf16_blocks(const SeiTokGradBlock *blocks, int nblocks, long lon
 int sei_tokgrad_bf16(const uint16_t *Y1, const uint16_t *Y2, int ldy, const uint16_t *X1, const uint16_t *X2, int ldx,
                      float *D, int ldd, int Mo, int Ni, long long K1, long long K2, void *stream);
 size_t sei_tokgrad_bf16_eligible(int Mo, int Ni, int ldy, int ldx, long long K1, long long K2);
+
+/* Streamed weight gradients of the U-Net's shallow levels (csrc/dw_stream.hip): D (Mo, ldd >= Ni) += Y^T X over K1 + K2
+ * pixels for every job of a table in ONE launch per block shape -- persistent workgroups that own a whole block of a gradient
+ * in their accumulators and stream a contiguous pixel range once (LDS-DMA ring), dealt to the jobs in proportion to their
+ * bytes. Replaces torch's conv2d weight gradient of the 1x1 convolutions of /root/reference/src/models/convolutional.py:40-42
+ * (ConvBlock.conv2 / conv3), :106 (Upsample) and :143 (Downsample) where (Mo, Ni) is (128, 256 k) / (256 k, 128), k <= 4,
+ * with K1, K2 multiples of 64, or (32, 128) / (128, 32) with K1, K2 multiples of 128; sei_dwstream_bf16_eligible() != 0
+ * says so, sei_gemm_bf16nt_dw2 serves everything else. Y (K, ldy == Mo) and X (K, ldx == Ni) are bf16, pixel-major as
+ * stored, in two row segments (the step's two model calls; K2 = 0: one). D is ADDED to with float atomics. */
+#define SEI_DWSTREAM_MAX_JOBS 64
+typedef struct SeiDwStreamJob {
+    const uint16_t *Y1, *Y2;         /* (K1, ldy) / (K2, ldy) bf16; Y2 unused when K2 = 0 */
+    const uint16_t *X1, *X2;         /* (K1, ldx) / (K2, ldx) */
+    int ldy, ldx, Mo, Ni;
+    float *D;
+    int ldd, reserved;
+    long long K1, K2;
+} SeiDwStreamJob;
+int sei_dwstream_bf16_jobs(const SeiDwStreamJob *jobs, int njobs, void *stream);
+size_t sei_dwstream_bf16_eligible(int Mo, int Ni, int ldy, int ldx, long long K1, long long K2);
 
 /* sei_rowgemm_bf16: D (M, N) = epilogue(A W^T): A (M, lda >= K) bf16 rows, W (N, ldw >= K) bf16 -- the layer's matrix as
  * nn.Linear stores it (forward) or its transpose (data gradient), zero-padded to N in {192, 384, 576} rows and

@@ -98,6 +98,7 @@ SIGNATURES = {
     "sei_rowgemm_gelu_bf16": [_P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _I, _I, _P],
     "sei_tokgrad_bf16_blocks": [_P, _I, _L, _L, _P],
     "sei_tokgrad_bf16": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _L, _L, _P],
+    "sei_dwstream_bf16_jobs": [_P, _I, _P],
     "sei_adam_fused": [_P, _P, _I, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _F, _P, _P],
     "sei_adam_scalars": [_F, _F, _F, _F, _F, _I, _P, _P],
     "sei_adam_scalars_to_device": [_F, _F, _F, _F, _F, _I, _P, _P],
@@ -110,6 +111,15 @@ class TokGradBlock(_c.Structure):
     """SeiTokGradBlock of include/sei_hip.h (one 192 x 192 block of a token-streamed weight gradient)."""
     _fields_ = [("Y1", _P), ("Y2", _P), ("X1", _P), ("X2", _P), ("ldy", _I), ("ldx", _I), ("y0", _I), ("x0", _I),
                 ("D", _P), ("ldd", _I)]
+
+
+class DwStreamJob(_c.Structure):
+    """SeiDwStreamJob of include/sei_hip.h (one weight gradient of a sei_dwstream_bf16_jobs table)."""
+    _fields_ = [("Y1", _P), ("Y2", _P), ("X1", _P), ("X2", _P), ("ldy", _I), ("ldx", _I), ("Mo", _I), ("Ni", _I),
+                ("D", _P), ("ldd", _I), ("reserved", _I), ("K1", _L), ("K2", _L)]
+
+
+DWSTREAM_MAX_JOBS = 64
 
 
 class FoldJob(_c.Structure):
@@ -131,6 +141,7 @@ SIZE_QUERIES = {
     "sei_sepmap2_bf16_pack_elems": [_I, _I, _I, _I],
     "sei_swin_partials_floats": [_I],
     "sei_tokgrad_bf16_eligible": [_I, _I, _I, _I, _L, _L],
+    "sei_dwstream_bf16_eligible": [_I, _I, _I, _I, _L, _L],
     "sei_rowgemm_bf16_eligible": [_L, _I, _I, _I, _I],
     "sei_rowgemm_lnbwd_bf16_eligible": [_L, _I, _I],
     "sei_rowgemm_lnbwd_work_floats": [_I],
@@ -139,7 +150,7 @@ SIZE_QUERIES = {
     "sei_rowgemm_dgelu_bf16_eligible": [_L, _I, _I],
     "sei_rowgemm_ln_bf16_eligible": [_L, _I, _I],
 }
-ABI_VERSION = 7       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
+ABI_VERSION = 8       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 
 
 class NativeLibraryError(RuntimeError):

@@ -555,7 +555,7 @@ def _fresh_state():
     return {"uses": 0, "arrivals": {}, "parked": {}, "written": set(), "store": False, "store_min": 0,
             "flush_queued": False, "merge": True, "seen": {}, "milestone": None, "milestone_done": False,
             "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set(), "flops_per_row": {},
-            "taps": {}, "merged_ok": {}, "folds": {}}
+            "taps": {}, "merged_ok": {}, "folds": {}, "dwjobs": []}
 
 
 class WeightGradState:
@@ -799,6 +799,8 @@ def _launch_weight_grad_inner(_DW, grad2d, pairs, store):
                    x2.data_ptr(), Kp, grad2d.data_ptr(), Np, Kp, K1, K2, 0 if store else 1, T, taps, Np * Kp)
         return
     per_row = _DW["flops_per_row"].get(key) or 2.0 * Np * Kp
+    if not store and _queue_dwstream(_DW, grad2d, pairs, per_row):
+        return
     if len(pairs) == 2:
         (g1, x1), (g2, x2) = pairs
         K1, K2 = g1.shape[0], g2.shape[0]
@@ -816,6 +818,45 @@ def _launch_weight_grad_inner(_DW, grad2d, pairs, store):
         store = False
 
 
+# Streamed weight gradients of the shallow levels (csrc/dw_stream.hip): the accumulating weight gradients whose shapes
+# sei_dwstream_bf16_eligible takes -- conv2 / conv3 of the C = 32 and C = 128 blocks, the 1x1 convolutions between the
+# 32-, 128- and 512-channel levels -- are not launched one by one on the tiled GEMM (a 128 x 128 output tile under up to
+# 256 K-splits) but collected, operands kept alive, and issued as ONE job table when the backward pass ends (the engine
+# callback that flushes parked pairs and deferred folds), or at once outside a backward pass. SEI_NO_DWSTREAM=1: the GEMMs.
+DWSTREAM = os.environ.get("SEI_NO_DWSTREAM") != "1"
+
+
+def _queue_dwstream(_DW, grad2d, pairs, per_row):
+    if not DWSTREAM or not grad2d.is_cuda or grad2d.dim() != 2 or grad2d.dtype != torch.float32 or len(pairs) > 2:
+        return False
+    Np, Kp = grad2d.shape
+    if grad2d.stride(1) != 1:
+        return False
+    for gy, x in pairs:
+        if not (gy.dtype == x.dtype == torch.bfloat16 and gy.is_contiguous() and x.is_contiguous()
+                and gy.dim() == 2 and x.dim() == 2 and gy.shape[1] == Np and x.shape[1] == Kp and gy.shape[0] == x.shape[0]):
+            return False
+    K1 = pairs[0][0].shape[0]
+    K2 = pairs[1][0].shape[0] if len(pairs) == 2 else 0
+    if not N.lib().sei_dwstream_bf16_eligible(Np, Kp, Np, Kp, K1, K2):
+        return False
+    (g1, x1), (g2, x2) = pairs[0], pairs[-1]
+    job = N.DwStreamJob(g1.data_ptr(), g2.data_ptr(), x1.data_ptr(), x2.data_ptr(), Np, Kp, Np, Kp, grad2d.data_ptr(),
+                        grad2d.stride(0), 0, K1, K2)
+    _DW["dwjobs"].append((job, (g1, x1, g2, x2, grad2d), per_row * (K1 + K2)))
+    if len(_DW["dwjobs"]) == N.DWSTREAM_MAX_JOBS or not _queue_flush(_DW):
+        flush_dwstream(_DW)
+    return True
+
+
+def flush_dwstream(_DW):
+    jobs, _DW["dwjobs"] = _DW["dwjobs"], []
+    if not jobs:
+        return
+    arr = (N.DwStreamJob * len(jobs))(*[j[0] for j in jobs])
+    _gemm_call(sum(j[2] for j in jobs), "sei_dwstream_bf16_jobs", arr, len(jobs))   # (the operands in `jobs` live until here)
+
+
 def flush_weight_grads(owner=None, _state=None):
     """Issue every parked weight gradient of `owner` (default state when None) on its own (no partner arrived)."""
     _DW = _state if _state is not None else state_of(owner)
@@ -827,6 +868,7 @@ def flush_weight_grads(owner=None, _state=None):
         else:
             gy16, x16, grad2d = entry
             _launch_weight_grad(_DW, grad2d, [(gy16, x16)])
+    flush_dwstream(_DW)
     flush_folds(_DW)
 
 

@@ -1032,3 +1032,84 @@ def test_deferred_folds_leave_the_gradients_bit_identical(ops, mode):
         ops.set_compute_dtype(prev)
     assert folds[False] == 0 and 1 <= folds[True] <= 2
     assert relerr(grads[True], grads[False]) < (1e-5 if mode == "f32" else 2e-3)
+
+
+@pytest.mark.parametrize("K1,K2", [(128, 0), (128, 256), (18432, 36864), (147456, 73728)])
+def test_streamed_weight_gradients_of_the_shallow_levels(K1, K2):
+    """sei_dwstream_bf16_jobs (autograd's weight gradient gy^T x of the 1x1 convolutions of reference
+    src/models/convolutional.py:40-42,106,143 at the 32- and 128-channel levels; both operands pixel-major as stored, the
+    step's two model calls as two segments) against the float32 product of the same bf16 operands, on top of a running
+    gradient: every block shape the kernel builds -- (128, 512), (512, 128), (128, 256), (32, 128), (128, 32): narrow
+    operand first or second, 256-column blocks, pixel pairs read as one row -- each as a table of its own and all of them in
+    ONE table; from a single k-tile (most workgroups idle) to more k-tiles than workgroups. The tiled GEMM it replaces
+    agrees to the float summation order; shapes the kernel does not build are refused."""
+    import _native as N
+    gen = torch.Generator(device="cuda").manual_seed(K1 + K2)
+    jobs, expect = [], []
+    for Mo, Ni in [(128, 512), (512, 128), (128, 256), (1024, 128), (32, 128), (128, 32)]:
+        gys = [(0.5 * torch.randn((k, Mo), device="cuda", generator=gen)).bfloat16() for k in (K1, K2) if k]
+        xs = [torch.randn((k, Ni), device="cuda", generator=gen).bfloat16() for k in (K1, K2) if k]
+        base = torch.randn((Mo, Ni), device="cuda", generator=gen)
+        ref = base + sum(g.float().T @ x.float() for g, x in zip(gys, xs))
+        assert N.lib().sei_dwstream_bf16_eligible(Mo, Ni, Mo, Ni, K1, K2) != 0
+        job = lambda d: N.DwStreamJob(gys[0].data_ptr(), gys[-1].data_ptr(), xs[0].data_ptr(), xs[-1].data_ptr(), Mo, Ni,
+                                      Mo, Ni, d.data_ptr(), Ni, 0, K1, K2)
+        d = base.clone()
+        N.call("sei_dwstream_bf16_jobs", (N.DwStreamJob * 1)(job(d)), 1)
+        assert relerr(d, ref) < 2e-5, (Mo, Ni, relerr(d, ref))
+        if K2 and (K1 + K2) % 8 == 0:                       # the launch it replaces
+            t = base.clone()
+            N.call("sei_gemm_bf16nt_dw2", gys[0].data_ptr(), gys[1].data_ptr(), Mo, xs[0].data_ptr(), xs[1].data_ptr(), Ni,
+                   t.data_ptr(), Mo, Ni, K1, K2, 1)
+            assert relerr(t, d) < 2e-5, (Mo, Ni, relerr(t, d))
+        dg = base.clone()
+        jobs.append(job(dg))
+        expect.append((dg, ref, gys, xs))
+    N.call("sei_dwstream_bf16_jobs", (N.DwStreamJob * len(jobs))(*jobs), len(jobs))
+    for dg, ref, _, _ in expect:
+        assert relerr(dg, ref) < 2e-5, relerr(dg, ref)
+    elig = N.lib().sei_dwstream_bf16_eligible
+    assert elig(128, 512, 128, 512, 96, 0) == 0 and elig(32, 128, 32, 128, 64, 0) == 0      # ragged pixel counts
+    assert elig(128, 512, 136, 512, 128, 0) == 0                                           # padded rows
+    assert elig(512, 2048, 512, 2048, 128, 0) == 0 and elig(64, 256, 64, 256, 128, 0) == 0 and elig(128, 128, 128, 128, 128, 0) == 0
+
+
+def test_streamed_weight_gradients_inside_a_backward_pass(ops):
+    """The U-Net's backward pass in bf16 mode with the shallow levels' weight gradients collected into one job table per
+    block shape at the end of the pass (models/_ops._queue_dwstream) against the same pass on the tiled GEMMs
+    (SEI_NO_DWSTREAM): two model calls per step, so every job carries two pixel segments. Equal up to the float atomics'
+    summation order and the bf16 roundings behind it: the bar is three times what two runs of the tiled path differ by
+    (or 3e-3); the streamed path issues one launch where the tiled path issues one per weight."""
+    import _native as N
+    from models.convolutional import ConvolutionalModel
+    torch.manual_seed(0)
+    m = ConvolutionalModel(in_channels=3, upsampling_rate=1, residual=True, inner_residual=True, num_conv_blocks=1,
+                           hidden_channels=32, inout_convs=True, scales=3).cuda()
+    y = torch.rand((4, 3, 48, 48), device="cuda"); y2 = torch.rand((2, 3, 48, 48), device="cuda")
+    ct = torch.randn((4, 3, 48, 48), device="cuda"); ct2 = torch.randn((2, 3, 48, 48), device="cuda")
+    prev = ops.set_compute_dtype("bf16")
+    grads, launches = {}, {}
+    try:
+        for streamed in (False, None, True):                  # (None: the tiled path a second time -- its own noise)
+            ops.DWSTREAM = bool(streamed)
+            m.zero_grad_flat()
+            N.record_calls(True)
+            ((m(y) * ct).sum() + (m(y2) * ct2).sum()).backward()
+            log = N.record_calls(False)
+            launches[streamed] = (sum(1 for name, _ in log if name == "sei_dwstream_bf16_jobs"),
+                                  sum(1 for name, _ in log if name.startswith("sei_gemm_bf16nt_dw2")))
+            grads[streamed] = m.flat_grads.clone()
+    finally:
+        ops.DWSTREAM = True
+        ops.set_compute_dtype(prev)
+    assert launches[False][0] == 0 and launches[True][0] == 1
+    assert launches[True][1] <= launches[False][1] - 8, launches          # levels 0 and 1: 2 x (conv2, conv3) + 4 between levels
+    # (whole passes differ by the float atomics and the bf16 roundings behind them upstream, run to run as much as path to
+    # path: a tolerance, on the gradients the two paths compute differently)
+    worst = []
+    for name, prm in m.named_parameters():
+        if prm.dim() == 4 and prm.shape[-1] == 1 and prm.shape[-2] == 1:
+            off = (prm._sei_grad_view.data_ptr() - m.flat_grads.data_ptr()) // 4
+            a, b, c = (grads[k][off:off + prm.numel()] for k in (True, False, None))
+            worst.append((relerr(a, b) / max(relerr(c, b), 1e-3), relerr(a, b), relerr(c, b), name))
+    assert len(worst) == 14 and max(worst)[0] < 3, sorted(worst, reverse=True)[:4]
