@@ -376,7 +376,11 @@ int sei_colsum_weighted_f32(const float *X, const float *row_weight, float *out,
  * hidden activation stays in registers (accumulator tiles re-used as MFMA operands).
  * sei_mlp_fused_bwd: from go (M, C) float: gh2 (M, C) float = gradient w.r.t. h2; go16 (M, C), h4 = gelu(h3) (M, 4C) and
  * gh3 (M, 4C) in bf16 = the operands of the two weight-gradient GEMMs (h3 = conv2(h2) is recomputed). W3T (4C, C) and
- * W2T (C, 4C) are the transposed bf16 weights. (Bias gradients: column sums of go and gh3, sei_colsum_*.) */
+ * W2T (C, 4C) are the transposed bf16 weights. (Bias gradients: column sums of go and gh3, sei_colsum_*.)
+ * sei_mlp_fused_eligible(M, C) != 0 where the fused form is built to win: C = 32, and C = 128 with M a multiple of 144
+ * (csrc/mlp128.hip: nine-wave workgroups of 144 pixels, the weights through an LDS-DMA ring); the entry points take any
+ * M for both widths, the caller takes the GEMMs where this says 0. */
+size_t sei_mlp_fused_eligible(long long M, int C);
 int sei_mlp_fused_fwd(const uint16_t *h2, const uint16_t *W2, const float *b2, const uint16_t *W3, const float *b3,
                       const float *x, float res_scale, float *out, int M, int C, void *stream);
 int sei_mlp_fused_bwd(const float *go, const uint16_t *h2, const uint16_t *W2, const float *b2, const uint16_t *W3T,

@@ -142,6 +142,7 @@ SIZE_QUERIES = {
     "sei_swin_partials_floats": [_I],
     "sei_tokgrad_bf16_eligible": [_I, _I, _I, _I, _L, _L],
     "sei_dwstream_bf16_eligible": [_I, _I, _I, _I, _L, _L],
+    "sei_mlp_fused_eligible": [_L, _I],
     "sei_rowgemm_bf16_eligible": [_L, _I, _I, _I, _I],
     "sei_rowgemm_lnbwd_bf16_eligible": [_L, _I, _I],
     "sei_rowgemm_lnbwd_work_floats": [_I],

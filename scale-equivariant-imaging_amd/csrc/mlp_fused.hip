@@ -326,12 +326,21 @@ inline unsigned mlp_grid(int M, int rows_per_group) {
 
 }  // namespace
 
+// 1 where the fused form is the faster one: the 32-channel level always, the 128-channel level for the pixel counts
+// csrc/mlp128.hip is cut for (multiples of 144 = a quarter of a 24 x 24 level image); the caller takes the GEMMs otherwise.
+extern "C" size_t sei_mlp_fused_eligible(long long M, int C) {
+    if (M <= 0 || M >= (1ll << 31)) return 0;
+    if (C == 32) return 1;
+    return sei_mlp128_eligible((int)M, C) ? 1 : 0;
+}
+
 extern "C" int sei_mlp_fused_fwd(const uint16_t *h2, const uint16_t *W2, const float *b2, const uint16_t *W3,
                                  const float *b3, const float *x, float res_scale, float *out, int M, int C,
                                  void *stream) {
     SEI_REQUIRE(h2 && W2 && b2 && W3 && b3 && x && out && M > 0 && (C == 32 || C == 128));
     SEI_REQUIRE((((uintptr_t)h2 | (uintptr_t)W2 | (uintptr_t)W3) & 15) == 0);
     hipStream_t s = (hipStream_t)stream;
+    if (sei_mlp128_eligible(M, C)) return sei_mlp128_fwd_launch(h2, W2, b2, W3, b3, x, res_scale, out, M, s);
     if (C == 32)
         hipLaunchKernelGGL((mlp_fwd_kernel<32, 2>), dim3(mlp_grid(M, 64 * WAVES)), dim3(THREADS), 0, s, h2, W2, b2, W3, b3,
                            x, res_scale, out, M);
@@ -348,6 +357,10 @@ extern "C" int sei_mlp_fused_bwd(const float *go, const uint16_t *h2, const uint
     SEI_REQUIRE((((uintptr_t)go | (uintptr_t)h2 | (uintptr_t)W2 | (uintptr_t)W3T | (uintptr_t)W2T | (uintptr_t)go16) & 15) == 0 &&
                 (((uintptr_t)h4 | (uintptr_t)gh3) & 7) == 0);
     hipStream_t s = (hipStream_t)stream;
+    if (sei_mlp128_eligible(M, C)) {
+        SEI_REQUIRE((((uintptr_t)gh2 | (uintptr_t)go) & 15) == 0);
+        return sei_mlp128_bwd_launch(go, h2, W2, b2, W3T, W2T, gh2, go16, h4, gh3, M, s);
+    }
     if (C == 32)
         hipLaunchKernelGGL((mlp_bwd_kernel<32, 2>), dim3(mlp_grid(M, 64 * WAVES)), dim3(THREADS), 0, s, go, h2, W2, b2, W3T,
                            W2T, gh2, go16, h4, gh3, M);

@@ -991,7 +991,26 @@ def use_bf16_blocks(C):
 # (forward 40 vs 56 us for the two GEMMs, backward 49 vs 76 us incl. the cast); C = 128 loses (forward 63 vs 51 us,
 # backward 139 vs 70 us): 36,864 pixels are 288 four-wave tiles, one per CU, and nothing overlaps the 16 serial
 # weight slices of a tile. SEI_FUSED_MLP=32,128 / SEI_FUSED_MLP= (empty) override for A/B runs.
-FUSED_MLP_CHANNELS = tuple(int(v) for v in __import__("os").environ.get("SEI_FUSED_MLP", "32").split(",") if v)
+# Round 4: the 128-channel level has a kernel of its own (csrc/mlp128.hip: nine-wave workgroups of 144 pixels, weights
+# through an LDS-DMA ring) for pixel counts that are multiples of 144 -- sei_mlp_fused_eligible says where the fused form is
+# the faster one; everything else keeps the GEMMs.
+FUSED_MLP_CHANNELS = tuple(int(v) for v in __import__("os").environ.get("SEI_FUSED_MLP", "32,128").split(",") if v)
+
+
+def fused_mlp_ok(M, C):
+    return C in FUSED_MLP_CHANNELS and N.lib().sei_mlp_fused_eligible(M, C) != 0
+
+
+def _transposed16_cached(p, w16):
+    """_transposed16 of a weight's bf16 copy, rebuilt only when the copy changed (one optimizer step = one rebuild, not
+    one per backward function: the step's two model calls share it)."""
+    plain = getattr(p, "_sei_plain_state", None)
+    key = (_generation(plain), p._version, w16.data_ptr())
+    hit = getattr(p, "_sei_shadow_t", None)
+    if hit is None or hit[0] != key or torch.cuda.is_current_stream_capturing() != hit[2]:
+        hit = (key, _transposed16(w16), torch.cuda.is_current_stream_capturing())
+        p._sei_shadow_t = hit
+    return hit[1]
 
 
 def _transposed16(w16):
@@ -1015,7 +1034,7 @@ class ConvBlockFn16(torch.autograd.Function):
         M = B * H * W
         h1, h2, mean, rstd = dwconv7_ln(x, w1, b1, gamma, beta, out16=True)
         w2_16, w3_16 = shadow(w2), shadow(w3)
-        ctx.fused = C in FUSED_MLP_CHANNELS
+        ctx.fused = fused_mlp_ok(M, C)
         if ctx.fused:
             out = torch.empty((M, C), dtype=torch.float32, device=x.device)
             N.call("sei_mlp_fused_fwd", h2.data_ptr(), w2_16.data_ptr(), b2.data_ptr(), w3_16.data_ptr(), b3.data_ptr(),
@@ -1079,7 +1098,7 @@ class ConvBlockFn16(torch.autograd.Function):
         go16 = torch.empty((M, C), dtype=torch.bfloat16, device=dev)
         h4 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=dev)
         gh3 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=dev)
-        w3t, w2t = _transposed16(w3_16), _transposed16(w2_16)    # (both kept alive until the launch is enqueued)
+        w3t, w2t = _transposed16_cached(w3, w3_16), _transposed16_cached(w2, w2_16)
         args = (go.data_ptr(), h2.data_ptr(), w2_16.data_ptr(), b2.data_ptr(), w3t.data_ptr(), w2t.data_ptr(),
                 gh2.data_ptr(), go16.data_ptr(), h4.data_ptr(), gh3.data_ptr(), M, C)
         N.call("sei_mlp_fused_bwd", *args)
