@@ -707,6 +707,9 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float *__restrict__ p, s
 }
 
 #ifdef SEI_TUNING
+// Tools-only build (make tuning -> libsei_hip_tuning.so): process-wide defaults for the tile / band arguments and a forced
+// K-split count, so that the experiment scripts under tools/ can steer launches. Not in libsei_hip.so.
+int g_tuning_tile = 0, g_tuning_band = 0, g_tuning_splitk = 0;
 #include "gemm_bf16pp.h"  // 256 x 256 ping-pong schedule on the same LDS images (tools-only build)
 #endif
 #include "gemm_bf16pq.h"
@@ -742,16 +745,23 @@ int launch_nt(NtArgs &g, hipStream_t s) {
         // 3456 k-tiles) capped at 16 splits kept 16 CUs busy for 147 us; its atomics are contiguous and few
         const size_t max_sk = ktiles / 4 < 256 ? ktiles / 4 : 256;
         const double overhead = 6.0 + (g.epilogue == SEI_EPI_ACCUM ? 0.0 : 2.0);   // in k-tile units
+        // a split launch that does not accumulate into a running gradient pays a zero-fill launch and its atomics on top:
+        // ~32 k-tiles' worth (round 4, tools/exp_skinny.py: 9216 x 128 x 512 24 -> 12.6 us and 2304 x 512 x 2048 37 -> 28 us
+        // unsplit, while 288 / 576 x 2048 x 8192 still want 8 / 6 splits)
+        const double split_cost = g.epilogue == SEI_EPI_ACCUM ? 2.0 : 32.0;
         double best = 1e30;
         size_t best_sk = 1;
         for (size_t sk = 1; sk <= max_sk; ++sk) {
             const double rounds = (double)sei_ceil_div(tiles * nbatch * sk, slots);
-            const double cost = rounds * ((double)sei_ceil_div(ktiles, sk) + overhead + (sk > 1 ? 2.0 : 0.0));
+            const double cost = rounds * ((double)sei_ceil_div(ktiles, sk) + overhead + (sk > 1 ? split_cost : 0.0));
             if (cost < best * 0.97) {            // prefer fewer splits unless the gain is real
                 best = cost;
                 best_sk = sk;
             }
         }
+#ifdef SEI_TUNING
+        if (g_tuning_splitk > 0) best_sk = (size_t)g_tuning_splitk < ktiles ? (size_t)g_tuning_splitk : ktiles;
+#endif
         if (best_sk > 1) {
             g.k_per_split = (int)(sei_ceil_div(ktiles, best_sk) * BK);
             g.splitk = (int)sei_ceil_div(g.K, g.k_per_split);
@@ -791,16 +801,14 @@ int launch_nt(NtArgs &g, hipStream_t s) {
     return sei_launch_status();
 }
 
-#ifdef SEI_TUNING
-// Tools-only build (make tuning -> libsei_hip_tuning.so): a process-wide default for the tile / band arguments,
-// so that the experiment scripts under tools/ can steer launches issued by the model code. Not in libsei_hip.so.
-int g_tuning_tile = 0, g_tuning_band = 0;
-#endif
-
 }  // namespace
 
 #ifdef SEI_TUNING
 extern "C" int sei_debug_set_nt_tile(int code) {
+    if (code >= 1000) {                // 1000 + n: force n K-splits on splittable launches (1000 = the cost model)
+        g_tuning_splitk = code - 1000;
+        return SEI_OK;
+    }
     if (code >= 100) {                 // 100 + band: force the band width of the tile order (100 = automatic)
         g_tuning_band = code - 100;
         return SEI_OK;
@@ -956,8 +964,10 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
             case 82: return launch_pq<8, 2, false, true>(g, s);
             default: break;
         }
-        // skinny data gradients (the bottleneck levels): 192 x 256 with two 128-column images of the weight
-        if (tile != 1 && N >= 2048 && K >= 2048 && M <= 768)
+        // skinny data gradients (the bottleneck levels): 192 x 256 with two 128-column images of the weight -- but not
+        // the float32 ones that split K (Downsample's convolution between the two deepest levels, 288 / 576 x 2048 x 8192:
+        // 65 / 75 us there against 40 / 55 on 128 x 128 tiles with 8 / 6 splits, tools/exp_skinny.py)
+        if (tile != 1 && N >= 2048 && K >= 2048 && M <= 768 && !would_split)
             return launch_nt<3, 2, 2, 4, false, true>(g, s);
         return launch_nt<2, 1, 2, 4, false, true>(g, s);
     }
@@ -985,7 +995,9 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
         case 82: return launch_pq<8, 2>(g, s);
         default: break;
     }
-    if (N >= 2048 && K >= 2048 && M <= 768) return launch_nt<3, 2, 2, 4>(g, s);               // 192 x 256
+    // (not the convolution behind the downsampler, which cannot split K: 288 / 576 x 8192 x 2048 run 56 / 48 us on 64
+    // tiles of 192 x 256 and 32 / 41 us on 128 x 128, tools/exp_skinny.py)
+    if (N >= 2048 && K >= 2048 && M <= 768 && epilogue != SEI_EPI_BIAS_ROWSCALE) return launch_nt<3, 2, 2, 4>(g, s);   // 192 x 256
     // short reductions are all prologue and epilogue: one LDS stage (32 KB) and <= 84 VGPRs put three workgroups
     // on a CU instead of two (36864 x 512 x 128: 34 -> 27 us; 9216 x 2048 x 512: 50 -> 44 us; loses from K ~ 2048)
     if (K <= 1024 && tile != 1) return launch_nt<2, 1, 2, 4, false, false, 1>(g, s);

@@ -462,6 +462,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
             float x[16 / RPI];
 #pragma unroll
             for (int p = 0; p < 16 / RPI; ++p) x[p] = patch[(p * RPI + sr) * LDW + sc] + sbias;
+            if (epi == SEI_EPI_BIAS_ROWSCALE && with_bias) {   // lead split: bias[n] * R1[m] instead of the plain bias
+#pragma unroll
+                for (int p = 0; p < 16 / RPI; ++p) {
+                    const int row = m0 + wr * 16 * RF + 16 * i + p * RPI + sr;
+                    x[p] += sbias * (g.R1[row < M ? row : 0] - 1.0f);
+                }
+            }
             if (aux1) {                                        // lead split of BIAS_RES: residuals, loads batched
 #pragma unroll
                 for (int p = 0; p < 16 / RPI; ++p) {
@@ -592,6 +599,9 @@ int launch_pq(NtArgs &g, hipStream_t s) {
                 best_sk = sk;
             }
         }
+#ifdef SEI_TUNING
+        if (g_tuning_splitk > 0) best_sk = (size_t)g_tuning_splitk < ktiles ? (size_t)g_tuning_splitk : ktiles;
+#endif
         if (best_sk > 1) {
             g.k_per_split = (int)(sei_ceil_div(ktiles, best_sk) * BK);
             g.splitk = (int)sei_ceil_div(g.K, g.k_per_split);
