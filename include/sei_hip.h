@@ -90,6 +90,11 @@ int sei_resample_sepband(const float *x, float *y, int planes, int Hi, int Wi, i
  * _bwd accumulates d x (must be zero-filled by the caller) -- only needed with
  * --no-ProposedLoss__stop_gradient.
  * ------------------------------------------------------------------------------------------- */
+/* The scale transform's per-image parameters from its two uniform draws (sample_from / sample_downsampling_parameters,
+ * /root/reference/src/transforms.py:5-24): rate[i] = table[floor(ntable * u[i])], center[2 i + k] = 2 v[2 i + k] - 1
+ * (u (B), v (B, 2) uniform in [0, 1) from the caller's generator): the reference's float32 operations, one launch. */
+int sei_scale_params(const float *u, const float *v, const float *table, int ntable, int B, float *rate, float *center,
+                     void *stream);
 int sei_scale_resample_fwd(const float *x, float *y, const float *rate, const float *center,
                            int B, int C, int Hi, int Wi, int H, int W, void *stream);
 int sei_scale_resample_bwd(const float *gy, float *gx, const float *rate, const float *center,
@@ -224,6 +229,13 @@ size_t sei_ln_bwd_part_count(size_t rows, int C);
 int sei_ln_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
                const float *gy, float *gx, float *ggamma, float *gbeta, size_t rows, int C,
                float *work, size_t work_floats, void *stream);
+/* The same with a second gradient of the LayerNorm's input added in the same pass: gx = LN'(gy) + res (res may be NULL).
+ * What autograd otherwise does with an extra elementwise kernel where a U-Net level's output feeds both the downsampler
+ * and the skip connection (/root/reference/src/models/convolutional.py:226-232: `skips.append(x)` next to
+ * `downsampling_layers[lvl](x)`). Shapes with sei_ln_bwd_part_count(rows, C) > 0 only. */
+int sei_ln_bwd_res(const float *x, const float *gamma, const float *mean, const float *rstd,
+                   const float *gy, const float *res, float *gx, float *ggamma, float *gbeta, size_t rows, int C,
+                   float *work, size_t work_floats, void *stream);
 
 /* The second stage of MANY two-stage reductions in one launch: the LayerNorm parameter gradients and depthwise weight
  * gradients of a whole backward pass (reference: the autograd of src/models/convolutional.py:21-39 accumulates each of

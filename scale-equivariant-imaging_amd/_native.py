@@ -31,6 +31,7 @@ SIGNATURES = {
     "sei_blur_sep_circ": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_blur_dense_circ": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_resample_sepband": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+    "sei_scale_params": [_P, _P, _P, _I, _I, _P, _P, _P],
     "sei_scale_resample_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_scale_resample_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_rotate_nearest_fwd": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
@@ -50,6 +51,7 @@ SIGNATURES = {
     "sei_dwconv7_ln_fwd_ex": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "sei_ln_fwd": [_P, _P, _P, _P, _P, _P, _Z, _I, _F, _P],
     "sei_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P, _Z, _P],
+    "sei_ln_bwd_res": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P, _Z, _P],
     "sei_gemm_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sei_gemm_f32_ex": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _L, _L, _L, _I, _P],
     "sei_gemm_bf16_ex": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _L, _L, _L, _I, _P],

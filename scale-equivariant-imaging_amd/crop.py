@@ -42,6 +42,32 @@ class CropPair(Module):
         self.location = location
         self.size = size
 
+    def draw_offsets(self, y_shape):
+        """(i, j, h, w): the crop offset `forward` would draw for a y of this shape -- the same two draws from the CPU
+        generator, over the MinSizePadding-padded extent (h, w) -- without touching any data. For callers that need the
+        cropped y only (graphs.GraphedLossStep with a loss that never reads x): `write_y` then fills the crop."""
+        s = self.size
+        fix = FIX_BATCHED_CROP
+        h0, w0 = (y_shape[-2], y_shape[-1]) if fix else (y_shape[1], y_shape[2])
+        h, w = y_shape[-2] + max(0, s - h0), y_shape[-1] + max(0, s - w0)
+        if self.location == "random":
+            i = torch.randint(0, h - s + 1, size=(1,)).item()
+            j = torch.randint(0, w - s + 1, size=(1,)).item()
+        else:
+            i, j = (h - s) // 2, (w - s) // 2
+        return i, j, h, w
+
+    def write_y(self, y, i, j, out):
+        """out <- the (size x size) crop of the zero-padded y at (i, j): one strided copy when the window lies inside y,
+        a zero fill in front of it when it reaches into the padding (the batched-crop quirk, module docstring)."""
+        s = self.size
+        vh, vw = min(s, y.shape[-2] - i), min(s, y.shape[-1] - j)
+        if vh < s or vw < s:
+            out.zero_()
+        if vh > 0 and vw > 0:
+            out[..., :vh, :vw].copy_(y[..., i:i + vh, j:j + vw])
+        return out
+
     def forward(self, x, y, xy_size_ratio=None):
         if xy_size_ratio is None:
             xy_size_ratio = int(ceil(x.shape[1] / y.shape[1]))

@@ -157,6 +157,28 @@ extern "C" int sei_axpy(const float *a, const float *b, float alpha, float *out,
     return sei_launch_status();
 }
 
+// The arithmetic behind the scale transform's two uniform draws (reference src/transforms.py:5-24): rate = table[floor(n u)],
+// centre = 2 u' - 1 -- the float32 operations torch performs one elementwise kernel at a time, in one launch.
+__global__ __launch_bounds__(256) void scale_params_kernel(const float *__restrict__ u, const float *__restrict__ v,
+                                                           const float *__restrict__ table, int ntable, int B,
+                                                           float *__restrict__ rate, float *__restrict__ center) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        int k = (int)floorf((float)ntable * u[i]);
+        k = k < 0 ? 0 : (k >= ntable ? ntable - 1 : k);            // (rand() < 1: never clamps)
+        rate[i] = table[k];
+    }
+    if (i < 2 * B) center[i] = 2.0f * v[i] - 1.0f;
+}
+
+extern "C" int sei_scale_params(const float *u, const float *v, const float *table, int ntable, int B, float *rate,
+                                float *center, void *stream) {
+    SEI_REQUIRE(u && v && table && rate && center && ntable > 0 && B > 0);
+    hipLaunchKernelGGL(scale_params_kernel, dim3((unsigned)sei_ceil_div((size_t)2 * B, 256)), dim3(256), 0,
+                       (hipStream_t)stream, u, v, table, ntable, B, rate, center);
+    return sei_launch_status();
+}
+
 extern "C" int sei_sure_terms(const float *y, const float *y1, const float *y2, const float *b, int planes,
                               int H, int W, int margin_div, int margin_mse, float tau, float c_mse,
                               float c_div, float *out2, float *g1, float *g2, float *work, void *stream) {

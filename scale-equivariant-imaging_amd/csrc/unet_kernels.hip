@@ -240,8 +240,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_wide_kernel(
 template <int G, int NV>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_vec_kernel(
     const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
-    const float *__restrict__ rstd, const float *__restrict__ gy, float *__restrict__ gx,
-    float *__restrict__ part, size_t rows) {
+    const float *__restrict__ rstd, const float *__restrict__ gy, const float *__restrict__ res,
+    float *__restrict__ gx, float *__restrict__ part, size_t rows) {
     constexpr int C = 4 * G * NV, RPB = LN_THREADS / G;
     __shared__ __attribute__((aligned(16))) float red[RPB * 2 * C];
     const int lg = threadIdx.x % G, rsub = threadIdx.x / G;
@@ -280,6 +280,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_vec_kernel(
             o4.y = rs * (g[e].y - s1 - xh[e].y * s2);
             o4.z = rs * (g[e].z - s1 - xh[e].z * s2);
             o4.w = rs * (g[e].w - s1 - xh[e].w * s2);
+            if (res) {                                           // a second gradient of the same tensor (skip connection)
+                const float4 r4 = *reinterpret_cast<const float4 *>(res + row * C + 4 * (lg + e * G));
+                o4.x += r4.x; o4.y += r4.y; o4.z += r4.z; o4.w += r4.w;
+            }
             *reinterpret_cast<float4 *>(gx + row * C + 4 * (lg + e * G)) = o4;
         }
     }
@@ -340,7 +344,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_rowstats_kernel(
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_cols_kernel(
     const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ gy, const float2 *__restrict__ stats,
-    float *__restrict__ gx, float *__restrict__ part, size_t rows, int C, int rows_per_chunk) {
+    const float *__restrict__ res, float *__restrict__ gx, float *__restrict__ part, size_t rows, int C,
+    int rows_per_chunk) {
     const int c = 4 * (blockIdx.x * LN_THREADS + threadIdx.x);
     if (c >= C) return;
     const float4 gm = *reinterpret_cast<const float4 *>(gamma + c);
@@ -362,6 +367,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_cols_kernel(
     }
         SEI_LN_COL_LANE(x) SEI_LN_COL_LANE(y) SEI_LN_COL_LANE(z) SEI_LN_COL_LANE(w)
 #undef SEI_LN_COL_LANE
+        if (res) {
+            const float4 r4 = *reinterpret_cast<const float4 *>(res + row * C + c);
+            o4.x += r4.x; o4.y += r4.y; o4.z += r4.z; o4.w += r4.w;
+        }
         *reinterpret_cast<float4 *>(gx + row * C + c) = o4;
     }
     float *out = part + (size_t)blockIdx.y * 2 * C;
@@ -1369,7 +1378,14 @@ extern "C" size_t sei_ln_bwd_part_count(size_t rows, int C) {
 extern "C" int sei_ln_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
                           const float *gy, float *gx, float *ggamma, float *gbeta, size_t rows, int C,
                           float *work, size_t work_floats, void *stream) {
+    return sei_ln_bwd_res(x, gamma, mean, rstd, gy, nullptr, gx, ggamma, gbeta, rows, C, work, work_floats, stream);
+}
+
+extern "C" int sei_ln_bwd_res(const float *x, const float *gamma, const float *mean, const float *rstd,
+                              const float *gy, const float *res, float *gx, float *ggamma, float *gbeta, size_t rows,
+                              int C, float *work, size_t work_floats, void *stream) {
     SEI_REQUIRE(x && gamma && mean && rstd && gy && gx && rows > 0 && C > 0);
+    SEI_REQUIRE(!res || sei_ln_bwd_part_count(rows, C) > 0);       // the residual rides in the vectorised kernels only
     // ggamma = gbeta = NULL: the partial sums stay in `work` for sei_fold_many (shapes with sei_ln_bwd_part_count > 0)
     SEI_REQUIRE((ggamma != nullptr) == (gbeta != nullptr));
     SEI_REQUIRE(ggamma || sei_ln_bwd_part_count(rows, C) > 0);
@@ -1383,7 +1399,7 @@ extern "C" int sei_ln_bwd(const float *x, const float *gamma, const float *mean,
         if (p.kind == 1) {
 #define SEI_LN_VEC(GG, NN)                                                                                    \
     hipLaunchKernelGGL((ln_bwd_vec_kernel<GG, NN>), dim3(p.grid), dim3(LN_THREADS), 0, s, x, gamma, mean, rstd, \
-                       gy, gx, part, rows);                                                                   \
+                       gy, res, gx, part, rows);                                                              \
     break;
             switch (p.G * 100 + p.NV) {
                 case 201: SEI_LN_VEC(2, 1)
@@ -1401,7 +1417,7 @@ extern "C" int sei_ln_bwd(const float *x, const float *gamma, const float *mean,
             hipLaunchKernelGGL(ln_bwd_rowstats_kernel, dim3((unsigned)rows), dim3(LN_THREADS), 0, s, x, gamma, mean,
                                rstd, gy, stats, C);
             hipLaunchKernelGGL(ln_bwd_cols_kernel, dim3(p.col_blocks, p.chunks), dim3(LN_THREADS), 0, s, x, gamma,
-                               mean, rstd, gy, (const float2 *)stats, gx, part, rows, C, p.rows_per_chunk);
+                               mean, rstd, gy, (const float2 *)stats, res, gx, part, rows, C, p.rows_per_chunk);
         }
         if (ggamma)
             hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3((unsigned)sei_ceil_div((size_t)2 * C, 16)), dim3(256), 0, s,

@@ -199,19 +199,29 @@ class GraphedLossStep:
         same tensors), copied into the buffers the graph reads."""
         if self.static_draws is None:
             return
+        if given is None and hasattr(self.inner, "draw_into") \
+                and self.inner.draw_into(self.static_draws, self.static_y, self.model):
+            return                                  # drawn straight into the static buffers (same calls, same order)
         fresh = given if given is not None else self.inner.draw(self.static_y, self.model)
         _copy_nested(self.static_draws, fresh)
 
     def __call__(self, x, y, draws=None):
         """One replay on the crop of (x, y); draws: inject the step's random numbers (tests) instead of drawing."""
         crop = self.loss_module.crop_fn
-        if crop is not None:
-            x, y = crop(x, y, xy_size_ratio=self.loss_module.xy_size_ratio)
-        if tuple(y.shape) != tuple(self.static_y.shape):
-            raise ValueError(f"graphed step was captured for {tuple(self.static_y.shape)}, got {tuple(y.shape)}")
-        self.static_y.copy_(y)
-        if self.static_x is not None:
-            self.static_x.copy_(x)
+        if crop is not None and self.static_x is None and hasattr(crop, "draw_offsets") \
+                and tuple(y.shape[:2]) == tuple(self.static_y.shape[:2]) and crop.size == self.static_y.shape[-1]:
+            # the loss never reads x: draw the offset exactly as CropPair.forward does and copy y's window straight into
+            # the static input -- no zero-padded copies of the two 256 x 256 batches first
+            i, j, _, _ = crop.draw_offsets(y.shape)
+            crop.write_y(y, i, j, self.static_y)
+        else:
+            if crop is not None:
+                x, y = crop(x, y, xy_size_ratio=self.loss_module.xy_size_ratio)
+            if tuple(y.shape) != tuple(self.static_y.shape):
+                raise ValueError(f"graphed step was captured for {tuple(self.static_y.shape)}, got {tuple(y.shape)}")
+            self.static_y.copy_(y)
+            if self.static_x is not None:
+                self.static_x.copy_(x)
         self._draw(draws)
         if not self._ops.plain_shadow_is_current(self.backbone):   # weights changed by something other than FlatAdam
             self._ops.refresh_plain_shadow(self.backbone)

@@ -185,6 +185,24 @@ class ProposedLoss(Module):
             draws["drop"] = drop
         return draws
 
+    def draw_into(self, static, y, model=None):
+        """`draw` with the numbers landing in the buffers of `static` (an earlier result of `draw`): the same generator
+        calls in the same order -- randn of the probe's interior, the transform's two uniform draws, randn of the
+        measurement noise -- without the fresh tensors and the copies (graphs.GraphedLossStep, before every replay).
+        False: not available for this configuration (stochastic depth masks ride along: the generic path copies)."""
+        if not self.graph_safe or "drop" in static or not hasattr(self.ei.T, "sample_into"):
+            return False
+        m = self.sure.div_margin
+        b = static["b"]
+        if m == 0:
+            torch.randn(tuple(y.shape), dtype=y.dtype, device=y.device, out=b)
+        else:                                       # the border of `b` is zero and stays zero
+            b[:, :, m:-m, m:-m].copy_(torch.randn(y.size(0), y.size(1), y.size(2) - 2 * m, y.size(3) - 2 * m,
+                                                  device=y.device, dtype=y.dtype))
+        self.ei.T.sample_into(static["rate"], static["center"])
+        torch.randn(tuple(y.shape), dtype=y.dtype, device=y.device, out=static["noise"])
+        return True
+
     def forward(self, x, y, model, draws=None):
         y = y.contiguous()
         if draws is None:

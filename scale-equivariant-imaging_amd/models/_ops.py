@@ -144,7 +144,9 @@ def layer_norm(x2d, gamma, beta):
     return y, mean, rstd
 
 
-def layer_norm_bwd(x2d, gamma, mean, rstd, gy, ggamma, gbeta):
+def layer_norm_bwd(x2d, gamma, mean, rstd, gy, ggamma, gbeta, res=None):
+    """res: a second gradient of the LayerNorm's input (rows, C), added to gx in the same kernel (the skip connection's
+    gradient where a level's output feeds the downsampler and the decoder: no autograd add kernel)."""
     rows, C = x2d.shape
     gx = torch.empty_like(x2d)
     need = N.lib().sei_ln_bwd_workspace(rows, C)
@@ -152,9 +154,12 @@ def layer_norm_bwd(x2d, gamma, mean, rstd, gy, ggamma, gbeta):
     parts = N.lib().sei_ln_bwd_part_count(rows, C)
     deferred = parts > 0 and defer_fold(ggamma, gbeta, None, 2 * C, C, N.FOLD_SPLIT, work,
                                         N.lib().sei_ln_bwd_part_offset(rows, C), parts)
-    N.call("sei_ln_bwd", x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gy.data_ptr(),
-           gx.data_ptr(), None if deferred else ggamma.data_ptr(), None if deferred else gbeta.data_ptr(), rows, C,
-           work.data_ptr(), need)
+    fused_res = res is not None and parts > 0
+    N.call("sei_ln_bwd_res", x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gy.data_ptr(),
+           res.data_ptr() if fused_res else None, gx.data_ptr(), None if deferred else ggamma.data_ptr(),
+           None if deferred else gbeta.data_ptr(), rows, C, work.data_ptr(), need)
+    if res is not None and not fused_res:
+        gx += res.view(rows, C)
     return gx
 
 
@@ -318,8 +323,11 @@ class DownsampleFn(torch.autograd.Function):
     full-resolution Co-channel tensor (75 MB per level at B = 32) never exists."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, w, b, rate):
+    def forward(ctx, x, gamma, beta, w, b, rate, with_skip=False):
+        """with_skip: also return x itself as a second output (the U-Net's skip connection): its gradient then arrives
+        HERE, next to the downsampler's, and is added inside the LayerNorm backward instead of by an autograd add."""
         ctx.dtype = get_compute_dtype()
+        ctx.set_materialize_grads(False)
         x = _nhwc(x)
         B, H, W, C = x.shape
         M, Co = B * H * W, w.shape[0]
@@ -332,10 +340,11 @@ class DownsampleFn(torch.autograd.Function):
         out = gemm(u.view(Mo, C), w, Mo, Co, C, 0, 1, EPI_BIAS_ROWSCALE, bias=b, R1=s)
         ctx.save_for_backward(x, mean, rstd, u, s)
         ctx.params, ctx.mats_t, ctx.hw = (gamma, beta, w, b), bwd, (H, W, Ho, Wo)
-        return out.view(B, Ho, Wo, Co)
+        out = out.view(B, Ho, Wo, Co)
+        return (out, x) if with_skip else out
 
     @_in_forward_mode
-    def backward(ctx, go):
+    def backward(ctx, go, gskip=None):
         x, mean, rstd, u, s = ctx.saved_tensors
         gamma, beta, w, b = ctx.params
         B, H, W, C = x.shape
@@ -346,8 +355,9 @@ class DownsampleFn(torch.autograd.Function):
         gemm(go2, u.view(Mo, C), Co, C, Mo, 1, 0, EPI_ACCUM, out=grad_of(w).view(Co, C))
         gu = gemm(go2, w, Mo, C, Co, 0, 0, EPI_NONE)
         gh = sepmap2(gu.view(B, Ho, Wo, C), ctx.mats_t, H, W).view(M, C)
-        gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
-        return (gx if ctx.needs_input_grad[0] else None), None, None, None, None, None
+        res = None if gskip is None else gskip.contiguous().view(M, C)
+        gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta), res=res).view(B, H, W, C)
+        return (gx if ctx.needs_input_grad[0] else None), None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1120,8 +1130,9 @@ class DownsampleFn16(torch.autograd.Function):
     """DownsampleFn (resampler before the convolution) with the three GEMMs on bf16 operands."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, w, b, rate):
+    def forward(ctx, x, gamma, beta, w, b, rate, with_skip=False):
         ctx.dtype = get_compute_dtype()
+        ctx.set_materialize_grads(False)
         x = _nhwc(x)
         B, H, W, C = x.shape
         M, Co = B * H * W, w.shape[0]
@@ -1136,10 +1147,11 @@ class DownsampleFn16(torch.autograd.Function):
         gemm_nt16(u16, shadow(w), Mo, Co, C, EPI_BIAS_ROWSCALE, out32=out, bias=b, R1=s)
         ctx.save_for_backward(x, mean, rstd, u16, s)
         ctx.params, ctx.mats_t, ctx.hw = (gamma, beta, w, b), bwd, (H, W, Ho, Wo)
-        return out.view(B, Ho, Wo, Co)
+        out = out.view(B, Ho, Wo, Co)
+        return (out, x) if with_skip else out
 
     @_in_forward_mode
-    def backward(ctx, go):
+    def backward(ctx, go, gskip=None):
         x, mean, rstd, u16, s = ctx.saved_tensors
         gamma, beta, w, b = ctx.params
         B, H, W, C = x.shape
@@ -1152,8 +1164,9 @@ class DownsampleFn16(torch.autograd.Function):
         gemm_nt16(go16, shadow(w), Mo, C, Co, EPI_NONE, out32=gu, b_rmajor=True)
         weight_grad16(go16, u16, grad_of(w).view(Co, C))           # after the data gradient: see ConvBlockFn16.backward
         gh = sepmap2_16(gu.view(B, Ho, Wo, C), ctx.mats_t, H, W).view(M, C)
-        gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
-        return (gx if ctx.needs_input_grad[0] else None), None, None, None, None, None
+        res = None if gskip is None else gskip.contiguous().view(M, C)
+        gx = layer_norm_bwd(x.view(M, C), gamma, mean, rstd, gh, grad_of(gamma), grad_of(beta), res=res).view(B, H, W, C)
+        return (gx if ctx.needs_input_grad[0] else None), None, None, None, None, None, None
 
 
 class UpsampleFn16(torch.autograd.Function):

@@ -124,9 +124,11 @@ class Downsample(Module):
         self.conv = Conv2d(self.in_channels, self.out_channels, kernel_size=1, stride=1)
         self.ideal_downsample = IdealDownsample(rate=self.rate)
 
-    def forward(self, x):
+    def forward(self, x, with_skip=False):
+        """with_skip: returns (downsampled, x) -- the second output is x handed on for the U-Net's skip connection, so that
+        both gradients of x meet inside this layer's backward (models/_ops.DownsampleFn)."""
         fn = _ops.DownsampleFn16 if _ops.use_bf16_blocks(x.shape[-1]) else _ops.DownsampleFn
-        return fn.apply(x, self.ln.ln.weight, self.ln.ln.bias, self.conv.weight, self.conv.bias, self.rate)
+        return fn.apply(x, self.ln.ln.weight, self.ln.ln.bias, self.conv.weight, self.conv.bias, self.rate, with_skip)
 
 
 class UNet(Module):
@@ -182,8 +184,8 @@ class UNet(Module):
         skips = []
         for lvl in range(self.scales - 1):
             x = self._stage(lvl, x, self.inner_residual)
-            skips.append(x)
-            x = self.downsampling_layers[lvl](x)
+            x, skip = self.downsampling_layers[lvl](x, with_skip=True)     # (reference :226-232: skips.append(x); down(x))
+            skips.append(skip)
         x = self._stage(self.scales - 1, x, False)
         for lvl in range(self.scales - 1):
             x = self.upsampling_layers[lvl](x, skips.pop())

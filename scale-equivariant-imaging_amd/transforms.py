@@ -33,11 +33,30 @@ def sample_from(values, shape=(1,), dtype=torch.float32, device="cpu"):
     return table[torch.floor(len(values) * u).to(torch.int)]
 
 
-def sample_downsampling_parameters(image_count, device, dtype, rates):
-    """Per-image (rate, centre in [-1,1]^2) (reference :15-24)."""
-    rate = sample_from(rates, shape=(image_count,), dtype=dtype, device=device)
-    center = 2 * torch.rand((image_count, 2), dtype=dtype, device=device) - 1
-    return rate, center.view(image_count, 1, 1, 2)
+def sample_downsampling_parameters(image_count, device, dtype, rates, out=None):
+    """Per-image (rate, centre in [-1,1]^2) (reference :15-24): rate = rates[floor(len(rates) u)], centre = 2 u' - 1 with
+    u = rand(B) and u' = rand(B, 2) drawn in this order. On the GPU the two uniform draws are torch's (the generator is
+    consumed exactly as by the reference's calls) and the arithmetic behind them -- scale, floor, table lookup, affine map:
+    seven elementwise torch kernels -- is one launch (sei_scale_params; the same float32 operations, bit-identical).
+    out = (rate (B,), centre (B, 1, 1, 2)): written in place (the static buffers of a captured step)."""
+    if torch.device(device).type != "cuda" or dtype != torch.float32:
+        rate = sample_from(rates, shape=(image_count,), dtype=dtype, device=device)
+        center = (2 * torch.rand((image_count, 2), dtype=dtype, device=device) - 1).view(image_count, 1, 1, 2)
+        if out is not None:
+            out[0].copy_(rate)
+            out[1].copy_(center)
+            return out
+        return rate, center
+    table = _table(rates, device, dtype)
+    u = torch.rand((image_count,), device=device, dtype=dtype)
+    v = torch.rand((image_count, 2), device=device, dtype=dtype)
+    rate, center = out if out is not None else (torch.empty_like(u), torch.empty((image_count, 1, 1, 2), device=device,
+                                                                                   dtype=dtype))
+    N.check_tensor(rate, "rate")
+    N.check_tensor(center, "center")
+    N.call("sei_scale_params", u.data_ptr(), v.data_ptr(), table.data_ptr(), len(rates), image_count, rate.data_ptr(),
+           center.data_ptr())
+    return rate, center
 
 
 class _ScaleResample(torch.autograd.Function):
@@ -109,6 +128,10 @@ class PaddedDownsamplingTransform(Module):
         return sample_downsampling_parameters(image_count=image_count, device=device, dtype=dtype,
                                               rates=self.downsampling_rates)
 
+    def sample_into(self, rate, center):
+        sample_downsampling_parameters(image_count=rate.numel(), device=rate.device, dtype=rate.dtype,
+                                       rates=self.downsampling_rates, out=(rate, center))
+
     def forward(self, x, params=None):
         """params: (rate (B,), centre (B,1,1,2)) drawn by the caller with `sample`; drawn here otherwise."""
         rate, center = params if params is not None else self.sample(x.shape[0], x.device, x.dtype)
@@ -149,6 +172,10 @@ class ScalingTransform(Module):
     def sample(self, image_count, device, dtype):
         """The padded kind's per-image draws (rate, centre), in the reference's order (:15-24)."""
         return self.transform.sample(image_count, device, dtype)
+
+    def sample_into(self, rate, center):
+        """`sample` written into existing buffers; only the padded kind draws on the device."""
+        self.transform.sample_into(rate, center)
 
     def forward(self, x, params=None):
         return self.transform(x) if params is None else self.transform(x, params=params)

@@ -993,7 +993,11 @@ def test_merged_and_stored_weight_grads_match_plain_accumulation():
                 lf(x=x, y=y, model=model).backward()
                 if mode == "merged":
                     records = _ops.profile_gemms(False)
-                    assert sum(r[1] == "sei_gemm_bf16nt_dw2" for r in records) > 10      # the merge happened
+                    merged = sum(r[1] == "sei_gemm_bf16nt_dw2" for r in records)          # the merge happened: two-segment
+                    for r in records:                                                     # GEMMs, and two-segment jobs of
+                        if r[1] == "sei_dwstream_bf16_jobs":                              # the streamed launch (levels 0-1)
+                            merged += sum(r[2][0][k].K2 > 0 for k in range(r[2][1]))
+                    assert merged > 10, merged
                 grads[mode] = bb.flat_grads.clone()
             finally:
                 _ops.set_weight_grad_merging(was, owner=bb)
