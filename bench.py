@@ -145,6 +145,8 @@ def _stream_bytes(name, a):
         return 6 * a[6] * a[7]
     if name == "sei_ln_bwd":
         return 12 * a[8] * a[9]
+    if name == "sei_ln_bwd_res":                          # + the skip connection's gradient rows
+        return (16 if a[5] else 12) * a[9] * a[10]
     if name == "sei_fold_many":                           # the partial sums of every job, read once
         return sum(4 * j.ncol * j.groups[k] for j in a[0][:a[1]] for k in range(j.nseg))
     if name == "sei_ln_fwd_bf16_pad":                     # f32 in, bf16 out (padded row)
@@ -170,9 +172,11 @@ def _stream_bytes(name, a):
         return B * H * W * width * (2 if bf16 else 4) * (8 if bwd else 4)
     if name == "sei_sepmap2_bf16_pack":
         return 0
-    if name in ("sei_sepmap2_packed", "sei_sepmap2_bf16"):
-        B, Hi, Wi, Ho, Wo, C = a[2:8]
+    if name in ("sei_sepmap2_packed", "sei_sepmap2_bf16", "sei_sepmap2_big"):
+        B, Hi, Wi, Ho, Wo, C = a[2:8]                     # (algorithmic: x in, y out; the bf16 intermediate of _big is its own)
         return 4 * B * C * (Hi * Wi + Ho * Wo)
+    if name == "sei_sepmap2_big_pack":
+        return 0
     if name == "sei_cast_transpose_bf16":
         return 6 * a[4] * a[5]
     if name == "sei_cast_bf16":
@@ -221,6 +225,8 @@ def _stream_bytes(name, a):
         return 4 * B * C * (Hi * Wi + H * W)
     if name == "sei_resample_sepband":
         return 4 * a[2] * (a[3] * a[4] + a[5] * a[6])
+    if name == "sei_scale_params":
+        return 24 * a[4]
     if name == "sei_axpy":
         return 12 * a[4]
     if name == "sei_sure_terms":
@@ -247,7 +253,7 @@ _STREAM_FAMILIES = [
     ("cast / colsum kernels (bf16 copies, bias gradients)", ("sei_cast_", "sei_colsum_")),
     ("conv3x3_* (in / out convolutions)", ("sei_conv3x3_",)),
     ("blur / scale_resample / axpy / sure / mse kernels (physics + loss terms)",
-     ("sei_blur_", "sei_scale_resample_", "sei_axpy", "sei_sure_terms", "sei_mse_terms", "sei_resample_")),
+     ("sei_blur_", "sei_scale_resample_", "sei_scale_params", "sei_axpy", "sei_sure_terms", "sei_mse_terms", "sei_resample_")),
 ]
 PMC_TRAFFIC_FILE = "r03_d_unet_pmc_gemm.json"      # the committed PMC pass `roofline.traffic` is read from
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)

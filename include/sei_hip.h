@@ -373,6 +373,18 @@ int sei_sepmap2_bf16_pack(const float *L1, const float *R1, const float *L2, con
                           int Wi, int Ho, int Wo, void *stream);
 size_t sei_sepmap2_bf16_eligible(int B, int Hi, int Wi, int Ho, int Wo, int C);
 size_t sei_sepmap2_bf16_pack_elems(int Hi, int Wi, int Ho, int Wo);
+/* The same map at LARGE extents (Hi or Wi in 65 .. 256: the x4 network's 96- and 192-pixel levels, the un-cropped 256-pixel
+ * series) on the matrix cores (csrc/sepmap_big.hip): both products as one batched constant-matrix GEMM kernel -- the matrix
+ * (bf16 head + remainder) in registers, the activations streamed once through LDS -- with a bf16 intermediate in `work`
+ * (sei_sepmap2_big_work_elems uint16). `packed` (sei_sepmap2_big_pack_elems uint16) from sei_sepmap2_big_pack, once per
+ * map. sei_sepmap2_big_eligible != 0 says which shapes are built (C % 16 == 0); others stay on sei_sepmap2_packed. */
+size_t sei_sepmap2_big_eligible(int B, int Hi, int Wi, int Ho, int Wo, int C);
+size_t sei_sepmap2_big_pack_elems(int Hi, int Wi, int Ho, int Wo);
+size_t sei_sepmap2_big_work_elems(int B, int Hi, int Wi, int Ho, int Wo, int C);
+int sei_sepmap2_big_pack(const float *L1, const float *R1, const float *L2, const float *R2, uint16_t *packed,
+                         int Hi, int Wi, int Ho, int Wo, void *stream);
+int sei_sepmap2_big(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C, const uint16_t *packed,
+                    uint16_t *work, void *stream);
 int sei_sepmap2_packed(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
                        const float *RW, const float *LH, float *work, size_t work_floats, void *stream);
 

@@ -70,6 +70,8 @@ SIGNATURES = {
     "sei_gemm_bf16nt_dw2_bf16out": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "sei_gemm_bf16nt_dw2_taps": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "sei_sepmap2": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P],
+    "sei_sepmap2_big_pack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sei_sepmap2_big": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "sei_sepmap2_packed": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P],
     "sei_sepmap2_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "sei_sepmap2_bf16_pack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -141,6 +143,9 @@ SIZE_QUERIES = {
     "sei_dwconv7_ln_fwd_launches": [_I, _I, _I, _I],
     "sei_sepmap2_bf16_eligible": [_I, _I, _I, _I, _I, _I],
     "sei_sepmap2_bf16_pack_elems": [_I, _I, _I, _I],
+    "sei_sepmap2_big_eligible": [_I, _I, _I, _I, _I, _I],
+    "sei_sepmap2_big_pack_elems": [_I, _I, _I, _I],
+    "sei_sepmap2_big_work_elems": [_I, _I, _I, _I, _I, _I],
     "sei_swin_partials_floats": [_I],
     "sei_tokgrad_bf16_eligible": [_I, _I, _I, _I, _L, _L],
     "sei_dwstream_bf16_eligible": [_I, _I, _I, _I, _L, _L],

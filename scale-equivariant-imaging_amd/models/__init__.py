@@ -19,12 +19,23 @@ from .convolutional import ConvolutionalModel
 from .swinir import SwinIR
 
 _OUT_OF_SCOPE = ("DeepImagePrior", "PlugAndPlay", "BM3D", "DiffPIR_DRUNet", "DiffPIR_DiffUNet", "DPS", "TV",
-                 "InverseFilter", "Upsample")
+                 "Upsample")
 
 
 class Identity(Module):
     def forward(self, y):
         return y
+
+
+class InverseFilter(Module):
+    """The least-squares pseudo-inverse of the physics as a "model" (reference :22-28): physics.A_dagger(y)."""
+
+    def __init__(self, physics):
+        super().__init__()
+        self.physics = physics
+
+    def forward(self, y):
+        return self.physics.A_dagger(y)
 
 
 class ProposedModel(Module):
@@ -65,6 +76,8 @@ class Model(Module):
                                        **blueprint[ProposedModel.__name__])
         elif kind == "Identity":
             self.model = Identity()
+        elif kind == "InverseFilter":
+            self.model = InverseFilter(physics=physics)
         elif kind in _OUT_OF_SCOPE:
             raise NotImplementedError(f"model kind {kind!r} is an evaluation baseline outside the training "
                                       "hot path this build implements")

@@ -232,9 +232,18 @@ def sepmap2_16(x, mats, Ho, Wo):
     """sepmap2 in the bf16 throughput mode: on the matrix cores where the shape is eligible (sei_sepmap2_bf16:
     activations rounded to bf16, matrices as bf16 head + remainder, f32 accumulation), else the f32 kernels."""
     B, Hi, Wi, C = x.shape
-    if _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_bf16_eligible(B, Hi, Wi, Ho, Wo, C):
+    big = _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_big_eligible(B, Hi, Wi, Ho, Wo, C)
+    if not big and _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_bf16_eligible(B, Hi, Wi, Ho, Wo, C):
         y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
         N.call("sei_sepmap2_bf16", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, _packed16(mats).data_ptr())
+        return y
+    if big:
+        # extents beyond one workgroup's LDS (the x4 network's 96- / 192-pixel levels, 256-pixel inputs): two launches of
+        # the constant-matrix GEMM kernel with a bf16 intermediate
+        y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        work = torch.empty(N.lib().sei_sepmap2_big_work_elems(B, Hi, Wi, Ho, Wo, C), dtype=torch.int16, device=x.device)
+        N.call("sei_sepmap2_big", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, _packed16(mats, big=True).data_ptr(),
+               work.data_ptr())
         return y
     return sepmap2(x, mats, Ho, Wo)
 
@@ -242,15 +251,17 @@ def sepmap2_16(x, mats, Ho, Wo):
 _PACKED16 = {}
 
 
-def _packed16(mats):
-    """The map's matrices in sei_sepmap2_bf16's image (bf16 head + remainder), packed once per matrix set."""
+def _packed16(mats, big=False):
+    """The map's matrices in sei_sepmap2_bf16's (big: sei_sepmap2_big's) image (bf16 head + remainder), packed once per
+    matrix set."""
     L1, R1, L2, R2 = mats[:4]
-    key = (L1.data_ptr(), R1.data_ptr(), L2.data_ptr(), R2.data_ptr(), tuple(L1.shape), tuple(R1.shape))
+    key = (L1.data_ptr(), R1.data_ptr(), L2.data_ptr(), R2.data_ptr(), tuple(L1.shape), tuple(R1.shape), big)
     hit = _PACKED16.get(key)
     if hit is None:
         (Ho, Hi), (Wo, Wi) = L1.shape, R1.shape
-        out = torch.empty(N.lib().sei_sepmap2_bf16_pack_elems(Hi, Wi, Ho, Wo), dtype=torch.int16, device=L1.device)
-        N.call("sei_sepmap2_bf16_pack", L1.data_ptr(), R1.data_ptr(), L2.data_ptr(), R2.data_ptr(), out.data_ptr(), Hi, Wi,
+        kind = "sei_sepmap2_big" if big else "sei_sepmap2_bf16"
+        out = torch.empty(getattr(N.lib(), kind + "_pack_elems")(Hi, Wi, Ho, Wo), dtype=torch.int16, device=L1.device)
+        N.call(kind + "_pack", L1.data_ptr(), R1.data_ptr(), L2.data_ptr(), R2.data_ptr(), out.data_ptr(), Hi, Wi,
                Ho, Wo)
         hit = _PACKED16[key] = (out, L1, R1, L2, R2)          # (keeps the sources alive: the key holds their addresses)
     return hit[0]

@@ -159,6 +159,38 @@ def test_physics_manager_surface(phys):
         phys.get_kernel("Gaussian_R7")
 
 
+def test_pseudo_inverse_and_the_inverse_filter_model(phys):
+    """LinearPhysics.A_dagger (deepinv v0.2.0's conjugate-gradient least squares, restated: UNPINNED) on the HIP blur and
+    downsampling operators, and the `InverseFilter` model kind built on it (/root/reference/src/models/__init__.py:22-28,
+    135-136): for the Gaussian_R1 blur (condition number ~150: conjugate gradients on the normal equations converge
+    slowly) the normal equations' residual falls below 1 % within 400 iterations and A(A_dagger(y)) returns y; for the x2
+    downsampler A(A_dagger(y)) returns y (the minimum-norm solution of an under-determined system)."""
+    import argparse
+    import models
+    args = argparse.Namespace(task="deblurring", kernel="Gaussian_R1", sr_factor=None, noise_level=0, physics_v2=True,
+                              physics_true_adjoint=True, model_kind="InverseFilter", ProposedModel__architecture="Convolutional",
+                              ConvolutionalModel__residual=True, ConvolutionalModel__inner_residual=True,
+                              ConvolutionalModel__num_conv_blocks=1, ConvolutionalModel__inout_convs=True,
+                              ConvolutionalModel__hidden_channels=8, ConvolutionalModel__scales=2, data_parallel_devices=None)
+    gen = torch.Generator().manual_seed(11)
+    x = torch.rand((2, 3, 24, 24), generator=gen).cuda()
+    p = phys.get_physics(args, device="cuda")
+    p.max_iter, p.tol = 400, 1e-6
+    model = models.get_model(args, p, "cuda")
+    y = p.A(x)
+    xd = model(y)
+    assert xd.shape == x.shape
+    r = p.A_adjoint(p.A(xd) - y)                                   # the normal equations' residual
+    assert float(r.norm() / p.A_adjoint(y).norm()) < 1e-2
+    assert relerr(p.A(xd), y) < 1e-2
+    args.task, args.sr_factor = "sr", 2
+    p = phys.get_physics(args, device="cuda")
+    p.max_iter, p.tol = 200, 1e-6
+    y = p.A(torch.rand((2, 3, 32, 32), generator=gen).cuda())
+    xd = p.A_dagger(y)
+    assert xd.shape == (2, 3, 32, 32) and relerr(p.A(xd), y) < 1e-3
+
+
 # ------------------------------------------------------------------ EI scale transform
 @pytest.mark.parametrize("tag", ["b4s48", "b2s96", "b1s20"])
 def test_scale_transform_vs_golden(golden, tag):

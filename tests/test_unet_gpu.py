@@ -246,7 +246,7 @@ def test_resampler_on_the_matrix_cores(ops, kind, B, H, W, C):
         assert torch.equal(y16, ops.sepmap2_16(xin, mats, ho, wo))
     assert _native.lib().sei_sepmap2_bf16_eligible(2, 6, 6, 12, 12, 2048) == 0     # small levels stay on the f32 kernels
     assert _native.lib().sei_sepmap2_bf16_eligible(2, 12, 12, 24, 24, 512) == 0
-    assert _native.lib().sei_sepmap2_bf16_eligible(2, 96, 96, 192, 192, 128) == 0  # the x4 network's fine levels too
+    assert _native.lib().sei_sepmap2_bf16_eligible(2, 96, 96, 192, 192, 128) == 0  # the x4 network's fine levels: sei_sepmap2_big
 
 
 @pytest.mark.parametrize("B,H,W,C", DW_SHAPES[:6])
@@ -810,6 +810,44 @@ def test_layernorm_fwd_bf16_output(ops, rows, C):
     assert float((y16.double().cpu() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) + 1e-6
     assert relerr(mean, x.double().mean(1)) < 1e-5
     assert relerr(rstd, 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-6)) < 1e-5
+
+
+@pytest.mark.parametrize("kind,B,H,W,C", [("down", 2, 192, 192, 32), ("up", 2, 96, 96, 128), ("down", 3, 96, 96, 128),
+                                          ("down", 1, 256, 256, 32), ("up", 1, 128, 128, 128), ("down", 2, 96, 128, 48),
+                                          ("up", 70, 96, 96, 16), ("up", 2, 48, 48, 128), ("up", 2, 64, 64, 32)])
+def test_resampler_on_the_matrix_cores_at_large_extents(ops, kind, B, H, W, C):
+    """sei_sepmap2_big (csrc/sepmap_big.hip: both products of Ideal{Down,Up}sample as one batched constant-matrix GEMM
+    kernel, bf16 intermediate; the 96- / 192-pixel levels of the x4 network, the 256-pixel inputs of the un-cropped
+    series; reference src/models/convolutional.py:54-133) against the f32 kernel and float64 on the matrices of
+    models/_mats.py, forward and transposed maps: the same bars as the small-extent kernel (a few bf16 roundings of the
+    data; the matrices are head + remainder). Non-square images, a channel count that leaves a 48-wide last tile, more items
+    than workgroups; bitwise repeatable (no atomics)."""
+    import _native
+    from models import _mats
+    fwd, bwd = _mats.resample_matrices(kind, H, W, 2, "cuda")
+    gen = torch.Generator().manual_seed(B + H + C)
+    x = torch.randn((B, H, W, C), generator=gen).cuda()
+    Ho, Wo = fwd[0].shape[0], fwd[1].shape[0]
+    ran = 0
+    for mats, xin, ho, wo in ((fwd, x, Ho, Wo), (bwd, torch.randn((B, Ho, Wo, C), generator=gen).cuda(), H, W)):
+        if not _native.lib().sei_sepmap2_big_eligible(xin.shape[0], xin.shape[1], xin.shape[2], ho, wo, C):
+            continue                                        # (a transposed map whose input is small enough for sei_sepmap2_bf16)
+        ran += 1
+        y16 = ops.sepmap2_16(xin, mats, ho, wo)
+        y32 = ops.sepmap2(xin, mats, ho, wo)
+        L1, R1, L2, R2 = (m.double().cpu() for m in mats[:4])
+        xd = xin.double().cpu()
+        ref = torch.einsum("pi,bijc,qj->bpqc", L1, xd, R1) + torch.einsum("pi,bijc,qj->bpqc", L2, xd, R2)
+        assert relerr(y32, ref) < 5e-6
+        scale = float(ref.abs().max())
+        err = float((y16.double().cpu() - ref).abs().max()) / scale
+        assert err < 1.5e-2, err
+        rms = float((y16.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        assert rms < 4e-3, rms
+        assert torch.equal(y16, ops.sepmap2_16(xin, mats, ho, wo))
+    assert ran >= 1
+    assert _native.lib().sei_sepmap2_big_eligible(2, 48, 48, 24, 24, 128) == 0      # small extents: sei_sepmap2_bf16's
+    assert _native.lib().sei_sepmap2_big_eligible(2, 96, 96, 48, 48, 3) == 0        # the x4 pre-upsampler's 3 channels
 
 
 @pytest.mark.parametrize("twice", [False, True])
