@@ -567,7 +567,8 @@ size_t sei_tokgrad_bf16_eligible(int Mo, int Ni, int ldy, int ldx, long long K1,
  * (ConvBlock.conv2 / conv3), :106 (Upsample) and :143 (Downsample) where (Mo, Ni) is (128, 256 k) / (256 k, 128), k <= 4,
  * with K1, K2 multiples of 64, or (32, 128) / (128, 32) with K1, K2 multiples of 128; sei_dwstream_bf16_eligible() != 0
  * says so, sei_gemm_bf16nt_dw2 serves everything else. Y (K, ldy == Mo) and X (K, ldx == Ni) are bf16, pixel-major as
- * stored, in two row segments (the step's two model calls; K2 = 0: one). D is ADDED to with float atomics. */
+ * stored, in two row segments (the step's two model calls; K2 = 0: one). D is ADDED to with float atomics; so is gbias
+ * (the bias gradient = the column sums of Y, from one more MFMA per fragment against a fragment of ones). */
 #define SEI_DWSTREAM_MAX_JOBS 64
 typedef struct SeiDwStreamJob {
     const uint16_t *Y1, *Y2;         /* (K1, ldy) / (K2, ldy) bf16; Y2 unused when K2 = 0 */
@@ -576,6 +577,7 @@ typedef struct SeiDwStreamJob {
     float *D;
     int ldd, reserved;
     long long K1, K2;
+    float *gbias;                    /* NULL, or (Mo): += the column sums of Y over all K1 + K2 pixels (the convolution's bias gradient) */
 } SeiDwStreamJob;
 int sei_dwstream_bf16_jobs(const SeiDwStreamJob *jobs, int njobs, void *stream);
 size_t sei_dwstream_bf16_eligible(int Mo, int Ni, int ldy, int ldx, long long K1, long long K2);

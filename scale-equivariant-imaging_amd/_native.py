@@ -120,7 +120,7 @@ class TokGradBlock(_c.Structure):
 class DwStreamJob(_c.Structure):
     """SeiDwStreamJob of include/sei_hip.h (one weight gradient of a sei_dwstream_bf16_jobs table)."""
     _fields_ = [("Y1", _P), ("Y2", _P), ("X1", _P), ("X2", _P), ("ldy", _I), ("ldx", _I), ("Mo", _I), ("Ni", _I),
-                ("D", _P), ("ldd", _I), ("reserved", _I), ("K1", _L), ("K2", _L)]
+                ("D", _P), ("ldd", _I), ("reserved", _I), ("K1", _L), ("K2", _L), ("gbias", _P)]
 
 
 DWSTREAM_MAX_JOBS = 64

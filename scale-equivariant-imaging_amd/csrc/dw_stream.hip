@@ -44,6 +44,7 @@ constexpr int DS_MAX_UNITS = 40;
 struct DwUnit {                    // one block of one gradient
     const unsigned short *P1, *P2, *Q1, *Q2;   // the two row segments of each operand (rows = pixels, or pixel pairs)
     float *D;                      // the block's first element of the gradient
+    float *bias;                   // NULL, or where this unit ADDS the column sums of its gy columns (the bias gradient)
     int ldp, ldq;                  // row strides in elements (of the rows as this kernel reads them)
     int q0;                        // first Q column of the block
     int ldd;                       // row stride of the gradient
@@ -125,6 +126,15 @@ __device__ __forceinline__ void dw_stream_body(const DwUnit &u, int worker, int 
 #pragma unroll
         for (int b = 0; b < BB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool works = !PAIR || wr == wc;                           // PAIR: the diagonal quadrants only (wave-uniform)
+    // Bias gradient = the column sums of gy = gy^T 1: one more MFMA per A fragment against a fragment of ones (gy is the
+    // MFMA's A operand in both orientations). Of the waves that hold the same gy tiles only one keeps the sums.
+    const bool sums = u.bias != nullptr && works && (PAIR || (SWAP ? wr == 0 : wc == 0));
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    f32x4 accb[AB];
+#pragma unroll
+    for (int a = 0; a < AB; ++a) accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // Every iteration issues one stage (past the end: the last k-tile again, into a stage nobody reads), so the counted
     // wait below always leaves exactly the NPW pieces of the next stage in flight.
@@ -155,6 +165,11 @@ __device__ __forceinline__ void dw_stream_body(const DwUnit &u, int worker, int 
                 for (int b = 0; b < BB; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SWAP ? fq[a] : fp[a], SWAP ? fp[b] : fq[b],
                                                                         acc[a][b], 0, 0, 0);
+            if (sums) {                                             // wave-uniform
+#pragma unroll
+                for (int a = 0; a < AB; ++a)
+                    accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(SWAP ? fq[a] : fp[a], ones, accb[a], 0, 0, 0);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the two clamped stages still in flight
@@ -173,6 +188,13 @@ __device__ __forceinline__ void dw_stream_body(const DwUnit &u, int worker, int 
         for (int b = 0; b < BB; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) atomicAdd(d + (size_t)(16 * a + r) * u.ldd + 16 * b, acc[a][b][r]);
+    if (sums && l16 == 0) {                                         // every column of accb holds the same sums
+        float *bp = u.bias + (SWAP ? q_base : p_base) + 4 * lg;
+#pragma unroll
+        for (int a = 0; a < AB; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(bp + 16 * a + r, accb[a][r]);
+    }
 }
 
 // Every unit of a job table in ONE launch, whatever its block shape: the workgroups of a launch are dealt to ALL units, so
@@ -277,6 +299,9 @@ extern "C" int sei_dwstream_bf16_jobs(const SeiDwStreamJob *jobs, int njobs, voi
             u.q0 = 256 * b;
             // the block's corner: not SWAP: columns q0 of D; SWAP: rows q0 of D
             u.D = swap ? j.D + (size_t)(256 * b) * j.ldd : j.D + 256 * b;
+            // gy's column sums: SWAP: gy is the wide operand, every block owns 256 of its columns; else the narrow one,
+            // which every block of the job reads whole: the first block alone adds
+            u.bias = !j.gbias ? nullptr : (swap ? j.gbias + 256 * b : (b == 0 ? j.gbias : nullptr));
             u.ldd = j.ldd;
             u.kt_seg = (int)(j.K1 / rows);
             u.kt_total = (int)((j.K1 + j.K2) / rows);

@@ -576,7 +576,7 @@ def _fresh_state():
     return {"uses": 0, "arrivals": {}, "parked": {}, "written": set(), "store": False, "store_min": 0,
             "flush_queued": False, "merge": True, "seen": {}, "milestone": None, "milestone_done": False,
             "adam": None, "adam_launched": set(), "direct16": None, "direct16_launched": set(), "flops_per_row": {},
-            "taps": {}, "merged_ok": {}, "folds": {}, "dwjobs": []}
+            "taps": {}, "merged_ok": {}, "folds": {}, "dwjobs": [], "bias_of": {}}
 
 
 class WeightGradState:
@@ -777,6 +777,17 @@ def merged_weight_grads(owner=None):
 
 
 def _launch_weight_grad_inner(_DW, grad2d, pairs, store):
+    """(weight_grad16(..., bias=): the bias gradient = gy's column sums rides in the streamed launch where that serves the
+    weight, else it is summed here, one column-sum launch per pair.)"""
+    bias = _DW["bias_of"].pop(grad2d.data_ptr(), None)
+    if bias is not None and not (not store and _dwstream_ok(grad2d, pairs)):
+        for gy16, _ in pairs:
+            colsum16_into(bias, gy16)
+        bias = None
+    _launch_weight_grad_inner2(_DW, grad2d, pairs, store, bias)
+
+
+def _launch_weight_grad_inner2(_DW, grad2d, pairs, store, bias):
     key = grad2d.data_ptr()
     Np, Kp = grad2d.shape[-2:]
     _DW["merged_ok"][key] = (len(pairs) == 2 and len(pairs) == _DW["uses"]
@@ -820,8 +831,9 @@ def _launch_weight_grad_inner(_DW, grad2d, pairs, store):
                    x2.data_ptr(), Kp, grad2d.data_ptr(), Np, Kp, K1, K2, 0 if store else 1, T, taps, Np * Kp)
         return
     per_row = _DW["flops_per_row"].get(key) or 2.0 * Np * Kp
-    if not store and _queue_dwstream(_DW, grad2d, pairs, per_row):
+    if not store and _queue_dwstream(_DW, grad2d, pairs, per_row, bias):
         return
+    assert bias is None
     if len(pairs) == 2:
         (g1, x1), (g2, x2) = pairs
         K1, K2 = g1.shape[0], g2.shape[0]
@@ -847,7 +859,8 @@ def _launch_weight_grad_inner(_DW, grad2d, pairs, store):
 DWSTREAM = os.environ.get("SEI_NO_DWSTREAM") != "1"
 
 
-def _queue_dwstream(_DW, grad2d, pairs, per_row):
+def _dwstream_ok(grad2d, pairs):
+    """The streamed launch serves this weight gradient (shapes, layouts, pixel counts)."""
     if not DWSTREAM or not grad2d.is_cuda or grad2d.dim() != 2 or grad2d.dtype != torch.float32 or len(pairs) > 2:
         return False
     Np, Kp = grad2d.shape
@@ -859,12 +872,19 @@ def _queue_dwstream(_DW, grad2d, pairs, per_row):
             return False
     K1 = pairs[0][0].shape[0]
     K2 = pairs[1][0].shape[0] if len(pairs) == 2 else 0
-    if not N.lib().sei_dwstream_bf16_eligible(Np, Kp, Np, Kp, K1, K2):
+    return N.lib().sei_dwstream_bf16_eligible(Np, Kp, Np, Kp, K1, K2) != 0
+
+
+def _queue_dwstream(_DW, grad2d, pairs, per_row, bias=None):
+    if not _dwstream_ok(grad2d, pairs):
         return False
+    Np, Kp = grad2d.shape
+    K1 = pairs[0][0].shape[0]
+    K2 = pairs[1][0].shape[0] if len(pairs) == 2 else 0
     (g1, x1), (g2, x2) = pairs[0], pairs[-1]
     job = N.DwStreamJob(g1.data_ptr(), g2.data_ptr(), x1.data_ptr(), x2.data_ptr(), Np, Kp, Np, Kp, grad2d.data_ptr(),
-                        grad2d.stride(0), 0, K1, K2)
-    _DW["dwjobs"].append((job, (g1, x1, g2, x2, grad2d), per_row * (K1 + K2)))
+                        grad2d.stride(0), 0, K1, K2, N.ptr(bias))
+    _DW["dwjobs"].append((job, (g1, x1, g2, x2, grad2d, bias), per_row * (K1 + K2)))
     if len(_DW["dwjobs"]) == N.DWSTREAM_MAX_JOBS or not _queue_flush(_DW):
         flush_dwstream(_DW)
     return True
@@ -893,7 +913,7 @@ def flush_weight_grads(owner=None, _state=None):
     flush_folds(_DW)
 
 
-def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None):
+def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None, bias=None):
     """grad (N', K') += gy^T x, gy16 (M, N') and x16 (M, K') bf16 as stored: both read reduction-major.
     May park the pair until the step's other model call reaches the same weight (see above). flops_per_row: the
     algorithmic FLOPs per reduction row to book for the roofline leg when the operands are zero-padded (2 N' K').
@@ -904,6 +924,8 @@ def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None):
     _DW = _state_for(key)
     _DW["seen"][key] = grad2d.numel()
     _DW["flops_per_row"][key] = flops_per_row
+    if bias is not None:                   # (M,)-shaped float32 gradient: += gy's column sums, with the weight's launch
+        _DW["bias_of"][key] = bias
     if tap_rows is not None:
         _DW["taps"][key] = tap_rows
     else:
@@ -1125,10 +1147,15 @@ class ConvBlockFn16(torch.autograd.Function):
         N.call("sei_mlp_fused_bwd", *args)
         if _GEMM_PROFILE is not None:                   # booked as the two data-gradient GEMMs it replaces
             _GEMM_PROFILE.append((4.0 * M * 4 * C * C, "sei_mlp_fused_bwd", args))
-        colsum_into(grad_of(b3), go.view(M, C))
-        colsum16_into(grad_of(b2), gh3)
-        weight_grad16(go16, h4, grad_of(w3).view(C, 4 * C))
-        weight_grad16(gh3, h2, grad_of(w2).view(4 * C, C))
+        if DWSTREAM and N.lib().sei_dwstream_bf16_eligible(C, 4 * C, C, 4 * C, M, 0):
+            # the bias gradients = column sums of go16 / gh3 ride in the streamed weight-gradient launch
+            weight_grad16(go16, h4, grad_of(w3).view(C, 4 * C), bias=grad_of(b3))
+            weight_grad16(gh3, h2, grad_of(w2).view(4 * C, C), bias=grad_of(b2))
+        else:                                           # ragged pixel counts: the column-sum kernels (go in float32)
+            colsum_into(grad_of(b3), go.view(M, C))
+            colsum16_into(grad_of(b2), gh3)
+            weight_grad16(go16, h4, grad_of(w3).view(C, 4 * C))
+            weight_grad16(gh3, h2, grad_of(w2).view(4 * C, C))
         gh1 = layer_norm_bwd(h1.view(M, C), gamma, mean, rstd, gh2, grad_of(gamma), grad_of(beta)).view(B, H, W, C)
         dwconv7_weight_grad(x, gh1, grad_of(w1), grad_of(b1))
         gx = None

@@ -890,7 +890,9 @@ def test_fused_mlp_block_matches_the_unfused_bf16_block(ops, B, H, W, C, twice):
         assert relerr(res["fused"][0], res["plain"][0]) < 1e-5
         assert relerr(res["fused"][1], res["plain"][1]) < 2e-3
         for a, b in zip(res["fused"][2], res["plain"][2]):
-            assert relerr(a, b) < 2e-3
+            # (1-D entries: bias gradients. Where the streamed launch serves the weight, conv3's bias gradient is summed from
+            # the bf16 copy of go -- the operand of its weight gradient -- instead of the float32 go: ~2^-8 per term)
+            assert relerr(a, b) < (5e-3 if a.dim() == 1 else 2e-3)
         # float64 evaluation of the same block
         ps = [p.detach().double().cpu().requires_grad_(True) for p in params()]
         with torch.no_grad():
@@ -1080,7 +1082,7 @@ def test_streamed_weight_gradients_of_the_shallow_levels(K1, K2):
     """sei_dwstream_bf16_jobs (autograd's weight gradient gy^T x of the 1x1 convolutions of reference
     src/models/convolutional.py:40-42,106,143 at the 32- and 128-channel levels; both operands pixel-major as stored, the
     step's two model calls as two segments) against the float32 product of the same bf16 operands, on top of a running
-    gradient: every block shape the kernel builds -- (128, 512), (512, 128), (128, 256), (32, 128), (128, 32): narrow
+    gradient (and, where asked, the bias gradient = gy's column sums from the same launch): every block shape the kernel builds -- (128, 512), (512, 128), (128, 256), (32, 128), (128, 32): narrow
     operand first or second, 256-column blocks, pixel pairs read as one row -- each as a table of its own and all of them in
     ONE table; from a single k-tile (most workgroups idle) to more k-tiles than workgroups. The tiled GEMM it replaces
     agrees to the float summation order; shapes the kernel does not build are refused."""
@@ -1093,11 +1095,14 @@ def test_streamed_weight_gradients_of_the_shallow_levels(K1, K2):
         base = torch.randn((Mo, Ni), device="cuda", generator=gen)
         ref = base + sum(g.float().T @ x.float() for g, x in zip(gys, xs))
         assert N.lib().sei_dwstream_bf16_eligible(Mo, Ni, Mo, Ni, K1, K2) != 0
-        job = lambda d: N.DwStreamJob(gys[0].data_ptr(), gys[-1].data_ptr(), xs[0].data_ptr(), xs[-1].data_ptr(), Mo, Ni,
-                                      Mo, Ni, d.data_ptr(), Ni, 0, K1, K2)
-        d = base.clone()
-        N.call("sei_dwstream_bf16_jobs", (N.DwStreamJob * 1)(job(d)), 1)
+        bbase = torch.randn(Mo, device="cuda", generator=gen)
+        bref = bbase + sum(g.float().sum(0) for g in gys)                 # the bias gradient: gy's column sums
+        job = lambda d, bg=None: N.DwStreamJob(gys[0].data_ptr(), gys[-1].data_ptr(), xs[0].data_ptr(), xs[-1].data_ptr(),
+                                               Mo, Ni, Mo, Ni, d.data_ptr(), Ni, 0, K1, K2, N.ptr(bg))
+        d, bg = base.clone(), bbase.clone()
+        N.call("sei_dwstream_bf16_jobs", (N.DwStreamJob * 1)(job(d, bg)), 1)
         assert relerr(d, ref) < 2e-5, (Mo, Ni, relerr(d, ref))
+        assert relerr(bg, bref) < 2e-5, (Mo, Ni, relerr(bg, bref))
         if K2 and (K1 + K2) % 8 == 0:                       # the launch it replaces
             t = base.clone()
             N.call("sei_gemm_bf16nt_dw2", gys[0].data_ptr(), gys[1].data_ptr(), Mo, xs[0].data_ptr(), xs[1].data_ptr(), Ni,
