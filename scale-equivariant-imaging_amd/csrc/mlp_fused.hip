@@ -340,7 +340,10 @@ extern "C" int sei_mlp_fused_fwd(const uint16_t *h2, const uint16_t *W2, const f
     SEI_REQUIRE(h2 && W2 && b2 && W3 && b3 && x && out && M > 0 && (C == 32 || C == 128));
     SEI_REQUIRE((((uintptr_t)h2 | (uintptr_t)W2 | (uintptr_t)W3) & 15) == 0);
     hipStream_t s = (hipStream_t)stream;
-    if (sei_mlp128_eligible(M, C)) return sei_mlp128_fwd_launch(h2, W2, b2, W3, b3, x, res_scale, out, M, s);
+    if (sei_mlp128_eligible(M, C)) {
+        SEI_REQUIRE((((uintptr_t)x | (uintptr_t)out) & 15) == 0);
+        return sei_mlp128_fwd_launch(h2, W2, b2, W3, b3, x, res_scale, out, M, C, s);
+    }
     if (C == 32)
         hipLaunchKernelGGL((mlp_fwd_kernel<32, 2>), dim3(mlp_grid(M, 64 * WAVES)), dim3(THREADS), 0, s, h2, W2, b2, W3, b3,
                            x, res_scale, out, M);
@@ -359,7 +362,7 @@ extern "C" int sei_mlp_fused_bwd(const float *go, const uint16_t *h2, const uint
     hipStream_t s = (hipStream_t)stream;
     if (sei_mlp128_eligible(M, C)) {
         SEI_REQUIRE((((uintptr_t)gh2 | (uintptr_t)go) & 15) == 0);
-        return sei_mlp128_bwd_launch(go, h2, W2, b2, W3T, W2T, gh2, go16, h4, gh3, M, s);
+        return sei_mlp128_bwd_launch(go, h2, W2, b2, W3T, W2T, gh2, go16, h4, gh3, M, C, s);
     }
     if (C == 32)
         hipLaunchKernelGGL((mlp_bwd_kernel<32, 2>), dim3(mlp_grid(M, 64 * WAVES)), dim3(THREADS), 0, s, go, h2, W2, b2, W3T,

@@ -96,9 +96,9 @@ __device__ __forceinline__ float sei_adam_element(float pi, float gi, float &mi,
 // dispatches to it from the sei_mlp_fused_* entry points)
 bool sei_mlp128_eligible(int M, int C);
 int sei_mlp128_fwd_launch(const uint16_t *h2, const uint16_t *W2, const float *b2, const uint16_t *W3, const float *b3,
-                          const float *x, float res_scale, float *out, int M, hipStream_t s);
+                          const float *x, float res_scale, float *out, int M, int C, hipStream_t s);
 int sei_mlp128_bwd_launch(const float *go, const uint16_t *h2, const uint16_t *W2, const float *b2, const uint16_t *W3T,
-                          const uint16_t *W2T, float *gh2, uint16_t *go16, uint16_t *h4, uint16_t *gh3, int M,
+                          const uint16_t *W2T, float *gh2, uint16_t *go16, uint16_t *h4, uint16_t *gh3, int M, int C,
                           hipStream_t s);
 
 // dwconv_pipe.hip: the pipelined depthwise 7x7 kernel (internal linkage between translation units, not part of the ABI)
