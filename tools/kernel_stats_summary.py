@@ -9,7 +9,7 @@ import re
 import shutil
 import sys
 
-FAMILIES = [("GEMM", r"gemm_|tokgrad"), ("Adam", r"adam_"), ("resampler maps", r"sepmap"), ("LayerNorm", r"ln_"),
+FAMILIES = [("GEMM", r"gemm_|tokgrad|dw_stream"), ("Adam", r"adam_"), ("resampler maps", r"sepmap"), ("LayerNorm", r"ln_"),
             ("depthwise 7x7", r"dwconv7"), ("casts / column sums", r"cast|colsum"), ("fills", r"fill|Fill"),
             ("conv3x3", r"conv3x3"), ("window attention", r"swin_attn"),
             ("pad / pack / partial folds", r"pad_nhwc|unpad|pack_kernel|unpack|rowscale|fold_partials|fold_many"), ("fused MLP", r"mlp_")]

@@ -37,6 +37,10 @@ def _first_dispatch(rows):
     return ends[0] - period + 1
 
 
+LONG = None        # (regex, microseconds): dispatches of matching kernels that take longer are booked under "<name> [long]"
+                   # (the HBM-bound bottleneck launches of a kernel whose other launches are MFMA-bound)
+
+
 def load(path, counter):
     d = collections.defaultdict(lambda: [0.0, 0, 0.0])
     rows = list(csv.DictReader(open(path)))
@@ -46,6 +50,8 @@ def load(path, counter):
             continue
         k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         k = re.sub(r"\(.*", "", k)
+        if LONG and re.search(LONG[0], k) and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 1e3 * LONG[1]:
+            k += " [long]"
         d[k][0] += float(r["Counter_Value"])
         d[k][1] += 1
         d[k][2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -56,13 +62,17 @@ def main():
     src, out = sys.argv[1], sys.argv[2]
     title = sys.argv[3] if len(sys.argv) > 3 else "PMC passes of bench.py (bf16, eager launches, 3 steps)"
     exclude = re.compile(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] else None   # kernels kept out of the GEMM family
-    global WINDOW
-    WINDOW = sys.argv[5] if len(sys.argv) > 5 else None
+    global WINDOW, LONG
+    WINDOW = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] else None
+    if len(sys.argv) > 6:                                   # "regex@us"
+        pat, us = sys.argv[6].rsplit("@", 1)
+        LONG = (pat, float(us))
     F = load(f"{src}/pmc_FETCH_SIZE/pmc_counter_collection.csv", "FETCH_SIZE")
     W = load(f"{src}/pmc_WRITE_SIZE/pmc_counter_collection.csv", "WRITE_SIZE")
     Mb = load(f"{src}/pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_counter_collection.csv", "SQ_VALU_MFMA_BUSY_CYCLES")
     G = load(f"{src}/pmc_SQ_VALU_MFMA_BUSY_CYCLES/pmc_counter_collection.csv", "GRBM_GUI_ACTIVE")
-    gem = [k for k in F if ("gemm_" in k or "tokgrad" in k or "mlp_fwd" in k or "mlp_bwd" in k) and not (exclude and exclude.search(k))]
+    gem = [k for k in F if ("gemm_" in k or "tokgrad" in k or "mlp_fwd" in k or "mlp_bwd" in k or "mlp128_" in k or "dw_stream" in k)
+           and not (exclude and exclude.search(k))]
     n = sum(F[k][1] for k in gem)
     fetch = sum(F[k][0] for k in gem) * 1024 * 2          # KiB -> B, x2 (gfx950 wide-stream correction)
     write = sum(W[k][0] for k in gem if k in W) * 1024
