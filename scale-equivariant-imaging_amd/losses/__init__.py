@@ -227,6 +227,13 @@ class ProposedLoss(Module):
         # but model(y) and model(y + tau b) share one pass of 2B images.
         B = y.shape[0]
         b = draws["b"] if draws is not None else draw_probe(y, self.sure.div_margin)
+        if self.ei.no_grad and drop is None:
+            # the second model call's input (A T x_net + noise) is a constant: the two calls' backward passes are
+            # independent and the backbone may run them as one (models/_joint.py)
+            backbone = model.get_backbone() if hasattr(model, "get_backbone") else model
+            if getattr(backbone, "flat_grads", None) is not None:
+                from models import _joint
+                _joint.recorder_of(backbone).expect_pair()
         both = calls[0](torch.cat([y, axpy(y, b, self.sure.tau)], dim=0))
         y12 = self.physics.A(both)
         x_net = both[:B]

@@ -33,6 +33,47 @@ def grad_of(p):
 
 
 # ---------------------------------------------------------------------------------------------
+# activations of a RECORDED model call come from the recorder's arena (models/_joint.py: the step's two model calls
+# share one backward pass over 3B-row tensors); everything else is torch.empty
+# ---------------------------------------------------------------------------------------------
+_ARENA = None            # the models._joint.Recorder of the model call being recorded, or None
+
+
+def _alloc(shape, dtype, device):
+    if _ARENA is None:
+        return torch.empty(tuple(shape), dtype=dtype, device=device)
+    return _ARENA.alloc(shape, dtype, device)
+
+
+def _tape(fn, ctx):
+    if _ARENA is not None:
+        _ARENA.record(fn, ctx)
+
+
+def _no_joint_form():
+    """Called by layer functions that have no joint backward (the float32 path, stand-alone resamplers / LayerNorms)."""
+    if _ARENA is not None:
+        _ARENA.unsupported()
+
+
+class recording:
+    """`with recording(recorder):` around a model call: its layer functions allocate from the arena and fill the tape."""
+
+    def __init__(self, rec):
+        self.rec = rec
+
+    def __enter__(self):
+        global _ARENA
+        self.prev, _ARENA = _ARENA, self.rec
+        return self.rec
+
+    def __exit__(self, *exc):
+        global _ARENA
+        _ARENA = self.prev
+        return False
+
+
+# ---------------------------------------------------------------------------------------------
 # thin launch helpers (pointers + sizes only; shapes are checked here, on the host)
 # ---------------------------------------------------------------------------------------------
 _GEMM_PROFILE = None     # bench.py: list of (flops, entry point, ctypes args) recorded while enabled
@@ -136,9 +177,9 @@ def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=Non
 
 def layer_norm(x2d, gamma, beta):
     rows, C = x2d.shape
-    y = torch.empty_like(x2d)
-    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
-    rstd = torch.empty_like(mean)
+    y = _alloc((rows, C), torch.float32, x2d.device)
+    mean = _alloc((rows,), torch.float32, x2d.device)
+    rstd = _alloc((rows,), torch.float32, x2d.device)
     N.call("sei_ln_fwd", x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
            rstd.data_ptr(), rows, C, LN_EPS)
     return y, mean, rstd
@@ -190,10 +231,10 @@ def dwconv7_ln(x, w, bias, gamma, beta, out16, fuse=0):
     form; tests). Returns h1 (f32, NHWC), h2 ((M, C) bf16 when out16 else f32), mean, rstd."""
     B, H, W, C = x.shape
     M = B * H * W
-    h1 = torch.empty_like(x)
-    h2 = torch.empty((M, C), dtype=torch.bfloat16 if out16 else torch.float32, device=x.device)
-    mean = torch.empty(M, dtype=torch.float32, device=x.device)
-    rstd = torch.empty_like(mean)
+    h1 = _alloc((B, H, W, C), torch.float32, x.device)
+    h2 = _alloc((M, C), torch.bfloat16 if out16 else torch.float32, x.device)
+    mean = _alloc((M,), torch.float32, x.device)
+    rstd = _alloc((M,), torch.float32, x.device)
     args = (x.data_ptr(), w.data_ptr(), N.ptr(bias), gamma.data_ptr(), beta.data_ptr(), h1.data_ptr(), h2.data_ptr(),
             int(out16), mean.data_ptr(), rstd.data_ptr(), B, H, W, C, LN_EPS)
     if fuse:
@@ -216,7 +257,7 @@ def sepmap2(x, mats, Ho, Wo):
     """mats: (L1, R1, L2, R2[, RW, LH]) -- the packed pair comes with `_mats.resample_matrices`; a bare 4-tuple
     (tests, experiments) is packed here."""
     B, Hi, Wi, C = x.shape
-    y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    y = _alloc((B, Ho, Wo, C), torch.float32, x.device)
     work = torch.empty(2 * B * Hi * Wo * C, dtype=torch.float32, device=x.device)
     RW, LH = (mats[4], mats[5]) if len(mats) >= 6 else _mats.pack_for_kernel(mats[:4], x.device)
     N.call("sei_sepmap2_packed", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, RW.data_ptr(), LH.data_ptr(),
@@ -234,13 +275,13 @@ def sepmap2_16(x, mats, Ho, Wo):
     B, Hi, Wi, C = x.shape
     big = _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_big_eligible(B, Hi, Wi, Ho, Wo, C)
     if not big and _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_bf16_eligible(B, Hi, Wi, Ho, Wo, C):
-        y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        y = _alloc((B, Ho, Wo, C), torch.float32, x.device)
         N.call("sei_sepmap2_bf16", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, _packed16(mats).data_ptr())
         return y
     if big:
         # extents beyond one workgroup's LDS (the x4 network's 96- / 192-pixel levels, 256-pixel inputs): two launches of
         # the constant-matrix GEMM kernel with a bf16 intermediate
-        y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        y = _alloc((B, Ho, Wo, C), torch.float32, x.device)
         work = torch.empty(N.lib().sei_sepmap2_big_work_elems(B, Hi, Wi, Ho, Wo, C), dtype=torch.int16, device=x.device)
         N.call("sei_sepmap2_big", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, _packed16(mats, big=True).data_ptr(),
                work.data_ptr())
@@ -282,6 +323,7 @@ def _nhwc(x):
 class ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, gamma, beta, w2, b2, w3, b3, twice):
+        _no_joint_form()
         ctx.dtype = get_compute_dtype()
         x = _nhwc(x)
         B, H, W, C = x.shape
@@ -337,6 +379,7 @@ class DownsampleFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, w, b, rate, with_skip=False):
         """with_skip: also return x itself as a second output (the U-Net's skip connection): its gradient then arrives
         HERE, next to the downsampler's, and is added inside the LayerNorm backward instead of by an autograd add."""
+        _no_joint_form()
         ctx.dtype = get_compute_dtype()
         ctx.set_materialize_grads(False)
         x = _nhwc(x)
@@ -377,6 +420,7 @@ class DownsampleFn(torch.autograd.Function):
 class UpsampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, skip, gamma, beta, w, b, rate):
+        _no_joint_form()
         ctx.dtype = get_compute_dtype()
         x = _nhwc(x)
         B, H, W, C = x.shape
@@ -527,9 +571,9 @@ def to_bf16(x):
 
 def layer_norm16(x2d, gamma, beta):
     rows, C = x2d.shape
-    y = torch.empty((rows, C), dtype=torch.bfloat16, device=x2d.device)
-    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
-    rstd = torch.empty_like(mean)
+    y = _alloc((rows, C), torch.bfloat16, x2d.device)
+    mean = _alloc((rows,), torch.float32, x2d.device)
+    rstd = _alloc((rows,), torch.float32, x2d.device)
     N.call("sei_ln_fwd_bf16", x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
            rstd.data_ptr(), rows, C, LN_EPS)
     return y, mean, rstd
@@ -553,7 +597,7 @@ def gemm_mixed(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=No
 def cast16(x2d, colsum_into_=None):
     """f32 (R, C) -> bf16 copy; colsum_into_: accumulate the column sums (a bias gradient) in the same pass."""
     R, C = x2d.shape
-    x16 = torch.empty((R, C), dtype=torch.bfloat16, device=x2d.device)
+    x16 = _alloc((R, C), torch.bfloat16, x2d.device)
     N.call("sei_cast_transpose_bf16", x2d.data_ptr(), 0, x16.data_ptr(), None, R, C, R, N.ptr(colsum_into_))
     return x16
 
@@ -635,6 +679,9 @@ def begin_step(store=False, store_min=0, owner=None):
     first launch of the step into a weight gradient of at least store_min elements stores (it was not zeroed)."""
     _DW = state_of(owner)
     flush_weight_grads(owner)
+    rec = owner.__dict__.get("_sei_joint") if owner is not None else None
+    if rec is not None:
+        rec.reset()
     _DW["uses"] = 0
     _DW["arrivals"].clear()
     _DW["written"].clear()
@@ -930,6 +977,14 @@ def weight_grad16(gy16, x16, grad2d, flops_per_row=None, tap_rows=None, bias=Non
         _DW["taps"][key] = tap_rows
     else:
         _DW["taps"].pop(key, None)          # the address may have belonged to a freed model's tap-major gradient
+    split = _DW.get("joint")
+    if split is not None and tap_rows is None:
+        # one backward pass for the step's two model calls (models/_joint.py): the operands hold both calls' rows -- the
+        # two row segments that two backward functions would otherwise have brought one after the other
+        M1 = gy16.shape[0] * split[0] // (split[0] + split[1])
+        _DW["arrivals"][key] = _DW["arrivals"].get(key, 0) + 2
+        _launch_weight_grad(_DW, grad2d, [(gy16[:M1], x16[:M1]), (gy16[M1:], x16[M1:])])
+        return
     n = _DW["arrivals"].get(key, 0) + 1
     _DW["arrivals"][key] = n
     partner = _DW["parked"].pop(key, None)
@@ -1078,8 +1133,9 @@ class ConvBlockFn16(torch.autograd.Function):
         h1, h2, mean, rstd = dwconv7_ln(x, w1, b1, gamma, beta, out16=True)
         w2_16, w3_16 = shadow(w2), shadow(w3)
         ctx.fused = fused_mlp_ok(M, C)
+        _tape(ConvBlockFn16, ctx)
         if ctx.fused:
-            out = torch.empty((M, C), dtype=torch.float32, device=x.device)
+            out = _alloc((M, C), torch.float32, x.device)
             N.call("sei_mlp_fused_fwd", h2.data_ptr(), w2_16.data_ptr(), b2.data_ptr(), w3_16.data_ptr(), b3.data_ptr(),
                    x.data_ptr(), 2.0 if twice else 1.0, out.data_ptr(), M, C)
             if _GEMM_PROFILE is not None:               # counted with the GEMM family (roofline leg): 2 GEMMs of M x 4C x C
@@ -1090,10 +1146,10 @@ class ConvBlockFn16(torch.autograd.Function):
             ctx.params = (w1, b1, gamma, beta, w2, b2, w3, b3)
             ctx.twice = twice
             return out.view(B, H, W, C)
-        h3 = torch.empty((M, 4 * C), dtype=torch.float32, device=x.device)
-        h4 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device)
+        h3 = _alloc((M, 4 * C), torch.float32, x.device)
+        h4 = _alloc((M, 4 * C), torch.bfloat16, x.device)
         gemm_nt16(h2, w2_16, M, 4 * C, C, EPI_BIAS_GELU, out32=h3, bias=b2, D2_16=h4)
-        out = torch.empty((M, C), dtype=torch.float32, device=x.device)
+        out = _alloc((M, C), torch.float32, x.device)
         gemm_nt16(h4, w3_16, M, C, 4 * C, EPI_BIAS_RES, out32=out, bias=b3, R1=x, R2=x if twice else None)
         ctx.save_for_backward(x, h1, mean, rstd, h2, h3, h4)
         ctx.params = (w1, b1, gamma, beta, w2, b2, w3, b3)
@@ -1181,10 +1237,12 @@ class DownsampleFn16(torch.autograd.Function):
         Mo = B * Ho * Wo
         s = _mats.constant_response("down", H, W, rate, x.device, B)
         u16 = cast16(u.view(Mo, C))
-        out = torch.empty((Mo, Co), dtype=torch.float32, device=x.device)
+        out = _alloc((Mo, Co), torch.float32, x.device)
         gemm_nt16(u16, shadow(w), Mo, Co, C, EPI_BIAS_ROWSCALE, out32=out, bias=b, R1=s)
         ctx.save_for_backward(x, mean, rstd, u16, s)
         ctx.params, ctx.mats_t, ctx.hw = (gamma, beta, w, b), bwd, (H, W, Ho, Wo)
+        ctx.with_skip, ctx.rate = with_skip, rate
+        _tape(DownsampleFn16, ctx)
         out = out.view(B, Ho, Wo, Co)
         return (out, x) if with_skip else out
 
@@ -1220,7 +1278,8 @@ class UpsampleFn16(torch.autograd.Function):
         M = B * Ho * Wo
         h, mean, rstd = layer_norm16(u.view(M, C), gamma, beta)
         w16 = shadow(w)
-        out = torch.empty((M, Co), dtype=torch.float32, device=x.device)
+        out = _alloc((M, Co), torch.float32, x.device)
+        _tape(UpsampleFn16, ctx)
         if skip is not None:
             skip = _nhwc(skip)
             if tuple(skip.shape) != (B, Ho, Wo, Co):
@@ -1264,7 +1323,8 @@ class Conv3x3Fn(torch.autograd.Function):
             B, _, H, W = x.shape
         else:
             B, H, W, _ = x.shape
-        y = torch.empty((B, Co, H, W) if nchw_out else (B, H, W, Co), dtype=torch.float32, device=x.device)
+        y = _alloc((B, Co, H, W) if nchw_out else (B, H, W, Co), torch.float32, x.device)
+        _tape(Conv3x3Fn, ctx)
         if res is not None:
             N.check_tensor(res, "conv3x3 residual")
             if res.shape != y.shape:
@@ -1290,3 +1350,67 @@ class Conv3x3Fn(torch.autograd.Function):
                    int(nchw_out), int(nchw_in), 1)
         gres = go if ctx.needs_input_grad[3] else None
         return gx, None, None, gres, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# One backward pass for the step's two model calls (models/_joint.py): joint ctx of each layer function, the walk
+# ---------------------------------------------------------------------------------------------
+class joint_rows:
+    """`with joint_rows(backbone, (B1, B2)):` -- weight_grad16 splits its operands' rows B1 : B2 into the two segments
+    of the step's two model calls (None: a single call walked alone, nothing to split)."""
+
+    def __init__(self, backbone, batches):
+        self.state, self.batches = state_of(backbone), batches
+
+    def __enter__(self):
+        self.prev = self.state.get("joint")
+        self.state["joint"] = self.batches
+        return self
+
+    def __exit__(self, *exc):
+        self.state["joint"] = self.prev
+        return False
+
+
+def joint_ctx(fn, c1, c2, rec):
+    """The ctx of a layer's backward over both calls: saved activations as 3B-row tensors (rec.joint raises where two
+    tensors are not the two parts of one arena buffer)."""
+    from ._joint import JointCtx
+    s1, s2 = c1.saved_tensors, c2.saved_tensors
+    if fn is Conv3x3Fn:
+        B, H, W, Ci, Co, nchw_in, nchw_out = c1.cfg
+        return JointCtx(c1, [rec.joint(s1[0], s2[0])], cfg=(B + c2.cfg[0], H, W, Ci, Co, nchw_in, nchw_out))
+    if fn is ConvBlockFn16:
+        if c1.fused != c2.fused or c1.twice != c2.twice:
+            from ._joint import _NotJoint
+            raise _NotJoint()
+        return JointCtx(c1, [rec.joint(a, b) for a, b in zip(s1, s2)])
+    if fn is DownsampleFn16:
+        x = rec.joint(s1[0], s2[0])
+        H, W = c1.hw[0], c1.hw[1]
+        s = _mats.constant_response("down", H, W, c1.rate, x.device, x.shape[0])
+        return JointCtx(c1, [x, rec.joint(s1[1], s2[1]), rec.joint(s1[2], s2[2]), rec.joint(s1[3], s2[3]), s])
+    if fn is UpsampleFn16:
+        return JointCtx(c1, [rec.joint(a, b) for a, b in zip(s1, s2)])
+    from ._joint import _NotJoint
+    raise _NotJoint()
+
+
+def walk_backward(fns, ctxs, go):
+    """Play a model call's tape (the layer functions in forward order, with their ctx -- or joint ctx --) backwards from
+    the gradient of the model output. The U-Net is a chain plus skip connections nested like brackets: an Upsample's skip
+    gradient waits on a stack for the Downsample that handed the skip on."""
+    skips = []
+    g = go
+    for fn, ctx in zip(reversed(fns), reversed(ctxs)):
+        if g is None:
+            break
+        if fn is UpsampleFn16:
+            outs = fn.backward(ctx, g)
+            g = outs[0]
+            skips.append(outs[1])
+        elif fn is DownsampleFn16:
+            gskip = skips.pop() if ctx.with_skip and skips else None
+            g = fn.backward(ctx, g, gskip)[0]
+        else:
+            g = fn.backward(ctx, g)[0]

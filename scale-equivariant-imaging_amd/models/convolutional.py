@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch.nn import GELU, Conv2d, LayerNorm as BaseLayerNorm, Module, ModuleList, Sequential
 
 import _native as N
-from . import _mats, _ops
+from . import _joint, _mats, _ops
 from ._flat import FlatParameterBucket
 
 
@@ -223,6 +223,22 @@ class ConvolutionalModel(FlatParameterBucket, Module):
         div = 2 ** (self.scales - 1)
         pad_h = (div - y.shape[-2] % div) % div
         pad_w = (div - y.shape[-1] % div) % div
+        # The step's two model calls (2B and B images, the second input a constant: ProposedLoss with stop_gradient) share
+        # ONE backward pass: this call is recorded -- activations from an arena, layer functions on a tape -- when the loss
+        # has announced the pair, the mode is bf16 and nothing around the U-Net needs torch ops (no padding, no pre-upsampler)
+        rec = _joint.recorder_of(self)
+        if rec.armed and self.upsampling_rate == 1 and pad_h == 0 and pad_w == 0 and hasattr(self.seq[-1], "in_conv") \
+                and _ops.get_compute_dtype() == "bf16" and rec.wants(y):
+            rec.begin(y)
+            with _ops.recording(rec):
+                y_in = _ops._alloc(tuple(y.shape), y.dtype, y.device)
+                y_in.copy_(y)
+                x_hat = self.seq[-1](y_in, x_is_nchw=True)
+            call, pair = rec.current, rec.pair
+            if not rec.end():
+                return x_hat.contiguous()               # (no joint form: an ordinary autograd graph)
+            pair.outputs[call] = x_hat                  # (its grad_fn keeps the layer nodes -- the tape's ctx objects -- alive)
+            return _joint._Top.apply(x_hat.detach(), self.seq[-1].out_conv.bias, pair, call, self)
         if pad_h != 0 or pad_w != 0:
             y = F.pad(y, (0, pad_w, 0, pad_h), mode="reflect")
         unet = self.seq[-1]

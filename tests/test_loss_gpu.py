@@ -1195,3 +1195,88 @@ def test_fused_optimizer_step_on_the_default_network():
         opt.step()
     finally:
         _ops.set_compute_dtype(prev)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_joint_backward_of_the_two_model_calls(graph):
+    """models/_joint.py: the backward passes of the step's two model calls (2B crops of the SURE term, B measurements of
+    the equivariance term: src/losses/__init__.py:133-142 with the default stop_gradient) run as ONE pass over 3B images
+    -- arena-allocated activations, the layers' own backward functions played from a tape -- against ordinary autograd over
+    the same graph (SEI_NO_JOINT_BACKWARD): same loss, gradients equal up to the float atomics' summation order and the
+    bf16 roundings behind it (bar: 3x what two runs of the ordinary path differ by, or 3e-3), and about a third fewer
+    launches in the backward pass. Eager and replayed from a hipGraph; a step that differentiates only ONE of the two
+    terms falls back to walking that call alone and still matches."""
+    import bench
+    import models
+    import physics
+    from graphs import GraphedLossStep
+    from losses import get_loss
+    from models import _joint, _ops
+    from optim import FlatAdam
+    import _native as N
+    prev = _ops.set_compute_dtype("bf16")
+    was = _joint.ENABLED
+    try:
+        args = bench.reference_args("cuda", 32, 3)
+        torch.manual_seed(0)
+        p = physics.get_physics(args, "cuda")
+        model = models.get_model(args, p, "cuda").to("cuda")
+        bb = model.get_backbone()
+        lf = get_loss(args, p)
+        opt = FlatAdam(model, lr=1e-4)
+        B = 4
+        gen = torch.Generator().manual_seed(5)
+        x = torch.rand((B, 3, 256, 256), generator=gen).cuda()
+        y = p(x)
+        b = torch.randn((B, 3, 36, 36), generator=gen)
+        from losses.sure import embed_probe
+        draws = {"b": embed_probe(torch.empty(B, 3, 48, 48, device="cuda"), b.cuda(), 6),
+                 "rate": torch.tensor([0.75, 0.5, 0.5, 0.75]).cuda(),
+                 "center": (2 * torch.rand((B, 2), generator=gen) - 1).cuda().view(B, 1, 1, 2),
+                 "noise": torch.randn((B, 3, 48, 48), generator=gen).cuda()}
+        grads, losses, launches = {}, {}, {}
+        graphed = {}
+        for mode in ("plain", "plain2", "joint"):
+            _joint.ENABLED = mode == "joint"
+            if graph:
+                graphed[mode] = GraphedLossStep(lf, model, opt, (B, 3, 48, 48))
+                bb.flat_grads.fill_(float("nan"))
+                torch.manual_seed(3)
+                val = graphed[mode](x, y, draws=draws)
+                launches[mode] = 0
+            else:
+                opt.zero_grad()
+                torch.manual_seed(3)
+                N.record_calls(True)
+                val = lf(x=x, y=y, model=model, draws=draws)
+                nfwd = len(N.record_calls(False))
+                N.record_calls(True)
+                val.backward()
+                launches[mode] = len(N.record_calls(False))
+            torch.cuda.synchronize()
+            grads[mode], losses[mode] = bb.flat_grads.clone(), float(val)
+        assert torch.isfinite(grads["joint"]).all()
+        assert abs(losses["joint"] - losses["plain"]) < 1e-5 * abs(losses["plain"])
+        noise = relerr(grads["plain2"], grads["plain"])
+        assert relerr(grads["joint"], grads["plain"]) < max(3e-3, 3 * noise), (relerr(grads["joint"], grads["plain"]), noise)
+        worst = 1.0
+        for name, prm in bb.named_parameters():
+            off = (prm._sei_grad_view.data_ptr() - bb.flat_grads.data_ptr()) // 4
+            a, c = (grads[k][off:off + prm.numel()].double() for k in ("joint", "plain"))
+            worst = min(worst, float(a @ c / (a.norm() * c.norm())))
+        assert worst > 0.9999, worst
+        if not graph:
+            assert launches["joint"] < 0.8 * launches["plain"], launches
+            # only the equivariance term differentiated: its call is walked alone at the end of the pass
+            _joint.ENABLED = True
+            opt.zero_grad()
+            torch.manual_seed(3)
+            lf.loss.keep_outputs = True
+            total = lf(x=x, y=y, model=model, draws=draws)
+            assert bb._sei_joint.pair.calls == 2 and not bb._sei_joint.pair.broken
+            total.backward()
+            assert bb._sei_joint.pair.done == [True, True]
+            assert relerr(bb.flat_grads, grads["plain"]) < max(3e-3, 3 * noise)
+    finally:
+        _joint.ENABLED = was
+        _ops.set_compute_dtype(prev)
