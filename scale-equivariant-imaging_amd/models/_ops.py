@@ -156,8 +156,26 @@ def gemm(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2
     return out
 
 
+_JOINT_SPLIT = None      # (B1, B2) while one backward pass serves the step's two model calls (joint_rows), else None
+
+
 def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=None, R2=None, D2_16=None,
-              lda=None, ldb=None, a_rmajor=False, b_rmajor=False, tile=0, band=0, flops=None):
+              lda=None, ldb=None, a_rmajor=False, b_rmajor=False, tile=0, band=0, flops=None, _whole=False):
+    if _JOINT_SPLIT is not None and not _whole and not a_rmajor and max(Nn, K) >= 2048 and not (tile or band) and lda is None:
+        # One backward pass over the rows of both model calls (models/_joint.py) -- but the deep levels' GEMMs are tuned to
+        # the row counts of the separate calls (2304 / 1152 and 576 / 288 rows are whole rounds of 288-row tiles on 256 CUs;
+        # 3456 and 864 rows are 1.5 rounds: measured 168 us against 79 + 58): their rows go as the two launches they were
+        B1, B2 = _JOINT_SPLIT
+        M1 = M * B1 // (B1 + B2)
+        if 0 < M1 < M and M1 % 8 == 0 and (M - M1) % 8 == 0:
+            cut = lambda t, lo, hi: None if t is None else t[lo:hi]
+            r1_rows = R1 is not None and R1.dim() == 1           # BIAS_ROWSCALE: one value per row
+            for lo, hi in ((0, M1), (M1, M)):
+                gemm_nt16(A16[lo:hi], B16, hi - lo, Nn, K, epi, out32=cut(out32, lo, hi), out16=cut(out16, lo, hi), bias=bias,
+                          R1=cut(R1, lo, hi) if (r1_rows or (R1 is not None and R1.shape[0] == M)) else R1,
+                          R2=cut(R2, lo, hi) if (R2 is not None and R2.shape[0] == M) else R2, D2_16=cut(D2_16, lo, hi),
+                          ldb=ldb, b_rmajor=b_rmajor, flops=None if flops is None else flops * (hi - lo) / M, _whole=True)
+            return
     """D[M,N] = op(A16) op(B16) on the direct-to-LDS bf16 kernel. A16 is (M,K) [or (K,M) when a_rmajor],
     B16 is (N,K) [or (K,N) when b_rmajor]; K % 8 == 0. Outputs as given. tile / band: an explicit schedule
     choice (sei_gemm_bf16nt_ex; tests and tools), 0 = the library's dispatch. flops: the algorithmic FLOP count
@@ -1363,12 +1381,14 @@ class joint_rows:
         self.state, self.batches = state_of(backbone), batches
 
     def __enter__(self):
-        self.prev = self.state.get("joint")
-        self.state["joint"] = self.batches
+        global _JOINT_SPLIT
+        self.prev = (self.state.get("joint"), _JOINT_SPLIT)
+        self.state["joint"] = _JOINT_SPLIT = self.batches
         return self
 
     def __exit__(self, *exc):
-        self.state["joint"] = self.prev
+        global _JOINT_SPLIT
+        self.state["joint"], _JOINT_SPLIT = self.prev
         return False
 
 
