@@ -165,11 +165,16 @@ def _stream_bytes(name, a):
         return 8 * a[4] * a[5]
     if name in ("sei_pack", "sei_unpack_add"):
         return 10 * a[3]
-    if name in ("sei_swin_attn_fwd_bf16", "sei_swin_attn_bwd_bf16", "sei_swin_attn_fwd", "sei_swin_attn_bwd"):
-        bf16, bwd = name.endswith("bf16"), "_bwd" in name
+    if name in ("sei_swin_attn_fwd", "sei_swin_attn_bwd"):
+        bwd = "_bwd" in name
         B, H, W, heads = (a[5:9] if bwd else a[3:7])
-        width = heads * (32 if bf16 else a[9 if bwd else 7])
-        return B * H * W * width * (2 if bf16 else 4) * (8 if bwd else 4)
+        return B * H * W * heads * a[9 if bwd else 7] * 4 * (8 if bwd else 4)
+    if name == "sei_swin_attn_fwd_bf16":                 # qkv in, out + the rows' log-sum-exp out
+        B, H, W, heads = a[4:8]
+        return B * H * W * heads * (32 * 2 * 4 + 4)
+    if name == "sei_swin_attn_bwd_bf16":                 # qkv, out, dout, lse in, dqkv out
+        B, H, W, heads = a[7:11]
+        return B * H * W * heads * (32 * 2 * 8 + 4)
     if name == "sei_sepmap2_bf16_pack":
         return 0
     if name in ("sei_sepmap2_packed", "sei_sepmap2_bf16", "sei_sepmap2_big"):

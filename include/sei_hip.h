@@ -32,7 +32,7 @@ extern "C" {
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
-#define SEI_ABI_VERSION 8
+#define SEI_ABI_VERSION 9
 int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
@@ -428,11 +428,16 @@ int sei_swin_attn_bwd(const float *qkv, const float *table, const float *dout, f
                       int B, int H, int W, int heads, int head_dim, int shift, float scale, void *stream);
 /* The same two on the bf16 MFMA (csrc/swin_attn_mfma.hip, throughput mode): qkv (B*H*W, 3*heads*32) and out / dout
  * (B*H*W, heads*32) in bf16, every head padded from 30 to 32 dims (the pad dims must be zero in qkv; they come out
- * zero). dqkv is bf16, dtable float (+=). */
-int sei_swin_attn_fwd_bf16(const uint16_t *qkv, const float *table, uint16_t *out, int B, int H, int W,
+ * zero). dqkv is bf16, dtable float (+=).
+ * lse (heads, B*(H/8)*(W/8) windows in partition order, 64 queries) float: the rows' log-sum-exp of the scaled, biased
+ * and masked scores in log2 units, written by the forward pass when non-NULL and REQUIRED by the backward pass, which
+ * rebuilds the probabilities from it (one exponential per element, no row maxima / sums) and takes
+ * rowsum(dout * out) from the forward output `out` (ABI 9). */
+int sei_swin_attn_fwd_bf16(const uint16_t *qkv, const float *table, uint16_t *out, float *lse, int B, int H, int W,
                            int heads, int shift, float scale, void *stream);
-int sei_swin_attn_bwd_bf16(const uint16_t *qkv, const float *table, const uint16_t *dout, uint16_t *dqkv,
-                           float *dtable, int B, int H, int W, int heads, int shift, float scale, void *stream);
+int sei_swin_attn_bwd_bf16(const uint16_t *qkv, const float *table, const uint16_t *out, const float *lse,
+                           const uint16_t *dout, uint16_t *dqkv, float *dtable, int B, int H, int W, int heads,
+                           int shift, float scale, void *stream);
 /* Padded-grid form of an NHWC batch for the 3x3 convolutions with many channels (RSTB.conv, conv_after_body,
  * conv_before_upsample, upsample.*): xp = guard_rows zero rows of C floats, then (B, H+2, W+2, C) with a zero
  * border, then guard_rows zero rows. On that grid the convolution is nine row-shifted GEMMs over the same flat

@@ -81,8 +81,8 @@ SIGNATURES = {
     "sei_mlp_fused_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "sei_swin_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
     "sei_swin_attn_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
-    "sei_swin_attn_fwd_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
-    "sei_swin_attn_bwd_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "sei_swin_attn_fwd_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "sei_swin_attn_bwd_bf16": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "sei_pad_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "sei_unpad_nhwc": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "sei_rowscale": [_P, _P, _P, _P, _Z, _I, _P],
@@ -158,7 +158,7 @@ SIZE_QUERIES = {
     "sei_rowgemm_dgelu_bf16_eligible": [_L, _I, _I],
     "sei_rowgemm_ln_bf16_eligible": [_L, _I, _I],
 }
-ABI_VERSION = 8       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
+ABI_VERSION = 9       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 
 
 class NativeLibraryError(RuntimeError):

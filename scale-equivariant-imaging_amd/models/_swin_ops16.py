@@ -307,7 +307,10 @@ class SwinBlockFn16(torch.autograd.Function):
         linear16(h1, wqkv, None, M, EPI_BIAS, 3 * heads * HP, out16=qkv, bias=pack.b(f"{key}.qkv_bias"), flops=2.0 * M * 3 * C * C)
         a = torch.empty((M, CP), dtype=torch.bfloat16, device=dev)
         scale = float((C // heads) ** -0.5)
-        N.call("sei_swin_attn_fwd_bf16", qkv.data_ptr(), table.data_ptr(), a.data_ptr(), B, H, W, heads, shift, scale)
+        # per (head, window, query) log-sum-exp of the scores: the backward pass rebuilds the probabilities from it
+        lse = torch.empty((heads, M), dtype=torch.float32, device=dev)
+        N.call("sei_swin_attn_fwd_bf16", qkv.data_ptr(), table.data_ptr(), a.data_ptr(), lse.data_ptr(), B, H, W, heads, shift,
+               scale)
         fused = linear_res_ln16(a, wproj, M, bproj, drop1, x2, g2, b2, 2.0 * M * C * C)    # proj, residual, norm2
         if fused is not None:
             x1, h2, mean2, rstd2 = fused
@@ -339,7 +342,7 @@ class SwinBlockFn16(torch.autograd.Function):
                 linear16(f4, w2, None, M, EPI_BIAS_RES, C, out32=out, bias=bm2, R1=x1, flops=2.0 * M * Chr * C)
             else:
                 linear16(f4, w2, None, M, EPI_BIAS_SCALE_RES, C, out32=out, bias=bm2, R1=drop2, R2=x1, flops=2.0 * M * Chr * C)
-        ctx.save_for_backward(x, mean1, rstd1, h1, qkv, a, x1, mean2, rstd2, h2, f3, f4, drop1, drop2)
+        ctx.save_for_backward(x, mean1, rstd1, h1, qkv, a, x1, mean2, rstd2, h2, f3, f4, drop1, drop2, lse)
         ctx.params = (g1, b1, table, bproj, g2, b2, bm1, bm2)
         ctx.cfg = (pack, key, heads, shift)
         ctx.extra_outputs = nxt is not None
@@ -355,7 +358,7 @@ class SwinBlockFn16(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, go, *unused):
-        x, mean1, rstd1, h1, qkv, a, x1, mean2, rstd2, h2, f3, f4, drop1, drop2 = ctx.saved_tensors
+        x, mean1, rstd1, h1, qkv, a, x1, mean2, rstd2, h2, f3, f4, drop1, drop2, lse = ctx.saved_tensors
         g1, b1, table, bproj, g2, b2, bm1, bm2 = ctx.params
         pack, key, heads, shift = ctx.cfg
         B, H, W, C = x.shape
@@ -388,8 +391,8 @@ class SwinBlockFn16(torch.autograd.Function):
         linear16(gy1, pack.w(f"{key}.projT"), wproj, M, EPI_NONE, CP, out16=ga, flops=2.0 * M * C * C)
         dqkv = torch.empty_like(qkv)
         scale = float((C // heads) ** -0.5)
-        N.call("sei_swin_attn_bwd_bf16", qkv.data_ptr(), table.data_ptr(), ga.data_ptr(), dqkv.data_ptr(),
-               grad_of(table).data_ptr(), B, H, W, heads, shift, scale)
+        N.call("sei_swin_attn_bwd_bf16", qkv.data_ptr(), table.data_ptr(), a.data_ptr(), lse.data_ptr(), ga.data_ptr(),
+               dqkv.data_ptr(), grad_of(table).data_ptr(), B, H, W, heads, shift, scale)
         gx, gy_prev = linear_lnbwd16(dqkv, pack.w(f"{key}.qkvT"), wqkv, M, x.view(M, C), g1, mean1, rstd1, gx1, grad_of(g1),
                                      grad_of(b1), row_scale=ctx.prev_scale, cast=ctx.prev_scale is not None)
         # the four weight gradients (+ the qkv / fc1 bias gradients, column C) over the same tokens: one launch

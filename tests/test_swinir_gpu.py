@@ -351,21 +351,24 @@ def test_window_attention_mfma_fwd_bwd(B, H, W, heads, shift):
     scale = 30 ** -0.5
     out16 = torch.full((M, heads * HP), float("nan"), dtype=torch.bfloat16, device="cuda")
     qc, tc, gc = qkv16.cuda(), table.cuda(), go16.cuda()
-    N.call("sei_swin_attn_fwd_bf16", qc.data_ptr(), tc.data_ptr(), out16.data_ptr(), B, H, W, heads, shift, scale)
+    lse = torch.full((heads, M), float("nan"), dtype=torch.float32, device="cuda")
+    N.call("sei_swin_attn_fwd_bf16", qc.data_ptr(), tc.data_ptr(), out16.data_ptr(), lse.data_ptr(), B, H, W, heads, shift,
+           scale)
+    assert bool(torch.isfinite(lse).all())
     out = out16.float().cpu().view(M, heads, HP)
     assert float(out[..., 30:].abs().max()) == 0.0
     assert relerr(out[..., :30].reshape(M, -1), ref) < 1e-2
     dqkv16 = torch.full((M, 3 * heads * HP), float("nan"), dtype=torch.bfloat16, device="cuda")
     dtable = torch.zeros_like(tc)
-    N.call("sei_swin_attn_bwd_bf16", qc.data_ptr(), tc.data_ptr(), gc.data_ptr(), dqkv16.data_ptr(), dtable.data_ptr(),
-           B, H, W, heads, shift, scale)
+    N.call("sei_swin_attn_bwd_bf16", qc.data_ptr(), tc.data_ptr(), out16.data_ptr(), lse.data_ptr(), gc.data_ptr(),
+           dqkv16.data_ptr(), dtable.data_ptr(), B, H, W, heads, shift, scale)
     dq = dqkv16.float().cpu().view(M, 3, heads, HP)
     assert float(dq[..., 30:].abs().max()) == 0.0
     assert relerr(dq[..., :30].reshape(M, -1), rq) < 2e-2
     assert relerr(dtable, rt) < 2e-2
     # run-to-run: the outputs involve no atomics
     out_b = torch.empty_like(out16)
-    N.call("sei_swin_attn_fwd_bf16", qc.data_ptr(), tc.data_ptr(), out_b.data_ptr(), B, H, W, heads, shift, scale)
+    N.call("sei_swin_attn_fwd_bf16", qc.data_ptr(), tc.data_ptr(), out_b.data_ptr(), 0, B, H, W, heads, shift, scale)
     assert torch.equal(out16, out_b)
 
 
