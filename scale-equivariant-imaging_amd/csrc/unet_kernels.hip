@@ -622,6 +622,61 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_pix_kernel(
     }
 }
 
+// Image (CS <= 4 channels, either layout) -> the 32 hidden channels in NHWC, and (transposed = 1) the data gradient of a
+// hidden -> image convolution: FOUR lanes per pixel, eight output channels each. The pixel-per-thread form above stores
+// its 32 values as 32 four-byte stores 128 bytes apart from lane to lane (0.06 of the HBM rate, all of it store issue);
+// here a pixel's 128 output bytes leave as 4 x 2 sixteen-byte stores of neighbouring lanes, the 9 x CS input values of
+// a pixel are loads shared by its four lanes, the weights are LDS reads of [ci][tap][32] rows (two float4 per lane).
+template <int CS>
+__global__ __launch_bounds__(C3_THREADS) void conv3x3_small_to_c32_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+    const float *__restrict__ res, float *__restrict__ y, int B, int H, int W, int nchw_in, int transposed) {
+    __shared__ __attribute__((aligned(16))) float sw[CS * 9 * 32];   // [ci][tap][co]
+    for (int e = threadIdx.x; e < CS * 9 * 32; e += C3_THREADS) {
+        const int co = e & 31, t = (e >> 5) % 9, ci = e / (32 * 9);
+        sw[e] = transposed ? w[((size_t)ci * 32 + co) * 9 + (8 - t)] : w[((size_t)co * CS + ci) * 9 + t];
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 3;
+    float4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (bias) {
+        b0 = *reinterpret_cast<const float4 *>(bias + 8 * q);
+        b1 = *reinterpret_cast<const float4 *>(bias + 8 * q + 4);
+    }
+    const size_t npix = (size_t)B * H * W;
+    for (size_t p = ((size_t)blockIdx.x * C3_THREADS + threadIdx.x) >> 2; p < npix; p += ((size_t)gridDim.x * C3_THREADS) >> 2) {
+        const int j = (int)(p % W), i = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+        float4 a0 = b0, a1 = b1;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ii = i + ky - 1;
+            if (ii < 0 || ii >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int jj = j + kx - 1;
+                if (jj < 0 || jj >= W) continue;
+#pragma unroll
+                for (int ci = 0; ci < CS; ++ci) {
+                    const float v = x[img_index(nchw_in, b, ci, ii, jj, CS, H, W)];
+                    const float4 w0 = *reinterpret_cast<const float4 *>(sw + (ci * 9 + ky * 3 + kx) * 32 + 8 * q);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(sw + (ci * 9 + ky * 3 + kx) * 32 + 8 * q + 4);
+                    a0.x = fmaf(w0.x, v, a0.x); a0.y = fmaf(w0.y, v, a0.y); a0.z = fmaf(w0.z, v, a0.z); a0.w = fmaf(w0.w, v, a0.w);
+                    a1.x = fmaf(w1.x, v, a1.x); a1.y = fmaf(w1.y, v, a1.y); a1.z = fmaf(w1.z, v, a1.z); a1.w = fmaf(w1.w, v, a1.w);
+                }
+            }
+        }
+        float *yp = y + p * 32 + 8 * q;
+        if (res) {
+            const float4 r0 = *reinterpret_cast<const float4 *>(res + p * 32 + 8 * q);
+            const float4 r1 = *reinterpret_cast<const float4 *>(res + p * 32 + 8 * q + 4);
+            a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w;
+            a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
+        }
+        *reinterpret_cast<float4 *>(yp) = a0;
+        *reinterpret_cast<float4 *>(yp + 4) = a1;
+    }
+}
+
 // Weight gradient, tiled: a workgroup stages P pixels of gy (P x Cout) and of the im2col'ed input
 // (P x Cin*9) in LDS, each thread owns a few of the Cout*Cin*9 outputs and reduces over the P pixels
 // out of LDS; one float atomic per output per workgroup.
@@ -1467,6 +1522,20 @@ extern "C" int sei_conv3x3_fwd(const float *x, const float *w, const float *bias
             default: SEI_C3_LANES(4)
         }
 #undef SEI_C3_LANES
+    }
+    if (Cout == 32 && Cin <= 4 && !nchw_out && (((uintptr_t)y | (uintptr_t)res | (uintptr_t)bias) & 15) == 0) {
+        const unsigned grid4 = capped_grid(npix * 4, C3_THREADS, 16384);
+#define SEI_C3_TO32(CS)                                                                                              \
+    hipLaunchKernelGGL(conv3x3_small_to_c32_kernel<CS>, dim3(grid4), dim3(C3_THREADS), 0, s, x, w, bias, res, y, B, \
+                       H, W, nchw_in ? 1 : 0, transposed ? 1 : 0);                                                  \
+    return sei_launch_status();
+        switch (Cin) {
+            case 1: SEI_C3_TO32(1)
+            case 2: SEI_C3_TO32(2)
+            case 3: SEI_C3_TO32(3)
+            default: SEI_C3_TO32(4)
+        }
+#undef SEI_C3_TO32
     }
 #define SEI_C3_PIX(CO)                                                                                          \
     hipLaunchKernelGGL(conv3x3_pix_kernel<CO>, dim3(pgrid), dim3(C3_THREADS), lds, s, x, w, bias, res, y, B, H, \
