@@ -201,6 +201,8 @@ constexpr int RG_EPI_LNBWD = 100;     // internal epilogue codes (sei_rowgemm_ln
 constexpr int RG_EPI_DGELU2 = 101;    // sei_rowgemm_ln_bf16: SEI_EPI_BIAS_RES / _BIAS_SCALE_RES followed by a LayerNorm)
 constexpr int RG_EPI_RES_LN = 102;
 constexpr int RG_EPI_SCALE_RES_LN = 103;
+constexpr int RG_EPI_GELU16 = 104;    // SEI_EPI_BIAS_GELU without the float32 pre-activation: bias + GELU in the accumulator
+                                      // layout, bf16 patch, 16-byte stores; small enough for TWO workgroups per CU
 
 template <int N>
 __device__ __forceinline__ void rg_wait_vmcnt() {
@@ -225,7 +227,7 @@ __device__ __forceinline__ unsigned rg_pack2(float a, float b) {
 // not fit otherwise (K = 576): the two partial sums then meet in the patch. NBT 16-column blocks are dealt to the WN
 // groups as evenly as they go (36 blocks on 8 groups: five each for the first four, four for the rest).
 template <int KT, int NBT, int TR, int WN, int WR, int EPI, bool OUT16>
-__global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
+__global__ __launch_bounds__(RG_NT, (EPI == RG_EPI_GELU16 ? 4 : 1)) void rowgemm_kernel(RowGemmArgs g) {
     constexpr int WK = 8 / (WN * WR);
     static_assert(WN * WR * WK == 8 && (WK == 1 || WK == 2), "eight waves");
     constexpr int NB = (NBT + WN - 1) / WN;           // blocks of the widest column group
@@ -250,7 +252,9 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     constexpr int GQ = (!LNX && (OUT16 || EPI == SEI_EPI_MUL_DGELU || TWO)) ? 2 : 1;
     // bf16-only outputs without auxiliary rows: bias and rounding happen in the accumulator layout and the patch holds bf16
     // (half the LDS bytes; the last pass is one 16-byte LDS read and one 16-byte store per eight values, no arithmetic)
-    constexpr bool P16 = ((EPI == SEI_EPI_BIAS || EPI == SEI_EPI_NONE) && OUT16) || TWO;
+    constexpr bool GELU16 = EPI == RG_EPI_GELU16;
+    static_assert(!GELU16 || (OUT16 && WK == 1 && NBX == 0), "bf16 output only; whole column blocks per wave, all of K");
+    constexpr bool P16 = ((EPI == SEI_EPI_BIAS || EPI == SEI_EPI_NONE) && OUT16) || TWO || GELU16;
     constexpr int LDP16 = NP + 8;                     // bf16 patch row stride: 4 rows = 64 B apart mod 256
     static_assert(!P16 || WK == 1, "the bf16 patch has nothing to add up");
     constexpr int IR = QR / GQ;                       // items per row
@@ -264,9 +268,11 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
     constexpr int UNR = IPT > 3 ? (GQ == 2 ? 2 : 3) : IPT;   // items in flight per thread in the last pass
     constexpr int NAUX = LNF ? 3 + (EPI == RG_EPI_SCALE_RES_LN ? 1 : 0) : LNB ? 8 + (OUT16 ? 1 : 0)
                              : (HAS_ROWS ? QPT : 0) + (EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 0);   // loads per thread and tile
-    __shared__ __attribute__((aligned(1024))) char smem[3 * STAGE + TR * LDP * 4 + (LNF ? 3 : 1) * NP * 4];
+    // (the two-workgroups-per-CU variant sizes its patch for what it holds: bf16 rows, no bias row behind them)
+    constexpr int PATCH_BYTES = GELU16 ? TR * LDP16 * 2 : TR * LDP * 4 + (LNF ? 3 : 1) * NP * 4;
+    __shared__ __attribute__((aligned(1024))) char smem[3 * STAGE + PATCH_BYTES];
     float *patch = reinterpret_cast<float *>(smem + 3 * STAGE);
-    float *lbias = patch + TR * LDP;
+    float *lbias = patch + TR * LDP;                   // (not touched by the variant without it)
     float *lgam = lbias + NP, *lbet = lgam + NP;       // (LNF only)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -315,8 +321,13 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(wf[nb][s]));
 
-    float biasr[(P16 && EPI == SEI_EPI_BIAS) ? NB : 1];
-    if constexpr (P16 && EPI == SEI_EPI_BIAS) {
+    float biasr[(P16 && (EPI == SEI_EPI_BIAS || GELU16)) ? NB : 1];
+    bool is_one[GELU16 ? NB : 1];                     // this lane's column of block nb is the ones column
+    if constexpr (GELU16) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) is_one[nb] = 16 * (nb0 + min(nb, nbw - 1)) + l16 == g.gelu_one_at;
+    }
+    if constexpr (P16 && (EPI == SEI_EPI_BIAS || GELU16)) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int c = 16 * (nb0 + min(nb, nbw - 1)) + l16;
@@ -465,7 +476,34 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         // ---- MFMAs: this wave's rows x columns of the tile (its half of K when WK = 2)
         const char *st = smem + (t % 3) * STAGE;
-        f32x4 acc[RB][NB];
+        f32x4 acc[GELU16 ? 1 : RB][NB];
+        if constexpr (GELU16) {
+            // one 16-row block at a time (half the accumulators: what lets two workgroups share a CU's registers; the
+            // GELU of one block's accumulators stands next to the other block's MFMAs in the instruction stream):
+            // MFMAs, bias + GELU in the accumulator layout, bf16 into the patch
+            unsigned short *pw16 = reinterpret_cast<unsigned short *>(patch) + (wr * RB * 16 + 4 * lg) * LDP16 + 16 * nb0 + l16;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[0][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const char *img = st + (s >> 1) * (TR * 128) + (wr * RB * 16 + l16) * 128 + (((4 * (s & 1) + lg) ^ (l16 >> 1)) * 16);
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(img + rb * 16 * 128);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf[nb][s], acc[0][nb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = is_one[nb] ? 1.0f : sei_gelu_bf16out(acc[0][nb][j] + biasr[nb]);
+                        const __bf16 h = (__bf16)v;
+                        pw16[(16 * rb + j) * LDP16 + 16 * nb] = __builtin_bit_cast(unsigned short, h);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -483,6 +521,7 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
                     acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf[nb][s], acc[rb][nb], 0, 0, 0);
                 }
             }
+        }
         }
         if constexpr (TWO) {
             // the GELU' input of these very elements, recomputed: acc2 = A2 W2^T in the same accumulator layout (same MFMA
@@ -518,7 +557,7 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
         if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NAUX + NDMA_HI>();
         else rg_wait_vmcnt<NAUX + NDMA_LO>();
         // ---- accumulators into the patch (WK = 2: the second half of K adds to the first)
-        if constexpr (P16) {
+        if constexpr (P16 && !GELU16) {
             unsigned short *pw16 = reinterpret_cast<unsigned short *>(patch) + (wr * RB * 16 + 4 * lg) * LDP16 + 16 * nb0 + l16;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
@@ -769,10 +808,10 @@ __global__ __launch_bounds__(RG_NT) void rowgemm_kernel(RowGemmArgs g) {
 }
 
 template <int KT, int NBT, int TR, int WN, int WR, int EPI, bool OUT16>
-int rg_launch(const RowGemmArgs &g, int M, hipStream_t s) {
+int rg_launch(const RowGemmArgs &g, int M, hipStream_t s, int per_cu = 1) {
     RowGemmArgs a = g;
     a.tiles = M / TR;
-    const int grid = a.tiles < 256 ? a.tiles : 256;
+    const int grid = a.tiles < 256 * per_cu ? a.tiles : 256 * per_cu;
     hipLaunchKernelGGL((rowgemm_kernel<KT, NBT, TR, WN, WR, EPI, OUT16>), dim3((unsigned)grid), dim3(RG_NT), 0, s, a);
     return sei_launch_status();
 }
@@ -878,7 +917,9 @@ extern "C" int sei_rowgemm_bf16(const uint16_t *A, int lda, const uint16_t *W, i
         case SEI_EPI_BIAS_SCALE_RES:
             return K == 192 ? rg_launch<3, 12, 64, 4, 2, SEI_EPI_BIAS_SCALE_RES, false>(g, m, s)
                             : rg_launch<6, 12, 32, 4, 2, SEI_EPI_BIAS_SCALE_RES, false>(g, m, s);
-        case SEI_EPI_BIAS_GELU: return rg_launch<3, 24, 32, 8, 1, SEI_EPI_BIAS_GELU, false>(g, m, s);
+        case SEI_EPI_BIAS_GELU:
+            if (!D32) return rg_launch<3, 24, 32, 8, 1, RG_EPI_GELU16, true>(g, m, s, 2);
+            return rg_launch<3, 24, 32, 8, 1, SEI_EPI_BIAS_GELU, false>(g, m, s);
         case SEI_EPI_MUL_DGELU: return rg_launch<3, 24, 32, 8, 1, SEI_EPI_MUL_DGELU, true>(g, m, s);
         default:
             if (K == 192) return rg_launch<3, 12, 64, 4, 2, SEI_EPI_NONE, true>(g, m, s);
@@ -974,5 +1015,5 @@ extern "C" int sei_rowgemm_gelu_bf16(const uint16_t *A, int lda, const uint16_t 
     SEI_REQUIRE((unsigned long long)64 * (size_t)lda * 2 < (1ull << 32) && one_at >= -1 && one_at < N);
     RowGemmArgs g = {};
     g.A = A; g.W = W; g.lda = lda; g.ldw = ldw; g.bias = bias; g.D16 = D16; g.ld16 = ld16; g.nv = nv; g.gelu_one_at = one_at;
-    return rg_launch<3, 24, 32, 8, 1, SEI_EPI_BIAS_GELU, false>(g, (int)M, (hipStream_t)stream);
+    return rg_launch<3, 24, 32, 8, 1, RG_EPI_GELU16, true>(g, (int)M, (hipStream_t)stream, 2);
 }
