@@ -28,11 +28,12 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 typedef short v4s __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // 16-B chunk swizzle of a [64 tokens][64 columns] image (128-B rows, two per 256-B bank row): as gemm_bf16pq.h
 __device__ __forceinline__ int tg_swz(int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); }
 
-constexpr int TG_NT = 256;                 // four waves, one per SIMD: 144 accumulator registers each
+constexpr int TG_NT = 256;                 // four waves, one per SIMD: 144 accumulator registers each (NW = 4)
 constexpr int TG_IMG = 64 * 128;           // one [64 tokens][64 columns] bf16 image
 constexpr int TG_STAGE = 6 * TG_IMG;       // 192 columns of dY + 192 columns of X
 constexpr int TG_NSTAGE = 3;
@@ -45,11 +46,17 @@ struct TokGradArgs {
     int workers_per_xcd;      // token ranges per XCD (each served by `nblk` workgroups of that XCD)
 };
 
-__global__ __launch_bounds__(TG_NT) void tokgrad_kernel(TokGradArgs g) {
+// NW = 4: four waves of 96 x 96; NW = 8: eight waves of 96 x 48, two per SIMD -- one wave's fragment reads under the
+// other's MFMAs (each stage is read 1.5 x as often from LDS, which has the room: the loop was bound by the read -> wait ->
+// MFMA sequence of its single wave per SIMD, not by LDS bandwidth)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void tokgrad_kernel(TokGradArgs g) {
+    constexpr int WRN = NW == 16 ? 4 : 2, WCN = NW / WRN;            // row groups x column groups of waves
+    constexpr int RBk = 12 / WRN, CB = 12 / WCN, NPIECE = 48 / NW;   // 16-row / 16-column blocks per wave, DMA pieces per wave
     __shared__ __attribute__((aligned(1024))) char smem[TG_NSTAGE * TG_STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WCN, wc = wave % WCN;
     const int l16 = lane & 15, lg = lane >> 4;
 
     // workgroups are dealt round-robin to the XCDs: slot s of XCD x = token range (s / nblk) * 8 + x, block s % nblk --
@@ -66,11 +73,11 @@ __global__ __launch_bounds__(TG_NT) void tokgrad_kernel(TokGradArgs g) {
     const unsigned short *Y1 = b.Y1, *Y2 = b.Y2, *X1 = b.X1, *X2 = b.X2;
     const int ldy = b.ldy, ldx = b.ldx;
 
-    // ---- DMA: 48 1-KiB pieces per stage, 12 per wave; piece q = image q / 8 (0-2: dY, 3-5: X), rows 8 (q % 8) ..
-    unsigned off[12];
+    // ---- DMA: 48 1-KiB pieces per stage, 48 / NW per wave; piece q = image q / 8 (0-2: dY, 3-5: X), rows 8 (q % 8) ..
+    unsigned off[NPIECE];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) {
-        const int q = wave + 4 * e, im = q >> 3, p = q & 7;
+    for (int e = 0; e < NPIECE; ++e) {
+        const int q = wave + NW * e, im = q >> 3, p = q & 7;
         const int krow = 8 * p + (lane >> 3);
         const int ch = (lane & 7) ^ tg_swz(krow);
         off[e] = im < 3 ? ((unsigned)krow * (unsigned)ldy + (unsigned)(b.y0 + im * 64 + 8 * ch)) * 2u
@@ -88,8 +95,8 @@ __global__ __launch_bounds__(TG_NT) void tokgrad_kernel(TokGradArgs g) {
         }
         char *dst = smem + (u % TG_NSTAGE) * TG_STAGE;
 #pragma unroll
-        for (int e = 0; e < 12; ++e) {
-            const int q = wave + 4 * e;                             // wave-uniform
+        for (int e = 0; e < NPIECE; ++e) {
+            const int q = wave + NW * e;                            // wave-uniform
             __builtin_amdgcn_global_load_lds((glb_void *)(((q >> 3) < 3 ? yb : xb) + off[e]),
                                              (lds_void *)(dst + q * 1024), 16, 0, 0);
         }
@@ -107,34 +114,40 @@ __global__ __launch_bounds__(TG_NT) void tokgrad_kernel(TokGradArgs g) {
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 
-    f32x4 acc[6][6];
+    f32x4 acc[RBk][CB];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < RBk; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < CB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // Every iteration issues one stage (past the end: the last k-tile again, into a stage nobody reads), so the
-    // counted wait below always leaves exactly the 12 pieces of the next stage in flight.
+    // counted wait below always leaves exactly the pieces of the next stage (12 or 6 per wave) in flight.
     issue(0);
     issue(1);
     for (int u = 0; u < nt; ++u) {
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");           // this wave's pieces of stage u have landed
+        if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // this wave's pieces of stage u have landed
+        else if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         __builtin_amdgcn_s_barrier();                               // ... everyone's; and stage u - 1 is read out
         issue(u + 2);
         const char *st = smem + (u % TG_NSTAGE) * TG_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[6], fb[6];
+            bf16x8 fa[RBk], fb[CB];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int bi = 6 * wr + i, bj = 6 * wc + i;
+            for (int i = 0; i < RBk; ++i) {
+                const int bi = RBk * wr + i;
                 fa[i] = frag(st + (bi >> 2) * TG_IMG, bi & 3, ks);
-                fb[i] = frag(st + (3 + (bj >> 2)) * TG_IMG, bj & 3, ks);
             }
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < CB; ++j) {
+                const int bj = CB * wc + j;
+                fb[j] = frag(st + (3 + (bj >> 2)) * TG_IMG, bj & 3, ks);
+            }
 #pragma unroll
-                for (int j = 0; j < 6; ++j)
+            for (int i = 0; i < RBk; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -144,11 +157,162 @@ __global__ __launch_bounds__(TG_NT) void tokgrad_kernel(TokGradArgs g) {
     // channel is what they cost (measured: 27 us for the 256 x 147 KB of a launch, whatever the scope or the number of
     // adders per address), which is why a launch should carry as many 192 x 192 blocks as it can: the token range of a
     // workgroup grows and the number of partial blocks per output shrinks with the block count.
-    float *d = b.D + (size_t)(96 * wr + 4 * lg) * b.ldd + 96 * wc + l16;
+    float *d = b.D + (size_t)(16 * RBk * wr + 4 * lg) * b.ldd + 16 * CB * wc + l16;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < RBk; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(d + (size_t)(16 * i + r) * b.ldd + 16 * j, acc[i][j][r]);
+}
+
+// The same product with the token stages travelling through REGISTERS: eight waves of 96 x 48, every wave loads its six
+// 1-KiB pieces of a stage with plain 16-byte loads THREE stages ahead (3 x 24 registers per lane), writes them into one of
+// two LDS stages one iteration before they are read, and computes as above. What the LDS-DMA ring is short of is bytes
+// in flight: three 48-KB stages fill the LDS, one of them is being read, so 96 KB per CU are on their way -- 4.2 TB/s at the
+// ~6 us a loaded request takes, where the same ring with nothing to compute (every slot reissued at once) streams 6.0.
+// Registers have the room the LDS lacks: 144 KB per CU in flight.
+__global__ __launch_bounds__(512, 2) void tokgrad_regs_kernel(TokGradArgs g) {
+    constexpr int NW = 8, WCN = 4, RBk = 6, CB = 3, NPIECE = 6;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * TG_STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave / WCN, wc = wave % WCN;
+    const int l16 = lane & 15, lg = lane >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wslot = slot / g.nblk, bsel = slot - wslot * g.nblk;
+    if (wslot >= g.workers_per_xcd) return;
+    const int worker = wslot * 8 + xcd, workers = 8 * g.workers_per_xcd;
+    const int kt0 = (int)((long long)g.kt_total * worker / workers);
+    const int kt1 = (int)((long long)g.kt_total * (worker + 1) / workers);
+    const int nt = kt1 - kt0;
+    if (nt <= 0) return;
+    const SeiTokGradBlock &b = g.blk[bsel];
+    const unsigned short *Y1 = b.Y1, *Y2 = b.Y2, *X1 = b.X1, *X2 = b.X2;
+    const int ldy = b.ldy, ldx = b.ldx;
+    unsigned off[NPIECE];
+#pragma unroll
+    for (int e = 0; e < NPIECE; ++e) {
+        const int q = wave + NW * e, im = q >> 3, p = q & 7;
+        const int krow = 8 * p + (lane >> 3);
+        const int ch = (lane & 7) ^ tg_swz(krow);
+        off[e] = im < 3 ? ((unsigned)krow * (unsigned)ldy + (unsigned)(b.y0 + im * 64 + 8 * ch)) * 2u
+                        : ((unsigned)krow * (unsigned)ldx + (unsigned)(b.x0 + (im - 3) * 64 + 8 * ch)) * 2u;
+    }
+    // loads the compiler does not track (it would wait for all of them at the first use of any): counted waits below
+    auto load = [&](int u, u32x4 (&r)[NPIECE]) {
+        const int kt = kt0 + min(u, nt - 1);
+        const char *yb, *xb;
+        if (kt < g.kt_seg) {
+            yb = reinterpret_cast<const char *>(Y1 + (size_t)kt * 64 * ldy);
+            xb = reinterpret_cast<const char *>(X1 + (size_t)kt * 64 * ldx);
+        } else {
+            yb = reinterpret_cast<const char *>(Y2 + (size_t)(kt - g.kt_seg) * 64 * ldy);
+            xb = reinterpret_cast<const char *>(X2 + (size_t)(kt - g.kt_seg) * 64 * ldx);
+        }
+#pragma unroll
+        for (int e = 0; e < NPIECE; ++e) {
+            const int q = wave + NW * e;
+            const char *src = ((q >> 3) < 3 ? yb : xb) + off[e];
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[e]) : "v"(src) : "memory");
+        }
+    };
+    auto commit = [&](int u, u32x4 (&r)[NPIECE]) {
+        char *dst = smem + (u & 1) * TG_STAGE + lane * 16;
+#pragma unroll
+        for (int e = 0; e < NPIECE; ++e) {
+            asm volatile("" : "+v"(r[e]));
+            *reinterpret_cast<u32x4 *>(dst + (wave + NW * e) * 1024) = r[e];
+        }
+    };
+    const int tq = l16 >> 2, tp = l16 & 3;
+    const int rm_lane = 128 * (8 * lg + tq) + 16 * ((tp >> 1) ^ tg_swz(8 * lg + tq)) + 8 * (tp & 1);
+    auto frag = [&](const char *img, int blk, int ks) -> bf16x8 {
+        const int base = rm_lane ^ (32 * blk);
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s *)(img + base + 128 * 32 * ks));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) v4s *)(img + base + 128 * (32 * ks + 4)));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    f32x4 acc[RBk][CB];
+#pragma unroll
+    for (int i = 0; i < RBk; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int u) {
+        const char *st = smem + (u & 1) * TG_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[RBk], fb[CB];
+#pragma unroll
+            for (int i = 0; i < RBk; ++i) {
+                const int bi = RBk * wr + i;
+                fa[i] = frag(st + (bi >> 2) * TG_IMG, bi & 3, ks);
+            }
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const int bj = CB * wc + j;
+                fb[j] = frag(st + (3 + (bj >> 2)) * TG_IMG, bj & 3, ks);
+            }
+#pragma unroll
+            for (int i = 0; i < RBk; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // Stage u lives in register set u % 3 from three iterations before its turn until one before, then in LDS stage
+    // u % 2. Iteration u: [stage u + 1 has landed: counted wait] [barrier: everyone is done reading LDS stage (u + 1) % 2
+    // (iteration u - 1) and stage u's writes (iteration u - 1) are visible] stage u + 1 into LDS, loads of stage u + 4
+    // into the freed set, MFMAs on stage u. No load is issued whose data is not used: an untracked load into a register
+    // the compiler believes free would land on whatever it has put there since. (nt >= 8: the host sends shorter ranges
+    // to the LDS-DMA kernel.)
+    u32x4 r0[NPIECE], r1[NPIECE], r2[NPIECE];
+    load(0, r0);
+    load(1, r1);
+    load(2, r2);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    commit(0, r0);
+    load(3, r0);
+#define TG_STEP(U, RN)                                                                                          \
+    {                                                                                                           \
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+        __builtin_amdgcn_s_barrier();                                                                           \
+        commit((U) + 1, RN);                                                                                    \
+        load((U) + 4, RN);                                                                                      \
+        compute(U);                                                                                             \
+    }
+#define TG_TAIL(U, RN)                                                                                          \
+    if ((U) < nt) {                                                                                             \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+        __builtin_amdgcn_s_barrier();                                                                           \
+        if ((U) + 1 < nt) commit((U) + 1, RN);                                                                  \
+        if ((U) + 4 < nt) load((U) + 4, RN);                                                                    \
+        compute(U);                                                                                             \
+    }
+    int u = 0;
+    for (; u + 6 < nt; u += 3) {
+        TG_STEP(u, r1)
+        TG_STEP(u + 1, r2)
+        TG_STEP(u + 2, r0)
+    }
+    TG_TAIL(u, r1)
+    TG_TAIL(u + 1, r2)
+    TG_TAIL(u + 2, r0)
+    TG_TAIL(u + 3, r1)
+    TG_TAIL(u + 4, r2)
+    TG_TAIL(u + 5, r0)
+#undef TG_STEP
+#undef TG_TAIL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float *d = b.D + (size_t)(16 * RBk * wr + 4 * lg) * b.ldd + 16 * CB * wc + l16;
+#pragma unroll
+    for (int i = 0; i < RBk; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) atomicAdd(d + (size_t)(16 * i + r) * b.ldd + 16 * j, acc[i][j][r]);
 }
@@ -841,8 +1005,14 @@ extern "C" int sei_tokgrad_bf16_blocks(const SeiTokGradBlock *blocks, int nblock
     g.kt_seg = (int)(K1 / 64);
     g.kt_total = (int)((K1 + K2) / 64);
     g.workers_per_xcd = 32 / nblocks;                               // 32 CUs per XCD, one workgroup each
-    hipLaunchKernelGGL(tokgrad_kernel, dim3(8 * (unsigned)(g.workers_per_xcd * nblocks)), dim3(TG_NT), 0,
-                       (hipStream_t)stream, g);
+    // Ranges of at least eight 64-token stages per workgroup: the stages travel through registers (three in flight);
+    // shorter ones: the LDS-DMA ring with eight waves.
+    if (g.kt_total / (8 * g.workers_per_xcd) >= 8)
+        hipLaunchKernelGGL(tokgrad_regs_kernel, dim3(8 * (unsigned)(g.workers_per_xcd * nblocks)), dim3(512), 0,
+                           (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(tokgrad_kernel<8>, dim3(8 * (unsigned)(g.workers_per_xcd * nblocks)), dim3(2 * TG_NT), 0,
+                           (hipStream_t)stream, g);
     return sei_launch_status();
 }
 

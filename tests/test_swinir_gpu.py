@@ -482,13 +482,15 @@ def test_conv_weight_gradient_taps_in_one_launch():
             assert relerr(out[5], dense) < 1e-4
 
 
-@pytest.mark.parametrize("K1,K2", [(4608, 2304), (64, 0), (320, 192), (50 * 64, 0)])
+@pytest.mark.parametrize("K1,K2", [(4608, 2304), (64, 0), (320, 192), (50 * 64, 0), (24576, 12288), (66 * 64 * 32, 0)])
 def test_token_streamed_weight_gradients(K1, K2):
     """sei_tokgrad_bf16 / sei_tokgrad_bf16_blocks (nn.Linear's weight gradient dY^T X of deepinv's SwinIR blocks, both
     operands token-major, the step's two model calls as two segments) against the float32 product of the same bf16
     operands, on top of a running gradient: one launch per weight, and the four weights of a block (3 + 1 + 2 + 2
     192 x 192 blocks, operands with padding columns beyond the block) in one launch. Token counts from one 64-token
-    k-tile (most workgroups idle) to more k-tiles than workgroups."""
+    k-tile (most workgroups idle) to more k-tiles than workgroups; the last two give every workgroup of the eight-block
+    launch (the last one: of every launch) eight stages or more -- the kernel whose stages travel through registers,
+    with the segment boundary inside a workgroup's range and stage counts of every remainder modulo 3."""
     import _native as N
     gen = torch.Generator(device="cuda").manual_seed(K1 + K2)
     blocks, expect = [], []
