@@ -547,9 +547,9 @@ int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A2, int lda,
  * sei_tokgrad_bf16: D (Mo, Ni; row stride ldd) += Y^T X over K1 + K2 tokens; Y1 / Y2: (K, ldy >= Mo), X1 / X2:
  * (K, ldx >= Ni) bf16, token-major as the layers store them; the two segments are the step's two model calls (K2 = 0:
  * one). Float atomics: D must hold the running gradient (or zeros). Eligible (sei_tokgrad_bf16_eligible != 0): Mo and Ni
- * multiples of 192 with at most eight 192 x 192 blocks, K1 and K2 multiples of 64, ldy and ldx multiples of 8, 16-byte
+ * multiples of 192 with at most eight 192 x 192 blocks (sei_tokgrad_bf16_blocks: sixteen), K1 and K2 multiples of 64, ldy and ldx multiples of 8, 16-byte
  * aligned operands. Same product as sei_gemm_bf16nt_dw2(..., accumulate = 1) up to the float summation order. */
-#define SEI_TOKGRAD_MAX_BLOCKS 8
+#define SEI_TOKGRAD_MAX_BLOCKS 16
 typedef struct SeiTokGradBlock {     /* one 192 x 192 block of a weight gradient: D += Y[:, y0:y0+192]^T X[:, x0:x0+192] */
     const uint16_t *Y1, *Y2;         /* (K1, ldy) / (K2, ldy) bf16; Y2 unused when K2 = 0 */
     const uint16_t *X1, *X2;         /* (K1, ldx) / (K2, ldx) */

@@ -117,6 +117,9 @@ class TokGradBlock(_c.Structure):
                 ("D", _P), ("ldd", _I)]
 
 
+TOKGRAD_MAX_BLOCKS = 16      # SEI_TOKGRAD_MAX_BLOCKS
+
+
 class DwStreamJob(_c.Structure):
     """SeiDwStreamJob of include/sei_hip.h (one weight gradient of a sei_dwstream_bf16_jobs table)."""
     _fields_ = [("Y1", _P), ("Y2", _P), ("X1", _P), ("X2", _P), ("ldy", _I), ("ldx", _I), ("Mo", _I), ("Ni", _I),

@@ -1019,7 +1019,7 @@ extern "C" int sei_tokgrad_bf16_blocks(const SeiTokGradBlock *blocks, int nblock
 extern "C" size_t sei_tokgrad_bf16_eligible(int Mo, int Ni, int ldy, int ldx, long long K1, long long K2) {
     if (Mo <= 0 || Ni <= 0 || Mo % 192 || Ni % 192) return 0;
     const int ng = (Mo / 192) * (Ni / 192);
-    if (ng > TG_MAX_BLOCKS || ldy % 8 || ldx % 8 || ldy < Mo || ldx < Ni) return 0;
+    if (ng > 8 || ldy % 8 || ldx % 8 || ldy < Mo || ldx < Ni) return 0;      // (one weight: at most eight blocks)
     if (K1 <= 0 || K2 < 0 || K1 % 64 || K2 % 64) return 0;
     if ((K1 + K2) / 64 >= (1ll << 24)) return 0;
     return (size_t)ng;

@@ -737,6 +737,7 @@ def set_weight_grad_milestone(keys, event, owner=None):
 # SEI_SWIN_TILED=1 (tests flip the flag to run the same step on both paths; shapes the streaming kernels do not take --
 # token counts that are not multiples of 64 -- use the tiled ones anyway).
 TOKEN_STREAMING = os.environ.get("SEI_SWIN_TILED") != "1"
+CONV_TOKGRAD = os.environ.get("SEI_NO_CONV_TOKGRAD") != "1"    # the 192-channel convolutions' tap gradients as token-streamed blocks
 
 
 def _check_milestone(_DW, key):
@@ -892,6 +893,19 @@ def _launch_weight_grad_inner2(_DW, grad2d, pairs, store, bias):
         per_row = _DW["flops_per_row"].get(key) or 2.0 * T * Np * Kp
         if (K1 + K2) % 8 != 0:
             raise ValueError("weight_grad16 with taps: the reduction length must be a multiple of 8 rows")
+        if TOKEN_STREAMING and CONV_TOKGRAD and not store and Np == 192 and Kp == 192 and T <= N.TOKGRAD_MAX_BLOCKS \
+                and K1 % 64 == 0 and K2 % 64 == 0 \
+                and g1.stride(0) == Np and x1.stride(0) == Kp and grad2d.is_contiguous():
+            # 192-channel convolutions (the body of the SwinIR network): the taps are blocks of ONE token-streamed launch --
+            # the same gy rows against the input rows shifted by each tap's offset, every block with its share of the CUs,
+            # the two operands crossing an XCD's L2 once for all nine (sei_tokgrad_bf16_blocks; the tiled kernel re-stages
+            # both operands for every 128 x 128 tile of every tap)
+            blocks = [N.TokGradBlock(g1.data_ptr(), g2.data_ptr(), x1.data_ptr() + 2 * Kp * int(taps[t]),
+                                     x2.data_ptr() + 2 * Kp * int(taps[t]), Np, Kp, 0, 0,
+                                     grad2d.data_ptr() + 4 * t * Np * Kp, Kp) for t in range(T)]
+            arr = (N.TokGradBlock * T)(*blocks)
+            _gemm_call(per_row * (K1 + K2), "sei_tokgrad_bf16_blocks", arr, T, K1, K2)
+            return
         _gemm_call(per_row * (K1 + K2), "sei_gemm_bf16nt_dw2_taps", g1.data_ptr(), g2.data_ptr(), Np, x1.data_ptr(),
                    x2.data_ptr(), Kp, grad2d.data_ptr(), Np, Kp, K1, K2, 0 if store else 1, T, taps, Np * Kp)
         return
