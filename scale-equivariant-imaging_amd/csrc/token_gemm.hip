@@ -640,16 +640,24 @@ __global__ __launch_bounds__(RG_NT, (EPI == RG_EPI_GELU16 ? 4 : 1)) void rowgemm
         __builtin_amdgcn_sched_barrier(0);
         // ---- MFMAs: this wave's rows x columns of the tile (its half of K when WK = 2)
         const char *st = smem + (t % 3) * STAGE;
-        f32x4 acc[GELU16 ? 1 : RB][NB];
-        if constexpr (GELU16) {
-            // one 16-row block at a time (half the accumulators: what lets two workgroups share a CU's registers; the
-            // GELU of one block's accumulators stands next to the other block's MFMAs in the instruction stream):
-            // MFMAs, bias + GELU in the accumulator layout, bf16 into the patch
+        f32x4 acc[(GELU16 || TWO) ? 1 : RB][NB];
+        if constexpr (GELU16 || TWO) {
+            // One 16-row block at a time: MFMAs, the element-wise function in the accumulator layout, bf16 into the patch.
+            // Half the accumulators (GELU16: what lets two workgroups share a CU's registers), and the VALU work of one
+            // block stands next to the other block's MFMAs in the instruction stream.
+            // TWO: the GELU' input of these very elements, recomputed -- acc2 = A2 W2^T in the same accumulator layout and
+            // the same MFMA order as the forward kernel (the same float32 values it fed to GELU) --, then
+            // acc * gelu'(acc2 + bias).
+            static_assert(WK == 1 && NBX == 0, "whole column blocks per wave, all of K");
             unsigned short *pw16 = reinterpret_cast<unsigned short *>(patch) + (wr * RB * 16 + 4 * lg) * LDP16 + 16 * nb0 + l16;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
+                f32x4 acc2[TWO ? NB : 1];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[0][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int nb = 0; nb < NB; ++nb) {
+                    acc[0][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (TWO) acc2[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     const char *img = st + (s >> 1) * (TR * 128) + (wr * RB * 16 + l16) * 128 + (((4 * (s & 1) + lg) ^ (l16 >> 1)) * 16);
@@ -657,12 +665,20 @@ __global__ __launch_bounds__(RG_NT, (EPI == RG_EPI_GELU16 ? 4 : 1)) void rowgemm
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
                         acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf[nb][s], acc[0][nb], 0, 0, 0);
+                    if constexpr (TWO) {
+                        const bf16x8 fa2 = *reinterpret_cast<const bf16x8 *>(img + KT * TR * 128 + rb * 16 * 128);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc2[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa2, wf2[nb][s], acc2[nb], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float v = is_one[nb] ? 1.0f : sei_gelu_bf16out(acc[0][nb][j] + biasr[nb]);
+                        float v;
+                        if constexpr (TWO) v = acc[0][nb][j] * sei_dgelu_bf16out(acc2[nb][j] + bias2[nb]);
+                        else v = is_one[nb] ? 1.0f : sei_gelu_bf16out(acc[0][nb][j] + biasr[nb]);
                         const __bf16 h = (__bf16)v;
                         pw16[(16 * rb + j) * LDP16 + 16 * nb] = __builtin_bit_cast(unsigned short, h);
                     }
@@ -687,41 +703,11 @@ __global__ __launch_bounds__(RG_NT, (EPI == RG_EPI_GELU16 ? 4 : 1)) void rowgemm
             }
         }
         }
-        if constexpr (TWO) {
-            // the GELU' input of these very elements, recomputed: acc2 = A2 W2^T in the same accumulator layout (same MFMA
-            // order as the forward kernel: the same float32 values it fed to GELU), then acc <- acc * gelu'(acc2 + bias)
-            f32x4 acc2[RB][NB];
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc2[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int sg = wk * KS + s;
-                const char *img = st + KT * TR * 128 + (sg >> 1) * (TR * 128) + (wr * RB * 16 + l16) * 128 +
-                                  (((4 * (sg & 1) + lg) ^ (l16 >> 1)) * 16);
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    const bf16x8 fa = *reinterpret_cast<const bf16x8 *>(img + rb * 16 * 128);
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        if (NBX != 0 && nb == NB - 1 && nbw < NB) break;
-                        acc2[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf2[nb][s], acc2[rb][nb], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[rb][nb][j] *= sei_dgelu_bf16out(acc2[rb][nb][j] + bias2[nb]);
-        }
         // tile t + 1 (issued one iteration ago) and everything older have landed; what this iteration issued may fly
         if (P % 8 != 0 && wave < P % 8) rg_wait_vmcnt<NAUX + NDMA_HI>();
         else rg_wait_vmcnt<NAUX + NDMA_LO>();
         // ---- accumulators into the patch (WK = 2: the second half of K adds to the first)
-        if constexpr (P16 && !GELU16) {
+        if constexpr (P16 && !GELU16 && !TWO) {
             unsigned short *pw16 = reinterpret_cast<unsigned short *>(patch) + (wr * RB * 16 + 4 * lg) * LDP16 + 16 * nb0 + l16;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
