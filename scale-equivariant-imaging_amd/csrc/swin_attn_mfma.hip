@@ -241,19 +241,28 @@ __global__ __launch_bounds__(64 * WAVES) void swin_attn_fwd_mfma_kernel(const un
                                                                           float *__restrict__ lse, MGeom g, float scale,
                                                                           int groups) {
     __shared__ WaveLds lds[WAVES];
-    __shared__ float bias_col[NB];
-    const int h = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int b = threadIdx.x; b < NB; b += 64 * WAVES) bias_col[b] = table[b * g.heads + h];
+    __shared__ float bias_pair[2][NB];
+    // A workgroup = two windows x a PAIR of neighbouring heads (as the backward kernel): the two heads' 64-byte row
+    // segments are the halves of the same 128-byte lines. (One head per workgroup fetched every line twice: 256 MB
+    // beyond L2 per launch for 124 MB of operands, profiles/r04_h_*.)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hsel = wave & 1, hreal = 2 * (int)blockIdx.y + hsel;
+    const bool head_ok = hreal < g.heads;                  // (odd head count: the last pair's second wave computes a copy)
+    const int h = head_ok ? hreal : g.heads - 1;
+    for (int b = threadIdx.x; b < 2 * NB; b += 64 * WAVES) {
+        const int hh = min(2 * (int)blockIdx.y + b / NB, g.heads - 1);
+        bias_pair[0][b] = table[(b % NB) * g.heads + hh];
+    }
     WaveLds &L = lds[wave];
-    const LaneGeom G = lane_geom(bias_col, lane);
+    const LaneGeom G = lane_geom(bias_pair[hsel], lane);
     const int C = g.heads * HP;
-    const int stride = groups * WAVES;
+    const int stride = groups * (WAVES / 2);
     const int rounds = (g.nwin + stride - 1) / stride;
-    auto window_of = [&](int rd) { return min((rd * groups + (int)blockIdx.x) * WAVES + wave, g.nwin - 1); };
+    auto window_of = [&](int rd) { return min((rd * groups + (int)blockIdx.x) * (WAVES / 2) + (wave >> 1), g.nwin - 1); };
     SWIN_STAGE_REGS
     SWIN_FETCH(window_of(0))
     for (int rd = 0; rd < rounds; ++rd) {
-        const bool live = (rd * groups + (int)blockIdx.x) * WAVES + wave < g.nwin;
+        const bool live = head_ok && (rd * groups + (int)blockIdx.x) * (WAVES / 2) + (wave >> 1) < g.nwin;
         const int win = window_of(rd);
         const int wloc = win % (g.nwy * g.nwx);
         const bool last_row = wloc / g.nwx == g.nwy - 1, last_col = wloc % g.nwx == g.nwx - 1;
@@ -600,15 +609,6 @@ inline int check(int B, int H, int W, int heads, int shift) {
     return SEI_OK;
 }
 
-// groups x heads workgroups, each looping over its windows. Two workgroups fit a CU (80 KB of LDS each): 512 resident.
-// 128 groups x 6 heads = 768 ran as one full round and a half-empty one; 85 x 6 = 510 are all resident and walk
-// more windows each.
-inline int group_count(int nwin, int heads, int resident = 512) {
-    const int groups = (nwin + WAVES - 1) / WAVES;
-    const int cap = resident / heads > 0 ? resident / heads : 1;
-    return groups > cap ? cap : groups;
-}
-
 }  // namespace
 
 extern "C" int sei_swin_attn_fwd_bf16(const uint16_t *qkv, const float *table, uint16_t *out, float *lse, int B, int H,
@@ -617,12 +617,15 @@ extern "C" int sei_swin_attn_fwd_bf16(const uint16_t *qkv, const float *table, u
     SEI_REQUIRE((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0);
     if (int rc = check(B, H, W, heads, shift)) return rc;
     MGeom g{H, W, H / WS, W / WS, shift, heads, B * (H / WS) * (W / WS)};
-    const int groups = group_count(g.nwin, heads);
+    // two workgroups per CU, each two windows x two heads at a time
+    const int pairs = (heads + 1) / 2;
+    const int want = (g.nwin + 1) / 2, cap = 512 / pairs > 0 ? 512 / pairs : 1;
+    const int groups = want > cap ? cap : want;
     if (shift)
-        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel<true>, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
+        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel<true>, dim3((unsigned)groups, (unsigned)pairs), dim3(64 * WAVES), 0,
                            (hipStream_t)stream, qkv, table, out, lse, g, scale, groups);
     else
-        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel<false>, dim3((unsigned)groups, (unsigned)heads), dim3(64 * WAVES), 0,
+        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel<false>, dim3((unsigned)groups, (unsigned)pairs), dim3(64 * WAVES), 0,
                            (hipStream_t)stream, qkv, table, out, lse, g, scale, groups);
     return sei_launch_status();
 }
