@@ -433,10 +433,18 @@ __global__ __launch_bounds__(RG_NT, (EPI == RG_EPI_GELU16 ? 4 : 1)) void rowgemm
     constexpr int NAUX = LNF ? 3 + (EPI == RG_EPI_SCALE_RES_LN ? 1 : 0) : LNB ? 8 + (OUT16 ? 1 : 0)
                              : (HAS_ROWS ? QPT : 0) + (EPI == SEI_EPI_BIAS_SCALE_RES ? QPT : 0);   // loads per thread and tile
     // (the two-workgroups-per-CU variant sizes its patch for what it holds: bf16 rows, no bias row behind them)
-    constexpr int PATCH_BYTES = GELU16 ? TR * LDP16 * 2 : TR * LDP * 4 + (LNF ? 3 : 1) * NP * 4;
-    __shared__ __attribute__((aligned(1024))) char smem[3 * STAGE + PATCH_BYTES];
-    float *patch = reinterpret_cast<float *>(smem + 3 * STAGE);
-    float *lbias = patch + TR * LDP;                   // (not touched by the variant without it)
+    // TWO PATCHES where the LDS has the room (everything but GELU16, which spends it on a second workgroup, and K = 576):
+    // tile t goes through patch t % 2, and the barrier that ended every tile ("the patch is free again") is gone -- a
+    // patch is rewritten two tiles later, behind the mid-tile barrier of the tile in between, which every wave reaches
+    // only after its last read of it; the ring stage of tile t is re-filled by the issue of tile t + 3, behind the
+    // mid-tile barrier of tile t as before. One barrier per tile (two with the K halves) instead of two (three): waves
+    // that are through with their rows start the next tile's MFMAs while the others still store.
+    constexpr int PATCH_ONE = (P16 ? TR * LDP16 * 2 : TR * LDP * 4 + 15) / 16 * 16;
+    constexpr int AUX_BYTES = GELU16 ? 0 : (LNF ? 3 : 1) * NP * 4;
+    constexpr bool PATCH2 = !GELU16 && 3 * STAGE + 2 * PATCH_ONE + AUX_BYTES <= 160 * 1024;
+    __shared__ __attribute__((aligned(1024))) char smem[3 * STAGE + (PATCH2 ? 2 : 1) * PATCH_ONE + AUX_BYTES];
+    float *const patch0 = reinterpret_cast<float *>(smem + 3 * STAGE);
+    float *lbias = reinterpret_cast<float *>(smem + 3 * STAGE + (PATCH2 ? 2 : 1) * PATCH_ONE);   // (not touched by the variant without it)
     float *lgam = lbias + NP, *lbet = lgam + NP;       // (LNF only)
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -633,6 +641,7 @@ __global__ __launch_bounds__(RG_NT, (EPI == RG_EPI_GELU16 ? 4 : 1)) void rowgemm
     rg_lds_barrier();
 
     for (int t = 0; t < nt; ++t) {
+        float *const patch = PATCH2 ? reinterpret_cast<float *>(reinterpret_cast<char *>(patch0) + (t & 1) * PATCH_ONE) : patch0;
         load_aux(t, cur, curs);                           // this tile's residual / GELU' rows: used after the MFMAs
         load_ln(t);
         __builtin_amdgcn_sched_barrier(0);                // (the order the counted wait below assumes)
@@ -932,7 +941,7 @@ __global__ __launch_bounds__(RG_NT, (EPI == RG_EPI_GELU16 ? 4 : 1)) void rowgemm
                 *reinterpret_cast<uint4 *>(g.D16 + row * g.ld16 + qc) = h;
             }
         }
-        rg_lds_barrier();                                 // the patch and stage t % 3 are free again
+        if constexpr (!PATCH2) rg_lds_barrier();          // the patch and stage t % 3 are free again
     }
     rg_wait_vmcnt<0>();                                   // the clamped stages still in flight
     if constexpr (LNB) {
