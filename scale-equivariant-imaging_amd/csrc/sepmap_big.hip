@@ -229,7 +229,9 @@ inline BigPlan big_plan(int Hi, int Wi, int Ho, int Wo, int C) {
     p.KHp = (2 * Hi + 31) / 32 * 32;
     // an extent beyond 64 on either side (csrc/sepmap_mfma.hip serves the rest; its 48 -> 96 calls measured no faster than
     // the f32 kernels: 455 us against 230 here), k-steps the kernel is instantiated for, 16-byte rows everywhere
-    p.ok = (Hi > 64 || Wi > 64 || Ho > 64 || Wo > 64) && Hi >= 32 && Wi >= 32 && Hi <= 256 && Wi <= 256 && Ho >= 16 && Wo >= 16 && Ho <= 512 && Wo <= 512 && C % 8 == 0 &&
+    // (an extent OF 64 counts too: 64 -> 32 and 32 -> 64 overflow the one-workgroup kernel's LDS and went to the f32
+    // kernels -- 1.3-3.8 ms per launch in the un-cropped 256-pixel series; the caller asks sei_sepmap2_bf16 first)
+    p.ok = (Hi >= 64 || Wi >= 64 || Ho >= 64 || Wo >= 64) && Hi >= 32 && Wi >= 32 && Hi <= 256 && Wi <= 256 && Ho >= 16 && Wo >= 16 && Ho <= 512 && Wo <= 512 && C % 8 == 0 &&
            p.KWp / 32 <= 16 && p.KHp / 32 <= 16 && C % 16 == 0;
     return p;
 }
@@ -255,7 +257,7 @@ int cmat_launch(CmatArgs &g, hipStream_t s) {
         hipLaunchKernelGGL((cmat_gemm_kernel<KSV, MTV, IN32, OUT16>), dim3(grid), dim3(64 * waves), 0, s, g);          \
         return sei_launch_status();                                                                                    \
     }
-    SB_CASE(2, 1) SB_CASE(2, 2) SB_CASE(2, 3) SB_CASE(3, 1) SB_CASE(3, 2) SB_CASE(3, 3) SB_CASE(4, 1) SB_CASE(4, 2) SB_CASE(4, 3)
+    SB_CASE(1, 1) SB_CASE(1, 2) SB_CASE(1, 3) SB_CASE(2, 1) SB_CASE(2, 2) SB_CASE(2, 3) SB_CASE(3, 1) SB_CASE(3, 2) SB_CASE(3, 3) SB_CASE(4, 1) SB_CASE(4, 2) SB_CASE(4, 3)
     SB_CASE(6, 1) SB_CASE(6, 2) SB_CASE(6, 3) SB_CASE(8, 1) SB_CASE(8, 2) SB_CASE(12, 1) SB_CASE(16, 1)
 #undef SB_CASE
     return SEI_ERR_BAD_ARG;
@@ -268,7 +270,7 @@ extern "C" size_t sei_sepmap2_big_eligible(int B, int Hi, int Wi, int Ho, int Wo
     const BigPlan p = big_plan(Hi, Wi, Ho, Wo, C);
     if (!p.ok) return 0;
     const int ksw = p.KWp / 32, ksh = p.KHp / 32;
-    auto built = [](int ks) { return ks == 2 || ks == 3 || ks == 4 || ks == 6 || ks == 8 || ks == 12 || ks == 16; };
+    auto built = [](int ks) { return ks == 1 || ks == 2 || ks == 3 || ks == 4 || ks == 6 || ks == 8 || ks == 12 || ks == 16; };
     return built(ksw) && built(ksh) ? 1 : 0;
 }
 

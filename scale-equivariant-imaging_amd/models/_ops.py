@@ -291,7 +291,8 @@ def sepmap2_16(x, mats, Ho, Wo):
     """sepmap2 in the bf16 throughput mode: on the matrix cores where the shape is eligible (sei_sepmap2_bf16:
     activations rounded to bf16, matrices as bf16 head + remainder, f32 accumulation), else the f32 kernels."""
     B, Hi, Wi, C = x.shape
-    big = _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_big_eligible(B, Hi, Wi, Ho, Wo, C)
+    small = _SEPMAP_MFMA and x.is_cuda and max(Hi, Wi, Ho, Wo) <= 64 and N.lib().sei_sepmap2_bf16_eligible(B, Hi, Wi, Ho, Wo, C)
+    big = not small and _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_big_eligible(B, Hi, Wi, Ho, Wo, C)
     if not big and _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_bf16_eligible(B, Hi, Wi, Ho, Wo, C):
         y = _alloc((B, Ho, Wo, C), torch.float32, x.device)
         N.call("sei_sepmap2_bf16", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, _packed16(mats).data_ptr())

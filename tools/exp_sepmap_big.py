@@ -11,7 +11,8 @@ def once(fn, iters=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 for kind, B, H, C in [("down", 64, 192, 32), ("up", 64, 96, 32), ("down", 64, 96, 128), ("up", 64, 48, 128),
-                      ("down", 32, 192, 32), ("down", 32, 256, 32), ("up", 32, 128, 32), ("down", 32, 128, 128)]:
+                      ("down", 32, 192, 32), ("down", 32, 256, 32), ("up", 32, 128, 32), ("down", 32, 128, 128),
+                      ("down", 32, 64, 512), ("up", 32, 32, 512), ("down", 32, 32, 2048), ("up", 32, 16, 2048)]:
     fwd, bwd = _mats.resample_matrices(kind, H, H, 2, "cuda")
     x = torch.randn((B, H, H, C), device="cuda")
     Ho = fwd[0].shape[0]
