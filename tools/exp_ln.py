@@ -3,6 +3,8 @@ another of 24 tensor sets (1.4 GB in all), so nothing is served from L2 / MALL a
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scale-equivariant-imaging_amd"))
 import _native as N
+if os.environ.get("SEI_LIB"):
+    N.LIB_PATH = os.path.abspath(os.environ["SEI_LIB"])      # another build of the library (A/B runs)
 def timeit(fn, iters=30):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -11,9 +13,10 @@ def timeit(fn, iters=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 B = 64
-SETS = 24
+H0 = int(sys.argv[1]) if len(sys.argv) > 1 else 48      # 192: the x4 network's grids
+SETS = 24 if H0 <= 48 else 6
 for lvl in range(5):
-    H = max(48 >> lvl, 3); C = 32 << (2 * lvl); rows = B * H * H
+    H = max(H0 >> lvl, 3); C = 32 << (2 * lvl); rows = B * H * H
     xs = [torch.randn((rows, C), device="cuda") for _ in range(SETS)]; gys = [torch.randn((rows, C), device="cuda") for _ in range(SETS)]
     gx = torch.empty((rows, C), device="cuda")
     y16 = torch.empty((rows, C), dtype=torch.bfloat16, device="cuda"); y = torch.empty((rows, C), device="cuda")
