@@ -327,10 +327,12 @@ def test_swinir_timed_configuration_vs_oracle():
 
 
 @pytest.mark.parametrize("shift", [0, 4])
-@pytest.mark.parametrize("B,H,W,heads", [(2, 16, 16, 6), (1, 24, 16, 3), (5, 48, 48, 6)])
+@pytest.mark.parametrize("B,H,W,heads", [(2, 16, 16, 6), (1, 24, 16, 3), (5, 48, 48, 6), (12, 48, 48, 6)])
 def test_window_attention_mfma_fwd_bwd(B, H, W, heads, shift):
     """The bf16 MFMA window attention (heads padded 30 -> 32, bf16 in / out) against the float64 reference on the
-    SAME bf16-rounded inputs: outputs and gradients to bf16 resolution, zero pad dims, bias-table gradient."""
+    SAME bf16-rounded inputs: outputs and gradients to bf16 resolution, zero pad dims, bias-table gradient. (An odd head
+    count: the last head pair has an idle wave; 12 images: more windows than resident waves -- the backward kernel's
+    prefetch of the next item and its two token tables.)"""
     import _native as N
     gen = torch.Generator().manual_seed(B + H + shift + heads)
     M, HP = B * H * W, 32
