@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsei_hip.so")
+# (SEI_HIP_LIBRARY: another build of the same ABI, for same-box A/B runs of tools/ and bench.py; never a fallback)
+LIB_PATH = os.environ.get("SEI_HIP_LIBRARY") or os.path.join(_HERE, "libsei_hip.so")
 
 SEI_REDUCE_BLOCKS = 256
 

@@ -2,9 +2,7 @@
 another of 24 tensor sets (1.4 GB in all), so nothing is served from L2 / MALL as it is when one set is re-run."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scale-equivariant-imaging_amd"))
-import _native as N
-if os.environ.get("SEI_LIB"):
-    N.LIB_PATH = os.path.abspath(os.environ["SEI_LIB"])      # another build of the library (A/B runs)
+import _native as N              # (SEI_HIP_LIBRARY=<path>: another build of the library, for A/B runs)
 def timeit(fn, iters=30):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
