@@ -177,7 +177,7 @@ constexpr bool patch_fits() {
 }
 
 template <int TM, int TN, int WM, int WN, bool ARM, bool BRM, int NSTAGE = 2, int ROWEPI = 0>
-__global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : (ROWEPI == 1 ? 4 : 1))) void gemm_bf16nt_kernel(NtArgs g) {
+__global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(NtArgs g) {
     static_assert(WM * WN == NWAVES, "8 waves per workgroup");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     static_assert(!ARM || BM == 128, "a reduction-major A tile is 64 x 128");
@@ -484,10 +484,6 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : (ROWEPI == 1 ? 4 : 1))) void
         const float beta1 = g.adam_h[0], beta2 = g.adam_h[1], eps = g.adam_h[2], wd = g.adam_h[3];
         const float step_size = g.adam_h[4], inv_bc2_sqrt = g.adam_h[5];
         float *patch = reinterpret_cast<float *>(smem);              // [64][128]
-#ifndef SEI_ADAM_Q
-#define SEI_ADAM_Q 4
-#endif
-        constexpr int ADAM_Q = SEI_ADAM_Q;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             __builtin_amdgcn_s_barrier();                            // operands (h = 0) / the previous half are done with
@@ -500,33 +496,33 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : (ROWEPI == 1 ? 4 : 1))) void
             }
             __syncthreads();
 #pragma unroll 1
-          for (int kk = 0; kk < 4; kk += ADAM_Q) {                   // ADAM_Q quads at a time
-            float4 pq[ADAM_Q], mq[ADAM_Q], vq[ADAM_Q];
+          for (int kk = 0; kk < 4; kk += 2) {                        // two quads at a time: registers for 3 workgroups / CU
+            float4 gq[2], pq[2], mq[2], vq[2];
+            size_t off[2];
+            bool ok[2];
 #pragma unroll
-            for (int k = 0; k < ADAM_Q; ++k) {                       // 3 ADAM_Q independent 16-byte loads per lane in flight
+            for (int k = 0; k < 2; ++k) {                            // 6 independent 16-byte loads per lane in flight
                 const int idx = threadIdx.x + NT * (kk + k), r = idx >> 5, c4 = idx & 31;
                 const int row = m0 + 64 * h + r, col = n0 + 4 * c4;
-                const size_t off = (row < M && col < N) ? (size_t)row * N + col : 0;     // N % 8 == 0: a quad is all in or all out
+                ok[k] = row < M && col < N;                          // N % 8 == 0: a quad is all in or all out
+                off[k] = ok[k] ? (size_t)row * N + col : 0;
+                gq[k] = *reinterpret_cast<const float4 *>(patch + r * 128 + 4 * c4);
                 // streamed once per step: non-temporal, so that they do not push the GEMM operands out of L2 / MALL
-                pq[k] = nt_load4(g.adam_p + off);
-                mq[k] = nt_load4(g.adam_m + off);
-                vq[k] = nt_load4(g.adam_v + off);
+                pq[k] = nt_load4(g.adam_p + off[k]);
+                mq[k] = nt_load4(g.adam_m + off[k]);
+                vq[k] = nt_load4(g.adam_v + off[k]);
             }
 #pragma unroll
-            for (int k = 0; k < ADAM_Q; ++k) {
-                const int idx = threadIdx.x + NT * (kk + k), r = idx >> 5, c4 = idx & 31;
-                const int row = m0 + 64 * h + r, col = n0 + 4 * c4;
-                if (!(row < M && col < N)) continue;
-                const size_t off = (size_t)row * N + col;
-                const float4 gq = *reinterpret_cast<const float4 *>(patch + r * 128 + 4 * c4);
+            for (int k = 0; k < 2; ++k) {
+                if (!ok[k]) continue;
                 float4 o;
-                o.x = sei_adam_element(pq[k].x, gq.x, mq[k].x, vq[k].x, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
-                o.y = sei_adam_element(pq[k].y, gq.y, mq[k].y, vq[k].y, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
-                o.z = sei_adam_element(pq[k].z, gq.z, mq[k].z, vq[k].z, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
-                o.w = sei_adam_element(pq[k].w, gq.w, mq[k].w, vq[k].w, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
-                nt_store4(g.adam_m + off, mq[k]);
-                nt_store4(g.adam_v + off, vq[k]);
-                nt_store4(g.adam_p + off, o);
+                o.x = sei_adam_element(pq[k].x, gq[k].x, mq[k].x, vq[k].x, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                o.y = sei_adam_element(pq[k].y, gq[k].y, mq[k].y, vq[k].y, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                o.z = sei_adam_element(pq[k].z, gq[k].z, mq[k].z, vq[k].z, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                o.w = sei_adam_element(pq[k].w, gq[k].w, mq[k].w, vq[k].w, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                nt_store4(g.adam_m + off[k], mq[k]);
+                nt_store4(g.adam_v + off[k], vq[k]);
+                nt_store4(g.adam_p + off[k], o);
                 if (g.adam_p16) {
                     uint2 w;
                     w.x = (unsigned)f2bf(o.x) | ((unsigned)f2bf(o.y) << 16);
@@ -534,7 +530,7 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : (ROWEPI == 1 ? 4 : 1))) void
                     typedef unsigned nt_u32x2 __attribute__((ext_vector_type(2)));
                     nt_u32x2 t;
                     t.x = w.x; t.y = w.y;
-                    __builtin_nontemporal_store(t, reinterpret_cast<nt_u32x2 *>(g.adam_p16 + off));
+                    __builtin_nontemporal_store(t, reinterpret_cast<nt_u32x2 *>(g.adam_p16 + off[k]));
                 }
             }
           }
