@@ -15,9 +15,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist1_worker.py")
 
 
+def _free_port():
+    """A port nobody holds right now (each case starts its own rendezvous: the port of the previous child may still be in
+    TIME_WAIT)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _run(extra):
     env = dict(os.environ, SEI_FORCE_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD_SIZE="1", RANK="0",
-               LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(30100 + os.getpid() % 400))
+               LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     env.pop("SEI_DIST_BACKEND", None)                         # the default on a GPU box: nccl = RCCL
     r = subprocess.run([sys.executable, WORKER] + extra, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
