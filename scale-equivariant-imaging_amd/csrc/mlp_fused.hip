@@ -331,8 +331,18 @@ inline unsigned mlp_grid(int M, int rows_per_group) {
 extern "C" size_t sei_mlp_fused_eligible(long long M, int C) {
     if (M <= 0 || M >= (1ll << 31)) return 0;
     if (C == 32) return 1;
-    return sei_mlp128_eligible((int)M, C) ? 1 : 0;
+    // C = 128: the nine-wave kernels on whole groups of 144 pixels (+ the first fused kernel on a tail of < 144: the
+    // 256-pixel grids of the un-cropped series are powers of two)
+    return (C == 128 && M >= 144 * 64) || sei_mlp128_eligible((int)M, C) ? 1 : 0;
 }
+
+namespace {
+// pixels the nine-wave kernels take when M is not a multiple of their 144-pixel groups (0: none, the old kernel takes all)
+inline int mlp128_main(int M, int C) {
+    if ((C != 32 && C != 128) || M < 144 * 64) return 0;
+    return M - M % 144;
+}
+}  // namespace
 
 extern "C" int sei_mlp_fused_fwd(const uint16_t *h2, const uint16_t *W2, const float *b2, const uint16_t *W3,
                                  const float *b3, const float *x, float res_scale, float *out, int M, int C,
@@ -343,6 +353,13 @@ extern "C" int sei_mlp_fused_fwd(const uint16_t *h2, const uint16_t *W2, const f
     if (sei_mlp128_eligible(M, C)) {
         SEI_REQUIRE((((uintptr_t)x | (uintptr_t)out) & 15) == 0);
         return sei_mlp128_fwd_launch(h2, W2, b2, W3, b3, x, res_scale, out, M, C, s);
+    }
+    if (const int main = mlp128_main(M, C)) {                        // whole 144-pixel groups there, the tail below
+        SEI_REQUIRE((((uintptr_t)x | (uintptr_t)out) & 15) == 0);
+        if (int rc = sei_mlp128_fwd_launch(h2, W2, b2, W3, b3, x, res_scale, out, main, C, s)) return rc;
+        const size_t o = (size_t)main * C;
+        h2 += o; x += o; out += o;
+        M -= main;
     }
     if (C == 32)
         hipLaunchKernelGGL((mlp_fwd_kernel<32, 2>), dim3(mlp_grid(M, 64 * WAVES)), dim3(THREADS), 0, s, h2, W2, b2, W3, b3,
@@ -363,6 +380,13 @@ extern "C" int sei_mlp_fused_bwd(const float *go, const uint16_t *h2, const uint
     if (sei_mlp128_eligible(M, C)) {
         SEI_REQUIRE((((uintptr_t)gh2 | (uintptr_t)go) & 15) == 0);
         return sei_mlp128_bwd_launch(go, h2, W2, b2, W3T, W2T, gh2, go16, h4, gh3, M, C, s);
+    }
+    if (const int main = mlp128_main(M, C)) {
+        SEI_REQUIRE((((uintptr_t)gh2 | (uintptr_t)go) & 15) == 0);
+        if (int rc = sei_mlp128_bwd_launch(go, h2, W2, b2, W3T, W2T, gh2, go16, h4, gh3, main, C, s)) return rc;
+        const size_t o = (size_t)main * C;
+        go += o; h2 += o; gh2 += o; go16 += o; h4 += 4 * o; gh3 += 4 * o;
+        M -= main;
     }
     if (C == 32)
         hipLaunchKernelGGL((mlp_bwd_kernel<32, 2>), dim3(mlp_grid(M, 64 * WAVES)), dim3(THREADS), 0, s, go, h2, W2, b2, W3T,

@@ -852,14 +852,15 @@ def test_resampler_on_the_matrix_cores_at_large_extents(ops, kind, B, H, W, C):
 
 @pytest.mark.parametrize("twice", [False, True])
 @pytest.mark.parametrize("B,H,W,C", [(2, 5, 7, 32), (3, 48, 48, 32), (1, 9, 11, 128), (2, 24, 24, 128), (1, 12, 12, 128),
-                                     (16, 24, 24, 128)])
+                                     (16, 24, 24, 128), (1, 128, 128, 128), (2, 128, 128, 32)])
 def test_fused_mlp_block_matches_the_unfused_bf16_block(ops, B, H, W, C, twice):
     """The fused pointwise MLP of the shallow levels (sei_mlp_fused_fwd / _bwd: conv2 -> GELU -> conv3 + residual
     with the hidden activation in registers, recomputed by the backward) against the unfused bf16 block on the same
     weights: identical bf16 products and roundings, so outputs and gradients agree to accumulation-order noise; and
     against a float64 evaluation of the block to bf16 resolution. Ragged pixel counts (not multiples of 32); at C = 128
-    pixel counts that are multiples of 144 take the nine-wave kernel of csrc/mlp128.hip (one workgroup, eight, 64), any other
-    count the GEMMs (sei_mlp_fused_eligible)."""
+    pixel counts that are multiples of 144 take the nine-wave kernel of csrc/mlp128.hip (one workgroup, eight, 64); from 9216
+    pixels on, counts that are not (the 128 x 128 grids: 16,384 and 32,768 pixels) are split into whole 144-pixel groups on
+    that kernel and a tail on the first fused kernel; small counts that are not: the GEMMs (sei_mlp_fused_eligible)."""
     prev = ops.set_compute_dtype("bf16")
     saved = ops.FUSED_MLP_CHANNELS
     try:
