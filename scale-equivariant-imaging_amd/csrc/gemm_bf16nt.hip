@@ -967,7 +967,9 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
         // skinny data gradients (the bottleneck levels): 192 x 256 with two 128-column images of the weight -- but not
         // the float32 ones that split K (Downsample's convolution between the two deepest levels, 288 / 576 x 2048 x 8192:
         // 65 / 75 us there against 40 / 55 on 128 x 128 tiles with 8 / 6 splits, tools/exp_skinny.py)
-        if (tile != 1 && N >= 2048 && K >= 2048 && M <= 768 && !would_split)
+        // (M <= 144 against a 32768-wide weight -- the reference's default batch of 8: 128 x 128 tiles, 256 of them, stream it
+        // faster than 128 tiles of 192 x 256: 189 / 157 us against 259 / 243 at 144 / 72 rows, tools/exp_b8.py)
+        if (tile != 1 && N >= 2048 && K >= 2048 && M <= 768 && !would_split && !(M <= 144 && N >= 16384))
             return launch_nt<3, 2, 2, 4, false, true>(g, s);
         return launch_nt<2, 1, 2, 4, false, true>(g, s);
     }
@@ -997,7 +999,9 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
     }
     // (not the convolution behind the downsampler, which cannot split K: 288 / 576 x 8192 x 2048 run 56 / 48 us on 64
     // tiles of 192 x 256 and 32 / 41 us on 128 x 128, tools/exp_skinny.py)
-    if (N >= 2048 && K >= 2048 && M <= 768 && epilogue != SEI_EPI_BIAS_ROWSCALE) return launch_nt<3, 2, 2, 4>(g, s);   // 192 x 256
+    // (and not M <= 144 against 32768 columns: 197 / 156 us on 128 x 128 against 236 / 210, tools/exp_b8.py)
+    if (N >= 2048 && K >= 2048 && M <= 768 && epilogue != SEI_EPI_BIAS_ROWSCALE && !(M <= 144 && N >= 16384))
+        return launch_nt<3, 2, 2, 4>(g, s);                                              // 192 x 256
     // short reductions are all prologue and epilogue: one LDS stage (32 KB) and <= 84 VGPRs put three workgroups
     // on a CU instead of two (36864 x 512 x 128: 34 -> 27 us; 9216 x 2048 x 512: 50 -> 44 us; loses from K ~ 2048)
     if (K <= 1024 && tile != 1) return launch_nt<2, 1, 2, 4, false, false, 1>(g, s);
