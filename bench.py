@@ -12,7 +12,10 @@ Workload: config[1] of BASELINE.json -- deblurring, Gaussian_R2, noise 5, propos
 default ConvolutionalModel (hidden 32, 5 scales, 645,063,043 parameters), per-GPU batch 32 (config[3]'s
 256 / 8), synthetic inputs resident in HBM, random-init weights (torch.manual_seed(0)).
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with these extra objects:
+The LAST stdout line of rank 0 is the contract's ONE JSON line -- the headline only, kept under 8 kB (`compact_line`;
+tests/test_bench_line.py) so that the driver parses it. Every secondary series is printed in full on an EARLIER line
+(`{"series": "<name>", ...}`) and the whole uncompacted object goes to gpurun_out/bench_full.json (or $SEI_BENCH_FULL).
+The headline carries these extra objects:
   roofline     -- the dominant kernel family (the bf16 MFMA GEMMs: all 1x1 convolutions and their gradients),
                   every launch of one step re-issued between HIP events on the launch stream.
   roofline_hbm -- the streaming kernel families of the same step (Adam, depthwise 7x7, LayerNorm, ideal resamplers,
@@ -52,9 +55,9 @@ def reference_args(device, hidden=32, scales=5, task="deblurring", sr_factor=Non
         ScalingTransform__kind="padded", ScalingTransform__antialias=False)
 
 
-def cpu_baseline(batch, hidden, scales, timed_steps=2):
+def cpu_baseline(batch, hidden, scales, timed_steps=3):
     """The oracle's restatement of the same training step on the host CPU (kind "port"), by the protocol of
-    BASELINE.md section 3 / SURVEY 8(d): batch 4, float32, all host cores, 1 warm-up step + >= 2 timed steps."""
+    BASELINE.md section 3 / SURVEY 8(d): batch 4, float32, all host cores, 1 warm-up step + 3 timed steps (~35 s)."""
     import oracle
     from oracle import torch_path as tp
     torch.manual_seed(0)
@@ -79,14 +82,20 @@ def cpu_baseline(batch, hidden, scales, timed_steps=2):
     t0 = time.perf_counter()
     step()                                                 # warm-up (first-call overheads, allocator, Adam state)
     t1 = time.perf_counter()
+    per_step = []
     for _ in range(timed_steps):
+        ts = time.perf_counter()
         step()
-    dt = (time.perf_counter() - t1) / timed_steps
+        per_step.append(time.perf_counter() - ts)
+    dt = sum(per_step) / timed_steps
+    # box-to-box spread of this figure has been +-9 % (0.457-0.540 images/s over rounds 3-4): context, not a target
     return {"value": round(batch / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "value_min": round(batch / max(per_step), 4), "value_max": round(batch / min(per_step), 4),
+            "timed_steps": timed_steps,
             "sample": f"{timed_steps} timed proposed-loss steps after 1 warm-up ({t1 - t0:.1f} s) of the same U-Net at "
                       f"batch {batch} (crop {CROP}, 3 fwd + 3 bwd + Adam), float32, torch CPU ops in the reference's "
-                      f"order (oracle/torch_path.py), {dt:.1f} s per step; {threads} intra-op threads = the CPUs this process may use "
-                      f"(affinity and cgroup quota; the host has {os.cpu_count()} logical CPUs)"}
+                      f"order (oracle/torch_path.py), {dt:.1f} s per step (min {min(per_step):.1f}, max {max(per_step):.1f}); "
+                      f"{threads} intra-op threads = the CPUs this process may use (host: {os.cpu_count()} logical CPUs)"}
 
 
 def cpu_baseline_swinir(batch, sr_factor=2, timed_steps=1):
@@ -241,6 +250,40 @@ def _stream_bytes(name, a):
     return None
 
 
+def _gemm_bytes(name, a):
+    """Algorithmic HBM bytes of one launch of a matrix-core entry point, from its own arguments: every operand read once,
+    every result written once (a weight gradient's two row blocks, a fused MLP's hidden activation staying on chip).
+    None = an entry point not modelled here (its launches are then left out of `algorithmic_bytes_per_launch`)."""
+    if name in ("sei_gemm_bf16nt", "sei_gemm_bf16nt_ex"):
+        M, Nn, K, epi = a[8:12]
+        extra = sum(4 for ptr in (a[13], a[14]) if ptr) if epi != 6 else 0          # R1 / R2 (BIAS_ROWSCALE: M floats)
+        return 2 * K * (M + Nn) + M * Nn * ((4 if a[6] else 0) + (2 if a[7] else 0) + extra + (2 if a[15] else 0)
+                                            + (4 if epi == 5 else 0))
+    if name in ("sei_gemm_bf16_ex", "sei_gemm_f32_ex"):
+        M, Nn, K = a[3:6]
+        return 4 * (K * (M + Nn) + M * Nn * (1 + sum(1 for ptr in a[10:13] if ptr) + (1 if a[8] == 5 else 0)))
+    if name == "sei_gemm_bf16_mixed":
+        M, Nn, K = a[5:8]
+        return K * (M * (2 if a[1] else 4) + Nn * (2 if a[3] else 4)) + 4 * M * Nn * (
+            1 + sum(1 for ptr in a[12:15] if ptr) + (1 if a[10] == 5 else 0))
+    if name in ("sei_gemm_bf16nt_dw2", "sei_gemm_bf16nt_dw2_bf16out", "sei_gemm_bf16nt_dw2_adam"):
+        if name.endswith("_adam"):
+            return _stream_bytes(name, a)
+        Np, Kp, K1, K2 = a[7:11]
+        out = 2 if name.endswith("_bf16out") else (8 if a[11] else 4)
+        return 2 * (K1 + K2) * (Np + Kp) + out * Np * Kp
+    if name == "sei_dwstream_bf16_jobs":                       # each job: both operands' row blocks once, D read + written
+        return sum(2 * (j.K1 + j.K2) * (j.Mo + j.Ni) + 8 * j.Mo * j.Ni for j in a[0][:a[1]])
+    if name == "sei_mlp_fused_fwd":                            # h2 (bf16) + x in, out out, the two weight matrices
+        M, C = a[8:10]
+        return M * C * 10 + 16 * C * C
+    if name == "sei_mlp_fused_bwd":                            # go + h2 in; gh2 (f32), go16, h4, gh3 (bf16) out; 3 matrices
+        M, C = a[10:12]
+        return M * C * (4 + 2 + 4 + 2 + 8 + 8) + 24 * C * C
+    return None
+
+
+# (label, entry-point prefixes); the text before " (" is the family's short name on the compact line
 _STREAM_FAMILIES = [
     ("adam_vec_kernel (fused Adam over the flat bucket)", ("sei_adam_fused",)),
     ("gemm_bf16nt_kernel<..., ADAM> (HBM-bound weight gradients whose epilogue applies the Adam step: the bottleneck pair)",
@@ -302,21 +345,25 @@ def stream_roofline(log, reps=3):
     return out
 
 
-def dist1_child(opt, timeout=420):
-    """`secondary.dist1`: configs[3]'s PER-RANK step on this one GPU -- the same workload with the whole N > 1 machinery live
-    on RCCL at world size 1 (SEI_FORCE_EXCHANGE=1: process group, reduce-scatter of every gradient chunk, Adam on the
-    share, all-gather of the updated weights, early release from inside the graph), hence stored float32 gradients and no
-    optimizer step inside the GEMMs. Run as a CHILD process (a fresh interpreter whose environment selects the backend
-    before its first GPU call; this process never re-execs), its JSON line embedded here."""
+def dist1_child(opt, grad_comm=None, timeout=420):
+    """`secondary.dist1` / `secondary.dist1_bf16`: configs[3]'s PER-RANK step on this one GPU -- the same workload with the
+    whole N > 1 machinery live on RCCL at world size 1 (SEI_FORCE_EXCHANGE=1: process group, reduce-scatter of every
+    gradient chunk, Adam on the share, all-gather of the updated weights, early release from inside the graph), hence
+    stored gradients and no optimizer step inside the GEMMs. `grad_comm`: the exchanged bucket's dtype (f32 = train.py's
+    default; bf16 = the compressed exchange with the deep levels' gradients stored as bf16 straight into the exchange
+    buffer). Run as a CHILD process (a fresh interpreter whose environment selects the backend before its first GPU call;
+    this process never re-execs), its JSON line embedded here."""
     import socket
     import subprocess
+    grad_comm = grad_comm or opt.grad_comm
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     env = dict(os.environ, SEI_FORCE_EXCHANGE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               SEI_BENCH_FULL=os.path.join(ROOT, "gpurun_out", f"bench_full_dist1_{grad_comm}.json"))
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "10", "--warmup", "3", "--batch",
-           str(opt.batch), "--no-secondary", "--no-cpu-baseline", "--grad-comm", opt.grad_comm, "--grad-comm-mode",
+           str(opt.batch), "--no-secondary", "--no-cpu-baseline", "--grad-comm", grad_comm, "--grad-comm-mode",
            opt.grad_comm_mode]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
@@ -330,11 +377,93 @@ def dist1_child(opt, timeout=420):
                                       "graph_kernel_nodes_per_step")}
     keep["workload"] = ("BASELINE configs[3], one rank of it: configs[1]'s step with the gradient exchange LIVE on RCCL at "
                         "world size 1 (reduce_scatter_tensor / all_gather_into_tensor through ProcessGroupNCCL, sharded "
-                        "FlatAdam, early release; stored f32 gradients, Adam not fused into the GEMMs): the per-rank "
-                        "compute + plumbing cost of the 8-GPU step, without the wire time")
+                        f"FlatAdam, early release; stored {'bf16' if grad_comm == 'bf16' else 'f32'} gradients, Adam not "
+                        "fused into the GEMMs): the per-rank compute + plumbing cost of the 8-GPU step, without the wire time")
     keep["grad_allreduce"] = child["config"].get("grad_allreduce")
     keep["launch"] = child["config"].get("launch")
     return keep
+
+
+LINE_LIMIT = 7800            # the driver keeps an 8,081-character tail of stdout: the whole headline line must fit in it
+
+_ROOFLINE_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                  "traffic_source", "launches_per_step", "avg_launch_us", "gemm_ms_per_step", "algorithmic_gflop_per_step",
+                  "gflop_per_step_inside_hbm_bound_launches")
+
+
+def _short(text, limit):
+    text = str(text)
+    return text if len(text) <= limit else text[:limit - 3] + "..."
+
+
+def compact_line(full, limit=LINE_LIMIT):
+    """The contract's one line from the full result object: the headline with its `roofline`, `roofline_hbm` and
+    `cpu_baseline`, and each secondary series reduced to {value, ms_per_step, steps, dtype, frac[, nodes]}. Pure (no GPU):
+    tests/test_bench_line.py builds it from a recorded run and asserts the size and the required keys. If the line is
+    still over `limit`, prose fields are shortened first, then dropped -- numbers never."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data") if k in full}
+    out["config"] = dict(full.get("config") or {})
+    roof = full.get("roofline")
+    out["roofline"] = None if roof is None else {k: roof[k] for k in _ROOFLINE_KEEP if k in roof}
+    hbm = full.get("roofline_hbm")
+    if hbm is not None:
+        out["roofline_hbm"] = [{("kernel" if k == "kernel" else k): (v.split(" (")[0] if k == "kernel" else v)
+                                for k, v in fam.items() if k not in ("peak", "unit")} for fam in hbm]
+        out["roofline_hbm_peak"] = {"peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    if full.get("graph_kernel_nodes_per_step") is not None:
+        out["graph_kernel_nodes_per_step"] = full["graph_kernel_nodes_per_step"]
+    sec = full.get("secondary")
+    if sec is not None:
+        out["secondary"] = {}
+        for key, entry in sec.items():
+            if "error" in entry:
+                out["secondary"][key] = {"error": _short(entry["error"], 120)}
+                continue
+            small = {k: entry.get(k) for k in ("value", "ms_per_step", "steps", "dtype") if entry.get(k) is not None}
+            r = entry.get("roofline")
+            if r:
+                small["roofline"] = {"frac": r.get("frac"), "bound": r.get("bound"), "gemm_ms_per_step": r.get("gemm_ms_per_step")}
+            if entry.get("graph_kernel_nodes_per_step") is not None:
+                small["nodes"] = entry["graph_kernel_nodes_per_step"]
+            out["secondary"][key] = small
+        out["secondary_full"] = "one earlier stdout line per series ({\"series\": name, ...}) and " + str(full.get("full_file"))
+    for key in ("cpu_baseline", "cpu_baseline_swinir"):
+        if key in full:
+            out[key] = dict(full[key])
+    line = json.dumps(out)
+    # prose gives way first (never a number): samples, sources, labels, workload text
+    for path, keep in ((("cpu_baseline_swinir", "sample"), 160), (("cpu_baseline", "sample"), 240),
+                       (("roofline", "traffic_source"), 120), (("roofline", "kernel"), 100),
+                       (("config", "workload"), 120), (("config", "optimizer"), 40), (("config", "launch"), 40),
+                       (("config", "grad_allreduce"), 60)):
+        if len(line) <= limit:
+            break
+        node = out.get(path[0])
+        if isinstance(node, dict) and isinstance(node.get(path[1]), str):
+            node[path[1]] = _short(node[path[1]], keep)
+            line = json.dumps(out)
+    for key in ("secondary_full", "cpu_baseline_swinir", "secondary", "graph_kernel_nodes_per_step"):
+        if len(line) <= limit:
+            break
+        out.pop(key, None)
+        line = json.dumps(out)
+    return line
+
+
+def emit(full):
+    """Rank 0's output: the full series first (one line each), the full object to a side file, the headline LAST."""
+    path = os.environ.get("SEI_BENCH_FULL") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        full["full_file"] = os.path.relpath(path, ROOT)
+    except OSError as exc:                                  # a read-only tree must not cost the run its line
+        full["full_file"] = f"(not written: {exc})"
+    for key, entry in (full.get("secondary") or {}).items():
+        print(json.dumps({"series": key, **entry}), flush=True)
+    print(compact_line(full), flush=True)
 
 
 class Leg:
@@ -519,7 +648,7 @@ def gemm_roofline(records, dtype, reps=3):
     families (stream_roofline), FLOPs and all; the level-3 ones (K = 3456) are MFMA-bound and are timed here. (Re-issuing
     any of them steps their weights again: `rooflines` restores the optimizer state afterwards.)"""
     import _native
-    total_ms, flops = 0.0, 0.0
+    total_ms, flops, abytes, amodelled = 0.0, 0.0, 0.0, 0
     hbm_side = lambda r: r[1] == "sei_gemm_bf16nt_dw2_adam" and not adam_gemm_is_mfma_bound(r[2])
     riding = sum(fl for fl, entry, a in records if hbm_side((fl, entry, a)))
     records = [r for r in records if not hbm_side(r)]
@@ -533,6 +662,9 @@ def gemm_roofline(records, dtype, reps=3):
         e1.synchronize()
         total_ms += e0.elapsed_time(e1) / reps
         flops += fl
+        nb = _gemm_bytes(entry, cargs)
+        if nb is not None:
+            abytes, amodelled = abytes + nb, amodelled + 1
         if os.environ.get("SEI_GEMM_TABLE"):            # per-launch table for kernel work (tools/, not the bench line)
             with open(os.environ["SEI_GEMM_TABLE"], "a") as f:
                 ints = [a for a in cargs if isinstance(a, int) and 0 <= a < (1 << 24)]
@@ -553,7 +685,10 @@ def gemm_roofline(records, dtype, reps=3):
     else:
         kernels = "gemm_f32_kernel<*>"
     return {"bound": "mfma", "kernel": kernels, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None, "traffic_source": None,
+            "frac": round(achieved / peak, 4), "traffic": None,
+            # operands once + results once, averaged over the launches (the figure `traffic` is to be read against)
+            "algorithmic_bytes_per_launch": round(abytes / amodelled) if amodelled else None,
+            "algorithmic_bytes_launches_modelled": amodelled, "traffic_source": None,
             "launches_per_step": len(records), "avg_launch_us": round(1e3 * total_ms / len(records), 2),
             "gemm_ms_per_step": round(total_ms, 2), "algorithmic_gflop_per_step": round(flops / 1e9, 1),
             "gflop_per_step_inside_hbm_bound_launches": round(riding / 1e9, 1),
@@ -600,7 +735,7 @@ def main():
     ap.add_argument("--scales", type=int, default=5)
     ap.add_argument("--cpu-baseline", action=argparse.BooleanOptionalAction, default=True)
     ap.add_argument("--cpu-batch", type=int, default=4, help="batch of the CPU baseline (BASELINE.md section 3: 4)")
-    ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU steps after one warm-up step")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps after one warm-up step")
     ap.add_argument("--profile-gemms", action=argparse.BooleanOptionalAction, default=True,
                     help="the roofline legs (GEMM family + streaming families) after the timed region")
     ap.add_argument("--secondary", action=argparse.BooleanOptionalAction, default=True,
@@ -725,7 +860,8 @@ def main():
                   "BASELINE configs[1] with every step's batch gathered from the GPU-resident pair cache "
                   "(datasets/device_cache.py, 256 synthetic pairs = 8 batches per epoch; src/datasets/__init__.py:67-90)",
                   feed=lambda lg: lg.feed_from_device_cache(256))
-        secondary["dist1"] = dist1_child(opt)
+        secondary["dist1"] = dist1_child(opt, "f32")
+        secondary["dist1_bf16"] = dist1_child(opt, "bf16")
 
     if rank == 0:
         images = opt.batch * world * opt.steps
@@ -768,7 +904,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(opt.cpu_batch, opt.hidden, opt.scales, opt.cpu_steps)
             if secondary is not None and "swinir_sr2" in secondary:
                 out["cpu_baseline_swinir"] = cpu_baseline_swinir(opt.cpu_batch)
-        print(json.dumps(out))
+        emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()
 
