@@ -616,9 +616,10 @@ class Leg:
         """One eager step with every native call logged (streaming families) and every GEMM launch recorded with its
         FLOPs, issued exactly as the timed (graphed) step issues them: merged weight gradients STORE."""
         import _native
-        from models import _ops
+        from models import _joint, _ops
         _ops.profile_gemms(True)
         _native.record_calls(True)
+        _joint.KEEP_ARENA = True               # (the joint backward's 3B-row activations are operands of the re-issues)
         fused = self.graphed is not None and bool(self.graphed.fused_views)
         if fused:                              # as the captured step: the bottleneck pair is stepped inside its GEMMs
             _ops.set_fused_adam(*self.graphed.fused_table, owner=self.backbone)
@@ -631,6 +632,7 @@ class Leg:
             keep = self.loss_fn(x=self.x, y=self.y, model=self.model)
             keep.backward(retain_graph=True)   # keeps the saved activations (GEMM operands) alive for the replay
         finally:
+            _joint.KEEP_ARENA = False
             if fused:
                 _ops.set_fused_adam(None, None, owner=self.backbone)
         if self.reducer is not None:

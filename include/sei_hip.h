@@ -32,7 +32,7 @@ extern "C" {
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
-#define SEI_ABI_VERSION 9
+#define SEI_ABI_VERSION 10
 int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
@@ -344,6 +344,16 @@ int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, const uint16_t 
 int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
                            const uint16_t *B2, int ldb, float *D32, int M, int N, int K1, int K2, int accumulate,
                            int tile, void *stream);
+
+/* The schedule sei_gemm_bf16nt would take for a GEMM of these shapes, WITHOUT launching anything (host arithmetic only:
+ * callable on a machine with no GPU): (family << 48) | (tile rows << 32) | (tile columns << 16) | K splits, with
+ * family 1 = gemm_bf16nt_kernel (the 128x128-style loop, whatever its tile), 2 = gemm_bf16pq_kernel (the quadrant
+ * schedule); 0 = arguments the entry point would refuse. out_f32 / out_bf16: which of D32 / D16 the call passes.
+ * Operands are taken as densely packed and 16-byte aligned. For tests that pin which kernels the TIMED batch runs
+ * (tests/test_loss_gpu.py::test_timed_configuration_vs_oracle): a dispatch change cannot silently move the benchmarked
+ * launch set away from what the oracle comparison covered. (The reference has no counterpart: its GEMMs are torch's,
+ * src/models/convolutional.py:33-51.) */
+size_t sei_gemm_bf16nt_plan(int a_rmajor, int b_rmajor, int out_f32, int out_bf16, int M, int N, int K, int epilogue);
 
 #ifdef SEI_TUNING
 /* Tools-only build (make tuning -> libsei_hip_tuning.so; not part of libsei_hip.so).

@@ -161,8 +161,9 @@ SIZE_QUERIES = {
     "sei_ln_bwd_part_count": [_Z, _I],
     "sei_rowgemm_dgelu_bf16_eligible": [_L, _I, _I],
     "sei_rowgemm_ln_bf16_eligible": [_L, _I, _I],
+    "sei_gemm_bf16nt_plan": [_I, _I, _I, _I, _I, _I, _I, _I],
 }
-ABI_VERSION = 9       # SEI_ABI_VERSION of include/sei_hip.h this table was written against
+ABI_VERSION = 10      # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 
 
 class NativeLibraryError(RuntimeError):
@@ -192,6 +193,15 @@ def lib():
             raise NativeLibraryError("libsei_hip.so was built from a different include/sei_hip.h")
         _lib = handle
     return _lib
+
+
+def gemm_plan(a_rmajor, b_rmajor, out_f32, out_bf16, M, Nn, K, epilogue):
+    """(family, tile rows, tile columns, K splits) of the launch sei_gemm_bf16nt would make (sei_gemm_bf16nt_plan: nothing
+    is launched); family "nt" = gemm_bf16nt_kernel, "pq" = gemm_bf16pq_kernel. Raises on shapes the entry point refuses."""
+    code = lib().sei_gemm_bf16nt_plan(int(a_rmajor), int(b_rmajor), int(out_f32), int(out_bf16), M, Nn, K, epilogue)
+    if code == 0:
+        raise NativeLibraryError("sei_gemm_bf16nt_plan: arguments sei_gemm_bf16nt would refuse")
+    return {1: "nt", 2: "pq"}[code >> 48], (code >> 32) & 0xFFFF, (code >> 16) & 0xFFFF, code & 0xFFFF
 
 
 def stream():

@@ -59,6 +59,9 @@ struct NtArgs {
     // host-side only (the kernels never read them): the caller's explicit tile / band choice of the _ex entry
     // points; 0 = the dispatcher decides. Per call, so the library holds no mutable state.
     int force_tile, force_band;
+    // host-side only: sei_gemm_bf16nt_plan. Non-null: the dispatcher writes (family, BM, BN, K splits) there and launches
+    // NOTHING -- the schedule a call with these shapes would take, for tests that pin the timed launch set.
+    unsigned long long *plan;
     // 3x3 convolution on a zero-bordered grid (sei_gemm_bf16nt_conv): K = 9 * conv_cin; k-tile kt reads A rows
     // shifted by conv_off[tap], tap = k / conv_cin, at column k - tap * conv_cin. conv_cin = 0: a plain GEMM.
     int conv_cin;
@@ -767,6 +770,10 @@ int launch_nt(NtArgs &g, hipStream_t s) {
             g.splitk = (int)sei_ceil_div(g.K, g.k_per_split);
         }
     }
+    if (g.plan) {
+        *g.plan = (1ull << 48) | ((unsigned long long)BM << 32) | ((unsigned long long)BN << 16) | (unsigned)g.splitk;
+        return SEI_OK;
+    }
     if (g.splitk > 1 && g.epilogue != SEI_EPI_ACCUM) {      // ACCUM adds into the running gradient as it is
         if (nbatch > 1) return SEI_ERR_BAD_ARG;             // (batched launches accumulate or run unsplit)
         const size_t n = (size_t)g.M * g.N;
@@ -853,10 +860,10 @@ int pq_choose(const NtArgs &g, bool would_split) {
 // transposing LDS reads). The kernel supports the layout (tile codes 30 / 33; tests) for later work on it.
 int pq_choose_rr(const NtArgs &) { return 0; }
 
-extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
-                                  float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
-                                  const float *R1, const float *R2, uint16_t *D2_16, int tile, int band,
-                                  void *stream) {
+static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                    float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
+                    const float *R1, const float *R2, uint16_t *D2_16, int tile, int band,
+                    void *stream, unsigned long long *plan) {
     SEI_REQUIRE(A && B && (D32 || D16) && M > 0 && N > 0 && K > 0);
     SEI_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0);
     SEI_REQUIRE(lda >= (a_rmajor ? M : K) && ldb >= (b_rmajor ? N : K));
@@ -874,12 +881,13 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
     if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D2_16);
     if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU) SEI_REQUIRE(R1);
     if (epilogue == SEI_EPI_ACCUM) SEI_REQUIRE(D32 && !D16);
-    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
     g.A2 = A; g.B2 = B; g.k_seg = K;                       // one reduction segment
     g.conv_cin = 0;
     g.batch = 1;
+    g.plan = plan;
     SEI_REQUIRE(tile >= 0 && band >= 0);
     if (epilogue == SEI_EPI_BIAS_SCALE_RES && tile == 0)                // the quadrant kernel has no such epilogue
         tile = (N > 128 && N <= 192) ? 6 : 1;
@@ -1008,11 +1016,41 @@ extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, cons
     return launch_nt<2, 1, 2, 4>(g, s);                                                  // 128 x 128
 }
 
+extern "C" int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                                  float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
+                                  const float *R1, const float *R2, uint16_t *D2_16, int tile, int band,
+                                  void *stream) {
+    return nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, D32, D16, M, N, K, epilogue, bias, R1, R2, D2_16, tile, band,
+                    stream, nullptr);
+}
+
 extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
                                float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
                                const float *R1, const float *R2, uint16_t *D2_16, void *stream) {
-    return sei_gemm_bf16nt_ex(A, lda, a_rmajor, B, ldb, b_rmajor, D32, D16, M, N, K, epilogue, bias, R1, R2, D2_16, 0,
-                              0, stream);
+    return nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, D32, D16, M, N, K, epilogue, bias, R1, R2, D2_16, 0, 0, stream,
+                    nullptr);
+}
+
+// The schedule sei_gemm_bf16nt would take for these shapes, launching nothing (host arithmetic only, no GPU needed):
+// (family << 48) | (tile rows << 32) | (tile columns << 16) | K splits, family 1 = the 128 x 128 loop's kernel
+// (gemm_bf16nt_kernel, whatever its tile), 2 = the quadrant schedule (gemm_bf16pq_kernel); 0 = arguments the entry point
+// would refuse. Operands are taken as densely packed and 16-byte aligned, which is what models/_ops.py passes.
+extern "C" size_t sei_gemm_bf16nt_plan(int a_rmajor, int b_rmajor, int out_f32, int out_bf16, int M, int N, int K,
+                                       int epilogue) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const uint16_t *fake16 = reinterpret_cast<const uint16_t *>(uintptr_t(1) << 20);      // never dereferenced
+    float *fake32 = reinterpret_cast<float *>(uintptr_t(1) << 20);
+    const bool with_bias = epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU || epilogue == SEI_EPI_BIAS_RES ||
+                           epilogue == SEI_EPI_BIAS_ROWSCALE || epilogue == SEI_EPI_BIAS_SCALE_RES;
+    const bool with_r1 = epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU ||
+                         epilogue == SEI_EPI_BIAS_ROWSCALE || epilogue == SEI_EPI_BIAS_SCALE_RES;
+    unsigned long long plan = 0;
+    const int rc = nt_entry(fake16, a_rmajor ? M : K, a_rmajor, fake16, b_rmajor ? N : K, b_rmajor,
+                            out_f32 ? fake32 : nullptr, out_bf16 ? const_cast<uint16_t *>(fake16) : nullptr, M, N, K,
+                            epilogue, with_bias ? fake32 : nullptr, with_r1 ? fake32 : nullptr,
+                            epilogue == SEI_EPI_BIAS_SCALE_RES ? fake32 : nullptr,
+                            epilogue == SEI_EPI_BIAS_GELU ? const_cast<uint16_t *>(fake16) : nullptr, 0, 0, nullptr, &plan);
+    return rc == SEI_OK ? (size_t)plan : 0;
 }
 
 extern "C" int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
@@ -1022,7 +1060,7 @@ extern "C" int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, in
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
-    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
@@ -1061,7 +1099,7 @@ extern "C" int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, 
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
     SEI_REQUIRE((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
                 ((uintptr_t)param_bf16 & 7) == 0);              // the epilogue moves whole quads
-    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = param; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = SEI_EPI_NONE;
@@ -1082,7 +1120,7 @@ extern "C" int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0 && ((uintptr_t)D16 & 7) == 0);
-    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = nullptr; g.D16 = D16; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = SEI_EPI_NONE;
@@ -1103,7 +1141,7 @@ extern "C" int sei_gemm_bf16nt_dw2_taps(const uint16_t *A1, const uint16_t *A2, 
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
-    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
@@ -1133,7 +1171,7 @@ extern "C" int sei_gemm_bf16nt_conv(const uint16_t *Ap, int cin_pad, const int *
     SEI_REQUIRE(ldb >= 9 * cin_pad && ldb % 8 == 0 && (((uintptr_t)Ap | (uintptr_t)B) & 15) == 0);
     SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS);
     if (epilogue == SEI_EPI_BIAS) SEI_REQUIRE(bias);
-    NtArgs g; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.batch = 1;
     g.A = Ap; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = 9 * cin_pad; g.lda = cin_pad; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
@@ -1156,6 +1194,7 @@ extern "C" int sei_gemm_bf16nt_conv_unpad(const uint16_t *Ap, int cin_pad, const
     SEI_REQUIRE((((uintptr_t)y | (uintptr_t)res) & 15) == 0 && (act == 0 || act == 1));
     SEI_REQUIRE((size_t)Bimg * (H + 2) * (W + 2) < ((size_t)1 << 31));
     NtArgs g;
+    g.plan = nullptr;
     g.batch = 1;
     g.A = Ap; g.B = B; g.D32 = y; g.D16 = nullptr; g.M = Bimg * (H + 2) * (W + 2); g.N = N; g.K = 9 * cin_pad;
     g.lda = cin_pad; g.ldb = ldb;

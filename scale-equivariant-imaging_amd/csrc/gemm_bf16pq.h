@@ -607,6 +607,10 @@ int launch_pq(NtArgs &g, hipStream_t s) {
             g.splitk = (int)sei_ceil_div(g.K, g.k_per_split);
         }
     }
+    if (g.plan) {
+        *g.plan = (2ull << 48) | ((unsigned long long)G::BM << 32) | ((unsigned long long)G::BN << 16) | (unsigned)g.splitk;
+        return SEI_OK;
+    }
     if (g.splitk > 1 && g.epilogue != SEI_EPI_ACCUM) {
         const size_t n = (size_t)g.M * g.N;
         size_t zg = sei_ceil_div(n / 4 + 1, 256);

@@ -33,6 +33,7 @@ import os
 import torch
 
 ENABLED = os.environ.get("SEI_NO_JOINT_BACKWARD") != "1"
+KEEP_ARENA = False       # bench.py's roofline leg re-issues a step's launches afterwards: their operands must stay allocated
 
 
 class JointCtx:
@@ -182,6 +183,11 @@ class _Top(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         rec, call = ctx.pair, ctx.call
+        if rec.done[call]:
+            # the tapes (and the layer nodes' saved activations) were released by the first walk: autograd's own graph
+            # raises here too ("backward through the graph a second time"); silently returning would lose gradients
+            raise RuntimeError("this recorded model call has already been walked backward (its saved activations are "
+                               "freed); a second backward pass through it needs SEI_NO_JOINT_BACKWARD=1")
         rec.parked[call] = go.contiguous()
         other = 1 - call
         if rec.calls == 2 and other in rec.parked and not rec.done[other]:
@@ -240,3 +246,6 @@ def _walk(rec, backbone, which):
     for c in which:                                          # the layer nodes and their saved activations may go
         rec.outputs[c] = None
         rec.tapes[c] = []
+        rec.parked.pop(c, None)
+    if not KEEP_ARENA and all(rec.done[c] or c >= rec.calls for c in (0, 1)):   # every recorded call is walked: the 3B-row arena may go too
+        rec.bases, rec.base_of = [], {}

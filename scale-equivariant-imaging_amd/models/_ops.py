@@ -161,6 +161,10 @@ _JOINT_SPLIT = None      # (B1, B2) while one backward pass serves the step's tw
 
 def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=None, R2=None, D2_16=None,
               lda=None, ldb=None, a_rmajor=False, b_rmajor=False, tile=0, band=0, flops=None, _whole=False):
+    """D[M,N] = op(A16) op(B16) on the direct-to-LDS bf16 kernel. A16 is (M,K) [or (K,M) when a_rmajor],
+    B16 is (N,K) [or (K,N) when b_rmajor]; K % 8 == 0. Outputs as given. tile / band: an explicit schedule
+    choice (sei_gemm_bf16nt_ex; tests and tools), 0 = the library's dispatch. flops: the algorithmic FLOP count
+    to book for the roofline leg when the operands are zero-padded (default 2 M N K)."""
     if _JOINT_SPLIT is not None and not _whole and not a_rmajor and max(Nn, K) >= 2048 and not (tile or band) and lda is None:
         # One backward pass over the rows of both model calls (models/_joint.py) -- but the deep levels' GEMMs are tuned to
         # the row counts of the separate calls (2304 / 1152 and 576 / 288 rows are whole rounds of 288-row tiles on 256 CUs;
@@ -168,18 +172,21 @@ def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=Non
         B1, B2 = _JOINT_SPLIT
         M1 = M * B1 // (B1 + B2)
         if 0 < M1 < M and M1 % 8 == 0 and (M - M1) % 8 == 0:
-            cut = lambda t, lo, hi: None if t is None else t[lo:hi]
-            r1_rows = R1 is not None and R1.dim() == 1           # BIAS_ROWSCALE: one value per row
+            # an epilogue operand is cut with the rows when it is per-row data: an (M, Nn) matrix in any view with M * Nn
+            # elements, or BIAS_ROWSCALE's M-vector -- never by a leading dimension that happens to equal M
+            def cut(t, lo, hi):
+                if t is None:
+                    return None
+                if t.dim() == 1 and t.numel() == M:
+                    return t[lo:hi]
+                if t.numel() == M * Nn:
+                    return t.reshape(M, Nn)[lo:hi]
+                return t
             for lo, hi in ((0, M1), (M1, M)):
                 gemm_nt16(A16[lo:hi], B16, hi - lo, Nn, K, epi, out32=cut(out32, lo, hi), out16=cut(out16, lo, hi), bias=bias,
-                          R1=cut(R1, lo, hi) if (r1_rows or (R1 is not None and R1.shape[0] == M)) else R1,
-                          R2=cut(R2, lo, hi) if (R2 is not None and R2.shape[0] == M) else R2, D2_16=cut(D2_16, lo, hi),
+                          R1=cut(R1, lo, hi), R2=cut(R2, lo, hi), D2_16=cut(D2_16, lo, hi),
                           ldb=ldb, b_rmajor=b_rmajor, flops=None if flops is None else flops * (hi - lo) / M, _whole=True)
             return
-    """D[M,N] = op(A16) op(B16) on the direct-to-LDS bf16 kernel. A16 is (M,K) [or (K,M) when a_rmajor],
-    B16 is (N,K) [or (K,N) when b_rmajor]; K % 8 == 0. Outputs as given. tile / band: an explicit schedule
-    choice (sei_gemm_bf16nt_ex; tests and tools), 0 = the library's dispatch. flops: the algorithmic FLOP count
-    to book for the roofline leg when the operands are zero-padded (default 2 M N K)."""
     if lda is None:
         lda = M if a_rmajor else K
     if ldb is None:
@@ -746,6 +753,10 @@ def _check_milestone(_DW, key):
     if ms is not None and key in ms[0] and ms[0] <= _DW["written"] and not _DW["milestone_done"]:
         # every gradient of the milestone has had its (single, merged) launch of this step
         if all(_DW["arrivals"].get(k, 0) >= max(_DW["uses"], 1) for k in ms[0]):
+            # a milestone gradient that was only QUEUED for the streamed launch (flush at the end of the backward pass)
+            # must be on the stream before the event that releases it to the reducer
+            if any(job[1][4].data_ptr() in ms[0] for job in _DW["dwjobs"]):
+                flush_dwstream(_DW)
             ms[1].record()
             _DW["milestone_done"] = True
 

@@ -171,7 +171,12 @@ class UNet(Module):
         xb = x
         for blk in blocks:
             x = blk(x)
-        return x + xb if inner else x
+        if not inner:
+            return x
+        # A torch add between taped layer functions: the tape (models/_joint.py) is a chain of layer functions and would
+        # drop the gradient that bypasses the blocks through xb -- this call stays an ordinary autograd graph.
+        _ops._no_joint_form()
+        return x + xb
 
     def forward(self, x, x_is_nchw=True):
         """x: NCHW image when x_is_nchw, else NHWC. Returns NCHW when the input was NCHW."""

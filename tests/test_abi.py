@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_native.LIB_PATH)       # loads on a GPU-less host: no HIP call at load time
     missing = [name for name in declared() if not hasattr(handle, name)]
     assert not missing, f"declared in sei_hip.h but not exported: {missing}"
-    assert handle.sei_abi_version() == _native.ABI_VERSION == 9
+    assert handle.sei_abi_version() == _native.ABI_VERSION == 10
     buf = ctypes.create_string_buffer(16)
     assert handle.sei_build_target(buf, 16) == 0 and buf.value == b"gfx950"
 
@@ -81,3 +81,18 @@ def test_product_refuses_cpu_tensors():
     op = physics.BlurV2(kernel=physics.get_kernel("Gaussian_R2")[None, None])
     with pytest.raises(_native.NativeLibraryError):
         op.A(torch.rand(1, 3, 16, 16))
+
+
+def test_gemm_plan_query_runs_without_a_gpu():
+    """sei_gemm_bf16nt_plan is host arithmetic: the schedules of the timed batch's bottleneck GEMMs (B = 32: 576 / 288
+    rows) and of the reference's default batch (B = 8: 144 / 72 rows), as tests/test_loss_gpu.py pins them on the GPU."""
+    import _native
+    BIAS_GELU, BIAS_RES, MUL_DGELU = 2, 3, 4
+    assert _native.gemm_plan(0, 0, True, False, 576, 32768, 8192, BIAS_GELU) == ("pq", 288, 256, 1)
+    assert _native.gemm_plan(0, 0, True, False, 288, 32768, 8192, BIAS_GELU)[:3] == ("pq", 288, 128)
+    fam, bm, bn, sk = _native.gemm_plan(0, 0, True, False, 576, 8192, 32768, BIAS_RES)
+    assert (fam, bm) == ("pq", 288) and sk > 1
+    assert _native.gemm_plan(0, 1, False, True, 288, 32768, 8192, MUL_DGELU)[:2] == ("pq", 288)
+    assert _native.gemm_plan(0, 0, True, False, 144, 32768, 8192, BIAS_GELU)[:3] == ("nt", 128, 128)
+    with pytest.raises(_native.NativeLibraryError):
+        _native.gemm_plan(0, 0, True, False, 0, 128, 64, 0)
