@@ -186,7 +186,7 @@ def _stream_bytes(name, a):
         return B * H * W * heads * (32 * 2 * 8 + 4)
     if name == "sei_sepmap2_bf16_pack":
         return 0
-    if name in ("sei_sepmap2_packed", "sei_sepmap2_bf16", "sei_sepmap2_big"):
+    if name in ("sei_sepmap2_packed", "sei_sepmap2_bf16", "sei_sepmap2_big", "sei_sepmap2_small"):
         B, Hi, Wi, Ho, Wo, C = a[2:8]                     # (algorithmic: x in, y out; the bf16 intermediate of _big is its own)
         return 4 * B * C * (Hi * Wi + Ho * Wo)
     if name == "sei_sepmap2_big_pack":
@@ -619,7 +619,7 @@ class Leg:
         from models import _joint, _ops
         _ops.profile_gemms(True)
         _native.record_calls(True)
-        _joint.KEEP_ARENA = True               # (the joint backward's 3B-row activations are operands of the re-issues)
+        keep_arena, _joint.KEEP_ARENA = _joint.KEEP_ARENA, True      # (the joint backward's 3B-row activations are operands of the re-issues)
         fused = self.graphed is not None and bool(self.graphed.fused_views)
         if fused:                              # as the captured step: the bottleneck pair is stepped inside its GEMMs
             _ops.set_fused_adam(*self.graphed.fused_table, owner=self.backbone)
@@ -632,7 +632,7 @@ class Leg:
             keep = self.loss_fn(x=self.x, y=self.y, model=self.model)
             keep.backward(retain_graph=True)   # keeps the saved activations (GEMM operands) alive for the replay
         finally:
-            _joint.KEEP_ARENA = False
+            _joint.KEEP_ARENA = keep_arena
             if fused:
                 _ops.set_fused_adam(None, None, owner=self.backbone)
         if self.reducer is not None:

@@ -335,7 +335,8 @@ int sei_gemm_bf16nt_dw2(const uint16_t *A1, const uint16_t *A2, int lda, const u
 /* The two entry points above with the caller's explicit schedule choice (tests of every tile variant, tools/):
  * tile = 0 lets the dispatcher decide (what the plain entry points pass); 1, 2, 3, 5 = 128x128, 128x256, 192x256,
  * 96x256 tiles of the 128x128-style loop; 15 / 16 = its single-stage / 128x256 reduction-major variants;
- * 30-33 = the quadrant schedule of gemm_bf16pq.h with 256x256, 288x256, 288x128, 256x128 tiles. band > 0 fixes
+ * 30-33 = the quadrant schedule of gemm_bf16pq.h with 256x256, 288x256, 288x128, 256x128 tiles (the 128-column ones on
+ * three LDS stages; 38 / 39 = 288x128 / 256x128 on two). band > 0 fixes
  * the band width of the XCD-aware tile order (0 = automatic). A choice the operands do not allow falls back to
  * the automatic one. Per call: the library keeps no mutable state. */
 int sei_gemm_bf16nt_ex(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
@@ -364,6 +365,15 @@ size_t sei_gemm_bf16nt_plan(int a_rmajor, int b_rmajor, int out_f32, int out_bf1
 int sei_debug_tr_probe(const uint16_t *in, uint16_t *out, int r0, int c0, void *stream);
 int sei_debug_set_nt_tile(int code);
 #endif
+
+/* The ideal resamplers of the DEEPEST levels in one pass (csrc/sepmap_small.hip): input extents <= 8, output extents
+ * <= 24, C % 64 == 0 -- the 6 x 6 and 3 x 3 images a 48-pixel crop becomes at 2048 - 8192 channels
+ * (IdealDownsample / IdealUpsample, src/models/convolutional.py:54-92,113-133). x (B, Hi, Wi, C) -> y (B, Ho, Wo, C), NHWC
+ * float32, y = L1 X R1^T + L2 X R2^T per image and channel, float32 FMAs; L1, L2: (Ho, Hi), R1, R2: (Wo, Wi) row-major
+ * device arrays. One workgroup item = one image x 64 channels through LDS; no HBM intermediate. _eligible: 1 / 0. */
+size_t sei_sepmap2_small_eligible(int B, int Hi, int Wi, int Ho, int Wo, int C);
+int sei_sepmap2_small(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C, const float *L1,
+                      const float *R1, const float *L2, const float *R2, void *stream);
 
 int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
                 const float *L1, const float *R1, const float *L2, const float *R2, float *work,

@@ -76,6 +76,7 @@ SIGNATURES = {
     "sei_sepmap2_packed": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P],
     "sei_sepmap2_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "sei_sepmap2_bf16_pack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sei_sepmap2_small": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sei_colsum_f32": [_P, _P, _Z, _I, _P],
     "sei_colsum_weighted_f32": [_P, _P, _P, _Z, _I, _P],
     "sei_mlp_fused_fwd": [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P],
@@ -162,6 +163,7 @@ SIZE_QUERIES = {
     "sei_rowgemm_dgelu_bf16_eligible": [_L, _I, _I],
     "sei_rowgemm_ln_bf16_eligible": [_L, _I, _I],
     "sei_gemm_bf16nt_plan": [_I, _I, _I, _I, _I, _I, _I, _I],
+    "sei_sepmap2_small_eligible": [_I, _I, _I, _I, _I, _I],
 }
 ABI_VERSION = 10      # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 

@@ -101,8 +101,9 @@ __device__ __forceinline__ void dw_stream_body(const DwUnit &u, int worker, int 
 #pragma unroll
         for (int e = 0; e < NPW; ++e) {
             const int q = wave + 4 * e;                             // wave-uniform
-            __builtin_amdgcn_global_load_lds((glb_void *)(((q >> 3) < PI ? pb : qb) + off[e]),
-                                             (lds_void *)(dst + q * 1024), 16, 0, 0);
+            // (inline-asm DMA: with the builtin the compiler drains vmcnt before every transposing read below -- the ring
+            // never had more than the current stage in flight; sei_common.h)
+            dma16_base((q >> 3) < PI ? pb : qb, off[e], dst + q * 1024);
         }
     };
 

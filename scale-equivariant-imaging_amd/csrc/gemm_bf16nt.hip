@@ -95,6 +95,8 @@ __device__ __forceinline__ void nt_store4(float *p, const float4 v) {
     __builtin_nontemporal_store(t, reinterpret_cast<nt_f32x4 *>(p));
 }
 
+// (LDS-DMA pieces go out through sei_common.h's dma16_base / dma16_lane: inline asm, see there)
+
 __device__ __forceinline__ unsigned short f2bf(float v) {
     const __bf16 b = (__bf16)v;
     return __builtin_bit_cast(unsigned short, b);
@@ -111,7 +113,7 @@ __device__ __forceinline__ void stage_piece(const unsigned short *__restrict__ G
         const int grow = min(row0 + row, row_lim - 1);     // rows past the edge re-read the last row
         const int k = k0 + 8 * c;
         const unsigned short *src = k < k_lim ? G + (size_t)grow * ld + k : g_zero_chunk;
-        __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
+        dma16_lane(src, lds_tile + q * 1024);
     }
 }
 template <int ROWS>
@@ -135,7 +137,7 @@ __device__ __forceinline__ void stage_piece_rmajor(const unsigned short *__restr
     const int k = k0 + row, o = o0 + 8 * ch;
     const unsigned short *rowp = k < k_seg ? G + (size_t)k * ld : G2 + (size_t)(k - k_seg) * ld;
     const unsigned short *src = (k < k_lim && o < o_lim) ? rowp + o : g_zero_chunk;
-    __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(lds_tile + q * 1024), 16, 0, 0);
+    dma16_lane(src, lds_tile + q * 1024);
 }
 __device__ __forceinline__ void stage_tile_rmajor(const unsigned short *__restrict__ G,
                                                   const unsigned short *__restrict__ G2, int k_seg, int ld, int o0,
@@ -345,8 +347,7 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
 #pragma unroll
             for (int e = 0; e < NPA; ++e)
                 if (ARM || wave + NWAVES * e < BM / 8)         // wave-uniform (a 96-row tile has 12 pieces)
-                    __builtin_amdgcn_global_load_lds((glb_void *)(ab + off_a[e]),
-                                                     (lds_void *)(dst + (wave + NWAVES * e) * 1024), 16, 0, 0);
+                    dma16_base(ab, off_a[e], dst + (wave + NWAVES * e) * 1024);
         } else {
             if constexpr (ARM) stage_tile_rmajor(g.A, g.A2, g.k_seg, g.lda, m0, M, k0, k_end, dst, wave, lane);
             else stage_tile<BM>(g.A, g.lda, m0, M, k0, k_end, dst, wave, lane);
@@ -356,8 +357,7 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
         if (bb) {
 #pragma unroll
             for (int e = 0; e < NPB; ++e)
-                __builtin_amdgcn_global_load_lds((glb_void *)(bb + off_b[e]),
-                                                 (lds_void *)(dst + BM * ROW_BYTES + (wave + NWAVES * e) * 1024), 16, 0, 0);
+                dma16_base(bb, off_b[e], dst + BM * ROW_BYTES + (wave + NWAVES * e) * 1024);
         } else if constexpr (BRM) {
 #pragma unroll
             for (int im = 0; im < BN / 128; ++im)           // 16 KB image per 128 columns
@@ -911,6 +911,8 @@ static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
                 case 31: return launch_pq<9, 4, false, true>(g, s);
                 case 32: return launch_pq<9, 2, false, true>(g, s);
                 case 33: return launch_pq<8, 2, false, true>(g, s);
+                case 38: return launch_pq<9, 2, false, true, 0, 2>(g, s);      // 288 x 128 on TWO LDS stages (round 4's)
+                case 39: return launch_pq<8, 2, false, true, 0, 2>(g, s);
                 default: break;
             }
         } else {
@@ -919,6 +921,8 @@ static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
                 case 31: return launch_pq<9, 4>(g, s);
                 case 32: return launch_pq<9, 2>(g, s);
                 case 33: return launch_pq<8, 2>(g, s);
+                case 38: return launch_pq<9, 2, false, false, 0, 2>(g, s);
+                case 39: return launch_pq<8, 2, false, false, 0, 2>(g, s);
 #ifdef SEI_TUNING
                 case 34: return launch_pq<8, 4, false, false, 2>(g, s);      // ablations: timing only, wrong results
                 case 35: return launch_pq<8, 4, false, false, 7>(g, s);

@@ -42,6 +42,13 @@ __device__ __forceinline__ void pq_wait_vmcnt() {
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
     else static_assert(N < 0, "add the immediate");
 }
 template <int N>
@@ -76,11 +83,29 @@ __device__ __forceinline__ int pq_swz_rm128(int row) { return (((row >> 1) & 1) 
 // ds_read_b64_tr_b16; the DMA base then advances 64 rows per k-tile.
 // ARM: A stored reduction-major as well (element (m, k) at A[k * lda + m]): the weight gradient dW = dY^T X, both
 // operands pixel-major; RF = 8 only. Both reduction-major: any K (zero rows past k_end), two K segments.
-template <int RF, int NF, bool ARM = false, bool BRM = false, int ABL = 0>
+// NS = 3: the FREE-RUNNING schedule of the 128-column tiles (round 5). Why: with NF = 2 a quadrant phase carries 10 MFMAs
+// per wave (160 cycles at 16 per v_mfma_f32_16x16x32_bf16) against a read segment of 12 ds_read_b128 plus ~1.6 LDS-DMA
+// pieces at 60-185 cycles each; the two wave groups alternate read and MFMA segments behind 8 barriers per k-tile, so the
+// k-tile takes 8 x max(read segment, MFMA segment) ~ 8 x 250 cycles of READ segments: 1.56 us per k-tile for 0.48 us of
+// matrix work (288 x 32768 x 8192: 200 us, and a third LDS stage in the same schedule changed nothing: 207 us,
+// tools/exp_ring3.py -- the loop is not short of bytes in flight). A 128-column tile's stage is 52 KB, so THREE fit (156 KB)
+// and the fragments of half a k-tile are 44 registers, so TWO sets fit beside the 72 accumulator registers. That allows:
+//   * ONE barrier per k-tile: before it every wave waits for its own pieces of tile t (vmcnt counted: the pieces of tile
+//     t + 1 stay in flight) and for its last fragment reads of tile t - 1 (lgkmcnt(0): the data is in registers); after
+//     it tile t has landed for everyone and the stage of tile t - 1 is free: tile t + 2 is issued into it, two k-tiles
+//     ahead of its first read;
+//   * per wave and k-tile: read half 0 of tile t into fragment set X, MFMAs on set Y (half 1 of tile t - 1, read before
+//     the barrier), read half 1 of tile t into Y, MFMAs on X -- every read has 18 MFMAs (288 cycles) to land under;
+//   * the two waves of a SIMD (wr = 0 / 1) issue their LDS-DMA pieces at different points of the iteration (right after
+//     the barrier / after the first MFMA block), so one wave's DMA issue sits under the other's MFMAs.
+// Tile order, LDS images, swizzles, piece tables, K tails and the epilogue are the quadrant schedule's.
+template <int RF, int NF, bool ARM = false, bool BRM = false, int ABL = 0, int NS = 2>
 __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     using G = PqGeom<RF, NF>;
     constexpr int QA0 = G::QA0, QA1 = G::QA1, QB = G::QB;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * G::STAGE];
+    static_assert(NS == 2 || NS == 3, "two LDS stages (quadrant phases) or three (free-running schedule)");
+    static_assert(NS * G::STAGE <= 160 * 1024, "the stages fit one CU's LDS");
+    __shared__ __attribute__((aligned(1024))) char smem[NS * G::STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -176,6 +201,10 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         ob0[e] = b_off(wave + 8 * e, 0);
         ob1[e] = b_off(wave + 8 * e, 1);
     }
+    // (its address once, not a GOT load per use: an s_load inside the loop also forces every LDS wait behind it to
+    // lgkmcnt(0), scalar loads returning out of order)
+    const unsigned short *zero_chunk = g_zero_chunk;
+    asm volatile("" : "+s"(zero_chunk));
     const bool third = G::PA0 % 8 != 0 && wave < G::PA0 % 8;   // this wave issues NA0 pieces of A(0), else NA0 - 1
     // uniform base of k-tile u for a reduction-major operand; nullptr = slow path
     auto rm_base = [&](const unsigned short *X1, const unsigned short *X2, int ld, int o0, int k0) -> const char * {
@@ -186,17 +215,17 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     auto rm_slow = [&](const unsigned short *X1, const unsigned short *X2, int ld, int o0, int k0, int krow, int col)
         -> const unsigned short * {
         const int k = k0 + krow;
-        if (k >= k_end) return g_zero_chunk;
+        if (k >= k_end) return zero_chunk;
         return k < g.k_seg ? X1 + (size_t)k * ld + o0 + col : X2 + (size_t)(k - g.k_seg) * ld + o0 + col;
     };
     // K-contiguous operand, last k-tile of a K that is not a multiple of 64: chunks past k_end come from the zero chunk
     auto kc_src = [&](const char *base, unsigned off, int p, int k0) -> const void * {
         const int c = (lane & 7) ^ ((4 * (p & 1) + (lane >> 4)) & 7);         // logical chunk of this lane in piece p
-        return k0 + 8 * c < k_end ? (const void *)(base + off) : (const void *)g_zero_chunk;
+        return k0 + 8 * c < k_end ? (const void *)(base + off) : (const void *)zero_chunk;
     };
     auto issue = [&](int u, int which) {                      // which: 0 = A(0), 1 = A(1), 2 = B(0), 3 = B(1)
         if constexpr (ABL & 2) { if (u > 1) return; }
-        char *stage = smem + (u & 1) * G::STAGE;
+        char *stage = smem + (NS == 2 ? (u & 1) : (u % NS)) * G::STAGE;
         const int k0 = k_begin + u * BK;
         const bool tail = k0 + BK > k_end;                    // wave-uniform
         if (which < 2) {
@@ -209,28 +238,24 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
                 for (int e = 0; e < G::NA1; ++e) {            // ARM: NA0 == NA1, uniform
                     int krow;
                     const int col = a_col(wave + 8 * e, which, krow);
-                    __builtin_amdgcn_global_load_lds((glb_void *)rm_slow(g.A, g.A2, g.lda, m0, k0, krow, col),
-                                                     (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
+                    dma16_lane(rm_slow(g.A, g.A2, g.lda, m0, k0, krow, col), dst + (wave + 8 * e) * 1024);
                 }
             } else if (!ARM && tail) {
 #pragma unroll
                 for (int e = 0; e < G::NA0; ++e) {
                     if (which ? e >= G::NA1 : (G::PA0 % 8 != 0 && e == G::NA0 - 1 && !third)) break;
-                    __builtin_amdgcn_global_load_lds((glb_void *)kc_src(ap, which ? oa1[e < G::NA1 ? e : 0] : oa0[e], wave + 8 * e, k0),
-                                                     (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
+                    dma16_lane(kc_src(ap, which ? oa1[e < G::NA1 ? e : 0] : oa0[e], wave + 8 * e, k0), dst + (wave + 8 * e) * 1024);
                 }
             } else if (which == 0) {
 #pragma unroll
                 for (int e = 0; e < G::NA0; ++e) {
                     if (G::PA0 % 8 != 0 && e == G::NA0 - 1 && !third) break;
-                    __builtin_amdgcn_global_load_lds((glb_void *)(ap + oa0[e]), (lds_void *)(dst + (wave + 8 * e) * 1024),
-                                                     16, 0, 0);
+                    dma16_base(ap, oa0[e], dst + (wave + 8 * e) * 1024);
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < G::NA1; ++e)
-                    __builtin_amdgcn_global_load_lds((glb_void *)(ap + oa1[e]), (lds_void *)(dst + (wave + 8 * e) * 1024),
-                                                     16, 0, 0);
+                    dma16_base(ap, oa1[e], dst + (wave + 8 * e) * 1024);
             }
         } else {
             const char *bp;
@@ -242,30 +267,29 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
                 for (int e = 0; e < G::NB; ++e) {
                     int krow;
                     const int col = b_col(wave + 8 * e, which - 2, krow);
-                    __builtin_amdgcn_global_load_lds((glb_void *)rm_slow(g.B, g.B2, g.ldb, n0, k0, krow, col),
-                                                     (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
+                    dma16_lane(rm_slow(g.B, g.B2, g.ldb, n0, k0, krow, col), dst + (wave + 8 * e) * 1024);
                 }
             } else if (!BRM && tail) {
 #pragma unroll
                 for (int e = 0; e < G::NB; ++e)
-                    __builtin_amdgcn_global_load_lds((glb_void *)kc_src(bp, which == 3 ? ob1[e] : ob0[e], wave + 8 * e, k0),
-                                                     (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
+                    dma16_lane(kc_src(bp, which == 3 ? ob1[e] : ob0[e], wave + 8 * e, k0), dst + (wave + 8 * e) * 1024);
             } else {
 #pragma unroll
                 for (int e = 0; e < G::NB; ++e)
-                    __builtin_amdgcn_global_load_lds((glb_void *)(bp + (which == 3 ? ob1[e] : ob0[e])),
-                                                     (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
+                    dma16_base(bp, which == 3 ? ob1[e] : ob0[e], dst + (wave + 8 * e) * 1024);
             }
         }
     };
-    // at most the pieces of B(0), A(0), B(1) of the tile after next stay in flight
+    // at most the pieces issued after the last piece of tile t + 1 stay in flight: B(0), A(0), B(1) of the NS - 1 tiles
+    // after it and A(1) of NS - 2 of them
     auto wait_tile = [&](bool full) {
         if (!full) { pq_wait_vmcnt<0>(); return; }
+        constexpr int LATE_A1 = (NS - 2) * G::NA1;
         if constexpr (G::PA0 % 8 != 0) {
-            if (third) pq_wait_vmcnt<2 * G::NB + G::NA0>();
-            else pq_wait_vmcnt<2 * G::NB + G::NA0 - 1>();
+            if (third) pq_wait_vmcnt<(NS - 1) * (2 * G::NB + G::NA0) + LATE_A1>();
+            else pq_wait_vmcnt<(NS - 1) * (2 * G::NB + G::NA0 - 1) + LATE_A1>();
         } else {
-            pq_wait_vmcnt<2 * G::NB + G::NA0>();
+            pq_wait_vmcnt<(NS - 1) * (2 * G::NB + G::NA0) + LATE_A1>();
         }
     };
 
@@ -344,29 +368,112 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     auto bar = [&]() { if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier(); };
     auto lds_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
 
-    // ---- prologue: k-tile 0 complete; B(0), A(0), B(1) of k-tile 1 in flight -------------------------------
+    if constexpr (NS == 3) {
+        static_assert(!ARM, "the free-running schedule reads A K-contiguous");
+        // ---- free-running schedule (header): fragment sets X / Y of half a k-tile each --------------------------
+        bf16x8 ax[RF], bx[NF], ay[RF], by[NF];
+        auto read_half = [&](const char *st, int ks, bf16x8 (&a)[RF], bf16x8 (&b)[NF]) {
+            const int fx = ks ? frag_x1 : frag_x0;
+            const char *a0 = st + G::OFF_A0 + wr * 16 * QA0 * ROW_BYTES, *a1 = st + G::OFF_A1 + wr * 16 * QA1 * ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < QA0; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(a0 + i * 16 * ROW_BYTES + fx);
+#pragma unroll
+            for (int i = 0; i < QA1; ++i) a[QA0 + i] = *reinterpret_cast<const bf16x8 *>(a1 + i * 16 * ROW_BYTES + fx);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int f = 0; f < QB; ++f) {
+                    if constexpr (BRM) b[q * QB + f] = frag_rm(st + (q ? G::OFF_B1 : G::OFF_B0), BRP, wc * QB + f, ks);
+                    else b[q * QB + f] = *reinterpret_cast<const bf16x8 *>(
+                        st + (q ? G::OFF_B1 : G::OFF_B0) + (wc * QB + f) * 16 * ROW_BYTES + fx);
+                }
+        };
+        auto mfma_half = [&](const bf16x8 (&a)[RF], const bf16x8 (&b)[NF]) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < RF; ++i)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[f], acc[i][f], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto issue_tile = [&](int u) {
+            issue(u, 2);
+            issue(u, 0);
+            issue(u, 3);
+            issue(u, 1);
+        };
+        // pieces this wave issues per tile: what may stay in flight when tile t must have landed (tile t + 1's)
+        auto wait_landed = [&](bool next_in_flight) {
+            if (!next_in_flight) { pq_wait_vmcnt<0>(); return; }
+            if constexpr (G::PA0 % 8 != 0) {
+                if (third) pq_wait_vmcnt<2 * G::NB + G::NA0 + G::NA1>();
+                else pq_wait_vmcnt<2 * G::NB + G::NA0 - 1 + G::NA1>();
+            } else {
+                pq_wait_vmcnt<2 * G::NB + G::NA0 + G::NA1>();
+            }
+        };
+        issue_tile(0);
+        if (nt > 1) issue_tile(1);
+        int ring = 0;
+        for (int t = 0; t < nt; ++t) {
+            const char *st = smem + ring * G::STAGE;
+            ring = ring == 2 ? 0 : ring + 1;
+            const bool more = t + 2 < nt;
+            // own pieces of tile t have landed, own reads of tile t - 1 are in registers; then everyone's
+            lds_done();
+            wait_landed(t + 1 < nt);
+            __builtin_amdgcn_sched_barrier(0);
+            bar();
+            __builtin_amdgcn_sched_barrier(0);
+            if (wr == 0 && more) issue_tile(t + 2);            // into the stage tile t - 1 was read from
+            __builtin_amdgcn_sched_barrier(0);
+            read_half(st, 0, ax, bx);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t > 0) mfma_half(ay, by);
+            __builtin_amdgcn_sched_barrier(0);
+            read_half(st, 1, ay, by);
+            __builtin_amdgcn_sched_barrier(0);
+            // (no control flow between the two read blocks: the compiler's wait for set X in front of its MFMAs is then
+            // the counted lgkmcnt(11) that leaves the reads of set Y in flight, not lgkmcnt(0))
+            if (wr == 1 && more) issue_tile(t + 2);            // the SIMD partner's pieces go under this wave's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(ax, bx);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_done();
+        bar();                                                 // every wave is done with the stages: the epilogue patches may go there
+        mfma_half(ay, by);
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+    // ---- prologue: k-tile 0 complete; the next NS - 2 whole tiles and B(0), A(0), B(1) of tile NS - 1 in flight ----
     issue(0, 0);
     issue(0, 2);
     issue(0, 3);
     issue(0, 1);
-    if (nt > 1) {
-        issue(1, 2);
-        issue(1, 0);
-        issue(1, 3);
+#pragma unroll
+    for (int u = 1; u < NS; ++u) {
+        if (u < nt) {
+            issue(u, 2);
+            issue(u, 0);
+            issue(u, 3);
+            if (u < NS - 1) issue(u, 1);
+        }
     }
-    wait_tile(nt > 1);
+    wait_tile(nt >= NS);                              // (shorter reductions: everything has landed)
     bar();
     if (wr == 1) bar();                               // group 1 runs one barrier behind from here on
 
+    int ring = 0;                                     // t % NS
     for (int t = 0; t < nt; ++t) {
-        const char *stage = smem + (t & 1) * G::STAGE;
-        const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
+        const char *stage = smem + ring * G::STAGE;
+        ring = ring + 1 == NS ? 0 : ring + 1;
+        const bool more1 = t + NS - 1 < nt, more2 = t + NS < nt;
         if constexpr (ABL & 1) abl_first = t == 0;
         // phase 1 (the B reads are issued first and retired before the barrier: B(0) is re-staged in phase 2)
         read_b(stage, 0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         read_a(stage, 0, 0);
-        if (more1) issue(t + 1, 1);
+        if (more1) issue(t + NS - 1, 1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(ABL & 1)) pq_wait_lgkmcnt<(ARM ? 2 : 1) * QA0>();      // the B reads have returned
         __builtin_amdgcn_sched_barrier(0);
@@ -380,7 +487,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         bar();
         // phase 2
         read_b(stage, 1, fb1);
-        if (more2) issue(t + 2, 2);
+        if (more2) issue(t + NS, 2);
         __builtin_amdgcn_sched_barrier(0);
         bar();
         lds_done();
@@ -391,7 +498,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         // phase 3
         read_a(stage, 1, 0);
         read_a(stage, 1, 1);
-        if (more2) issue(t + 2, 0);
+        if (more2) issue(t + NS, 0);
         __builtin_amdgcn_sched_barrier(0);
         bar();
         lds_done();
@@ -400,7 +507,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         bar();
         // phase 4
-        if (more2) issue(t + 2, 3);
+        if (more2) issue(t + NS, 3);
         __builtin_amdgcn_sched_barrier(0);
         if (wr == 1) wait_tile(more2);
         bar();
@@ -410,6 +517,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         bar();
     }
     if (wr == 0) bar();                               // rebalance the barrier count of the two groups
+    }
 
     // ---- epilogue through a wave-private LDS patch: 16 rows x 16 NF columns at a time ------------------------
     const int epi = g.epilogue;
@@ -570,7 +678,8 @@ inline bool pq_eligible(const NtArgs &g, bool = false) {
            (!g.R2 || (reinterpret_cast<uintptr_t>(g.R2) & 15) == 0);
 }
 
-template <int RF, int NF, bool ARM = false, bool BRM = false, int ABL = 0>
+// (three LDS stages wherever they fit and the operands are K-contiguous or B reduction-major: the 128-column tiles)
+template <int RF, int NF, bool ARM = false, bool BRM = false, int ABL = 0, int NS = ((NF == 2 && !ARM) ? 3 : 2)>
 int launch_pq(NtArgs &g, hipStream_t s) {
     using G = PqGeom<RF, NF>;
     g.tiles_m = (int)sei_ceil_div(g.M, G::BM);
@@ -617,7 +726,7 @@ int launch_pq(NtArgs &g, hipStream_t s) {
         if (zg > 2048) zg = 2048;
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
-    hipLaunchKernelGGL((gemm_bf16pq_kernel<RF, NF, ARM, BRM, ABL>), dim3((unsigned)(8 * (size_t)g.tiles_per_xcd * g.splitk)),
+    hipLaunchKernelGGL((gemm_bf16pq_kernel<RF, NF, ARM, BRM, ABL, NS>), dim3((unsigned)(8 * (size_t)g.tiles_per_xcd * g.splitk)),
                        dim3(NT), 0, s, g);
     return sei_launch_status();
 }

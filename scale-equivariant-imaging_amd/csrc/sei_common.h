@@ -44,6 +44,30 @@ __device__ __forceinline__ float sei_block_sum(float v, float *scratch) {
     return r;
 }
 
+// LDS-DMA (one 1-KiB piece: 16 bytes per lane to M0 + 16 lane) issued by INLINE ASM, not by
+// __builtin_amdgcn_global_load_lds (round 5). With the builtin the compiler knows an LDS store is in flight and puts
+// `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that follows (it has no alias information for the
+// transposing read's intrinsic; plain ds_read_b128 loads are not affected): in every kernel with a reduction-major
+// operand -- all weight gradients, every data gradient dX = dY W -- the DMA of the next k-tile was drained before the
+// current tile's first fragment read, i.e. nothing was prefetched (found in the ISA of the loops: "global_load_lds x10;
+// s_waitcnt vmcnt(0); ds_read_b64_tr_b16 x15"). The kernels that use these helpers wait for their DMA explicitly anyway (counted
+// s_waitcnt vmcnt + s_barrier), so the compiler's tracking buys nothing. M0 is written inside the asm; a kernel
+// that uses these helpers issues NO LDS-DMA through the builtin (a hoisted M0 of the compiler's own would be clobbered).
+// dma16_base: uniform 64-bit base + per-lane 32-bit byte offset (the lean path); dma16_lane: per-lane 64-bit address.
+// (The "m0" clobber makes the asm a definition of M0 for the backend's M0-initialisation hoisting; clang warns that a
+// reserved register on a clobber list is not saved around the asm, which is exactly what is wanted here.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dma16_base(const char *base, unsigned off, char *lds_dst) {
+    const unsigned m = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_dst;
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(m) : "memory", "m0");
+}
+__device__ __forceinline__ void dma16_lane(const void *src, char *lds_dst) {
+    const unsigned m = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_dst;
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 // exact (erf) GELU and its derivative, as torch.nn.GELU() (approximate='none')
 __device__ __forceinline__ float sei_gelu(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));

@@ -1,0 +1,134 @@
+// sepmap_small_kernel: the ideal resamplers of the DEEP levels in one pass (round 5).
+//
+//   y[b, :, :, c] = L1 X R1^T + L2 X R2^T,   X = x[b, :, :, c]  (Hi x Wi),  L: (Ho, Hi), R: (Wo, Wi)
+//
+// (reference: IdealDownsample / IdealUpsample, src/models/convolutional.py:54-92,113-133 -- rfft2, fftshift, crop or
+// embed, the discarded ifftshift, irfft2 -- which models/_mats.py states as this separable rank-2 map.)
+//
+// The 48-pixel crop reaches the deep levels as 12 x 12, 6 x 6 and 3 x 3 images with 512 - 8192 channels. sepmap_mfma_kernel
+// takes extents of 24 - 64; below that the maps ran on the two-launch float32 kernels (W pass into a two-plane HBM
+// intermediate, H pass out of it): 15 of a step's 24 resampler launches, ~28 us each for 24 - 94 MB of traffic.
+// Here a workgroup item is one image x 64 channels: its Hi x Wi x 64 input tile goes through LDS once (<= 48 KB: three or
+// more workgroups per CU overlap each other's loads), a thread owns (channel, output column): the W pass of both terms
+// stays in registers (2 Hi values), the H pass reads them back from there, whole 256-byte channel rows are stored; the
+// matrix entries are wave-uniform and come through the scalar cache. Nothing but x in and y out touches HBM; the
+// arithmetic is float32 FMAs (so the bf16 mode loses no precision here).
+//
+// Measured (tools/exp_sepmap_small.py, 64 / 96 images, us per launch, this kernel vs the two launches): 6 -> 3 at 2048
+// channels 12.4 vs 15.5 / 12.3 vs 19.3; 3 -> 6 at 8192 33.9 vs 39.8 / 47.2 vs 60.6; 6 -> 12 at 2048 38.9 vs 41.5 / 49.5 vs 58.7
+// (2.4 - 3.0 TB/s of x + y). With 12 x 12 inputs it LOSES -- 12 -> 6 at 512 channels 23.8 vs 17.2, 12 -> 24 112 vs 49: 144
+// ds_read_b32 and 288 + 576 FMAs per (lane, output column) and 24 dependent scalar-load rounds make it VALU- and latency-
+// bound -- so input extents stop at 8 and those maps stay on the two-launch kernels.
+#include "sei_common.h"
+
+namespace {
+
+constexpr int SS_THREADS = 256;
+constexpr int SS_CH = 64;              // channels per item (one per lane)
+constexpr int SS_MAX_IN = 8;           // largest input extent: 12 x 12 inputs LOSE to the two-launch kernels (below)
+constexpr int SS_MAX_OUT = 24;         // largest output extent
+constexpr int SS_MAX_PIX = 64;         // Hi * Wi: the tile is Hi * Wi * 256 bytes of LDS (<= 16 KB)
+
+struct SsGeom {
+    int B, Hi, Wi, Ho, Wo, C;
+};
+
+template <int MAXE>
+__global__ __launch_bounds__(SS_THREADS) void sepmap_small_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                  const float *__restrict__ L1, const float *__restrict__ R1,
+                                                                  const float *__restrict__ L2, const float *__restrict__ R2,
+                                                                  SsGeom g, int items) {
+    extern __shared__ __attribute__((aligned(16))) float sX[];  // [Hi * Wi][64]
+    const int tid = threadIdx.x, Hi = g.Hi, Wi = g.Wi, Ho = g.Ho, Wo = g.Wo, C = g.C;
+    const int groups = C / SS_CH, npix = Hi * Wi;
+    const int q = tid & 15, p0 = tid >> 4;                     // tile loads: 16 lanes x float4 per 64-channel pixel row
+    const int c = tid & 63;                                    // arithmetic: lane = channel, wave = output column (+ 4 k)
+    const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int b = item / groups, c0 = (item - b * groups) * SS_CH;
+        __syncthreads();                                       // the previous item's reads of sX
+        const float *xb = x + (size_t)b * npix * C + c0 + 4 * q;
+        for (int p = p0; p < npix; p += SS_THREADS / 16)
+            *reinterpret_cast<float4 *>(sX + p * SS_CH + 4 * q) = *reinterpret_cast<const float4 *>(xb + (size_t)p * C);
+        __syncthreads();
+        for (int wo = w0; wo < Wo; wo += SS_THREADS / 64) {    // wave-uniform: the matrix entries below are SCALAR loads
+            // (every coefficient is the same for the 64 lanes of a wave: read through the scalar cache into SGPRs, an FMA
+            // takes it as its scalar operand. As LDS broadcast reads they were one LDS instruction per FMA: 12 -> 24 at
+            // 512 channels spent ~750 LDS instructions per wave and output column, 576 of them coefficients -- 48 us per
+            // launch against 28 on the two-launch kernels this one replaces.)
+            const float *r1p = R1 + wo * Wi, *r2p = R2 + wo * Wi;
+            float t1[MAXE], t2[MAXE];
+#pragma unroll
+            for (int hi = 0; hi < MAXE; ++hi) {
+                float a1 = 0.f, a2 = 0.f;
+                if (hi < Hi) {
+#pragma unroll
+                    for (int wi = 0; wi < MAXE; ++wi) {
+                        if (wi < Wi) {
+                            const float v = sX[(hi * Wi + wi) * SS_CH + c];
+                            a1 = fmaf(r1p[wi], v, a1);
+                            a2 = fmaf(r2p[wi], v, a2);
+                        }
+                    }
+                }
+                t1[hi] = a1;
+                t2[hi] = a2;
+            }
+            float *yb = y + ((size_t)b * Ho * Wo + wo) * C + c0 + c;
+            for (int ho = 0; ho < Ho; ++ho) {
+                const float *l1p = L1 + ho * Hi, *l2p = L2 + ho * Hi;
+                float acc = 0.f;
+#pragma unroll
+                for (int hi = 0; hi < MAXE; ++hi) {
+                    if (hi < Hi) {
+                        acc = fmaf(l1p[hi], t1[hi], acc);
+                        acc = fmaf(l2p[hi], t2[hi], acc);
+                    }
+                }
+                yb[(size_t)ho * Wo * C] = acc;
+            }
+        }
+    }
+}
+
+inline bool ss_plan(int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    if (B <= 0 || C <= 0 || C % SS_CH != 0) return false;
+    if (Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || Hi > SS_MAX_IN || Wi > SS_MAX_IN || Ho > SS_MAX_OUT || Wo > SS_MAX_OUT)
+        return false;
+    if (Hi * Wi > SS_MAX_PIX) return false;
+    return (size_t)B * (C / SS_CH) < ((size_t)1 << 31) && (size_t)B * Ho * Wo * C < ((size_t)1 << 40);
+}
+
+template <int MAXE>
+int ss_launch(const float *x, float *y, const float *L1, const float *R1, const float *L2, const float *R2, const SsGeom &g,
+              hipStream_t s) {
+    const int items = g.B * (g.C / SS_CH);
+    const size_t lds = (size_t)(g.Hi * g.Wi * SS_CH) * sizeof(float);
+    // resident workgroups per CU by LDS (160 KB), at most 8; a persistent grid of that many walks the items
+    size_t per_cu = (160 * 1024) / lds;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) return SEI_ERR_TOO_LARGE;
+    const size_t grid = (size_t)items < 256 * per_cu ? (size_t)items : 256 * per_cu;
+    hipLaunchKernelGGL(sepmap_small_kernel<MAXE>, dim3((unsigned)grid), dim3(SS_THREADS), lds, s, x, y, L1, R1, L2, R2, g, items);
+    return sei_launch_status();
+}
+
+}  // namespace
+
+// 1 when sei_sepmap2_small serves this shape (input extents <= 8, output extents <= 24, C % 64 == 0), else 0.
+extern "C" size_t sei_sepmap2_small_eligible(int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    return ss_plan(B, Hi, Wi, Ho, Wo, C) ? 1 : 0;
+}
+
+// x: (B, Hi, Wi, C) -> y: (B, Ho, Wo, C), NHWC float32; L1, L2: (Ho, Hi), R1, R2: (Wo, Wi) float32 row-major (device).
+extern "C" int sei_sepmap2_small(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C, const float *L1,
+                                 const float *R1, const float *L2, const float *R2, void *stream) {
+    SEI_REQUIRE(x && y && L1 && R1 && L2 && R2 && x != y);
+    SEI_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+    if (!ss_plan(B, Hi, Wi, Ho, Wo, C)) return SEI_ERR_BAD_ARG;
+    SsGeom g{B, Hi, Wi, Ho, Wo, C};
+    hipStream_t s = (hipStream_t)stream;
+    const int e = Hi > Wi ? Hi : Wi;
+    if (e <= 4) return ss_launch<4>(x, y, L1, R1, L2, R2, g, s);
+    return ss_launch<8>(x, y, L1, R1, L2, R2, g, s);
+}

@@ -33,7 +33,7 @@ import os
 import torch
 
 ENABLED = os.environ.get("SEI_NO_JOINT_BACKWARD") != "1"
-KEEP_ARENA = False       # bench.py's roofline leg re-issues a step's launches afterwards: their operands must stay allocated
+KEEP_ARENA = os.environ.get("SEI_KEEP_ARENA") == "1"       # bench.py's roofline leg re-issues a step's launches afterwards: their operands must stay allocated
 
 
 class JointCtx:

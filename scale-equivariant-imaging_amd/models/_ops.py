@@ -292,12 +292,20 @@ def sepmap2(x, mats, Ho, Wo):
 
 # SEI_SEPMAP_F32=1 keeps the resamplers of the bf16 mode on the f32 FMA kernels (A/B runs)
 _SEPMAP_MFMA = __import__("os").environ.get("SEI_SEPMAP_F32") != "1"
+_SEPMAP_SMALL = __import__("os").environ.get("SEI_NO_SEPMAP_SMALL") != "1"     # (A/B runs: the two-launch f32 kernels instead)
 
 
 def sepmap2_16(x, mats, Ho, Wo):
     """sepmap2 in the bf16 throughput mode: on the matrix cores where the shape is eligible (sei_sepmap2_bf16:
     activations rounded to bf16, matrices as bf16 head + remainder, f32 accumulation), else the f32 kernels."""
     B, Hi, Wi, C = x.shape
+    if _SEPMAP_SMALL and x.is_cuda and N.lib().sei_sepmap2_small_eligible(B, Hi, Wi, Ho, Wo, C):
+        # the deep levels' 12-, 6- and 3-pixel images: one float32 pass through LDS, no HBM intermediate (round 5)
+        y = _alloc((B, Ho, Wo, C), torch.float32, x.device)
+        L1, R1, L2, R2 = mats[:4]
+        N.call("sei_sepmap2_small", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, L1.data_ptr(), R1.data_ptr(),
+               L2.data_ptr(), R2.data_ptr())
+        return y
     small = _SEPMAP_MFMA and x.is_cuda and max(Hi, Wi, Ho, Wo) <= 64 and N.lib().sei_sepmap2_bf16_eligible(B, Hi, Wi, Ho, Wo, C)
     big = not small and _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_big_eligible(B, Hi, Wi, Ho, Wo, C)
     if not big and _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_bf16_eligible(B, Hi, Wi, Ho, Wo, C):

@@ -249,6 +249,43 @@ def test_resampler_on_the_matrix_cores(ops, kind, B, H, W, C):
     assert _native.lib().sei_sepmap2_bf16_eligible(2, 96, 96, 192, 192, 128) == 0  # the x4 network's fine levels: sei_sepmap2_big
 
 
+@pytest.mark.parametrize("kind,B,H,W,C", [("down", 64, 6, 6, 2048), ("up", 2, 3, 3, 8192), ("up", 5, 6, 6, 2048),
+                                          ("down", 2, 8, 6, 64), ("up", 1, 2, 2, 128), ("down", 3, 8, 4, 192),
+                                          ("down", 700, 4, 4, 64), ("up", 3, 8, 8, 128)])
+def test_resampler_of_the_deep_levels_in_one_pass(ops, kind, B, H, W, C):
+    """sei_sepmap2_small (Ideal{Down,Up}sample at input extents <= 8: the 6- and 3-pixel images of a 48-pixel crop,
+    reference src/models/convolutional.py:54-92,113-133) against float64 on the matrices of models/_mats.py and against the
+    two-launch float32 kernels it replaces in the bf16 mode: float32 FMAs, so the float32 bar (5e-6) holds; forward and
+    transposed (backward) maps, non-square images, more items than resident workgroups, every register-array width."""
+    import _native
+    from models import _mats
+    fwd, bwd = _mats.resample_matrices(kind, H, W, 2, "cuda")
+    gen = torch.Generator().manual_seed(B + H + C)
+    x = torch.randn((B, H, W, C), generator=gen).cuda()
+    Ho, Wo = fwd[0].shape[0], fwd[1].shape[0]
+    assert _native.lib().sei_sepmap2_small_eligible(B, H, W, Ho, Wo, C) == 1
+    ran = 0
+    for mats, xin, ho, wo in ((fwd, x, Ho, Wo), (bwd, torch.randn((B, Ho, Wo, C), generator=gen).cuda(), H, W)):
+        if not _native.lib().sei_sepmap2_small_eligible(xin.shape[0], xin.shape[1], xin.shape[2], ho, wo, C):
+            continue                                        # (the transposed map of an upsampler to 24 pixels: input 24)
+        ran += 1
+        _native.record_calls(True)
+        y = ops.sepmap2_16(xin, mats, ho, wo)
+        assert [n for n, _ in _native.record_calls(False)] == ["sei_sepmap2_small"]
+        y32 = ops.sepmap2(xin, mats, ho, wo)
+        L1, R1, L2, R2 = (m.double().cpu() for m in mats[:4])
+        xd = xin.double().cpu()
+        ref = torch.einsum("pi,bijc,qj->bpqc", L1, xd, R1) + torch.einsum("pi,bijc,qj->bpqc", L2, xd, R2)
+        assert y.shape == ref.shape
+        assert relerr(y, ref) < 5e-6, relerr(y, ref)
+        assert relerr(y, y32) < 5e-6
+        assert torch.equal(y, ops.sepmap2_16(xin, mats, ho, wo))     # no atomics: run-to-run identical
+    assert ran >= 1
+    assert _native.lib().sei_sepmap2_small_eligible(2, 24, 24, 12, 12, 128) == 0     # sei_sepmap2_bf16's extents
+    assert _native.lib().sei_sepmap2_small_eligible(2, 6, 6, 3, 3, 32) == 0          # C % 64
+    assert _native.lib().sei_sepmap2_small_eligible(2, 12, 12, 6, 6, 512) == 0       # 12 x 12 inputs: the two-launch kernels win
+
+
 @pytest.mark.parametrize("B,H,W,C", DW_SHAPES[:6])
 def test_dwconv7(ops, B, H, W, C):
     from _native import call
