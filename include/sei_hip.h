@@ -535,6 +535,12 @@ int sei_adam_fused(float *param, const void *grad, int grad_is_bf16, float *exp_
 int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1, const uint16_t *B2,
                              int ldb, float *param, float *exp_avg, float *exp_avg_sq, uint16_t *param_bf16,
                              const float *hyper, int M, int N, int K1, int K2, void *stream);
+/* The same with the caller's schedule choice (tests of both kernels, tools/): tile 0 = the dispatcher's choice, 1 = the
+ * 128 x 128 loop (gemm_bf16nt_kernel<..., ADAM>), 30 / 33 = the quadrant schedule's 256 x 256 / 256 x 128 tiles with the
+ * same epilogue (gemm_bf16pq_kernel<..., ADAM>); a choice the operands do not allow falls back to the loop. */
+int sei_gemm_bf16nt_dw2_adam_ex(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1, const uint16_t *B2,
+                                int ldb, float *param, float *exp_avg, float *exp_avg_sq, uint16_t *param_bf16,
+                                const float *hyper, int M, int N, int K1, int K2, int tile, void *stream);
 int sei_adam_scalars(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float *out6_host,
                      void *stream);
 /* the same values written to a DEVICE array by a launch on `stream` (what a training loop calls before every replay of

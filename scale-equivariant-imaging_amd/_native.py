@@ -68,6 +68,7 @@ SIGNATURES = {
     "sei_gemm_bf16nt_ex": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     "sei_gemm_bf16nt_dw2_ex": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_gemm_bf16nt_dw2_adam": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sei_gemm_bf16nt_dw2_adam_ex": [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "sei_gemm_bf16nt_dw2_bf16out": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "sei_gemm_bf16nt_dw2_taps": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "sei_sepmap2": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P],

@@ -860,6 +860,10 @@ int pq_choose(const NtArgs &g, bool would_split) {
 // transposing LDS reads). The kernel supports the layout (tile codes 30 / 33; tests) for later work on it.
 int pq_choose_rr(const NtArgs &) { return 0; }
 
+// The weight-gradient GEMMs whose epilogue applies the Adam step: quadrant schedule or the 128 x 128 loop (decided by
+// measurement, tools/exp_dw_adam_pq.py).
+bool pq_adam_auto(const NtArgs &) { return false; }
+
 static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
                     float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
                     const float *R1, const float *R2, uint16_t *D2_16, int tile, int band,
@@ -1093,10 +1097,10 @@ extern "C" int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, in
     return launch_nt<2, 1, 2, 4, true, true>(g, (hipStream_t)stream);
 }
 
-extern "C" int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
-                                        const uint16_t *B2, int ldb, float *param, float *exp_avg, float *exp_avg_sq,
-                                        uint16_t *param_bf16, const float *hyper, int M, int N, int K1, int K2,
-                                        void *stream) {
+extern "C" int sei_gemm_bf16nt_dw2_adam_ex(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
+                                           const uint16_t *B2, int ldb, float *param, float *exp_avg, float *exp_avg_sq,
+                                           uint16_t *param_bf16, const float *hyper, int M, int N, int K1, int K2,
+                                           int tile, void *stream) {
     SEI_REQUIRE(A1 && A2 && B1 && B2 && param && exp_avg && exp_avg_sq && hyper && M > 0 && N > 0 && K1 > 0 && K2 > 0);
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
@@ -1112,9 +1116,24 @@ extern "C" int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, 
     g.batch = 1;
     g.force_tile = 0; g.force_band = 0;
     g.adam_p = param; g.adam_m = exp_avg; g.adam_v = exp_avg_sq; g.adam_p16 = param_bf16; g.adam_h = hyper;
-    // (always the double-buffered loop: with the Adam epilogue's 112 registers only two workgroups fit a CU, which is what
+    SEI_REQUIRE(tile == 0 || tile == 1 || tile == 30 || tile == 33);
+    // tile 30 / 33: the quadrant schedule's 256 x 256 / 256 x 128 tiles with the Adam epilogue (round 5): half the operand
+    // bytes per output element of the 128 x 128 loop
+    if ((tile == 30 || tile == 33 || (tile == 0 && pq_adam_auto(g))) && pq_eligible(g, true)) {
+        if (tile == 33) return launch_pq<8, 2, true, true, 0, 2, true>(g, (hipStream_t)stream);
+        return launch_pq<8, 4, true, true, 0, 2, true>(g, (hipStream_t)stream);
+    }
+    // (the double-buffered loop: with the Adam epilogue's 112 registers only two workgroups fit a CU, which is what
     // the one-stage loop was meant to beat with three; measured at K = 864: 1416-1421 us against 1426-1459)
     return launch_nt<2, 1, 2, 4, true, true, 2, 1>(g, (hipStream_t)stream);
+}
+
+extern "C" int sei_gemm_bf16nt_dw2_adam(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,
+                                        const uint16_t *B2, int ldb, float *param, float *exp_avg, float *exp_avg_sq,
+                                        uint16_t *param_bf16, const float *hyper, int M, int N, int K1, int K2,
+                                        void *stream) {
+    return sei_gemm_bf16nt_dw2_adam_ex(A1, A2, lda, B1, B2, ldb, param, exp_avg, exp_avg_sq, param_bf16, hyper, M, N, K1, K2,
+                                       0, stream);
 }
 
 extern "C" int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A2, int lda, const uint16_t *B1,

@@ -99,7 +99,9 @@ __device__ __forceinline__ int pq_swz_rm128(int row) { return (((row >> 1) & 1) 
 //   * the two waves of a SIMD (wr = 0 / 1) issue their LDS-DMA pieces at different points of the iteration (right after
 //     the barrier / after the first MFMA block), so one wave's DMA issue sits under the other's MFMAs.
 // Tile order, LDS images, swizzles, piece tables, K tails and the epilogue are the quadrant schedule's.
-template <int RF, int NF, bool ARM = false, bool BRM = false, int ABL = 0, int NS = 2>
+// ADAM: the accumulator is the COMPLETE gradient of its element and the epilogue applies the optimizer step instead of
+// storing it (parameter, both moments, bf16 shadow in D's layout; NtArgs::adam_*), as gemm_bf16nt_kernel's ROWEPI = 1.
+template <int RF, int NF, bool ARM = false, bool BRM = false, int ABL = 0, int NS = 2, bool ADAM = false>
 __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     using G = PqGeom<RF, NF>;
     constexpr int QA0 = G::QA0, QA1 = G::QA1, QB = G::QB;
@@ -544,6 +546,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         aux1 = g.R1;
         aux2 = g.R2;
     }
+    float beta1 = 0.f, beta2 = 0.f, eps = 0.f, wd = 0.f, step_size = 0.f, inv_bc2_sqrt = 0.f;
+    if constexpr (ADAM) {
+        beta1 = g.adam_h[0]; beta2 = g.adam_h[1]; eps = g.adam_h[2]; wd = g.adam_h[3];
+        step_size = g.adam_h[4]; inv_bc2_sqrt = g.adam_h[5];
+    }
 #pragma unroll 1
     for (int i = 0; i < RF; ++i) {
         f32x4 c[NF];
@@ -596,6 +603,44 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
             continue;
         }
         const int row_base = m0 + wr * 16 * RF + 16 * i + prow;
+        if constexpr (ADAM) {
+            // 3 NF independent 16-byte loads per lane in flight (parameter, both moments: streamed once per step, non-temporal
+            // so that they do not push the GEMM operands out of L2 / MALL), then the element-wise step and four stores
+            float4 gq[NF], pq[NF], mq[NF], vq[NF];
+            size_t off[NF];
+            bool ok[NF];
+#pragma unroll
+            for (int p = 0; p < NF; ++p) {
+                const int row = row_base + p * RPP;
+                ok[p] = col_ok && row < M;
+                off[p] = ok[p] ? (size_t)row * N + col : 0;
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(patch + (p * RPP + prow) * LDW + pc4);
+                gq[p] = make_float4(t[0], t[1], t[2], t[3]);
+                pq[p] = nt_load4(g.adam_p + off[p]);
+                mq[p] = nt_load4(g.adam_m + off[p]);
+                vq[p] = nt_load4(g.adam_v + off[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < NF; ++p) {
+                if (!ok[p]) continue;
+                float4 o;
+                o.x = sei_adam_element(pq[p].x, gq[p].x, mq[p].x, vq[p].x, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                o.y = sei_adam_element(pq[p].y, gq[p].y, mq[p].y, vq[p].y, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                o.z = sei_adam_element(pq[p].z, gq[p].z, mq[p].z, vq[p].z, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                o.w = sei_adam_element(pq[p].w, gq[p].w, mq[p].w, vq[p].w, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                nt_store4(g.adam_m + off[p], mq[p]);
+                nt_store4(g.adam_v + off[p], vq[p]);
+                nt_store4(g.adam_p + off[p], o);
+                if (g.adam_p16) {
+                    typedef unsigned pq_u32x2 __attribute__((ext_vector_type(2)));
+                    pq_u32x2 t;
+                    t.x = (unsigned)f2bf(o.x) | ((unsigned)f2bf(o.y) << 16);
+                    t.y = (unsigned)f2bf(o.z) | ((unsigned)f2bf(o.w) << 16);
+                    __builtin_nontemporal_store(t, reinterpret_cast<pq_u32x2 *>(g.adam_p16 + off[p]));
+                }
+            }
+            continue;
+        }
         f32x4 v[NF], a1[NF], a2[NF];
 #pragma unroll
         for (int p = 0; p < NF; ++p) {
@@ -679,7 +724,8 @@ inline bool pq_eligible(const NtArgs &g, bool = false) {
 }
 
 // (three LDS stages wherever they fit and the operands are K-contiguous or B reduction-major: the 128-column tiles)
-template <int RF, int NF, bool ARM = false, bool BRM = false, int ABL = 0, int NS = ((NF == 2 && !ARM) ? 3 : 2)>
+template <int RF, int NF, bool ARM = false, bool BRM = false, int ABL = 0, int NS = ((NF == 2 && !ARM) ? 3 : 2),
+          bool ADAM = false>
 int launch_pq(NtArgs &g, hipStream_t s) {
     using G = PqGeom<RF, NF>;
     g.tiles_m = (int)sei_ceil_div(g.M, G::BM);
@@ -694,7 +740,7 @@ int launch_pq(NtArgs &g, hipStream_t s) {
     g.k_per_split = g.K;
     const bool splittable = g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
                             g.epilogue == SEI_EPI_BIAS_RES || g.epilogue == SEI_EPI_ACCUM;
-    if (splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {
+    if (!ADAM && splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {         // (the Adam epilogue needs the complete sum)
         const size_t slots = 256, ktiles = sei_ceil_div(g.K, BK);
         const size_t max_sk = ktiles / 4 < 16 ? ktiles / 4 : 16;
         const double overhead = 8.0 + (g.epilogue == SEI_EPI_ACCUM ? 0.0 : 2.0);
@@ -726,7 +772,7 @@ int launch_pq(NtArgs &g, hipStream_t s) {
         if (zg > 2048) zg = 2048;
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zg), dim3(256), 0, s, g.D32, n);
     }
-    hipLaunchKernelGGL((gemm_bf16pq_kernel<RF, NF, ARM, BRM, ABL, NS>), dim3((unsigned)(8 * (size_t)g.tiles_per_xcd * g.splitk)),
+    hipLaunchKernelGGL((gemm_bf16pq_kernel<RF, NF, ARM, BRM, ABL, NS, ADAM>), dim3((unsigned)(8 * (size_t)g.tiles_per_xcd * g.splitk)),
                        dim3(NT), 0, s, g);
     return sei_launch_status();
 }

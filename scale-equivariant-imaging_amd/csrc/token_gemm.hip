@@ -97,8 +97,7 @@ __global__ __launch_bounds__(64 * NW) void tokgrad_kernel(TokGradArgs g) {
 #pragma unroll
         for (int e = 0; e < NPIECE; ++e) {
             const int q = wave + NW * e;                            // wave-uniform
-            __builtin_amdgcn_global_load_lds((glb_void *)(((q >> 3) < 3 ? yb : xb) + off[e]),
-                                             (lds_void *)(dst + q * 1024), 16, 0, 0);
+            dma16_base((q >> 3) < 3 ? yb : xb, off[e], dst + q * 1024);      // (inline asm: sei_common.h)
         }
     };
 
@@ -534,15 +533,14 @@ __global__ __launch_bounds__(RG_NT, (EPI == RG_EPI_GELU16 ? 4 : 1)) void rowgemm
 #pragma unroll
         for (int e = 0; e < EMAX; ++e) {
             if (P % 8 != 0 && e == EMAX - 1 && wave >= P % 8) break;           // wave-uniform
-            __builtin_amdgcn_global_load_lds((glb_void *)(ab + offa[e]), (lds_void *)(dst + (wave + 8 * e) * 1024), 16, 0, 0);
+            dma16_base(ab, offa[e], dst + (wave + 8 * e) * 1024);
         }
         if constexpr (TWO) {
             const char *a2 = reinterpret_cast<const char *>(g.A2 + (size_t)tile * TR * g.lda2);
 #pragma unroll
             for (int e = 0; e < EMAX; ++e) {
                 if (P % 8 != 0 && e == EMAX - 1 && wave >= P % 8) break;
-                __builtin_amdgcn_global_load_lds((glb_void *)(a2 + offa2[e]),
-                                                 (lds_void *)(dst + KT * TR * 128 + (wave + 8 * e) * 1024), 16, 0, 0);
+                dma16_base(a2, offa2[e], dst + KT * TR * 128 + (wave + 8 * e) * 1024);
             }
         }
     };
