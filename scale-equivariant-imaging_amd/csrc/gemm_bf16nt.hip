@@ -854,14 +854,23 @@ int pq_choose(const NtArgs &g, bool would_split) {
     return 0;
 }
 
-// Weight gradients (both operands reduction-major) do NOT take the quadrant schedule by default: measured on the
-// two deepest levels it ties the 128 x 128 loop at K = 3456 (160 vs 155 us) and loses at K = 864 (912 vs 720 us:
-// 13 k-tiles per tile do not amortise one workgroup's unoverlapped 256-KB epilogue, and every fragment is two
-// transposing LDS reads). The kernel supports the layout (tile codes 30 / 33; tests) for later work on it.
-int pq_choose_rr(const NtArgs &) { return 0; }
+// Weight gradients (both operands reduction-major). Rounds 1-4 kept them all on the 128 x 128 loop: the quadrant schedule
+// tied at K = 3456 and lost at K = 864 -- measured while the compiler drained vmcnt in front of every transposing read
+// (sei_common.h, dma16_*). Re-measured with the inline-asm DMA (tools/exp_dw_pq.py, float32 store): 2048 x 8192 x 3456
+// 138 -> 124 us, 8192 x 2048 x 3456 137 -> 116 us on 256 x 256 tiles (930-1000 TFLOP/s); K = 864 still ties (639 vs 619 us:
+// 13 k-tiles per tile do not amortise one workgroup's unoverlapped epilogue) and 256 x 128 tiles lose everywhere. So: whole
+// 256 x 256 tiles that fill the chip and a reduction of at least 2048.
+int pq_choose_rr(const NtArgs &g) {
+    if (g.force_tile != 0 || g.K < 2048 || g.M % 256 != 0 || g.N % 256 != 0 || !pq_eligible(g, true)) return 0;
+    const size_t t4 = (size_t)(g.M / 256) * (size_t)(g.N / 256);
+    if (t4 < 192 || (double)t4 / (double)(sei_ceil_div(t4, 256) * 256) < 0.8) return 0;
+    return 84;
+}
 
-// The weight-gradient GEMMs whose epilogue applies the Adam step: quadrant schedule or the 128 x 128 loop (decided by
-// measurement, tools/exp_dw_adam_pq.py).
+// The weight-gradient GEMMs whose epilogue applies the Adam step stay on the 128 x 128 loop: two workgroups per CU overlap
+// one's 26-byte-per-element epilogue with the other's main loop (tools/exp_dw_adam_pq.py: 8192 x 32768 x 864 1288 us =
+// 5.5 TB/s against 1537 us on 256 x 256 quadrant tiles, 2048 x 8192 x 3456 178 against 182 us). The quadrant kernel's Adam
+// epilogue stays reachable through sei_gemm_bf16nt_dw2_adam_ex (tile 30 / 33) and is held to the loop's results by a test.
 bool pq_adam_auto(const NtArgs &) { return false; }
 
 static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,

@@ -984,6 +984,37 @@ def test_weight_gradient_gemm_with_the_adam_epilogue():
         assert torch.equal(pc, pb)
 
 
+@pytest.mark.parametrize("M,Nn,K1,K2", [(2048, 6144, 640, 1032), (512, 768, 96, 200), (2048, 8192, 1152, 2304)])
+def test_adam_epilogue_of_the_quadrant_schedule(M, Nn, K1, K2):
+    """sei_gemm_bf16nt_dw2_adam_ex: the quadrant kernel's Adam epilogue (tiles 30 / 33: 256 x 256 / 256 x 128) against the
+    128 x 128 loop's (tile 1), same state, scalars and operands: the two kernels add the same products in another order
+    (16x16x32 against 32x32x16 MFMAs), so gradient-dependent results agree to float32 rounding of the sum; the bf16 shadow
+    is the rounded new parameter in each; K tails and the straddled K segment included."""
+    import ctypes
+    import _native as N
+    gen = torch.Generator(device="cuda").manual_seed(M + K1)
+    A1, A2 = ((0.05 * torch.randn((k, M), device="cuda", generator=gen)).bfloat16() for k in (K1, K2))
+    B1, B2 = (torch.randn((k, Nn), device="cuda", generator=gen).bfloat16() for k in (K1, K2))
+    p0 = 0.02 * torch.randn((M, Nn), device="cuda", generator=gen)
+    host = (ctypes.c_float * 6)()
+    N.call("sei_adam_scalars", 2e-4, 0.9, 0.99, 1e-8, 0.01, 5, ctypes.cast(host, ctypes.c_void_p))
+    hyper = torch.tensor(list(host), device="cuda")
+    out = {}
+    for tile in (1, 30, 33, 0):
+        p, m, v = p0.clone(), torch.full_like(p0, 1e-3), torch.full_like(p0, 1e-5)
+        sh = torch.zeros((M, Nn), device="cuda", dtype=torch.bfloat16)
+        N.call("sei_gemm_bf16nt_dw2_adam_ex", A1.data_ptr(), A2.data_ptr(), M, B1.data_ptr(), B2.data_ptr(), Nn, p.data_ptr(),
+               m.data_ptr(), v.data_ptr(), sh.data_ptr(), hyper.data_ptr(), M, Nn, K1, K2, tile)
+        out[tile] = (p, m, v, sh)
+    assert float((out[1][0] - p0).abs().max()) > 1e-5
+    for tile in (30, 33):
+        for a, b in zip(out[tile][:3], out[1][:3]):
+            assert relerr(a, b) < 2e-5, (tile, relerr(a, b))
+        assert torch.equal(out[tile][3], out[tile][0].bfloat16())
+    for a, b in zip(out[0], out[1]):                    # the dispatcher keeps these launches on the loop (tools/exp_dw_adam_pq.py)
+        assert torch.equal(a, b)
+
+
 def test_weight_gradient_gemm_with_bf16_output():
     """sei_gemm_bf16nt_dw2_bf16out == the bf16 rounding of the float32 gradient sei_gemm_bf16nt_dw2 stores (no K split
     at 768 whole tiles; ragged tiles to rounding): what the reducer's cast pass would have put into the exchange buffer."""

@@ -1,0 +1,17 @@
+"""Level-2 (512-channel) GEMMs of the step on the candidate schedules after round 5's faster 128-column quadrant tiles:
+automatic choice (0), 288 x 128 (32), 256 x 128 (33), the 128 x 128 loop (1)."""
+import os, sys, statistics, torch
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tools"))
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "scale-equivariant-imaging_amd"))
+from exp_ring3 import build, once
+for (M, N, K, kind) in [(9216, 512, 2048, "res"), (9216, 512, 2048, "none_kr"), (4608, 512, 2048, "res"), (4608, 512, 2048, "none_kr"),
+                        (9216, 2048, 512, "gelu"), (9216, 2048, 512, "dgelu_kr"), (4608, 2048, 512, "gelu"), (4608, 2048, 512, "dgelu_kr"),
+                        (2304, 512, 2048, "none_kr"), (576, 2048, 8192, "none_kr"), (288, 2048, 8192, "none_kr")]:
+    f, _, _ = build(M, N, K, kind)
+    codes = [0, 32, 33, 1]
+    times = {c: [] for c in codes}
+    for rnd in range(5):
+        for code in codes:
+            f(code); torch.cuda.synchronize()
+            times[code].append(once(lambda: f(code)))
+    print(f"{M}x{N}x{K} {kind}: " + "  ".join(f"tile {c} {statistics.median(t):.1f}us" for c, t in times.items()), flush=True)
