@@ -243,9 +243,9 @@ def _stream_bytes(name, a):
         return 24 * a[4]
     if name == "sei_axpy":
         return 12 * a[4]
-    if name == "sei_sure_terms":
+    if name in ("sei_sure_terms", "sei_sure_loss"):
         return 24 * a[4] * a[5] * a[6]
-    if name == "sei_mse_terms":
+    if name in ("sei_mse_terms", "sei_mse_loss"):
         return 12 * a[2]
     return None
 
@@ -301,7 +301,8 @@ _STREAM_FAMILIES = [
     ("cast / colsum kernels (bf16 copies, bias gradients)", ("sei_cast_", "sei_colsum_")),
     ("conv3x3_* (in / out convolutions)", ("sei_conv3x3_",)),
     ("blur / scale_resample / axpy / sure / mse kernels (physics + loss terms)",
-     ("sei_blur_", "sei_scale_resample_", "sei_scale_params", "sei_axpy", "sei_sure_terms", "sei_mse_terms", "sei_resample_")),
+     ("sei_blur_", "sei_scale_resample_", "sei_scale_params", "sei_axpy", "sei_sure_terms", "sei_sure_loss", "sei_mse_terms", "sei_mse_loss",
+      "sei_resample_")),
 ]
 PMC_TRAFFIC_FILE = "r04_f_unet_pmc_gemm.json"      # the committed PMC pass `roofline.traffic` is read from
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)

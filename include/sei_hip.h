@@ -136,6 +136,17 @@ int sei_sure_terms(const float *y, const float *y1, const float *y2, const float
                    float c_div, float *out2, float *g1, float *g2, float *work, void *stream);
 int sei_mse_terms(const float *a, const float *b, size_t n, float scale, float *out1, float *ga,
                   float *work, void *stream);
+
+/* The two entry points above with the LOSS VALUE formed on the device as well (no chain of 0-dim torch kernels behind them):
+ * sei_sure_loss: out3[0] = divergence sum, out3[1] = squared-error sum, out3[2] = c_mse out3[1] + c_div out3[0] - cst
+ * (src/losses/sure.py:57-66: mse + 2 sigma^2 div - sigma^2 / B); y1 / y2 and g1 / g2 may be the two halves of one 2B-image
+ * tensor (ProposedLoss evaluates A on both model outputs at once). sei_mse_loss: out2[0] = sum (a - b)^2, out2[1] =
+ * value_scale out2[0] (deepinv's mse metric times the EI weight, src/losses/__init__.py:117-122). */
+int sei_sure_loss(const float *y, const float *y1, const float *y2, const float *b, int planes, int H, int W,
+                  int margin_div, int margin_mse, float tau, float c_mse, float c_div, float cst, float *out3, float *g1,
+                  float *g2, float *work, void *stream);
+int sei_mse_loss(const float *a, const float *b, size_t n, float grad_scale, float value_scale, float *out2, float *ga,
+                 float *work, void *stream);
 /* Numerator of the luma PSNR of the evaluation step (reference src/metrics.py:10-13: kornia rgb_to_ycbcr's
  * Y = 0.299 R + 0.587 G + 0.114 B, torchmetrics PSNR with data_range 1): out1[0] = sum over the npix pixels of
  * (Y(a) - Y(b))^2 for planar RGB images a, b of shape (3, npix). `work` holds SEI_REDUCE_BLOCKS floats. */

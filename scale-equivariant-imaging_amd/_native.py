@@ -41,6 +41,8 @@ SIGNATURES = {
     "sei_zero_ranges": [_P, _P, _I, _P],
     "sei_sure_terms": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     "sei_mse_terms": [_P, _P, _Z, _F, _P, _P, _P, _P],
+    "sei_sure_loss": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P, _P, _P, _P, _P],
+    "sei_mse_loss": [_P, _P, _Z, _F, _F, _P, _P, _P, _P],
     "sei_luma_sqerr": [_P, _P, _Z, _P, _P, _P],
     "sei_conv3x3_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sei_conv3x3_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -109,6 +109,26 @@ __global__ __launch_bounds__(RED_THREADS) void finish_sums_kernel(const float *_
     }
 }
 
+// stage 2 with the loss value formed on the device: out[nout] = sum_q coef[q] * out[q] + bias (the SURE loss = c_mse * mse sum
+// + c_div * div sum - constant; the weighted mean squared error): the step's scalar arithmetic is not a chain of 0-dim
+// torch kernels (round 5: five fewer launches in the forward pass of a proposed-loss step)
+struct FinishCoef {
+    float coef[2], bias;
+};
+__global__ __launch_bounds__(RED_THREADS) void finish_loss_kernel(const float *__restrict__ work, int nparts, int nout,
+                                                                  FinishCoef fc, float *__restrict__ out) {
+    __shared__ float scratch[RED_THREADS / 64];
+    float total = fc.bias;
+    for (int q = 0; q < nout; ++q) {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += RED_THREADS) v += work[q * SEI_REDUCE_BLOCKS + i];
+        const float s = sei_block_sum<RED_THREADS>(v, scratch);
+        if (threadIdx.x == 0) out[q] = s;
+        total = fmaf(fc.coef[q], s, total);             // (only thread 0's `s` is the block sum; only it writes below)
+    }
+    if (threadIdx.x == 0) out[nout] = total;
+}
+
 inline int reduce_blocks(size_t n) {
     size_t g = sei_ceil_div(n, (size_t)RED_THREADS * 4);
     if (g < 1) g = 1;
@@ -191,6 +211,38 @@ extern "C" int sei_sure_terms(const float *y, const float *y1, const float *y2, 
                        total, H, W, margin_div, margin_mse, 1.0f / tau, c_mse, c_div, g1, g2, work);
     hipLaunchKernelGGL(finish_sums_kernel, dim3(1), dim3(RED_THREADS), 0, (hipStream_t)stream,
                        (const float *)work, grid, 2, out2);
+    return sei_launch_status();
+}
+
+// sei_sure_terms + the loss value: out3[0] = div sum, out3[1] = mse sum, out3[2] = c_mse out3[1] + c_div out3[0] - cst.
+extern "C" int sei_sure_loss(const float *y, const float *y1, const float *y2, const float *b, int planes, int H, int W,
+                             int margin_div, int margin_mse, float tau, float c_mse, float c_div, float cst, float *out3,
+                             float *g1, float *g2, float *work, void *stream) {
+    SEI_REQUIRE(y && y1 && y2 && b && out3 && g1 && g2 && work);
+    SEI_REQUIRE(planes > 0 && H > 0 && W > 0 && margin_div >= 0 && margin_mse >= 0 && tau != 0.f);
+    SEI_REQUIRE(2 * margin_div < H && 2 * margin_div < W && 2 * margin_mse < H && 2 * margin_mse < W);
+    const size_t total = (size_t)planes * H * W;
+    const int grid = reduce_blocks(total);
+    hipLaunchKernelGGL(sure_terms_kernel, dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, y, y1, y2, b,
+                       total, H, W, margin_div, margin_mse, 1.0f / tau, c_mse, c_div, g1, g2, work);
+    FinishCoef fc;
+    fc.coef[0] = c_div; fc.coef[1] = c_mse; fc.bias = -cst;
+    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(RED_THREADS), 0, (hipStream_t)stream, (const float *)work, grid, 2,
+                       fc, out3);
+    return sei_launch_status();
+}
+
+// sei_mse_terms + the loss value: out2[0] = sum (a - b)^2, out2[1] = value_scale * out2[0].
+extern "C" int sei_mse_loss(const float *a, const float *b, size_t n, float grad_scale, float value_scale, float *out2,
+                            float *ga, float *work, void *stream) {
+    SEI_REQUIRE(a && b && out2 && ga && work && n > 0);
+    const int grid = reduce_blocks(n);
+    hipLaunchKernelGGL(mse_terms_kernel, dim3(grid), dim3(RED_THREADS), 0, (hipStream_t)stream, a, b, n, grad_scale, ga,
+                       work);
+    FinishCoef fc;
+    fc.coef[0] = value_scale; fc.coef[1] = 0.f; fc.bias = 0.f;
+    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(RED_THREADS), 0, (hipStream_t)stream, (const float *)work, grid, 1,
+                       fc, out2);
     return sei_launch_status();
 }
 

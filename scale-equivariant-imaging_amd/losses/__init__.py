@@ -237,7 +237,7 @@ class ProposedLoss(Module):
         both = calls[0](torch.cat([y, axpy(y, b, self.sure.tau)], dim=0))
         y12 = self.physics.A(both)
         x_net = both[:B]
-        loss = self.sure(y=y, x_net=x_net, physics=self.physics, model=model, b=b, y1=y12[:B], y2=y12[B:])
+        loss = self.sure(y=y, x_net=x_net, physics=self.physics, model=model, b=b, y12=y12)
         if self.keep_outputs:
             self.kept = {"x_net": x_net.detach()}
         return loss + self.ei(x=x, x_net=x_net, y=y, physics=self.physics, model=calls[-1], **ei_kw)

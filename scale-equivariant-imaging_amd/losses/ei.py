@@ -19,13 +19,13 @@ class _MseTerms(torch.autograd.Function):
         if a.shape != b.shape:
             raise ValueError(f"mse: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
         n = a.numel()
-        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        out = torch.empty(2, dtype=torch.float32, device=a.device)
         ga = torch.empty_like(a)
         work = torch.empty(N.SEI_REDUCE_BLOCKS, dtype=torch.float32, device=a.device)
-        N.call("sei_mse_terms", a.data_ptr(), b.data_ptr(), n, 2.0 * weight / n, out.data_ptr(), ga.data_ptr(),
-               work.data_ptr())
+        N.call("sei_mse_loss", a.data_ptr(), b.data_ptr(), n, 2.0 * weight / n, weight / n, out.data_ptr(), ga.data_ptr(),
+               work.data_ptr())                  # (the weighted mean is formed by the kernel's last stage: no 0-dim torch mul)
         ctx.save_for_backward(ga)
-        return out[0] * (weight / n)
+        return out[1]
 
     @staticmethod
     def backward(ctx, go):

@@ -16,28 +16,43 @@ from physics._ops import axpy
 
 class _SureTerms(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, y1, y2, b, margin_div, margin_mse, tau, sigma2):
-        for name, t in (("y", y), ("y1", y1), ("y2", y2), ("b", b)):
-            N.check_tensor(t, name)
-            if t.shape != y.shape:
-                raise ValueError("SURE: y, A(x_net), A(f(y + tau b)) and b must share one shape")
+    def forward(ctx, y, y1, y2, b, margin_div, margin_mse, tau, sigma2, cst):
+        """y2 None: `y1` is [A(x_net); A(f(y + tau b))] as ONE tensor of 2B images (ProposedLoss evaluates the operator on both
+        model outputs at once): its halves are read in place and one gradient tensor comes back for it -- autograd then has
+        no slices to differentiate (two zero fills, two copies and an add per step). The loss value
+        c_mse * mse_sum + c_div * div_sum - cst is formed by the kernel's own last stage (sei_sure_loss)."""
+        joint = y2 is None
         B, C, H, W = y.shape
+        for name, t in (("y", y), ("y1", y1), ("b", b)) + (() if joint else (("y2", y2),)):
+            N.check_tensor(t, name)
+            if t.shape != ((2 * B, C, H, W) if joint and name == "y1" else y.shape):
+                raise ValueError("SURE: y, A(x_net), A(f(y + tau b)) and b must share one shape")
         n_div = B * C * (H - 2 * margin_div) * (W - 2 * margin_div)
         n_mse = B * C * (H - 2 * margin_mse) * (W - 2 * margin_mse)
         c_mse, c_div = 1.0 / n_mse, 2.0 * sigma2 / n_div
-        out = torch.empty(2, dtype=torch.float32, device=y.device)
-        g1, g2 = torch.empty_like(y), torch.empty_like(y)
+        out = torch.empty(3, dtype=torch.float32, device=y.device)
         work = torch.empty(2 * N.SEI_REDUCE_BLOCKS, dtype=torch.float32, device=y.device)
-        N.call("sei_sure_terms", y.data_ptr(), y1.data_ptr(), y2.data_ptr(), b.data_ptr(), B * C, H, W,
-               margin_div, margin_mse, tau, c_mse, c_div, out.data_ptr(), g1.data_ptr(), g2.data_ptr(),
-               work.data_ptr())
-        ctx.save_for_backward(g1, g2)
-        return c_mse * out[1] + c_div * out[0]
+        if joint:
+            g = torch.empty_like(y1)
+            half = y.numel() * y.element_size()
+            ptrs = (y1.data_ptr(), y1.data_ptr() + half, g.data_ptr(), g.data_ptr() + half)
+            ctx.save_for_backward(g)
+        else:
+            g1, g2 = torch.empty_like(y), torch.empty_like(y)
+            ptrs = (y1.data_ptr(), y2.data_ptr(), g1.data_ptr(), g2.data_ptr())
+            ctx.save_for_backward(g1, g2)
+        ctx.joint = joint
+        N.call("sei_sure_loss", y.data_ptr(), ptrs[0], ptrs[1], b.data_ptr(), B * C, H, W, margin_div, margin_mse, tau,
+               c_mse, c_div, float(cst), out.data_ptr(), ptrs[2], ptrs[3], work.data_ptr())
+        return out[2]
 
     @staticmethod
     def backward(ctx, go):
+        if ctx.joint:
+            (g,) = ctx.saved_tensors
+            return (None, g * go) + (None,) * 7
         g1, g2 = ctx.saved_tensors
-        return None, g1 * go, g2 * go, None, None, None, None, None
+        return (None, g1 * go, g2 * go) + (None,) * 6
 
 
 def draw_probe(y, margin):
@@ -74,20 +89,23 @@ class SureGaussianLoss(nn.Module):
     def div_margin(self):
         return self.margin if self.cropped_div else 0
 
-    def forward(self, y, x_net, physics, model, b=None, y1=None, y2=None, **kwargs):
+    def forward(self, y, x_net, physics, model, b=None, y1=None, y2=None, y12=None, **kwargs):
         """`b` (full-size probe), `y1` = A(x_net) and `y2` = A(model(y + tau b)) may be supplied by a
-        caller that has already evaluated them (ProposedLoss batches the two network passes)."""
+        caller that has already evaluated them (ProposedLoss batches the two network passes: `y12` = both as one
+        tensor of 2B images)."""
         y = y.contiguous()
-        if y1 is None:
-            y1 = physics.A(x_net)
         if b is None:
             b = draw_probe(y, self.div_margin)
-        if y2 is None:
-            y2 = physics.A(model(axpy(y, b, self.tau)))
-        loss = _SureTerms.apply(y, y1.contiguous(), y2.contiguous(), b, self.div_margin, self.margin, self.tau,
-                                self.sigma2)
         cst = self.sigma2 if self.averaged_cst else self.sigma2 / y.size(0)
-        loss = loss - cst
+        if y12 is not None:
+            loss = _SureTerms.apply(y, y12.contiguous(), None, b, self.div_margin, self.margin, self.tau, self.sigma2, cst)
+        else:
+            if y1 is None:
+                y1 = physics.A(x_net)
+            if y2 is None:
+                y2 = physics.A(model(axpy(y, b, self.tau)))
+            loss = _SureTerms.apply(y, y1.contiguous(), y2.contiguous(), b, self.div_margin, self.margin, self.tau,
+                                    self.sigma2, cst)
         from os import environ
         if "_TEMPORARY_HOTFIX" in environ:       # reference :68-74
             assert physics.rate is not None

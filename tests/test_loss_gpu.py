@@ -1189,7 +1189,7 @@ def test_fused_optimizer_step_on_the_default_network():
     try:
         args = bench.reference_args("cuda", 32, 5)
         runs = {}
-        for fuse in (False, True):
+        for fuse in (False, "again", True):           # the plain step twice: the step's own run-to-run noise is the bar
             torch.manual_seed(0)
             p = physics.get_physics(args, "cuda")
             model = models.get_model(args, p, "cuda").to("cuda")
@@ -1199,8 +1199,8 @@ def test_fused_optimizer_step_on_the_default_network():
             x = torch.rand(8, 3, 256, 256, device="cuda")
             torch.cuda.manual_seed(7)
             y = p(x)
-            g = GraphedLossStep(lf, model, opt, (8, 3, 48, 48), fuse_optimizer=fuse)
-            if fuse:
+            g = GraphedLossStep(lf, model, opt, (8, 3, 48, 48), fuse_optimizer=fuse is True)
+            if fuse is True:
                 assert len(g.fused_views) == 8, [tuple(v.shape) for v in g.fused_views]
                 ranges = list(opt._fused_ranges)          # the bottleneck pair + level 3's two blocks, down and up conv
                 assert sum(hi - lo for lo, hi in ranges) == 2 * 8192 * 32768 + 6 * 2048 * 8192      # 98.8 % of the bucket
@@ -1209,11 +1209,16 @@ def test_fused_optimizer_step_on_the_default_network():
             loss = float(g(x, y))
             opt.step()
             st = opt.state[bb.flat_params]
-            runs[fuse] = (loss, bb.flat_params, st["exp_avg"], st["exp_avg_sq"], bb.flat_shadow)
+            runs[fuse] = (loss, bb.flat_params, st["exp_avg"], st["exp_avg_sq"], bb.flat_shadow) if fuse != "again" else (loss,)
             del g, opt, model, lf
-        # (two runs of the SAME step already differ in the sixth digit: the deep levels' forward GEMMs split K over float
-        # atomics; the bit-for-bit statement lives at kernel level, tests/test_unet_gpu.py)
-        assert abs(runs[False][0] - runs[True][0]) < 1e-4 * runs[False][0]
+        # Two runs of the SAME step differ: the deep levels' forward GEMMs split K over float atomics, and a last-bit
+        # difference there flips bf16 roundings of later activations; at random initialisation the Monte-Carlo divergence
+        # (differences of two network outputs over tau = 0.01) carries that into the fourth-fifth digit of the loss (observed
+        # between 1e-6 and 1e-4 relative over the boxes of rounds 4-5). The fused step must sit within 3x of what the plain
+        # step differs from itself by in this very process (floor 1e-4); the bit-for-bit statements live at kernel level
+        # (tests/test_unet_gpu.py::test_weight_gradient_gemm_with_the_adam_epilogue).
+        noise = abs(runs[False][0] - runs["again"][0])
+        assert abs(runs[False][0] - runs[True][0]) < max(1e-4 * runs[False][0], 3 * noise), (runs[False][0], runs[True][0], noise)
         for lo, hi in ranges:
             assert relerr(runs[True][2][lo:hi], runs[False][2][lo:hi]) < 2e-2           # exp_avg = 0.1 * gradient
             moved = (runs[True][1][lo:hi] - runs[False][1][lo:hi]).abs()
