@@ -1215,10 +1215,10 @@ def test_fused_optimizer_step_on_the_default_network():
         # difference there flips bf16 roundings of later activations; at random initialisation the Monte-Carlo divergence
         # (differences of two network outputs over tau = 0.01) carries that into the fourth-fifth digit of the loss (observed
         # between 1e-6 and 1e-4 relative over the boxes of rounds 4-5). The fused step must sit within 3x of what the plain
-        # step differs from itself by in this very process (floor 1e-4); the bit-for-bit statements live at kernel level
+        # step differs from itself by in this very process (floor 3e-4 = 3x the largest observed); the bit-for-bit statements live at kernel level
         # (tests/test_unet_gpu.py::test_weight_gradient_gemm_with_the_adam_epilogue).
         noise = abs(runs[False][0] - runs["again"][0])
-        assert abs(runs[False][0] - runs[True][0]) < max(1e-4 * runs[False][0], 3 * noise), (runs[False][0], runs[True][0], noise)
+        assert abs(runs[False][0] - runs[True][0]) < max(3e-4 * runs[False][0], 3 * noise), (runs[False][0], runs[True][0], noise)
         for lo, hi in ranges:
             assert relerr(runs[True][2][lo:hi], runs[False][2][lo:hi]) < 2e-2           # exp_avg = 0.1 * gradient
             moved = (runs[True][1][lo:hi] - runs[False][1][lo:hi]).abs()
