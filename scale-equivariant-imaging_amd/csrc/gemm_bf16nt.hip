@@ -848,7 +848,9 @@ int pq_choose(const NtArgs &g, bool would_split) {
     if (t2 >= 192 && t4 < 192 && fills(t2)) return 10 * rf + 2;
     if (would_split) {
         if (K < 8192 || N < 2048 || (M < 2304 && N < 8192)) return 0;
-        return 10 * rf + ((t4 >= 64 && N >= 8192) ? 4 : 2);
+        // (256-column tiles from 96 of them on: the joint backward's 3456 x 2048 x 8192 runs 153 us there against 192 on
+        // 128-column tiles, while 2304 rows -- 64 tiles -- prefer the narrow ones: 104 vs 124, tools/exp_joint_rows.py)
+        return 10 * rf + ((t4 >= 96 || (t4 >= 64 && N >= 8192)) ? 4 : 2);
     }
     if (t2 >= 128 && t4 < 192) return 10 * rf + 2;             // half the chip on 288-row tiles beats 96 tiles of 192x256
     return 0;

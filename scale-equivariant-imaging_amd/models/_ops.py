@@ -165,7 +165,14 @@ def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=Non
     B16 is (N,K) [or (K,N) when b_rmajor]; K % 8 == 0. Outputs as given. tile / band: an explicit schedule
     choice (sei_gemm_bf16nt_ex; tests and tools), 0 = the library's dispatch. flops: the algorithmic FLOP count
     to book for the roofline leg when the operands are zero-padded (default 2 M N K)."""
-    if _JOINT_SPLIT is not None and not _whole and not a_rmajor and max(Nn, K) >= 2048 and not (tile or band) and lda is None:
+    # (the CONTRACTING data gradients gh2 = gh3 W2 -- float32 out, K = 4 N, split K -- run faster on the joint rows: their
+    # K splits fill the rounds whatever the row count. tools/exp_joint_rows.py, merged vs the two launches: 3456 x 2048 x 8192
+    # 153 vs 104 + 71 us, 864 x 8192 x 32768 479 vs 310 + 187, 13824 x 512 x 2048 44 vs 37 + 30; the expanding ones with
+    # GELU' lose merged: 3456 x 8192 x 2048 147 vs 85 + 51, 864 x 32768 x 8192 492 vs 287 + 169.)
+    contracting = (out32 is not None and out16 is None and epi in (EPI_NONE, EPI_ACCUM) and b_rmajor and K == 4 * Nn
+                   and (M >= 3456 or Nn >= 8192))
+    if _JOINT_SPLIT is not None and not _whole and not a_rmajor and max(Nn, K) >= 2048 and not (tile or band) and lda is None \
+            and not contracting:
         # One backward pass over the rows of both model calls (models/_joint.py) -- but the deep levels' GEMMs are tuned to
         # the row counts of the separate calls (2304 / 1152 and 576 / 288 rows are whole rounds of 288-row tiles on 256 CUs;
         # 3456 and 864 rows are 1.5 rounds: measured 168 us against 79 + 58): their rows go as the two launches they were
