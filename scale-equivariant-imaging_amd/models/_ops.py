@@ -170,7 +170,7 @@ def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=Non
     # 153 vs 104 + 71 us, 864 x 8192 x 32768 479 vs 310 + 187, 13824 x 512 x 2048 44 vs 37 + 30; the expanding ones with
     # GELU' lose merged: 3456 x 8192 x 2048 147 vs 85 + 51, 864 x 32768 x 8192 492 vs 287 + 169.)
     contracting = (out32 is not None and out16 is None and epi in (EPI_NONE, EPI_ACCUM) and b_rmajor and K == 4 * Nn
-                   and (M >= 3456 or Nn >= 8192))
+                   and (M >= 3456 or K >= 8192))               # (also 864 x 2048 x 8192: 61 vs 53 + 39, exp_joint_rows2.py)
     if _JOINT_SPLIT is not None and not _whole and not a_rmajor and max(Nn, K) >= 2048 and not (tile or band) and lda is None \
             and not contracting:
         # One backward pass over the rows of both model calls (models/_joint.py) -- but the deep levels' GEMMs are tuned to
