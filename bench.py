@@ -186,9 +186,15 @@ def _stream_bytes(name, a):
         return B * H * W * heads * (32 * 2 * 8 + 4)
     if name == "sei_sepmap2_bf16_pack":
         return 0
-    if name in ("sei_sepmap2_packed", "sei_sepmap2_bf16", "sei_sepmap2_big", "sei_sepmap2_small"):
+    if name in ("sei_sepmap2_packed", "sei_sepmap2_bf16", "sei_sepmap2_big"):
         B, Hi, Wi, Ho, Wo, C = a[2:8]                     # (algorithmic: x in, y out; the bf16 intermediate of _big is its own)
         return 4 * B * C * (Hi * Wi + Ho * Wo)
+    if name == "sei_sepmap2_bf16_out16":                  # bf16 result
+        B, Hi, Wi, Ho, Wo, C = a[2:8]
+        return B * C * (4 * Hi * Wi + 2 * Ho * Wo)
+    if name == "sei_sepmap2_small":
+        B, Hi, Wi, Ho, Wo, C = a[3:9]
+        return B * C * (4 * Hi * Wi + (2 if a[2] else 4) * Ho * Wo)
     if name == "sei_sepmap2_big_pack":
         return 0
     if name == "sei_cast_transpose_bf16":

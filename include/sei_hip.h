@@ -383,8 +383,13 @@ int sei_debug_set_nt_tile(int code);
  * float32, y = L1 X R1^T + L2 X R2^T per image and channel, float32 FMAs; L1, L2: (Ho, Hi), R1, R2: (Wo, Wi) row-major
  * device arrays. One workgroup item = one image x 64 channels through LDS; no HBM intermediate. _eligible: 1 / 0. */
 size_t sei_sepmap2_small_eligible(int B, int Hi, int Wi, int Ho, int Wo, int C);
-int sei_sepmap2_small(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C, const float *L1,
-                      const float *R1, const float *L2, const float *R2, void *stream);
+int sei_sepmap2_small(const float *x, void *y, int out_bf16, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                      const float *L1, const float *R1, const float *L2, const float *R2, void *stream);
+/* out_bf16 = 1 (and sei_sepmap2_bf16_out16 below for the matrix-core kernel): y is bf16, the float32 result rounded once
+ * to nearest even -- the operand of the 1x1 convolution that models/_ops.DownsampleFn16 evaluates BEHIND the ideal
+ * downsampler (src/models/convolutional.py:136-150 commuted): no float32 copy of the resampled tensor, no cast pass. */
+int sei_sepmap2_bf16_out16(const float *x, uint16_t *y16, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                           const uint16_t *packed, void *stream);
 
 int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
                 const float *L1, const float *R1, const float *L2, const float *R2, float *work,

@@ -79,7 +79,8 @@ SIGNATURES = {
     "sei_sepmap2_packed": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P],
     "sei_sepmap2_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "sei_sepmap2_bf16_pack": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "sei_sepmap2_small": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "sei_sepmap2_small": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "sei_sepmap2_bf16_out16": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "sei_colsum_f32": [_P, _P, _Z, _I, _P],
     "sei_colsum_weighted_f32": [_P, _P, _P, _Z, _I, _P],
     "sei_mlp_fused_fwd": [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P],

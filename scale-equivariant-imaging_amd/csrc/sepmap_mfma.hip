@@ -49,6 +49,7 @@ struct SmmGeom {
     int HoT, WoT;          // 16-row tiles of the outputs
     int ldR, ldL, ldT;     // LDS row strides in elements (K extent + SMM_PADK)
     int offRlo, offL, offLlo, offT;   // element offsets of the LDS sections (R head at 0)
+    int out16;             // y is bf16 (sei_sepmap2_bf16_out16): rounded once from the float32 accumulator
 };
 
 // The four matrices in the kernel's LDS image (sei_sepmap2_bf16_pack, once per map): bf16 head + remainder, zero-padded
@@ -169,7 +170,9 @@ __global__ __launch_bounds__(SMM_THREADS, 2) void sepmap_mfma_kernel(const float
     // accumulator holds FOUR CONSECUTIVE CHANNELS of one output pixel per lane: one 16-byte store instead of four
     // 4-byte ones. Two (jo, io-tile) items per iteration: independent chains, so the LDS reads and MFMAs of one cover
     // the latencies of the other.
-    float *yb = y + (size_t)b * g.Ho * g.Wo * g.C + c0 + 4 * lg;
+    const size_t ybase = (size_t)b * g.Ho * g.Wo * g.C + c0 + 4 * lg;
+    float *yb = y + ybase;
+    unsigned short *yb16 = reinterpret_cast<unsigned short *>(y) + ybase;
     const int hitems = g.Wo * g.HoT;
     auto h_item = [&](int it, f32x4 &acc) {
         const int jo = it / g.HoT, ht = it - jo * g.HoT;
@@ -192,8 +195,15 @@ __global__ __launch_bounds__(SMM_THREADS, 2) void sepmap_mfma_kernel(const float
     auto h_store = [&](int it, const f32x4 &acc) {
         const int jo = it / g.HoT, ht = it - jo * g.HoT;
         const int io = ht * 16 + lc;                              // accumulator: column = io, rows = channels 4 lg .. 4 lg + 3
-        if (io < g.Ho)
-            *reinterpret_cast<float4 *>(yb + ((size_t)io * g.Wo + jo) * g.C) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (io < g.Ho) {
+            if (g.out16) {
+                ushort4 h;
+                h.x = smm_f2bf(acc[0]); h.y = smm_f2bf(acc[1]); h.z = smm_f2bf(acc[2]); h.w = smm_f2bf(acc[3]);
+                *reinterpret_cast<ushort4 *>(yb16 + ((size_t)io * g.Wo + jo) * g.C) = h;
+            } else {
+                *reinterpret_cast<float4 *>(yb + ((size_t)io * g.Wo + jo) * g.C) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
     };
     for (int it = wave; it < hitems; it += 2 * SMM_WAVES) {
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -211,7 +221,7 @@ inline bool smm_plan(int B, int Hi, int Wi, int Ho, int Wo, int C, SmmGeom &g) {
     if (B <= 0 || C <= 0 || C % SMM_NC != 0) return false;
     // (smaller images: too little work per workgroup item, the f32 kernels tie or win -- 64 x 12 x 12 x 512: 48 us there)
     if (Hi < 24 || Wi < 24 || Hi > 64 || Wi > 64 || Ho < 1 || Wo < 1 || Ho > 128 || Wo > 128) return false;
-    g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.C = C;
+    g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.C = C; g.out16 = 0;
     g.HiP = (Hi + 31) / 32 * 32;
     g.WiP = (Wi + 31) / 32 * 32;
     if (g.HiP > 64 || g.WiP > 64) return false;
@@ -256,14 +266,28 @@ extern "C" int sei_sepmap2_bf16_pack(const float *L1, const float *R1, const flo
 
 // y[b,:,:,c] = L1 X R1^T + L2 X R2^T with bf16-rounded activations on the matrix cores (bf16 throughput mode); `packed`
 // from sei_sepmap2_bf16_pack for the same (Hi, Wi, Ho, Wo), 16-byte aligned. SEI_ERR_BAD_ARG when not eligible.
-extern "C" int sei_sepmap2_bf16(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
-                                const uint16_t *packed, void *stream) {
+static int smm_launch(const float *x, float *y, int out16, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                      const uint16_t *packed, void *stream) {
     SEI_REQUIRE(x && y && packed && x != y && (reinterpret_cast<uintptr_t>(packed) & 15) == 0);
+    SEI_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0);
     SmmGeom g;
     if (!smm_plan(B, Hi, Wi, Ho, Wo, C, g)) return SEI_ERR_BAD_ARG;
+    g.out16 = out16;
     const int items = B * (C / SMM_NC);
     const int grid = items < 256 ? items : 256;                 // one resident workgroup per CU walks its items
     hipLaunchKernelGGL(sepmap_mfma_kernel, dim3((unsigned)grid), dim3(SMM_THREADS), 0, (hipStream_t)stream, x, y, packed, g,
                        items);
     return sei_launch_status();
+}
+
+extern "C" int sei_sepmap2_bf16(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                const uint16_t *packed, void *stream) {
+    return smm_launch(x, y, 0, B, Hi, Wi, Ho, Wo, C, packed, stream);
+}
+
+// The same map with a bf16 result (the float32 accumulator rounded once, to nearest even): what a 1x1 convolution behind
+// the resampler reads as its GEMM operand -- no float32 copy of the resampled tensor, no cast pass.
+extern "C" int sei_sepmap2_bf16_out16(const float *x, uint16_t *y16, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                      const uint16_t *packed, void *stream) {
+    return smm_launch(x, reinterpret_cast<float *>(y16), 1, B, Hi, Wi, Ho, Wo, C, packed, stream);
 }

@@ -31,7 +31,8 @@ constexpr int SS_MAX_PIX = 64;         // Hi * Wi: the tile is Hi * Wi * 256 byt
 
 struct SsGeom {
     int B, Hi, Wi, Ho, Wo, C;
-};
+    int out16;             // y is bf16 (round to nearest even of the float32 result): the GEMM operand the Downsample's
+};                         // 1x1 convolution reads -- no float32 copy, no cast pass
 
 template <int MAXE>
 __global__ __launch_bounds__(SS_THREADS) void sepmap_small_kernel(const float *__restrict__ x, float *__restrict__ y,
@@ -74,7 +75,9 @@ __global__ __launch_bounds__(SS_THREADS) void sepmap_small_kernel(const float *_
                 t1[hi] = a1;
                 t2[hi] = a2;
             }
-            float *yb = y + ((size_t)b * Ho * Wo + wo) * C + c0 + c;
+            const size_t ybase = ((size_t)b * Ho * Wo + wo) * C + c0 + c;
+            float *yb = y + ybase;
+            unsigned short *yb16 = reinterpret_cast<unsigned short *>(y) + ybase;
             for (int ho = 0; ho < Ho; ++ho) {
                 const float *l1p = L1 + ho * Hi, *l2p = L2 + ho * Hi;
                 float acc = 0.f;
@@ -85,7 +88,12 @@ __global__ __launch_bounds__(SS_THREADS) void sepmap_small_kernel(const float *_
                         acc = fmaf(l2p[hi], t2[hi], acc);
                     }
                 }
-                yb[(size_t)ho * Wo * C] = acc;
+                if (g.out16) {
+                    const __bf16 h = (__bf16)acc;
+                    yb16[(size_t)ho * Wo * C] = __builtin_bit_cast(unsigned short, h);
+                } else {
+                    yb[(size_t)ho * Wo * C] = acc;
+                }
             }
         }
     }
@@ -120,15 +128,16 @@ extern "C" size_t sei_sepmap2_small_eligible(int B, int Hi, int Wi, int Ho, int 
     return ss_plan(B, Hi, Wi, Ho, Wo, C) ? 1 : 0;
 }
 
-// x: (B, Hi, Wi, C) -> y: (B, Ho, Wo, C), NHWC float32; L1, L2: (Ho, Hi), R1, R2: (Wo, Wi) float32 row-major (device).
-extern "C" int sei_sepmap2_small(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo, int C, const float *L1,
-                                 const float *R1, const float *L2, const float *R2, void *stream) {
-    SEI_REQUIRE(x && y && L1 && R1 && L2 && R2 && x != y);
-    SEI_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+// x: (B, Hi, Wi, C) -> y: (B, Ho, Wo, C), NHWC; x float32, y float32 or (out_bf16) bf16; L1, L2: (Ho, Hi), R1, R2: (Wo, Wi)
+// float32 row-major (device).
+extern "C" int sei_sepmap2_small(const float *x, void *y, int out_bf16, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                 const float *L1, const float *R1, const float *L2, const float *R2, void *stream) {
+    SEI_REQUIRE(x && y && L1 && R1 && L2 && R2 && (const void *)x != (const void *)y);
+    SEI_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0 && (out_bf16 == 0 || out_bf16 == 1));
     if (!ss_plan(B, Hi, Wi, Ho, Wo, C)) return SEI_ERR_BAD_ARG;
-    SsGeom g{B, Hi, Wi, Ho, Wo, C};
+    SsGeom g{B, Hi, Wi, Ho, Wo, C, out_bf16};
     hipStream_t s = (hipStream_t)stream;
     const int e = Hi > Wi ? Hi : Wi;
-    if (e <= 4) return ss_launch<4>(x, y, L1, R1, L2, R2, g, s);
-    return ss_launch<8>(x, y, L1, R1, L2, R2, g, s);
+    if (e <= 4) return ss_launch<4>(x, reinterpret_cast<float *>(y), L1, R1, L2, R2, g, s);
+    return ss_launch<8>(x, reinterpret_cast<float *>(y), L1, R1, L2, R2, g, s);
 }

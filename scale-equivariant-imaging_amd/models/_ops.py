@@ -302,22 +302,26 @@ _SEPMAP_MFMA = __import__("os").environ.get("SEI_SEPMAP_F32") != "1"
 _SEPMAP_SMALL = __import__("os").environ.get("SEI_NO_SEPMAP_SMALL") != "1"     # (A/B runs: the two-launch f32 kernels instead)
 
 
-def sepmap2_16(x, mats, Ho, Wo):
+def sepmap2_16(x, mats, Ho, Wo, out16=False):
     """sepmap2 in the bf16 throughput mode: on the matrix cores where the shape is eligible (sei_sepmap2_bf16:
-    activations rounded to bf16, matrices as bf16 head + remainder, f32 accumulation), else the f32 kernels."""
+    activations rounded to bf16, matrices as bf16 head + remainder, f32 accumulation), else the f32 kernels.
+    out16: the caller wants the result as a bf16 GEMM operand; the kernels that can write it directly (the one-pass kernel of
+    the deepest levels, the matrix-core kernel of the 24 - 64-pixel extents) return a bfloat16 tensor -- the float32
+    accumulator rounded once, exactly what a cast pass would have produced -- the others float32 (the caller casts)."""
     B, Hi, Wi, C = x.shape
     if _SEPMAP_SMALL and x.is_cuda and N.lib().sei_sepmap2_small_eligible(B, Hi, Wi, Ho, Wo, C):
-        # the deep levels' 12-, 6- and 3-pixel images: one float32 pass through LDS, no HBM intermediate (round 5)
-        y = _alloc((B, Ho, Wo, C), torch.float32, x.device)
+        # the deep levels' 6- and 3-pixel images: one float32 pass through LDS, no HBM intermediate (round 5)
+        y = _alloc((B, Ho, Wo, C), torch.bfloat16 if out16 else torch.float32, x.device)
         L1, R1, L2, R2 = mats[:4]
-        N.call("sei_sepmap2_small", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, L1.data_ptr(), R1.data_ptr(),
-               L2.data_ptr(), R2.data_ptr())
+        N.call("sei_sepmap2_small", x.data_ptr(), y.data_ptr(), int(out16), B, Hi, Wi, Ho, Wo, C, L1.data_ptr(),
+               R1.data_ptr(), L2.data_ptr(), R2.data_ptr())
         return y
     small = _SEPMAP_MFMA and x.is_cuda and max(Hi, Wi, Ho, Wo) <= 64 and N.lib().sei_sepmap2_bf16_eligible(B, Hi, Wi, Ho, Wo, C)
     big = not small and _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_big_eligible(B, Hi, Wi, Ho, Wo, C)
     if not big and _SEPMAP_MFMA and x.is_cuda and N.lib().sei_sepmap2_bf16_eligible(B, Hi, Wi, Ho, Wo, C):
-        y = _alloc((B, Ho, Wo, C), torch.float32, x.device)
-        N.call("sei_sepmap2_bf16", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C, _packed16(mats).data_ptr())
+        y = _alloc((B, Ho, Wo, C), torch.bfloat16 if out16 else torch.float32, x.device)
+        N.call("sei_sepmap2_bf16_out16" if out16 else "sei_sepmap2_bf16", x.data_ptr(), y.data_ptr(), B, Hi, Wi, Ho, Wo, C,
+               _packed16(mats).data_ptr())
         return y
     if big:
         # extents beyond one workgroup's LDS (the x4 network's 96- / 192-pixel levels, 256-pixel inputs): two launches of
@@ -1292,10 +1296,10 @@ class DownsampleFn16(torch.autograd.Function):
         h, mean, rstd = layer_norm(x.view(M, C), gamma, beta)
         fwd, bwd = _mats.resample_matrices("down", H, W, rate, x.device)
         Ho, Wo = fwd[0].shape[0], fwd[1].shape[0]
-        u = sepmap2_16(h.view(B, H, W, C), fwd, Ho, Wo)
+        u = sepmap2_16(h.view(B, H, W, C), fwd, Ho, Wo, out16=True)
         Mo = B * Ho * Wo
         s = _mats.constant_response("down", H, W, rate, x.device, B)
-        u16 = cast16(u.view(Mo, C))
+        u16 = u.view(Mo, C) if u.dtype == torch.bfloat16 else cast16(u.view(Mo, C))     # (straight from the resampler where it can)
         out = _alloc((Mo, Co), torch.float32, x.device)
         gemm_nt16(u16, shadow(w), Mo, Co, C, EPI_BIAS_ROWSCALE, out32=out, bias=b, R1=s)
         ctx.save_for_backward(x, mean, rstd, u16, s)

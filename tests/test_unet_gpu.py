@@ -244,6 +244,8 @@ def test_resampler_on_the_matrix_cores(ops, kind, B, H, W, C):
         # exact on data that bf16 represents: integers through a 0/1 matrix-free check is not available here, so the
         # run-to-run determinism (no atomics) is asserted instead
         assert torch.equal(y16, ops.sepmap2_16(xin, mats, ho, wo))
+        yb = ops.sepmap2_16(xin, mats, ho, wo, out16=True)           # sei_sepmap2_bf16_out16: the same accumulators, rounded once
+        assert yb.dtype == torch.bfloat16 and torch.equal(yb, y16.bfloat16())
     assert _native.lib().sei_sepmap2_bf16_eligible(2, 6, 6, 12, 12, 2048) == 0     # small levels stay on the f32 kernels
     assert _native.lib().sei_sepmap2_bf16_eligible(2, 12, 12, 24, 24, 512) == 0
     assert _native.lib().sei_sepmap2_bf16_eligible(2, 96, 96, 192, 192, 128) == 0  # the x4 network's fine levels: sei_sepmap2_big
@@ -280,6 +282,8 @@ def test_resampler_of_the_deep_levels_in_one_pass(ops, kind, B, H, W, C):
         assert relerr(y, ref) < 5e-6, relerr(y, ref)
         assert relerr(y, y32) < 5e-6
         assert torch.equal(y, ops.sepmap2_16(xin, mats, ho, wo))     # no atomics: run-to-run identical
+        y16 = ops.sepmap2_16(xin, mats, ho, wo, out16=True)          # the bf16 result = the float32 one rounded once
+        assert y16.dtype == torch.bfloat16 and torch.equal(y16, y.bfloat16())
     assert ran >= 1
     assert _native.lib().sei_sepmap2_small_eligible(2, 24, 24, 12, 12, 128) == 0     # sei_sepmap2_bf16's extents
     assert _native.lib().sei_sepmap2_small_eligible(2, 6, 6, 3, 3, 32) == 0          # C % 64
