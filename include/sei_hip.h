@@ -317,6 +317,18 @@ int sei_colsum_bf16(const uint16_t *X, float *out, size_t M, int N, void *stream
 int sei_cast_transpose_bf16(const void *x, int x_is_bf16, uint16_t *x16, uint16_t *xt16, int R, int C,
                             int ldt, float *colsum, void *stream);
 
+/* Several bf16 transposes in ONE launch: job k copies src (R, C) bf16 to dst (C, R). The fused pointwise MLP's backward
+ * (sei_mlp_fused_bwd) reads both 1x1 weights of a ConvBlock transposed (src/models/convolutional.py:33-51: conv2 / conv3);
+ * their bf16 copies change with every optimizer step, so a step re-transposes the 8 small matrices of the two fused
+ * levels: one launch instead of 8 of ~9 us. */
+#define SEI_TRANSPOSE_MAX_JOBS 16
+typedef struct SeiTransposeJob {
+    const uint16_t *src;
+    uint16_t *dst;
+    int R, C;
+} SeiTransposeJob;
+int sei_transpose_bf16_many(const SeiTransposeJob *jobs, int njobs, void *stream);
+
 /* Large-shape bf16 GEMM with bf16 operands in HBM:  D[M,N] = op(A) * op(B),  f32 accumulation.
  * Each operand is stored either K-contiguous (a_rmajor = 0: A is (M,K) row-major, b_rmajor = 0: B is (N,K)
  * row-major -- the "NT" form) or reduction-major (a_rmajor = 1: A is (K,M) row-major; b_rmajor = 1: B is

@@ -66,6 +66,7 @@ SIGNATURES = {
     "sei_cast_transpose_bf16": [_P, _I, _P, _P, _I, _I, _I, _P, _P],
     "sei_gemm_bf16nt": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sei_fold_many": [_P, _I, _P],
+    "sei_transpose_bf16_many": [_P, _I, _P],
     "sei_gemm_bf16nt_dw2": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "sei_gemm_bf16nt_ex": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     "sei_gemm_bf16nt_dw2_ex": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -142,6 +143,14 @@ class FoldJob(_c.Structure):
 
 
 FOLD_SPLIT, FOLD_DWCONV7, FOLD_MAX_JOBS = 0, 1, 40
+
+
+class TransposeJob(_c.Structure):
+    """SeiTransposeJob of include/sei_hip.h (one matrix of a sei_transpose_bf16_many table)."""
+    _fields_ = [("src", _P), ("dst", _P), ("R", _I), ("C", _I)]
+
+
+TRANSPOSE_MAX_JOBS = 16
 
 
 # size queries: return size_t, take no stream

@@ -433,6 +433,49 @@ extern "C" int sei_cast_bf16(const float *x, uint16_t *y, size_t n, void *stream
     return sei_launch_status();
 }
 
+// sei_transpose_bf16_many: the job table travels in the kernel arguments; a workgroup owns one 64 x 64 tile of one job
+struct TransposeManyArgs {
+    SeiTransposeJob job[SEI_TRANSPOSE_MAX_JOBS];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void transpose_many_kernel(TransposeManyArgs g) {
+    __shared__ unsigned short tile[64][66];
+    int j = 0, first = 0, tc = 0;
+    for (; j < g.njobs; ++j) {                                  // (uniform: scalar loads from the argument block)
+        tc = (g.job[j].C + 63) >> 6;
+        const int tiles = tc * ((g.job[j].R + 63) >> 6);
+        if ((int)blockIdx.x < first + tiles) break;
+        first += tiles;
+    }
+    if (j >= g.njobs) return;
+    const SeiTransposeJob &J = g.job[j];
+    const int t = (int)blockIdx.x - first, r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        tile[r][c] = (r0 + r < J.R && c0 + c < J.C) ? J.src[(size_t)(r0 + r) * J.C + c0 + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int c = e >> 6, r = e & 63;
+        if (r0 + r < J.R && c0 + c < J.C) J.dst[(size_t)(c0 + c) * J.R + r0 + r] = tile[r][c];
+    }
+}
+
+extern "C" int sei_transpose_bf16_many(const SeiTransposeJob *jobs, int njobs, void *stream) {
+    SEI_REQUIRE(jobs && njobs > 0 && njobs <= SEI_TRANSPOSE_MAX_JOBS);
+    TransposeManyArgs g;
+    size_t tiles = 0;
+    for (int k = 0; k < njobs; ++k) {
+        SEI_REQUIRE(jobs[k].src && jobs[k].dst && jobs[k].src != jobs[k].dst && jobs[k].R > 0 && jobs[k].C > 0);
+        g.job[k] = jobs[k];
+        tiles += sei_ceil_div((size_t)jobs[k].R, 64) * sei_ceil_div((size_t)jobs[k].C, 64);
+    }
+    g.njobs = njobs;
+    SEI_REQUIRE(tiles < ((size_t)1 << 31));
+    hipLaunchKernelGGL(transpose_many_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, g);
+    return sei_launch_status();
+}
+
 extern "C" int sei_weight_shadow_bf16(const float *w, uint16_t *w16, uint16_t *wt16, int R, int C, void *stream) {
     SEI_REQUIRE(w && (w16 || wt16) && R > 0 && C > 0);
     hipLaunchKernelGGL(cast_transpose_kernel<float>, dim3((unsigned)sei_ceil_div(C, 64), (unsigned)sei_ceil_div(R, 64)),

@@ -1232,3 +1232,19 @@ def test_streamed_weight_gradients_inside_a_backward_pass(ops):
             a, b, c = (grads[k][off:off + prm.numel()] for k in (True, False, None))
             worst.append((relerr(a, b) / max(relerr(c, b), 1e-3), relerr(a, b), relerr(c, b), name))
     assert len(worst) == 14 and max(worst)[0] < 3, sorted(worst, reverse=True)[:4]
+
+
+def test_batched_transposes_of_the_fused_levels_weights(ops):
+    """sei_transpose_bf16_many: several (R, C) bf16 matrices -> their (C, R) transposes in one launch, ragged extents
+    included; and models/_ops._transposed16_cached rebuilds every remembered stale weight with ONE launch."""
+    import _native as N
+    gen = torch.Generator().manual_seed(4)
+    mats = [torch.randn((r, c), generator=gen).bfloat16().cuda() for r, c in ((128, 32), (32, 128), (512, 128), (128, 512),
+                                                                             (70, 200), (1, 5), (64, 64))]
+    outs = [torch.full((m.shape[1], m.shape[0]), 7.0, dtype=torch.bfloat16, device="cuda") for m in mats]
+    jobs = (N.TransposeJob * len(mats))(*[N.TransposeJob(m.data_ptr(), o.data_ptr(), m.shape[0], m.shape[1])
+                                         for m, o in zip(mats, outs)])
+    N.call("sei_transpose_bf16_many", jobs, len(mats))
+    for m, o in zip(mats, outs):
+        assert torch.equal(o, m.t().contiguous())
+    assert N.lib().sei_transpose_bf16_many(jobs, 0, None) == 10001 and N.lib().sei_transpose_bf16_many(jobs, 17, None) == 10001
