@@ -199,6 +199,8 @@ def _stream_bytes(name, a):
         return 0
     if name == "sei_cast_transpose_bf16":
         return 6 * a[4] * a[5]
+    if name == "sei_transpose_bf16_many":                  # every matrix in and out once (bf16)
+        return sum(4 * a[0][k].R * a[0][k].C for k in range(a[1]))
     if name == "sei_cast_bf16":
         return 6 * a[2]
     if name == "sei_colsum_bf16":
@@ -304,7 +306,7 @@ _STREAM_FAMILIES = [
     ("swin_attn_* (8x8-window attention: qkv in, out / dqkv out)", ("sei_swin_attn_",)),
     ("pad / unpad / rowscale / pack kernels (padded-grid copies, weight re-layout)",
      ("sei_pad_nhwc", "sei_unpad_nhwc", "sei_rowscale", "sei_pack", "sei_unpack_add")),
-    ("cast / colsum kernels (bf16 copies, bias gradients)", ("sei_cast_", "sei_colsum_")),
+    ("cast / colsum kernels (bf16 copies, bias gradients)", ("sei_cast_", "sei_colsum_", "sei_transpose_bf16_many")),
     ("conv3x3_* (in / out convolutions)", ("sei_conv3x3_",)),
     ("blur / scale_resample / axpy / sure / mse kernels (physics + loss terms)",
      ("sei_blur_", "sei_scale_resample_", "sei_scale_params", "sei_axpy", "sei_sure_terms", "sei_sure_loss", "sei_mse_terms", "sei_mse_loss",
