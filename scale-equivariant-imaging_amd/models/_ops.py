@@ -236,13 +236,58 @@ def layer_norm_bwd(x2d, gamma, mean, rstd, gy, ggamma, gbeta, res=None):
     return gx
 
 
-def colsum_into(acc, x2d, row_weight=None):
-    """acc[n] += sum_m x2d[m, n] (times row_weight[m] if given)."""
+# ---------------------------------------------------------------------------------------------
+# Leaf launches beside the chain (round 5). A backward pass is a CHAIN of launches (each layer's data gradient feeds the
+# next) with LEAVES hanging off it: parameter gradients that nothing else in the pass reads -- bias column sums, the
+# depthwise and 3x3 weight gradients. At this model's sizes both are latency-bound launches of 10-60 us that leave most of
+# the chip idle. Leaves are issued on a side stream that waits for everything enqueued so far (their operands) and is
+# joined when the pass ends (the engine callback that flushes parked pairs and deferred folds, `flush_weight_grads`): in
+# the captured step they become a parallel branch of the hipGraph and run under the chain. Operands are kept alive until
+# the join (the caching allocator may not hand their memory to the chain meanwhile).
+# MEASURED AND OFF BY DEFAULT (SEI_LEAF_STREAM=1 switches it on): same box, same run, the captured step took 13.22 ms with
+# the ~20 leaves (0.5 ms of launches) on the branch against 12.97 ms in line -- as with the Adam-epilogue GEMMs on a second
+# branch in rounds 2 and 4, what the branch gains in idle CUs the fork / join edges and the shared memory system take back.
+# ---------------------------------------------------------------------------------------------
+LEAF_STREAM = os.environ.get("SEI_LEAF_STREAM") == "1"
+_LEAF_SIDE = {}
+
+
+def leaf_call(grad, name, *args, keep=()):
+    """N.call(name, *args) for a launch that only produces (part of) the parameter gradient `grad`."""
+    _DW = _state_for(grad.data_ptr()) if grad.is_cuda else None
+    if not LEAF_STREAM or _DW is None or not _queue_flush(_DW):
+        N.call(name, *args)                     # (no backward pass running: nobody would join the side stream)
+        return
+    dev = grad.device
+    side = _LEAF_SIDE.get(dev)
+    if side is None:
+        side = _LEAF_SIDE[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        N.call(name, *args)
+    _DW.setdefault("leaf", []).append((side, keep))
+
+
+def _join_leaves(_DW):
+    leaves = _DW.pop("leaf", None)
+    if leaves:
+        torch.cuda.current_stream(leaves[0][0].device).wait_stream(leaves[0][0])
+
+
+def colsum_into(acc, x2d, row_weight=None, leaf=True):
+    """acc[n] += sum_m x2d[m, n] (times row_weight[m] if given). `acc` is a parameter (bias) gradient of the U-Net: a leaf
+    launch. leaf=False (the Swin blocks, whose staged gradients are unpacked inside the pass): in line."""
     M, Nn = x2d.shape
+    call = leaf_call if leaf else (lambda _g, name, *a, keep=(): N.call(name, *a))
     if row_weight is None:
-        N.call("sei_colsum_f32", x2d.data_ptr(), acc.data_ptr(), M, Nn)
+        call(acc, "sei_colsum_f32", x2d.data_ptr(), acc.data_ptr(), M, Nn, keep=(x2d,))
     else:
-        N.call("sei_colsum_weighted_f32", x2d.data_ptr(), row_weight.data_ptr(), acc.data_ptr(), M, Nn)
+        call(acc, "sei_colsum_weighted_f32", x2d.data_ptr(), row_weight.data_ptr(), acc.data_ptr(), M, Nn,
+             keep=(x2d, row_weight))
+
+
+def colsum_into_inline(acc, x2d, row_weight=None):
+    colsum_into(acc, x2d, row_weight, leaf=False)
 
 
 def dwconv7(x, w, bias, flip=False, res=None, res_scale=1.0, seg=0):
@@ -281,8 +326,8 @@ def dwconv7_weight_grad(x, gy, gw, gb, seg=0):
     need = N.lib().sei_dwconv7_bwd_weight_workspace_ex(B, H, W, C, int(seg))
     work = torch.empty(need, dtype=torch.float32, device=x.device)
     deferred = need > 0 and defer_fold(gw, gb, None, 50 * C, C, N.FOLD_DWCONV7, work, 0, need // (50 * C))
-    N.call("sei_dwconv7_bwd_weight_ex", x.data_ptr(), gy.data_ptr(), None if deferred else gw.data_ptr(),
-           None if deferred else N.ptr(gb), B, H, W, C, work.data_ptr(), need, int(seg))
+    leaf_call(gw, "sei_dwconv7_bwd_weight_ex", x.data_ptr(), gy.data_ptr(), None if deferred else gw.data_ptr(),
+              None if deferred else N.ptr(gb), B, H, W, C, work.data_ptr(), need, int(seg), keep=(x, gy, work))
 
 
 def sepmap2(x, mats, Ho, Wo):
@@ -624,9 +669,16 @@ def layer_norm16(x2d, gamma, beta):
     return y, mean, rstd
 
 
-def colsum16_into(acc, x16):
+def colsum16_into(acc, x16, leaf=True):
     M, Nn = x16.shape
-    N.call("sei_colsum_bf16", x16.data_ptr(), acc.data_ptr(), M, Nn)
+    if leaf:
+        leaf_call(acc, "sei_colsum_bf16", x16.data_ptr(), acc.data_ptr(), M, Nn, keep=(x16,))
+    else:
+        N.call("sei_colsum_bf16", x16.data_ptr(), acc.data_ptr(), M, Nn)
+
+
+def colsum16_into_inline(acc, x16):
+    colsum16_into(acc, x16, leaf=False)
 
 
 def gemm_mixed(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2=None, allow_splitk=True):
@@ -879,7 +931,7 @@ def _launch_weight_grad_inner(_DW, grad2d, pairs, store):
     bias = _DW["bias_of"].pop(grad2d.data_ptr(), None)
     if bias is not None and not (not store and _dwstream_ok(grad2d, pairs)):
         for gy16, _ in pairs:
-            colsum16_into(bias, gy16)
+            colsum16_into(bias, gy16, leaf=False)
         bias = None
     _launch_weight_grad_inner2(_DW, grad2d, pairs, store, bias)
 
@@ -1012,6 +1064,7 @@ def flush_weight_grads(owner=None, _state=None):
     """Issue every parked weight gradient of `owner` (default state when None) on its own (no partner arrived)."""
     _DW = _state if _state is not None else state_of(owner)
     _DW["flush_queued"] = False
+    _join_leaves(_DW)                                  # (before the deferred folds below, which read the leaves' partial sums)
     parked, _DW["parked"] = _DW["parked"], {}
     for entry in parked.values():
         if isinstance(entry, list):                    # a parked group (weight_grad16_group)
@@ -1429,8 +1482,8 @@ class Conv3x3Fn(torch.autograd.Function):
         w, b = ctx.params
         B, H, W, Ci, Co, nchw_in, nchw_out = ctx.cfg
         go = go.contiguous()
-        N.call("sei_conv3x3_bwd_weight", x.data_ptr(), go.data_ptr(), grad_of(w).data_ptr(),
-               grad_of(b).data_ptr(), B, H, W, Ci, Co, int(nchw_in), int(nchw_out))
+        leaf_call(grad_of(w), "sei_conv3x3_bwd_weight", x.data_ptr(), go.data_ptr(), grad_of(w).data_ptr(),
+                  grad_of(b).data_ptr(), B, H, W, Ci, Co, int(nchw_in), int(nchw_out), keep=(x, go))
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)

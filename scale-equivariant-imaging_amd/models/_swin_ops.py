@@ -11,7 +11,8 @@ import torch
 
 import _native as N
 from . import _ops
-from ._ops import (EPI_ACCUM, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_NONE, colsum_into, gemm, grad_of)
+from ._ops import (EPI_ACCUM, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_NONE, colsum_into_inline as colsum_into, gemm,
+                   grad_of)
 
 EPI_BIAS_SCALE_RES = 7
 LN_EPS = 1e-5                   # torch.nn.LayerNorm default, which SwinIR uses (the U-Net passes 1e-6)

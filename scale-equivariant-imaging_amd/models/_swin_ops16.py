@@ -15,7 +15,8 @@ import torch
 
 import _native as N
 from . import _ops
-from ._ops import (EPI_ACCUM, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_NONE, colsum16_into, colsum_into,
+from ._ops import (EPI_ACCUM, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_NONE, colsum16_into_inline as colsum16_into,
+                   colsum_into_inline as colsum_into,
                    gemm_nt16, grad_of, weight_grad16, weight_grad16_group)
 from ._swin_ops import EPI_BIAS_SCALE_RES, LN_EPS, rowscale
 
