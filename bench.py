@@ -262,6 +262,9 @@ def _gemm_bytes(name, a):
     """Algorithmic HBM bytes of one launch of a matrix-core entry point, from its own arguments: every operand read once,
     every result written once (a weight gradient's two row blocks, a fused MLP's hidden activation staying on chip).
     None = an entry point not modelled here (its launches are then left out of `algorithmic_bytes_per_launch`)."""
+    if name == "sei_gemm_bf16nt_colsum":                       # operands + the GELU' input in, the bf16 result out
+        M, Nn, K = a[7:10]
+        return 2 * K * (M + Nn) + M * Nn * (2 + (4 if a[11] else 0))
     if name in ("sei_gemm_bf16nt", "sei_gemm_bf16nt_ex"):
         M, Nn, K, epi = a[8:12]
         extra = sum(4 for ptr in (a[13], a[14]) if ptr) if epi != 6 else 0          # R1 / R2 (BIAS_ROWSCALE: M floats)

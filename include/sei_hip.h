@@ -369,6 +369,14 @@ int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, int lda, cons
                            const uint16_t *B2, int ldb, float *D32, int M, int N, int K1, int K2, int accumulate,
                            int tile, void *stream);
 
+/* sei_gemm_bf16nt with a bf16 result (SEI_EPI_MUL_DGELU or SEI_EPI_NONE) that also accumulates the result's column sums:
+ * colsum[n] += sum_m D16[m][n] (the rounded values, as sei_colsum_bf16 over D16 would add them). In a ConvBlock's backward
+ * (src/models/convolutional.py:33-51) D16 = gh3 = (dY W3) gelu'(h3) and its column sums are conv2's bias gradient: where
+ * the launch takes the quadrant kernel unsplit they ride in its epilogue (no pass over gh3), elsewhere the column-sum
+ * kernel follows. */
+int sei_gemm_bf16nt_colsum(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                           uint16_t *D16, int M, int N, int K, int epilogue, const float *R1, float *colsum, void *stream);
+
 /* The schedule sei_gemm_bf16nt would take for a GEMM of these shapes, WITHOUT launching anything (host arithmetic only:
  * callable on a machine with no GPU): (family << 48) | (tile rows << 32) | (tile columns << 16) | K splits, with
  * family 1 = gemm_bf16nt_kernel (the 128x128-style loop, whatever its tile), 2 = gemm_bf16pq_kernel (the quadrant

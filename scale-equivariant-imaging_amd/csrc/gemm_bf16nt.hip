@@ -59,6 +59,9 @@ struct NtArgs {
     // host-side only (the kernels never read them): the caller's explicit tile / band choice of the _ex entry
     // points; 0 = the dispatcher decides. Per call, so the library holds no mutable state.
     int force_tile, force_band;
+    // quadrant kernel, unsplit launches whose result is rounded to bf16 (sei_gemm_bf16nt_colsum): colsum[n] += sum_m of the
+    // ROUNDED results D16[m][n] -- the bias gradient b2 = column sums of gh3 = (dY W3) gelu'(h3) without a pass over gh3.
+    float *colsum;
     // host-side only: sei_gemm_bf16nt_plan. Non-null: the dispatcher writes (family, BM, BN, K splits) there and launches
     // NOTHING -- the schedule a call with these shapes would take, for tests that pin the timed launch set.
     unsigned long long *plan;
@@ -875,10 +878,33 @@ int pq_choose_rr(const NtArgs &g) {
 // epilogue stays reachable through sei_gemm_bf16nt_dw2_adam_ex (tile 30 / 33) and is held to the loop's results by a test.
 bool pq_adam_auto(const NtArgs &) { return false; }
 
+extern "C" int sei_colsum_bf16(const uint16_t *X, float *out, size_t M, int N, void *stream);     // bf16_support.hip
+
 static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
                     float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
                     const float *R1, const float *R2, uint16_t *D2_16, int tile, int band,
-                    void *stream, unsigned long long *plan) {
+                    void *stream, unsigned long long *plan, float *colsum = nullptr);
+
+// The column sums ride in the quadrant kernel's epilogue where the launch takes it unsplit with a bf16 result; any other
+// schedule is followed by the column-sum kernel over the result (same quantity, one more launch).
+static int nt_entry_colsum(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                           uint16_t *D16, int M, int N, int K, int epilogue, const float *R1, float *colsum, void *stream) {
+    unsigned long long plan = 0;
+    int rc = nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, nullptr, D16, M, N, K, epilogue, nullptr, R1, nullptr, nullptr, 0, 0,
+                      stream, &plan);
+    if (rc != SEI_OK) return rc;
+    const bool rides = (plan >> 48) == 2 && (plan & 0xFFFF) == 1 && N % 4 == 0 &&
+                       (reinterpret_cast<uintptr_t>(colsum) & 15) == 0;
+    rc = nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, nullptr, D16, M, N, K, epilogue, nullptr, R1, nullptr, nullptr, 0, 0,
+                  stream, nullptr, rides ? colsum : nullptr);
+    if (rc != SEI_OK || rides) return rc;
+    return sei_colsum_bf16(D16, colsum, (size_t)M, N, stream);
+}
+
+static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                    float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
+                    const float *R1, const float *R2, uint16_t *D2_16, int tile, int band,
+                    void *stream, unsigned long long *plan, float *colsum) {
     SEI_REQUIRE(A && B && (D32 || D16) && M > 0 && N > 0 && K > 0);
     SEI_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0);
     SEI_REQUIRE(lda >= (a_rmajor ? M : K) && ldb >= (b_rmajor ? N : K));
@@ -896,13 +922,14 @@ static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
     if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D2_16);
     if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU) SEI_REQUIRE(R1);
     if (epilogue == SEI_EPI_ACCUM) SEI_REQUIRE(D32 && !D16);
-    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
     g.A2 = A; g.B2 = B; g.k_seg = K;                       // one reduction segment
     g.conv_cin = 0;
     g.batch = 1;
     g.plan = plan;
+    g.colsum = colsum;
     SEI_REQUIRE(tile >= 0 && band >= 0);
     if (epilogue == SEI_EPI_BIAS_SCALE_RES && tile == 0)                // the quadrant kernel has no such epilogue
         tile = (N > 128 && N <= 192) ? 6 : 1;
@@ -1050,6 +1077,15 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
                     nullptr);
 }
 
+// D16 = (A op(B)) gelu'(R1) rounded to bf16 (SEI_EPI_MUL_DGELU) or the plain product (SEI_EPI_NONE), and colsum[n] += the
+// column sums of the rounded result: the data gradient gh3 of a ConvBlock's conv3 together with conv2's bias gradient.
+extern "C" int sei_gemm_bf16nt_colsum(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                                      uint16_t *D16, int M, int N, int K, int epilogue, const float *R1, float *colsum,
+                                      void *stream) {
+    SEI_REQUIRE(D16 && colsum && (epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_NONE));
+    return nt_entry_colsum(A, lda, a_rmajor, B, ldb, b_rmajor, D16, M, N, K, epilogue, R1, colsum, stream);
+}
+
 // The schedule sei_gemm_bf16nt would take for these shapes, launching nothing (host arithmetic only, no GPU needed):
 // (family << 48) | (tile rows << 32) | (tile columns << 16) | K splits, family 1 = the 128 x 128 loop's kernel
 // (gemm_bf16nt_kernel, whatever its tile), 2 = the quadrant schedule (gemm_bf16pq_kernel); 0 = arguments the entry point
@@ -1079,7 +1115,7 @@ extern "C" int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, in
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
-    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
@@ -1118,7 +1154,7 @@ extern "C" int sei_gemm_bf16nt_dw2_adam_ex(const uint16_t *A1, const uint16_t *A
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
     SEI_REQUIRE((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
                 ((uintptr_t)param_bf16 & 7) == 0);              // the epilogue moves whole quads
-    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = param; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = SEI_EPI_NONE;
@@ -1154,7 +1190,7 @@ extern "C" int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0 && ((uintptr_t)D16 & 7) == 0);
-    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = nullptr; g.D16 = D16; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = SEI_EPI_NONE;
@@ -1175,7 +1211,7 @@ extern "C" int sei_gemm_bf16nt_dw2_taps(const uint16_t *A1, const uint16_t *A2, 
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
-    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
@@ -1205,7 +1241,7 @@ extern "C" int sei_gemm_bf16nt_conv(const uint16_t *Ap, int cin_pad, const int *
     SEI_REQUIRE(ldb >= 9 * cin_pad && ldb % 8 == 0 && (((uintptr_t)Ap | (uintptr_t)B) & 15) == 0);
     SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS);
     if (epilogue == SEI_EPI_BIAS) SEI_REQUIRE(bias);
-    NtArgs g; g.plan = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.batch = 1;
     g.A = Ap; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = 9 * cin_pad; g.lda = cin_pad; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
@@ -1229,6 +1265,7 @@ extern "C" int sei_gemm_bf16nt_conv_unpad(const uint16_t *Ap, int cin_pad, const
     SEI_REQUIRE((size_t)Bimg * (H + 2) * (W + 2) < ((size_t)1 << 31));
     NtArgs g;
     g.plan = nullptr;
+    g.colsum = nullptr;
     g.batch = 1;
     g.A = Ap; g.B = B; g.D32 = y; g.D16 = nullptr; g.M = Bimg * (H + 2) * (W + 2); g.N = N; g.K = 9 * cin_pad;
     g.lda = cin_pad; g.ldb = ldb;

@@ -551,6 +551,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         beta1 = g.adam_h[0]; beta2 = g.adam_h[1]; eps = g.adam_h[2]; wd = g.adam_h[3];
         step_size = g.adam_h[4]; inv_bc2_sqrt = g.adam_h[5];
     }
+    f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};            // NtArgs::colsum: this lane's four columns over its rows of the tile
 #pragma unroll 1
     for (int i = 0; i < RF; ++i) {
         f32x4 c[NF];
@@ -707,7 +708,25 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
                 ushort4 h;
                 h.x = f2bf(v[p][0]); h.y = f2bf(v[p][1]); h.z = f2bf(v[p][2]); h.w = f2bf(v[p][3]);
                 *reinterpret_cast<ushort4 *>(g.D16 + o) = h;
+                if (g.colsum) {                                   // (uniform) the ROUNDED values, as a pass over D16 would read them
+                    csum[0] += __builtin_bit_cast(float, (unsigned)h.x << 16);
+                    csum[1] += __builtin_bit_cast(float, (unsigned)h.y << 16);
+                    csum[2] += __builtin_bit_cast(float, (unsigned)h.z << 16);
+                    csum[3] += __builtin_bit_cast(float, (unsigned)h.w << 16);
+                }
             }
+        }
+    }
+    if (g.colsum && !split) {
+        // lanes that share pc4 (lane % LPR) hold the same four columns for different patch rows: fold them, then one float
+        // atomic per column and wave (two row halves x tiles_m workgroups add into each column)
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) csum[j] += __shfl_xor(csum[j], off, 64);
+        if (prow == 0 && col_ok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(g.colsum + col + j, csum[j]);
         }
     }
 }

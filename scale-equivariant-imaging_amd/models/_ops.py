@@ -160,11 +160,12 @@ _JOINT_SPLIT = None      # (B1, B2) while one backward pass serves the step's tw
 
 
 def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=None, R2=None, D2_16=None,
-              lda=None, ldb=None, a_rmajor=False, b_rmajor=False, tile=0, band=0, flops=None, _whole=False):
+              lda=None, ldb=None, a_rmajor=False, b_rmajor=False, tile=0, band=0, flops=None, _whole=False, colsum=None):
     """D[M,N] = op(A16) op(B16) on the direct-to-LDS bf16 kernel. A16 is (M,K) [or (K,M) when a_rmajor],
     B16 is (N,K) [or (K,N) when b_rmajor]; K % 8 == 0. Outputs as given. tile / band: an explicit schedule
     choice (sei_gemm_bf16nt_ex; tests and tools), 0 = the library's dispatch. flops: the algorithmic FLOP count
-    to book for the roofline leg when the operands are zero-padded (default 2 M N K)."""
+    to book for the roofline leg when the operands are zero-padded (default 2 M N K). colsum (float32, (N,)): += the column
+    sums of the bf16 result out16 (sei_gemm_bf16nt_colsum: a bias gradient riding in the data gradient's epilogue)."""
     # (the CONTRACTING data gradients gh2 = gh3 W2 -- float32 out, K = 4 N, split K -- run faster on the joint rows: their
     # K splits fill the rounds whatever the row count. tools/exp_joint_rows.py, merged vs the two launches: 3456 x 2048 x 8192
     # 153 vs 104 + 71 us, 864 x 8192 x 32768 479 vs 310 + 187, 13824 x 512 x 2048 44 vs 37 + 30; the expanding ones with
@@ -192,7 +193,8 @@ def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=Non
             for lo, hi in ((0, M1), (M1, M)):
                 gemm_nt16(A16[lo:hi], B16, hi - lo, Nn, K, epi, out32=cut(out32, lo, hi), out16=cut(out16, lo, hi), bias=bias,
                           R1=cut(R1, lo, hi), R2=cut(R2, lo, hi), D2_16=cut(D2_16, lo, hi),
-                          ldb=ldb, b_rmajor=b_rmajor, flops=None if flops is None else flops * (hi - lo) / M, _whole=True)
+                          ldb=ldb, b_rmajor=b_rmajor, flops=None if flops is None else flops * (hi - lo) / M, _whole=True,
+                          colsum=colsum)
             return
     if lda is None:
         lda = M if a_rmajor else K
@@ -201,6 +203,13 @@ def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=Non
     args = (A16.data_ptr(), lda, int(a_rmajor), B16.data_ptr(), ldb, int(b_rmajor), N.ptr(out32), N.ptr(out16), M, Nn,
             K, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2_16))
     fl = 2.0 * M * Nn * K if flops is None else float(flops)
+    if colsum is not None:
+        if out32 is not None or out16 is None or epi not in (EPI_NONE, EPI_MUL_DGELU) or tile or band or bias is not None \
+                or R2 is not None or D2_16 is not None:
+            raise ValueError("gemm_nt16(colsum=): a bf16 result with EPI_NONE / EPI_MUL_DGELU on the automatic dispatch")
+        _gemm_call(fl, "sei_gemm_bf16nt_colsum", A16.data_ptr(), lda, int(a_rmajor), B16.data_ptr(), ldb, int(b_rmajor),
+                   out16.data_ptr(), M, Nn, K, epi, N.ptr(R1), colsum.data_ptr())
+        return
     if tile or band:
         _gemm_call(fl, "sei_gemm_bf16nt_ex", *args, int(tile), int(band))
     else:
@@ -1311,9 +1320,9 @@ class ConvBlockFn16(torch.autograd.Function):
         # gradient GEMM (set_fused_adam) that launch rewrites the weight's bf16 shadow, which the data gradient reads.
         go16 = cast16(go2, colsum_into_=grad_of(b3))
         gh3 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device)
-        gemm_nt16(go16, shadow(w3), M, 4 * C, C, EPI_MUL_DGELU, out16=gh3, R1=h3, b_rmajor=True)   # (go W3) gelu'
+        # (go W3) gelu'(h3), with conv2's bias gradient = its column sums riding in the epilogue (no pass over gh3)
+        gemm_nt16(go16, shadow(w3), M, 4 * C, C, EPI_MUL_DGELU, out16=gh3, R1=h3, b_rmajor=True, colsum=grad_of(b2))
         weight_grad16(go16, h4, grad_of(w3).view(C, 4 * C))
-        colsum16_into(grad_of(b2), gh3)
         gh2 = torch.empty((M, C), dtype=torch.float32, device=x.device)
         gemm_nt16(gh3, shadow(w2), M, C, 4 * C, EPI_NONE, out32=gh2, b_rmajor=True)
         weight_grad16(gh3, h2, grad_of(w2).view(4 * C, C))

@@ -234,6 +234,11 @@ def _launch_plans(records):
     import _native
     plans = {}
     for _, entry, a in records:
+        if entry == "sei_gemm_bf16nt_colsum":               # (bf16 result + its column sums: the same dispatch)
+            M, Nn, K, epi = a[7:11]
+            fam, bm, bn, sk = _native.gemm_plan(a[2], a[5], False, True, M, Nn, K, epi)
+            plans.setdefault((fam, bm, bn), set()).add((M, Nn, K, sk))
+            continue
         if entry != "sei_gemm_bf16nt":
             continue
         M, Nn, K, epi = a[8:12]

@@ -988,6 +988,33 @@ def test_weight_gradient_gemm_with_the_adam_epilogue():
         assert torch.equal(pc, pb)
 
 
+@pytest.mark.parametrize("M,N,K,brm", [(576, 1024, 512, 1), (288, 2048, 256, 1), (2304, 2048, 512, 0), (300, 520, 328, 1),
+                                       (1152, 8192, 2048, 1), (64, 128, 64, 0)])
+def test_gemm_with_the_result_s_column_sums_in_the_epilogue(ops, M, N, K, brm):
+    """sei_gemm_bf16nt_colsum: D16 = (A op(B)) gelu'(R1) in bf16 and colsum[n] += sum_m D16[m][n] -- against the plain launch
+    followed by sei_colsum_bf16 over its result: D16 bit-identical (the same kernel), the sums equal up to the float atomics'
+    order. Quadrant tiles of both widths (the sums ride in the epilogue), a ragged shape and a small one (the 128 x 128 loop:
+    the column-sum kernel follows), both weight orientations; the sums ACCUMULATE."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((M, K), generator=gen).bfloat16().cuda()
+    B = (torch.randn((K, N) if brm else (N, K), generator=gen) / K ** 0.5).bfloat16().cuda()
+    R1 = torch.randn((M, N), generator=gen).cuda()
+    ref16 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_MUL_DGELU, out16=ref16, R1=R1, b_rmajor=bool(brm))
+    base = torch.randn(N, generator=gen).cuda()
+    want = base.clone()
+    ops.colsum16_into(want, ref16, leaf=False)
+    got16 = torch.empty_like(ref16)
+    got = base.clone()
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_MUL_DGELU, out16=got16, R1=R1, b_rmajor=bool(brm), colsum=got)
+    assert torch.equal(got16, ref16)
+    exact = ref16.double().sum(0) + base.double()
+    assert relerr(got, exact) < 2e-6 and relerr(want, exact) < 2e-6
+    plain16, plain = torch.empty_like(ref16), torch.zeros(N, device="cuda")
+    ops.gemm_nt16(A, B, M, N, K, ops.EPI_NONE, out16=plain16, b_rmajor=bool(brm), colsum=plain)     # the plain product
+    assert relerr(plain, plain16.double().sum(0)) < 2e-6
+
+
 @pytest.mark.parametrize("M,Nn,K1,K2", [(2048, 6144, 640, 1032), (512, 768, 96, 200), (2048, 8192, 1152, 2304)])
 def test_adam_epilogue_of_the_quadrant_schedule(M, Nn, K1, K2):
     """sei_gemm_bf16nt_dw2_adam_ex: the quadrant kernel's Adam epilogue (tiles 30 / 33: 256 x 256 / 256 x 128) against the
