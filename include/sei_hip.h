@@ -316,6 +316,12 @@ int sei_colsum_bf16(const uint16_t *X, float *out, size_t M, int N, void *stream
  * colsum (optional): colsum[c] += sum_r x[r][c] in float32 -- the bias gradient, from the same pass. */
 int sei_cast_transpose_bf16(const void *x, int x_is_bf16, uint16_t *x16, uint16_t *xt16, int R, int C,
                             int ldt, float *colsum, void *stream);
+/* The plain cast with a WEIGHTED column sum in the same pass: colsum[c] += sum_r row_weight[r] x[r][c] (un-rounded input).
+ * In models/_ops.DownsampleFn16 the 1x1 convolution runs behind the ideal downsampler (src/models/convolutional.py:136-150
+ * commuted), where its bias enters as bias[c] * s[row], s = the resampler's response to a constant image: the bias gradient
+ * is this weighted sum of the output gradient's rows, taken while that gradient is cast for the GEMMs. C % 4 == 0. */
+int sei_cast_bf16_colsum_weighted(const float *x, uint16_t *x16, const float *row_weight, float *colsum, int R, int C,
+                                  void *stream);
 
 /* Several bf16 transposes in ONE launch: job k copies src (R, C) bf16 to dst (C, R). The fused pointwise MLP's backward
  * (sei_mlp_fused_bwd) reads both 1x1 weights of a ConvBlock transposed (src/models/convolutional.py:33-51: conv2 / conv3);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "sei_ln_fwd_bf16": [_P, _P, _P, _P, _P, _P, _Z, _I, _F, _P],
     "sei_colsum_bf16": [_P, _P, _Z, _I, _P],
     "sei_cast_transpose_bf16": [_P, _I, _P, _P, _I, _I, _I, _P, _P],
+    "sei_cast_bf16_colsum_weighted": [_P, _P, _P, _P, _I, _I, _P],
     "sei_gemm_bf16nt": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sei_gemm_bf16nt_colsum": [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P],
     "sei_fold_many": [_P, _I, _P],

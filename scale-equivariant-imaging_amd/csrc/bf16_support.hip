@@ -68,10 +68,12 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const T *__restrict
 // f32 (R, C) -> bf16 copy (+ optional column sums of the un-rounded input), no transpose: a lane owns 4
 // consecutive columns (float4 in, 8 bytes out) and walks rows, 4 in flight; the row sub-groups of a workgroup
 // are folded through LDS and the column sums leave as coalesced atomics (one per column per workgroup).
+// row_weight (optional): colsum[c] += sum_r row_weight[r] x[r][c] (the bias gradient of the convolution evaluated behind the
+// ideal downsampler, whose bias enters as bias[c] * s[row]: models/_ops.DownsampleFn16).
 __global__ __launch_bounds__(256) void cast_colsum_kernel(const float *__restrict__ x,
                                                           unsigned short *__restrict__ x16,
                                                           float *__restrict__ colsum, size_t R, int C, int tpr,
-                                                          size_t rows_per_block) {
+                                                          size_t rows_per_block, const float *__restrict__ row_weight) {
     __shared__ float red[256 * 4];
     const int rsubs = 256 / tpr;
     const int cl = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
@@ -79,7 +81,12 @@ __global__ __launch_bounds__(256) void cast_colsum_kernel(const float *__restric
     const size_t r0 = (size_t)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     auto emit = [&](size_t r, const float4 v) {
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        if (row_weight) {
+            const float w = row_weight[r];
+            s.x = fmaf(w, v.x, s.x); s.y = fmaf(w, v.y, s.y); s.z = fmaf(w, v.z, s.z); s.w = fmaf(w, v.w, s.w);
+        } else {
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
         uint2 o;
         o.x = (unsigned)to_bf(v.x) | ((unsigned)to_bf(v.y) << 16);
         o.y = (unsigned)to_bf(v.z) | ((unsigned)to_bf(v.w) << 16);
@@ -483,22 +490,34 @@ extern "C" int sei_weight_shadow_bf16(const float *w, uint16_t *w16, uint16_t *w
     return sei_launch_status();
 }
 
+static int cast_colsum_launch(const float *x, uint16_t *x16, float *colsum, const float *row_weight, int R, int C,
+                              void *stream) {
+    const int quads = C / 4;
+    int tpr = 1;
+    while (tpr < quads && tpr < 256) tpr <<= 1;
+    const unsigned col_blocks = (unsigned)sei_ceil_div(quads, tpr);
+    size_t rpb = (size_t)(256 / tpr) * 4;
+    while (sei_ceil_div((size_t)R, rpb) * col_blocks > 512 && rpb < (size_t)R) rpb *= 2;
+    hipLaunchKernelGGL(cast_colsum_kernel, dim3((unsigned)sei_ceil_div((size_t)R, rpb), col_blocks), dim3(256), 0,
+                       (hipStream_t)stream, x, x16, colsum, (size_t)R, C, tpr, rpb, row_weight);
+    return sei_launch_status();
+}
+
+// x (R, C) float32 -> x16 bf16 copy, and colsum[c] += sum_r row_weight[r] x[r][c] from the same pass (un-rounded input).
+extern "C" int sei_cast_bf16_colsum_weighted(const float *x, uint16_t *x16, const float *row_weight, float *colsum, int R,
+                                             int C, void *stream) {
+    SEI_REQUIRE(x && x16 && row_weight && colsum && R > 0 && C > 0 && C % 4 == 0);
+    SEI_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(x16) & 7) == 0);
+    return cast_colsum_launch(x, x16, colsum, row_weight, R, C, stream);
+}
+
 extern "C" int sei_cast_transpose_bf16(const void *x, int x_is_bf16, uint16_t *x16, uint16_t *xt16, int R, int C,
                                        int ldt, float *colsum, void *stream) {
     SEI_REQUIRE(x && (x16 || xt16 || colsum) && R > 0 && C > 0 && ldt >= R);
     SEI_REQUIRE(!(x_is_bf16 && x16));
     if (!x_is_bf16 && x16 && !xt16 && C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-        (reinterpret_cast<uintptr_t>(x16) & 7) == 0) {            // plain cast (+ column sums): streaming kernel
-        const int quads = C / 4;
-        int tpr = 1;
-        while (tpr < quads && tpr < 256) tpr <<= 1;
-        const unsigned col_blocks = (unsigned)sei_ceil_div(quads, tpr);
-        size_t rpb = (size_t)(256 / tpr) * 4;
-        while (sei_ceil_div((size_t)R, rpb) * col_blocks > 512 && rpb < (size_t)R) rpb *= 2;
-        hipLaunchKernelGGL(cast_colsum_kernel, dim3((unsigned)sei_ceil_div((size_t)R, rpb), col_blocks), dim3(256), 0,
-                           (hipStream_t)stream, (const float *)x, x16, colsum, (size_t)R, C, tpr, rpb);
-        return sei_launch_status();
-    }
+        (reinterpret_cast<uintptr_t>(x16) & 7) == 0)              // plain cast (+ column sums): streaming kernel
+        return cast_colsum_launch((const float *)x, x16, colsum, nullptr, R, C, stream);
     // the grid covers ldt rows so that the zero padding of xt16 is written too
     dim3 grid((unsigned)sei_ceil_div(C, 64), (unsigned)sei_ceil_div(xt16 ? ldt : R, 64));
     if (x_is_bf16)

@@ -700,10 +700,18 @@ def gemm_mixed(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=No
     return out
 
 
-def cast16(x2d, colsum_into_=None):
-    """f32 (R, C) -> bf16 copy; colsum_into_: accumulate the column sums (a bias gradient) in the same pass."""
+def cast16(x2d, colsum_into_=None, row_weight=None):
+    """f32 (R, C) -> bf16 copy; colsum_into_: accumulate the column sums (a bias gradient) in the same pass, each row
+    times row_weight[r] when given (the downsampler's convolution: DownsampleFn16)."""
     R, C = x2d.shape
     x16 = _alloc((R, C), torch.bfloat16, x2d.device)
+    if row_weight is not None and colsum_into_ is not None and C % 4 == 0:
+        N.call("sei_cast_bf16_colsum_weighted", x2d.data_ptr(), x16.data_ptr(), row_weight.data_ptr(), colsum_into_.data_ptr(),
+               R, C)
+        return x16
+    if row_weight is not None and colsum_into_ is not None:
+        colsum_into(colsum_into_, x2d, row_weight=row_weight)
+        colsum_into_ = None
     N.call("sei_cast_transpose_bf16", x2d.data_ptr(), 0, x16.data_ptr(), None, R, C, R, N.ptr(colsum_into_))
     return x16
 
@@ -1404,8 +1412,7 @@ class DownsampleFn16(torch.autograd.Function):
         Ho, Wo = ctx.hw[2], ctx.hw[3]
         M, Mo, Co = B * H * W, B * Ho * Wo, w.shape[0]
         go2 = go.contiguous().view(Mo, Co)
-        colsum_into(grad_of(b), go2, row_weight=s)
-        go16 = cast16(go2)
+        go16 = cast16(go2, colsum_into_=grad_of(b), row_weight=s)           # (the bias gradient from the cast's own pass)
         gu = torch.empty((Mo, C), dtype=torch.float32, device=x.device)
         gemm_nt16(go16, shadow(w), Mo, C, Co, EPI_NONE, out32=gu, b_rmajor=True)
         weight_grad16(go16, u16, grad_of(w).view(Co, C))           # after the data gradient: see ConvBlockFn16.backward

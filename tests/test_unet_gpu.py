@@ -1287,3 +1287,18 @@ def test_batched_transposes_of_the_fused_levels_weights(ops):
     for m, o in zip(mats, outs):
         assert torch.equal(o, m.t().contiguous())
     assert N.lib().sei_transpose_bf16_many(jobs, 0, None) == 10001 and N.lib().sei_transpose_bf16_many(jobs, 17, None) == 10001
+
+
+@pytest.mark.parametrize("R,C", [(2304, 2048), (300, 512), (147456, 128), (7, 8)])
+def test_cast_with_a_weighted_column_sum(ops, R, C):
+    """sei_cast_bf16_colsum_weighted: the bf16 copy equals the plain cast's, colsum[c] += sum_r w[r] x[r][c] against float64
+    (the Downsample's bias gradient: models/_ops.DownsampleFn16.backward)."""
+    gen = torch.Generator().manual_seed(R + C)
+    x = torch.randn((R, C), generator=gen).cuda()
+    w = torch.rand(R, generator=gen).cuda()
+    base = torch.randn(C, generator=gen).cuda()
+    acc = base.clone()
+    x16 = ops.cast16(x, colsum_into_=acc, row_weight=w)
+    assert torch.equal(x16, ops.cast16(x))
+    ref = base.double() + (w.double()[:, None] * x.double()).sum(0)
+    assert relerr(acc, ref) < 5e-6
