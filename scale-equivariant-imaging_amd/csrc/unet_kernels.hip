@@ -950,6 +950,87 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_wgrad_c32_kernel(
     }
 }
 
+// Weight gradients of the network's two end convolutions on the matrix cores, exact float32 (round 5).
+//   hidden tensor BIG (NHWC, 32 channels), small tensor SMALL (CS <= 3 channels, either layout):
+//     SMALL_IS_OUT = false (in_conv, x = SMALL, gy = BIG):  gw[co][ci][t] = sum_p BIG[p][co] SMALL[p + off(t)][ci]
+//     SMALL_IS_OUT = true  (out_conv, x = BIG, gy = SMALL): gw[co][ci][t] = sum_q BIG[q][ci] SMALL[q - off(t)][co]
+//   i.e. one 32 x 32 product  G[m][n] = sum_pixels BIG[pixel][m] P[pixel][n]  with n = (small channel, tap) <= 27 columns of
+//   shifted SMALL values (zero outside the image), reduced over all B H W pixels: v_mfma_f32_32x32x2_f32 with two pixels per
+//   instruction -- lane (m = lane % 32, k = lane / 32) reads BIG as whole 128-byte pixel rows, lane (n, k) gathers its own
+//   shifted SMALL value (a few MB: L2). Column 27 of P is 1 for in_conv: the bias gradient sum_p gy[p][co] falls out of the
+//   same product; for out_conv it is the sum of the centre-tap column's values, kept per lane.
+// The lane-per-channel kernels above spent 61-68 us per launch (27 FMAs + ~10 loads per pixel and half-wave, 512 workgroups
+// adding 864 atomics each onto the same 864 addresses); here a wave owns a contiguous pixel range, a workgroup folds its eight
+// accumulator tiles through LDS and 256 workgroups add.
+template <bool SMALL_IS_OUT>
+__global__ __launch_bounds__(512) void conv3x3_wgrad_mfma_kernel(const float *__restrict__ big, const float *__restrict__ sm,
+                                                                 float *__restrict__ gw, float *__restrict__ gb, int B, int H,
+                                                                 int W, int CS, int nchw_small, int pix_per_wave) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    __shared__ float red[8][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, kk = lane >> 5;                    // A: row m = n; B: column n; both: pixel k = kk of the pair
+    // this lane's column of P: small channel cn and tap (dy, dx); column 27: ones (in_conv's bias gradient); above: zeros
+    const int cn = n / 9, tn = n - 9 * cn;
+    const bool col_real = n < 9 * CS, col_ones = !SMALL_IS_OUT && n == 27;
+    const int sgn = SMALL_IS_OUT ? -1 : 1;
+    const int dy = sgn * (tn / 3 - 1), dx = sgn * (tn % 3 - 1);
+    const long long npix = (long long)B * H * W;
+    const long long p_begin = ((long long)blockIdx.x * 8 + wave) * pix_per_wave;
+    const long long p_end = p_begin + pix_per_wave < npix ? p_begin + pix_per_wave : npix;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float bsum = 0.f;                                            // out_conv: the centre-tap column's running sum
+    constexpr int U = 8;                                         // MFMAs (pixel pairs) per batch of loads
+    for (long long p0 = p_begin; p0 < p_end; p0 += 2 * U) {
+        float av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long p = p0 + 2 * u + kk;
+            const bool live = p < p_end;
+            const long long pc = live ? p : p_begin;
+            const int j = (int)(pc % W);
+            const long long bi = pc / W;
+            const int i = (int)(bi % H), b = (int)(bi / H);
+            av[u] = live ? big[(size_t)pc * 32 + n] : 0.f;
+            const int ii = i + dy, jj = j + dx;
+            const bool inside = live && col_real && ii >= 0 && ii < H && jj >= 0 && jj < W;
+            const float v = inside ? sm[img_index(nchw_small, b, cn, ii, jj, CS, H, W)] : 0.f;
+            bv[u] = (col_ones && live) ? 1.f : v;
+            if (SMALL_IS_OUT && tn == 4) bsum += v;              // (dy, dx) = (0, 0): SMALL[q][cn] itself
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    // accumulator element e of lane (n, kk): G[m = 8 (e / 4) + 4 kk + e % 4][n]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave][(8 * (e >> 2) + 4 * kk + (e & 3)) * 32 + n] = acc[e];
+    __shared__ float bred[8][64];
+    bred[wave][lane] = bsum;
+    __syncthreads();
+    for (int o = threadIdx.x; o < 1024; o += 512) {
+        const int m = o >> 5, nn = o & 31;
+        float t = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) t += red[w8][o];
+        if (nn < 9 * CS) {
+            const int c = nn / 9, tap = nn - 9 * c;
+            // in_conv: gw[co = m][ci = c][tap]; out_conv: gw[co = c][ci = m][tap]
+            atomicAdd(gw + (SMALL_IS_OUT ? ((size_t)c * 32 + m) * 9 + tap : ((size_t)m * CS + c) * 9 + tap), t);
+        } else if (!SMALL_IS_OUT && nn == 27 && gb) {
+            atomicAdd(gb + m, t);
+        }
+    }
+    if (SMALL_IS_OUT && gb && (int)threadIdx.x < CS) {           // centre-tap lanes: n = 9 c + 4, both pixel halves, all waves
+        float t = 0.f;
+        const int c = threadIdx.x;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) t += bred[w8][9 * c + 4] + bred[w8][32 + 9 * c + 4];
+        atomicAdd(gb + c, t);
+    }
+}
+
 // =================================================================================================
 // separable rank-2 spatial map, NHWC:  y[b,i',j',c] = sum_t sum_i L_t[i',i] sum_j R_t[j',j] x[b,i,j,c]
 // pass W: T[b][t][i][j'][c] = sum_j R_t[j',j] x[b,i,j,c]      (workspace, 2*B*Hi*Wo*C floats)
@@ -1562,6 +1643,21 @@ extern "C" int sei_conv3x3_bwd_weight(const float *x, const float *gy, float *gw
     const int KC = Cin * 9;
     {   // the two real layers of the default network: lanes = the 32 hidden channels
         const bool small_out = Cin == 32 && Cout <= 4 && !nchw_x, small_in = Cout == 32 && Cin <= 4 && !nchw_gy;
+        if ((small_out || small_in) && (small_out ? Cout : Cin) <= 3 && npix < ((size_t)1 << 40)) {
+            // (28 columns of the 32 x 32 product: three small channels x nine taps + the bias column)
+            const int CSm = small_out ? Cout : Cin;
+            size_t ppw = sei_ceil_div(npix, (size_t)256 * 8);          // one workgroup per CU, eight waves each
+            ppw = sei_ceil_div(ppw, 16) * 16;                           // whole batches of 16 pixels
+            const unsigned grid = (unsigned)sei_ceil_div(npix, ppw * 8);
+            hipStream_t st = (hipStream_t)stream;
+            if (small_out)
+                hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<true>, dim3(grid), dim3(512), 0, st, x, gy, gw, gb, B, H, W, CSm,
+                                   nchw_gy ? 1 : 0, (int)ppw);
+            else
+                hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<false>, dim3(grid), dim3(512), 0, st, gy, x, gw, gb, B, H, W, CSm,
+                                   nchw_x ? 1 : 0, (int)ppw);
+            return sei_launch_status();
+        }
         if (small_out || small_in) {
             const int nruns_row = (int)sei_ceil_div(W, C3L_RUN);
             const size_t runs = (size_t)B * H * nruns_row;
