@@ -983,22 +983,32 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_mfma_kernel(const float *__
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     float bsum = 0.f;                                            // out_conv: the centre-tap column's running sum
     constexpr int U = 8;                                         // MFMAs (pixel pairs) per batch of loads
+    // this lane's pixel (b, i, j): decomposed ONCE, then advanced by two per MFMA (a 64-bit division per pixel and lane made
+    // the first version of this kernel VALU-bound: 47 us)
+    long long p = p_begin + kk;
+    int j = (int)(p % W);
+    long long rest = p / W;
+    int i = (int)(rest % H), b = (int)(rest / H);
     for (long long p0 = p_begin; p0 < p_end; p0 += 2 * U) {
         float av[U], bv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long p = p0 + 2 * u + kk;
             const bool live = p < p_end;
-            const long long pc = live ? p : p_begin;
-            const int j = (int)(pc % W);
-            const long long bi = pc / W;
-            const int i = (int)(bi % H), b = (int)(bi / H);
-            av[u] = live ? big[(size_t)pc * 32 + n] : 0.f;
+            av[u] = live ? big[(size_t)p * 32 + n] : 0.f;
             const int ii = i + dy, jj = j + dx;
             const bool inside = live && col_real && ii >= 0 && ii < H && jj >= 0 && jj < W;
             const float v = inside ? sm[img_index(nchw_small, b, cn, ii, jj, CS, H, W)] : 0.f;
             bv[u] = (col_ones && live) ? 1.f : v;
             if (SMALL_IS_OUT && tn == 4) bsum += v;              // (dy, dx) = (0, 0): SMALL[q][cn] itself
+            p += 2;
+            j += 2;
+            while (j >= W) {                                     // (W = 1: two rows per step)
+                j -= W;
+                if (++i == H) {
+                    i = 0;
+                    ++b;
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
