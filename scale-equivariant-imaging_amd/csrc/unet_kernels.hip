@@ -989,8 +989,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_mfma_kernel(const float *__
     int j = (int)(p % W);
     long long rest = p / W;
     int i = (int)(rest % H), b = (int)(rest / H);
-    for (long long p0 = p_begin; p0 < p_end; p0 += 2 * U) {
-        float av[U], bv[U];
+    auto load_batch = [&](float (&av)[U], float (&bv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool live = p < p_end;
@@ -1010,8 +1009,20 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_mfma_kernel(const float *__
                 }
             }
         }
+    };
+    auto mfma_batch = [&](const float (&av)[U], const float (&bv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    };
+    // two batches in registers: the loads of the next 16 pixels are in flight under the MFMAs of these (a wave has ~7
+    // batches in all: with load -> wait -> multiply in sequence it spent its time waiting: 32 us per launch)
+    float a0[U], b0[U], a1[U], b1[U];
+    load_batch(a0, b0);
+    for (long long p0 = p_begin; p0 < p_end; p0 += 4 * U) {
+        load_batch(a1, b1);                                      // (past the end: all lanes dead, zeros)
+        mfma_batch(a0, b0);
+        load_batch(a0, b0);
+        mfma_batch(a1, b1);
     }
     // accumulator element e of lane (n, kk): G[m = 8 (e / 4) + 4 kk + e % 4][n]
 #pragma unroll
