@@ -217,6 +217,9 @@ def _stream_bytes(name, a):
     if name == "sei_conv3x3_bwd_weight":
         B, H, W, Ci, Co = a[4:9]
         return 4 * B * H * W * (Ci + Co)
+    if name == "sei_conv3x3_bwd_weight_parts":
+        B, H, W, Ci, Co = a[3:8]
+        return 4 * B * H * W * (Ci + Co)
     if name == "sei_adam_fused":
         return a[5] * (24 + (2 if a[2] else 4) + (2 if a[-1] else 0))
     if name == "sei_gemm_bf16nt_dw2_adam":                # param / exp_avg / exp_avg_sq in and out, shadow out, operands

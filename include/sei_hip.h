@@ -190,6 +190,13 @@ int sei_conv3x3_fwd(const float *x, const float *w, const float *bias, const flo
                     void *stream);
 int sei_conv3x3_bwd_weight(const float *x, const float *gy, float *gw, float *gb, int B, int H, int W,
                            int Cin, int Cout, int nchw_x, int nchw_gy, void *stream);
+/* Two-stage form for the network's end convolutions (3 <-> 32 channels, UNet.in_conv / out_conv): _parts_count = the number
+ * of partial rows the launch leaves (0: shape not served -- use sei_conv3x3_bwd_weight), each Cout * Cin * 9 + Cout floats:
+ * the weight gradient in torch's (Cout, Cin, 3, 3) layout followed by the bias gradient. sei_fold_many adds the rows into
+ * the gradients (SEI_FOLD_SPLIT with split = Cout * Cin * 9: a = gw, b = gb). No atomics. */
+size_t sei_conv3x3_bwd_weight_parts_count(int B, int H, int W, int Cin, int Cout, int nchw_x, int nchw_gy);
+int sei_conv3x3_bwd_weight_parts(const float *x, const float *gy, float *part, int B, int H, int W, int Cin, int Cout,
+                                 int nchw_x, int nchw_gy, void *stream);
 
 int sei_dwconv7_fwd(const float *x, const float *w, const float *bias, const float *res,
                     float res_scale, float *y, int B, int H, int W, int C, int flip, void *stream);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "sei_luma_sqerr": [_P, _P, _Z, _P, _P, _P],
     "sei_conv3x3_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sei_conv3x3_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "sei_conv3x3_bwd_weight_parts": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "sei_dwconv7_fwd": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
     "sei_dwconv7_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P],
     "sei_dwconv7_fwd_ex": [_P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -178,6 +179,7 @@ SIZE_QUERIES = {
     "sei_rowgemm_dgelu_bf16_eligible": [_L, _I, _I],
     "sei_rowgemm_ln_bf16_eligible": [_L, _I, _I],
     "sei_gemm_bf16nt_plan": [_I, _I, _I, _I, _I, _I, _I, _I],
+    "sei_conv3x3_bwd_weight_parts_count": [_I, _I, _I, _I, _I, _I, _I],
     "sei_sepmap2_small_eligible": [_I, _I, _I, _I, _I, _I],
 }
 ABI_VERSION = 10      # SEI_ABI_VERSION of include/sei_hip.h this table was written against

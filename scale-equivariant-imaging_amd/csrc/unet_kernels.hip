@@ -962,10 +962,13 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_wgrad_c32_kernel(
 // The lane-per-channel kernels above spent 61-68 us per launch (27 FMAs + ~10 loads per pixel and half-wave, 512 workgroups
 // adding 864 atomics each onto the same 864 addresses); here a wave owns a contiguous pixel range, a workgroup folds its eight
 // accumulator tiles through LDS and 256 workgroups add.
+// part != NULL: no atomics -- workgroup g leaves its sums as row g of part ([workgroups][9 * 32 * CS + bias entries], the
+// weight gradient in torch's layout followed by the bias gradient) for sei_fold_many (SEI_FOLD_SPLIT, split = 288 CS).
 template <bool SMALL_IS_OUT>
 __global__ __launch_bounds__(512) void conv3x3_wgrad_mfma_kernel(const float *__restrict__ big, const float *__restrict__ sm,
                                                                  float *__restrict__ gw, float *__restrict__ gb, int B, int H,
-                                                                 int W, int CS, int nchw_small, int pix_per_wave) {
+                                                                 int W, int CS, int nchw_small, int pix_per_wave,
+                                                                 float *__restrict__ part) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     __shared__ float red[8][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1035,20 +1038,26 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_mfma_kernel(const float *__
         float t = 0.f;
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) t += red[w8][o];
+        const int nw = 288 * CS;                                 // entries of gw
+        float *row = part ? part + (size_t)blockIdx.x * (nw + (SMALL_IS_OUT ? CS : 32)) : nullptr;
         if (nn < 9 * CS) {
             const int c = nn / 9, tap = nn - 9 * c;
             // in_conv: gw[co = m][ci = c][tap]; out_conv: gw[co = c][ci = m][tap]
-            atomicAdd(gw + (SMALL_IS_OUT ? ((size_t)c * 32 + m) * 9 + tap : ((size_t)m * CS + c) * 9 + tap), t);
-        } else if (!SMALL_IS_OUT && nn == 27 && gb) {
-            atomicAdd(gb + m, t);
+            const size_t at = SMALL_IS_OUT ? ((size_t)c * 32 + m) * 9 + tap : ((size_t)m * CS + c) * 9 + tap;
+            if (row) row[at] = t;
+            else atomicAdd(gw + at, t);
+        } else if (!SMALL_IS_OUT && nn == 27) {
+            if (row) row[nw + m] = t;
+            else if (gb) atomicAdd(gb + m, t);
         }
     }
-    if (SMALL_IS_OUT && gb && (int)threadIdx.x < CS) {           // centre-tap lanes: n = 9 c + 4, both pixel halves, all waves
+    if (SMALL_IS_OUT && (int)threadIdx.x < CS) {                 // centre-tap lanes: n = 9 c + 4, both pixel halves, all waves
         float t = 0.f;
         const int c = threadIdx.x;
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) t += bred[w8][9 * c + 4] + bred[w8][32 + 9 * c + 4];
-        atomicAdd(gb + c, t);
+        if (part) part[(size_t)blockIdx.x * (288 * CS + CS) + 288 * CS + c] = t;
+        else if (gb) atomicAdd(gb + c, t);
     }
 }
 
@@ -1657,6 +1666,49 @@ extern "C" int sei_conv3x3_fwd(const float *x, const float *w, const float *bias
     return sei_launch_status();
 }
 
+namespace {
+inline bool c3_mfma_ok(size_t npix, int Cin, int Cout, int nchw_x, int nchw_gy) {
+    const bool small_out = Cin == 32 && Cout <= 3 && !nchw_x, small_in = Cout == 32 && Cin <= 3 && !nchw_gy;
+    return (small_out || small_in) && npix < ((size_t)1 << 40);
+}
+inline unsigned c3_mfma_grid(size_t npix, size_t workgroups, size_t &ppw) {
+    ppw = sei_ceil_div(npix, workgroups * 8);                            // pixels per wave, eight waves per workgroup
+    ppw = sei_ceil_div(ppw, 16) * 16;                                   // whole batches of 16 pixels
+    return (unsigned)sei_ceil_div(npix, ppw * 8);
+}
+inline void c3_mfma_launch(const float *x, const float *gy, float *gw, float *gb, float *part, int B, int H, int W, int Cin,
+                           int Cout, int nchw_x, int nchw_gy, unsigned grid, size_t ppw, hipStream_t st) {
+    if (Cin == 32)
+        hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<true>, dim3(grid), dim3(512), 0, st, x, gy, gw, gb, B, H, W, Cout,
+                           nchw_gy ? 1 : 0, (int)ppw, part);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<false>, dim3(grid), dim3(512), 0, st, gy, x, gw, gb, B, H, W, Cin,
+                           nchw_x ? 1 : 0, (int)ppw, part);
+}
+}  // namespace
+
+// Two-stage form of sei_conv3x3_bwd_weight for the network's end convolutions (3 <-> 32 channels): _parts_count = how many
+// partial rows the launch leaves (0: shape not served, use sei_conv3x3_bwd_weight), each Cout * Cin * 9 + Cout floats (the
+// weight gradient in torch's layout, then the bias gradient); sei_fold_many adds them up (SEI_FOLD_SPLIT, split = Cout * Cin * 9).
+// No atomics: 1024 workgroups instead of 256.
+extern "C" size_t sei_conv3x3_bwd_weight_parts_count(int B, int H, int W, int Cin, int Cout, int nchw_x, int nchw_gy) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t npix = (size_t)B * H * W;
+    if (!c3_mfma_ok(npix, Cin, Cout, nchw_x, nchw_gy)) return 0;
+    size_t ppw;
+    return c3_mfma_grid(npix, 1024, ppw);
+}
+extern "C" int sei_conv3x3_bwd_weight_parts(const float *x, const float *gy, float *part, int B, int H, int W, int Cin,
+                                            int Cout, int nchw_x, int nchw_gy, void *stream) {
+    SEI_REQUIRE(x && gy && part && B > 0 && H > 0 && W > 0);
+    const size_t npix = (size_t)B * H * W;
+    SEI_REQUIRE(c3_mfma_ok(npix, Cin, Cout, nchw_x, nchw_gy));
+    size_t ppw;
+    const unsigned grid = c3_mfma_grid(npix, 1024, ppw);
+    c3_mfma_launch(x, gy, nullptr, nullptr, part, B, H, W, Cin, Cout, nchw_x, nchw_gy, grid, ppw, (hipStream_t)stream);
+    return sei_launch_status();
+}
+
 extern "C" int sei_conv3x3_bwd_weight(const float *x, const float *gy, float *gw, float *gb, int B, int H,
                                       int W, int Cin, int Cout, int nchw_x, int nchw_gy, void *stream) {
     SEI_REQUIRE(x && gy && gw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
@@ -1664,19 +1716,11 @@ extern "C" int sei_conv3x3_bwd_weight(const float *x, const float *gy, float *gw
     const int KC = Cin * 9;
     {   // the two real layers of the default network: lanes = the 32 hidden channels
         const bool small_out = Cin == 32 && Cout <= 4 && !nchw_x, small_in = Cout == 32 && Cin <= 4 && !nchw_gy;
-        if ((small_out || small_in) && (small_out ? Cout : Cin) <= 3 && npix < ((size_t)1 << 40)) {
+        if (c3_mfma_ok(npix, Cin, Cout, nchw_x, nchw_gy)) {
             // (28 columns of the 32 x 32 product: three small channels x nine taps + the bias column)
-            const int CSm = small_out ? Cout : Cin;
-            size_t ppw = sei_ceil_div(npix, (size_t)256 * 8);          // one workgroup per CU, eight waves each
-            ppw = sei_ceil_div(ppw, 16) * 16;                           // whole batches of 16 pixels
-            const unsigned grid = (unsigned)sei_ceil_div(npix, ppw * 8);
-            hipStream_t st = (hipStream_t)stream;
-            if (small_out)
-                hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<true>, dim3(grid), dim3(512), 0, st, x, gy, gw, gb, B, H, W, CSm,
-                                   nchw_gy ? 1 : 0, (int)ppw);
-            else
-                hipLaunchKernelGGL(conv3x3_wgrad_mfma_kernel<false>, dim3(grid), dim3(512), 0, st, gy, x, gw, gb, B, H, W, CSm,
-                                   nchw_x ? 1 : 0, (int)ppw);
+            size_t ppw;
+            const unsigned grid = c3_mfma_grid(npix, 256, ppw);        // one workgroup per CU: 256-way atomics per output
+            c3_mfma_launch(x, gy, gw, gb, nullptr, B, H, W, Cin, Cout, nchw_x, nchw_gy, grid, ppw, (hipStream_t)stream);
             return sei_launch_status();
         }
         if (small_out || small_in) {

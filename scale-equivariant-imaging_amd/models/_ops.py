@@ -1498,8 +1498,16 @@ class Conv3x3Fn(torch.autograd.Function):
         w, b = ctx.params
         B, H, W, Ci, Co, nchw_in, nchw_out = ctx.cfg
         go = go.contiguous()
-        leaf_call(grad_of(w), "sei_conv3x3_bwd_weight", x.data_ptr(), go.data_ptr(), grad_of(w).data_ptr(),
-                  grad_of(b).data_ptr(), B, H, W, Ci, Co, int(nchw_in), int(nchw_out), keep=(x, go))
+        parts = N.lib().sei_conv3x3_bwd_weight_parts_count(B, H, W, Ci, Co, int(nchw_in), int(nchw_out)) if x.is_cuda else 0
+        ncol = Co * Ci * 9 + Co
+        work = torch.empty(parts * ncol, dtype=torch.float32, device=x.device) if parts else None
+        if parts and defer_fold(grad_of(w), grad_of(b), None, ncol, Co * Ci * 9, N.FOLD_SPLIT, work, 0, parts):
+            # the end convolutions on the matrix cores, per-workgroup sums folded with the pass's other partial sums
+            N.call("sei_conv3x3_bwd_weight_parts", x.data_ptr(), go.data_ptr(), work.data_ptr(), B, H, W, Ci, Co,
+                   int(nchw_in), int(nchw_out))
+        else:
+            leaf_call(grad_of(w), "sei_conv3x3_bwd_weight", x.data_ptr(), go.data_ptr(), grad_of(w).data_ptr(),
+                      grad_of(b).data_ptr(), B, H, W, Ci, Co, int(nchw_in), int(nchw_out), keep=(x, go))
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)

@@ -333,6 +333,47 @@ def test_conv3x3(ops, Ci, Co, nchw_in, nchw_out):
     assert relerr(wp.grad, rgw) < 2e-5 and relerr(bp.grad, rgb) < 2e-5
 
 
+@pytest.mark.parametrize("Ci,Co,nchw_small,B,H,W", [(3, 32, 1, 3, 48, 48), (32, 3, 1, 3, 48, 48), (3, 32, 0, 2, 20, 24),
+                                                    (32, 3, 0, 2, 20, 24), (1, 32, 1, 1, 7, 5), (32, 2, 0, 5, 9, 1)])
+def test_end_convolution_weight_gradients_on_the_matrix_cores(ops, Ci, Co, nchw_small, B, H, W):
+    """conv3x3_wgrad_mfma_kernel (v_mfma_f32_32x32x2_f32: exact float32 products) through both entry points -- sei_conv3x3_bwd_
+    weight (atomics; accumulates into gw / gb) and sei_conv3x3_bwd_weight_parts (per-workgroup rows, folded by sei_fold_many)
+    -- against float64 torch.autograd of F.conv2d (src/models/convolutional.py:174-176: UNet.in_conv / out_conv): both
+    layouts of the small tensor, a single small channel, one-pixel-wide images, ranges that end inside a batch of 16 pixels."""
+    import ctypes
+    import _native as N
+    gen = torch.Generator().manual_seed(Ci + Co + H)
+    x = torch.randn((B, Ci, H, W), generator=gen)
+    gy = torch.randn((B, Co, H, W), generator=gen)
+    w = torch.zeros((Co, Ci, 3, 3), dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+    rgw, rgb = torch.autograd.grad(F.conv2d(x.double(), w, bias, padding=1), [w, bias], gy.double())
+    small_is_x = Ci <= 3
+    lay = lambda t, small: (t if (small and nchw_small) else nhwc(t)).contiguous().cuda()
+    xd, gyd = lay(x, small_is_x), lay(gy, not small_is_x)
+    nchw_x, nchw_gy = int(small_is_x and nchw_small), int((not small_is_x) and nchw_small)
+    base_w, base_b = torch.randn((Co, Ci, 3, 3), generator=gen).cuda(), torch.randn(Co, generator=gen).cuda()
+    gw, gb = base_w.clone(), base_b.clone()
+    N.call("sei_conv3x3_bwd_weight", xd.data_ptr(), gyd.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, H, W, Ci, Co, nchw_x, nchw_gy)
+    assert relerr(gw - base_w, rgw) < 2e-5 and relerr(gb - base_b, rgb) < 2e-5
+    parts = N.lib().sei_conv3x3_bwd_weight_parts_count(B, H, W, Ci, Co, nchw_x, nchw_gy)
+    assert parts >= 1
+    ncol = Co * Ci * 9 + Co
+    work = torch.full((parts, ncol), float("nan"), device="cuda")
+    N.call("sei_conv3x3_bwd_weight_parts", xd.data_ptr(), gyd.data_ptr(), work.data_ptr(), B, H, W, Ci, Co, nchw_x, nchw_gy)
+    assert torch.isfinite(work).all()                          # every entry of every row is written
+    total = work.double().sum(0)
+    assert relerr(total[:Co * Ci * 9].view(Co, Ci, 3, 3), rgw) < 2e-5 and relerr(total[Co * Ci * 9:], rgb) < 2e-5
+    gw2, gb2 = base_w.clone(), base_b.clone()                  # ... and sei_fold_many adds the rows into the gradients
+    job = N.FoldJob()
+    job.a, job.b, job.c = gw2.data_ptr(), gb2.data_ptr(), None
+    job.ncol, job.split, job.kind, job.nseg = ncol, Co * Ci * 9, N.FOLD_SPLIT, 1
+    job.part[0], job.groups[0] = work.data_ptr(), parts
+    N.call("sei_fold_many", (N.FoldJob * 1)(job), 1)
+    assert relerr(gw2 - base_w, rgw) < 2e-5 and relerr(gb2 - base_b, rgb) < 2e-5
+    assert N.lib().sei_conv3x3_bwd_weight_parts_count(B, H, W, 8, 8, 0, 0) == 0     # other shapes: the FMA kernels
+
+
 def test_colsum_and_adam(ops):
     from _native import call
     gen = torch.Generator().manual_seed(8)
