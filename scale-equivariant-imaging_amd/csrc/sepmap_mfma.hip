@@ -9,14 +9,24 @@
 // K = 12 ... 48 and N = the channel count, i.e. v_mfma_f32_16x16x32_bf16 work with the CONSTANT matrix as the A operand
 // and 16 channels on the lanes' columns.
 //
-// One workgroup (8 waves) = one image x 16 channels:
-//   pass W: a wave takes image rows i = wave, wave + 8, ...; its B fragments (8 consecutive input columns of one
-//           channel per lane) come straight from global memory (f32 -> bf16 in registers: every element of x is
-//           loaded once), the A fragments (rows of R) from LDS; the result tile has the output column on the
+// One workgroup (12 waves, one per CU: T fills LDS) walks items = one image x 16 channels:
+//   pass W: a wave takes image rows i = wave, wave + 12, ...; its B fragments (8 consecutive input columns of one
+//           channel per lane) come straight from global memory (buffer loads, f32 -> bf16 in registers: every element
+//           of x is loaded once), the A fragments (rows of R) from LDS; the result tile has the output column on the
 //           accumulator rows and the channel on the lane, and goes to LDS as bf16 in the layout the next product
 //           reads K-contiguous:  T[t][jo][c][i];
-//   pass H: a wave takes (output column jo, 16-row tile of Ho) pairs: A = rows of [L1 L2] from LDS, B = T[t][jo][c][i..]
-//           (one ds_read_b128 per fragment), f32 results straight to y (64-byte segments: 16 channels).
+//   pass H: a wave owns ONE 16-row tile of Ho and every n-th output column jo: A = T[t][jo][c][i..] (one ds_read_b128
+//           per fragment), B = rows of [L1 L2], held in registers for the whole launch; f32 (or bf16) results straight
+//           to y (64-byte segments: 16 channels).
+// Round 5 (tools/exp_sepmap_mfma.py; 96 x 24 x 24 x 128 -> 48 and its transpose, us per launch: 52.0 / 66.8 before):
+//   * items in XCD order (each XCD walks a contiguous eighth: the two 64-byte halves of a line meet in one L2)  49.3 / 59.7
+//   * the next item's first rows are loaded before pass H (which only reads LDS and stores y), as buffer loads off
+//     16 constant lane offsets (the 64-bit addresses took 96 VGPRs)                                           46.7 / 47.0
+//   * 16, then 12 waves per workgroup with pass H's constant operand hoisted into registers                  38.9 / 38.1
+//   * barriers that settle LDS only (s_waitcnt lgkmcnt(0); s_barrier) and the reduction depths as template
+//     arguments (the compiler's s_waitcnt vmcnt(0) at every join of the ks branches is gone)                 35.7 / 35.6
+//   = 4.0 TB/s of x + y. With every HBM access taken out the launch still took 27 us: what is left is the
+//   latency of the short dependent chains (LDS read -> 2-4 MFMAs -> LDS write / store) at 3 waves per SIMD.
 // The matrices are split into a bf16 head and a bf16 remainder (two MFMAs per product): the operator itself stays
 // exact to ~2^-17 and only the ACTIVATIONS are rounded to bf16 (x before the W product, T between the products) -- the
 // rounding every GEMM operand of this mode already has. Matrix-core time is negligible (a few hundred MFMAs per
@@ -30,7 +40,7 @@ namespace {
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int SMM_THREADS = 512, SMM_WAVES = 8;
+constexpr int SMM_WAVES = 12, SMM_THREADS = 64 * SMM_WAVES;
 constexpr int SMM_NC = 16;                        // channels per workgroup = the MFMA's N
 constexpr int SMM_PADK = 8;                       // bf16 elements of padding per K-contiguous LDS row (bank spread)
 constexpr int SMM_LDS = 152 * 1024;
@@ -79,7 +89,8 @@ __global__ __launch_bounds__(256) void sepmap_pack_kernel(const float *__restric
     }
 }
 
-__global__ __launch_bounds__(SMM_THREADS, 2) void sepmap_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
+template <int ksW, int ksH>
+__global__ __launch_bounds__(SMM_THREADS) void sepmap_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                    const unsigned short *__restrict__ mats, SmmGeom g,
                                                                    int items) {
     __shared__ __attribute__((aligned(16))) unsigned short lds[SMM_LDS / 2];
@@ -104,20 +115,91 @@ __global__ __launch_bounds__(SMM_THREADS, 2) void sepmap_mfma_kernel(const float
     }
     __syncthreads();
 
-    const int ksW = g.WiP / 32, ksH = g.HiP / 32;
-    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    // Between the passes only LDS has to be settled. __syncthreads() is a workgroup fence first: s_waitcnt vmcnt(0) in
+    // front of the s_barrier, i.e. every wave sat out the write latency of its y stores and the whole prefetch of the next
+    // image at each barrier (stamped: pass H of the 48 -> 24 map 16 k cycles for two iterations of arithmetic).
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // Pass H's share of a wave: ONE 16-row tile of the output rows (h_ht) and every h_nk-th output column from h_k on.
+    // Its operand from the constant matrices -- rows of [L1 L2], head and remainder -- does not depend on the column or
+    // the item: it is read from LDS once, here, and stays in registers (8 - 16 fragments). Re-read per (column, tile)
+    // pair it was two thirds of the pass's LDS traffic (6 KB of ds_read_b128 per pair against 2 KB for T's fragment:
+    // 860 KB per item on the 24 -> 48 map), and with the loads of x hidden behind pass H (below) LDS was what the
+    // kernel waited for: 30.7 of its 40.3 us remained with every load and store of HBM taken out.
+    const int h_ht = wave % g.HoT;                             // (HoT <= 8 < SMM_WAVES: every tile has its waves)
+    const int h_k = wave / g.HoT, h_nk = (SMM_WAVES - wave % g.HoT + g.HoT - 1) / g.HoT;
+    constexpr bool HOIST_LO = ksW + ksH < 4;                   // (48 - 64 pixel inputs both ways: the remainders would spill)
+    bf16x8 Lf[2][2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int lrow = (t * g.HoT * 16 + h_ht * 16 + lc) * g.ldL + lg * 8 + ks * 32;
+            if (ks < ksH) {
+                Lf[t][ks][0] = *reinterpret_cast<const bf16x8 *>(Lh + lrow);
+                Lf[t][ks][1] = HOIST_LO ? *reinterpret_cast<const bf16x8 *>(Ll + lrow) : bf16x8{};
+            } else {
+                Lf[t][ks][0] = Lf[t][ks][1] = bf16x8{};
+            }
+        }
+    // Item order: a workgroup's 16 channels are 64 bytes of every pixel -- HALF a 128-byte line, whose other half belongs
+    // to the next channel tile. Workgroups go to the 8 XCDs round-robin (blockIdx % 8), each with its own L2: with the
+    // plain order item = blockIdx the two halves were fetched by two XCDs and every line of x crossed the fabric twice
+    // (profiles/r05_b: 3.1 bytes fetched per byte written, where the maps of a step read as much as they write). Each XCD
+    // walks its own contiguous eighth of the items instead, so neighbouring channel tiles run side by side on one L2.
+    const int chunk = (items + 7) / 8, its = 8 * chunk;
+    auto item_at = [&](int it) { return (it & 7) * chunk + (it >> 3); };
+    auto advance = [&](int it) {                                // the next position of this workgroup that holds an item
+        while (it < its && item_at(it) >= items) it += gridDim.x;
+        return it;
+    };
+    // A lane's 8 (16) input columns of row i, one channel: 4-byte BUFFER loads -- the item's slice of x as the resource,
+    // 16 lane offsets that never change (VGPRs, set once), the row offset in an SGPR. As 48 separately computed 64-bit
+    // addresses the three rows in flight took 96 address registers (239 VGPRs, spills once the prefetch below was added),
+    // and the address temporaries aliased load destinations still in flight (an s_waitcnt vmcnt in front of the address
+    // arithmetic). Columns j >= Wi are CLAMPED to the row's last pixel rather than masked: they meet the zero padding of
+    // R's rows, and a finite value times zero is what a masked zero gives (a NaN in that pixel reaches every output of
+    // the row through the dense R anyway).
+    unsigned offs[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int j = (e >> 3) * 32 + lg * 8 + (e & 7);
+        offs[e] = (unsigned)(((j < g.Wi ? j : g.Wi - 1) * g.C + lc) * 4);
+    }
+    const unsigned row_bytes = (unsigned)g.Wi * g.C * 4, slice_bytes = (unsigned)g.Hi * row_bytes;
+    typedef __amdgpu_buffer_rsrc_t rsrc_t;
+    auto load_row = [&](rsrc_t xr, int i, float (&v)[16]) {
+        const unsigned rb = (unsigned)i * row_bytes;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offs[e], rb, 0));
+        if constexpr (ksW > 1) {
+#pragma unroll
+            for (int e = 8; e < 16; ++e)
+                v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, offs[e], rb, 0));
+        } else {
+#pragma unroll
+            for (int e = 8; e < 16; ++e) v[e] = 0.f;
+        }
+    };
+    auto x_of = [&](int item) {                                 // (wave-uniform) the item's image, from its first channel on
+        const int b = item / ctiles, c0 = (item - b * ctiles) * SMM_NC;
+        float *base = const_cast<float *>(x) + (size_t)b * g.Hi * g.Wi * g.C + c0;
+        return __builtin_amdgcn_make_buffer_rsrc(base, 0, slice_bytes - (unsigned)c0 * 4, 0x00020000);
+    };
+    // Three rows in flight per wave (rows wave, wave + 8, wave + 16 of the item): loaded for the FIRST item here, for every
+    // later one right before the previous item's pass H -- that pass only reads LDS and stores y, so the next image's
+    // loads run under it (with 24-row images: all of them).
+    float va[16], vb[16];
+    int it = advance(blockIdx.x);
+    if (it < its) {
+        const rsrc_t xb = x_of(item_at(it));
+        if (wave < g.Hi) load_row(xb, wave, va);
+        if (wave + SMM_WAVES < g.Hi) load_row(xb, wave + SMM_WAVES, vb);
+    }
+    while (it < its) {
+    const int item = item_at(it);
     const int b = item / ctiles, c0 = (item - b * ctiles) * SMM_NC;
     // ---- pass W: T[t][jo][c][i] = sum_j R_t[jo][j] x[b][i][j][c0 + c] --------------------------------------------
-    const float *xb = x + (size_t)b * g.Hi * g.Wi * g.C + c0 + lc;
-    auto load_row = [&](int i, float (&v)[16]) {               // this lane's 8 (16) input columns of row i, one channel
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int j = ks * 32 + lg * 8 + jj;
-                v[ks * 8 + jj] = (ks < ksW && j < g.Wi) ? xb[((size_t)i * g.Wi + j) * g.C] : 0.f;
-            }
-    };
+    const rsrc_t xb = x_of(item);
     auto w_row = [&](int i, const float (&v)[16]) {
         bf16x8 bx[2];
 #pragma unroll
@@ -144,26 +226,25 @@ __global__ __launch_bounds__(SMM_THREADS, 2) void sepmap_mfma_kernel(const float
             }
         }
     };
-    {   // three rows in flight per wave: the loads of rows i + 8 and i + 16 are issued before row i is multiplied
-        float va[16], vb[16], vc[16];
+    {   // the first two rows are in va / vb; rows i + 32 follow as their buffers come free
         int i = wave;
-        if (i < g.Hi) load_row(i, va);
-        if (i + SMM_WAVES < g.Hi) load_row(i + SMM_WAVES, vb);
         while (i < g.Hi) {
-            if (i + 2 * SMM_WAVES < g.Hi) load_row(i + 2 * SMM_WAVES, vc);
             w_row(i, va);
+            if (i + 2 * SMM_WAVES < g.Hi) load_row(xb, i + 2 * SMM_WAVES, va);
             i += SMM_WAVES;
             if (i >= g.Hi) break;
-            if (i + 2 * SMM_WAVES < g.Hi) load_row(i + 2 * SMM_WAVES, va);
             w_row(i, vb);
-            i += SMM_WAVES;
-            if (i >= g.Hi) break;
-            if (i + 2 * SMM_WAVES < g.Hi) load_row(i + 2 * SMM_WAVES, vb);
-            w_row(i, vc);
+            if (i + 2 * SMM_WAVES < g.Hi) load_row(xb, i + 2 * SMM_WAVES, vb);
             i += SMM_WAVES;
         }
     }
-    __syncthreads();
+    lds_barrier();
+    it = advance(it + gridDim.x);
+    if (it < its) {                                             // the next item's first rows: in flight during pass H
+        const rsrc_t xn = x_of(item_at(it));
+        if (wave < g.Hi) load_row(xn, wave, va);
+        if (wave + SMM_WAVES < g.Hi) load_row(xn, wave + SMM_WAVES, vb);
+    }
 
     // ---- pass H: y[b][io][jo][c0 + c] = sum_t sum_i L_t[io][i] T[t][jo][c][i] --------------------------------------
     // Operand roles swapped against pass W: A = T[t][jo][c][i..] (row = channel), B = L_t[io][i..] (column = io), so the
@@ -173,28 +254,25 @@ __global__ __launch_bounds__(SMM_THREADS, 2) void sepmap_mfma_kernel(const float
     const size_t ybase = (size_t)b * g.Ho * g.Wo * g.C + c0 + 4 * lg;
     float *yb = y + ybase;
     unsigned short *yb16 = reinterpret_cast<unsigned short *>(y) + ybase;
-    const int hitems = g.Wo * g.HoT;
-    auto h_item = [&](int it, f32x4 &acc) {
-        const int jo = it / g.HoT, ht = it - jo * g.HoT;
+    auto h_col = [&](int jo, f32x4 &acc) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int lrow = (t * g.HoT * 16 + ht * 16 + lc) * g.ldL + lg * 8;
             const size_t trow = ((size_t)(t * g.Wo + jo) * SMM_NC + lc) * g.ldT + lg * 8;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (ks < ksH) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(Lh + lrow + ks * 32);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(Ll + lrow + ks * 32);
                     const bf16x8 at = *reinterpret_cast<const bf16x8 *>(T + trow + ks * 32);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at, bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at, Lf[t][ks][0], acc, 0, 0, 0);
+                    const bf16x8 lo = HOIST_LO ? Lf[t][ks][1]
+                                               : *reinterpret_cast<const bf16x8 *>(
+                                                     Ll + (t * g.HoT * 16 + h_ht * 16 + lc) * g.ldL + lg * 8 + ks * 32);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at, lo, acc, 0, 0, 0);
                 }
             }
         }
     };
-    auto h_store = [&](int it, const f32x4 &acc) {
-        const int jo = it / g.HoT, ht = it - jo * g.HoT;
-        const int io = ht * 16 + lc;                              // accumulator: column = io, rows = channels 4 lg .. 4 lg + 3
+    auto h_store = [&](int jo, const f32x4 &acc) {
+        const int io = h_ht * 16 + lc;                            // accumulator: column = io, rows = channels 4 lg .. 4 lg + 3
         if (io < g.Ho) {
             if (g.out16) {
                 ushort4 h;
@@ -205,15 +283,17 @@ __global__ __launch_bounds__(SMM_THREADS, 2) void sepmap_mfma_kernel(const float
             }
         }
     };
-    for (int it = wave; it < hitems; it += 2 * SMM_WAVES) {
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        const int it1 = it + SMM_WAVES;
-        h_item(it, a0);
-        if (it1 < hitems) h_item(it1, a1);
-        h_store(it, a0);
-        if (it1 < hitems) h_store(it1, a1);
+    {
+        for (int jo = h_k; jo < g.Wo; jo += 2 * h_nk) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+            const int jo1 = jo + h_nk;
+            h_col(jo, a0);
+            if (jo1 < g.Wo) h_col(jo1, a1);
+            h_store(jo, a0);
+            if (jo1 < g.Wo) h_store(jo1, a1);
+        }
     }
-    __syncthreads();                                            // T is rewritten by the next item's pass W
+    lds_barrier();                                              // T is rewritten by the next item's pass W
     }
 }
 
@@ -237,6 +317,7 @@ inline bool smm_plan(int B, int Hi, int Wi, int Ho, int Wo, int C, SmmGeom &g) {
     g.offLlo = (int)(2 * nR + nL);
     g.offT = (int)(2 * nR + 2 * nL);
     if ((size_t)B * (C / SMM_NC) >= ((size_t)1 << 31)) return false;
+    if ((size_t)Hi * Wi * C * 4 >= ((size_t)1 << 31)) return false;   // an image is one buffer resource (32-bit offsets)
     return (2 * nR + 2 * nL + nT) * 2 <= (size_t)SMM_LDS;
 }
 
@@ -275,8 +356,14 @@ static int smm_launch(const float *x, float *y, int out16, int B, int Hi, int Wi
     g.out16 = out16;
     const int items = B * (C / SMM_NC);
     const int grid = items < 256 ? items : 256;                 // one resident workgroup per CU walks its items
-    hipLaunchKernelGGL(sepmap_mfma_kernel, dim3((unsigned)grid), dim3(SMM_THREADS), 0, (hipStream_t)stream, x, y, packed, g,
-                       items);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(SMM_THREADS), 0, (hipStream_t)stream, x, y, packed, g, items);
+    };
+    const int ksW = g.WiP / 32, ksH = g.HiP / 32;              // 32-wide reduction steps of the two passes: 1 or 2 each
+    if (ksW == 1 && ksH == 1) go(sepmap_mfma_kernel<1, 1>);
+    else if (ksW == 1) go(sepmap_mfma_kernel<1, 2>);
+    else if (ksH == 1) go(sepmap_mfma_kernel<2, 1>);
+    else go(sepmap_mfma_kernel<2, 2>);
     return sei_launch_status();
 }
 

@@ -22,7 +22,8 @@ def timed(fn, reps=20):
 
 
 for kind, B, H, C in [("down", 64, 48, 32), ("up", 64, 24, 128), ("down", 64, 24, 128), ("up", 64, 12, 512),
-                      ("down", 64, 12, 512), ("up", 32, 24, 128), ("down", 32, 48, 32)]:
+                      ("down", 64, 12, 512), ("up", 32, 24, 128), ("down", 32, 48, 32), ("down", 96, 48, 32), ("up", 96, 24, 128),
+                      ("down", 96, 24, 128)]:
     fwd, bwd = _mats.resample_matrices(kind, H, H, 2, "cuda")
     Ho = fwd[0].shape[0]
     x = torch.randn((B, H, H, C), device="cuda")
