@@ -432,7 +432,7 @@ int sei_sepmap2(const float *x, float *y, int B, int Hi, int Wi, int Ho, int Wo,
  * to a multiple of 24. Results are bit-identical to sei_sepmap2. */
 /* The same map in the bf16 throughput mode, on the matrix cores (sepmap_mfma.hip): activations rounded to bf16 (x before
  * the W product, the intermediate between the products), the four matrices as bf16 head + remainder (exact to ~2^-17),
- * f32 accumulation and output. Eligible shapes only (sei_sepmap2_bf16_eligible: 24 <= Hi, Wi <= 64 with the
+ * f32 accumulation and output. Eligible shapes only (sei_sepmap2_bf16_eligible: 12 <= Hi, Wi <= 64 with the
  * intermediate of one image x 16 channels in LDS, C % 16 == 0); SEI_ERR_BAD_ARG otherwise -- the caller takes
  * sei_sepmap2_packed. `packed`: the matrices in the kernel's LDS image, made once per map by sei_sepmap2_bf16_pack from
  * L1, L2: (Ho, Hi), R1, R2: (Wo, Wi) float32 row-major into sei_sepmap2_bf16_pack_elems(..) uint16 elements. */

@@ -31,8 +31,9 @@
 // exact to ~2^-17 and only the ACTIVATIONS are rounded to bf16 (x before the W product, T between the products) -- the
 // rounding every GEMM operand of this mode already has. Matrix-core time is negligible (a few hundred MFMAs per
 // workgroup); the kernel streams x once and y once.
-// Eligible: 24 <= Hi, Wi <= 48 (the T image of one workgroup must fit LDS), C % 16 == 0; everything else stays on the
-// f32 kernels (the 3x3 / 6x6 levels cost ~13 us there; larger images -- the x4 network -- need T tiled over jo).
+// Eligible: 12 <= Hi, Wi <= 64 with the T image of one workgroup inside LDS, C % 16 == 0 (12 -> 24 at 512 channels, 64
+// images: 47.8 us on the f32 kernels, 30.6 here since round 5); everything else stays on sei_sepmap2_small (extents <= 8),
+// sei_sepmap2_big (the x4 network's fine levels) or the f32 kernels.
 #include "sei_common.h"
 
 namespace {
@@ -299,8 +300,8 @@ __global__ __launch_bounds__(SMM_THREADS) void sepmap_mfma_kernel(const float *_
 
 inline bool smm_plan(int B, int Hi, int Wi, int Ho, int Wo, int C, SmmGeom &g) {
     if (B <= 0 || C <= 0 || C % SMM_NC != 0) return false;
-    // (smaller images: too little work per workgroup item, the f32 kernels tie or win -- 64 x 12 x 12 x 512: 48 us there)
-    if (Hi < 24 || Wi < 24 || Hi > 64 || Wi > 64 || Ho < 1 || Wo < 1 || Ho > 128 || Wo > 128) return false;
+    // (extents <= 8: sei_sepmap2_small)
+    if (Hi < 12 || Wi < 12 || Hi > 64 || Wi > 64 || Ho < 1 || Wo < 1 || Ho > 128 || Wo > 128) return false;
     g.B = B; g.Hi = Hi; g.Wi = Wi; g.Ho = Ho; g.Wo = Wo; g.C = C; g.out16 = 0;
     g.HiP = (Hi + 31) / 32 * 32;
     g.WiP = (Wi + 31) / 32 * 32;

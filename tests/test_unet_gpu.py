@@ -213,7 +213,8 @@ def test_dwconv7_layernorm_fused_forward(ops, B, H, W, C, out16):
 
 @pytest.mark.parametrize("kind,B,H,W,C", [("down", 3, 48, 48, 32), ("up", 2, 24, 24, 128), ("down", 2, 24, 24, 128),
                                           ("down", 5, 28, 24, 64), ("up", 1, 24, 24, 48), ("down", 2, 40, 28, 48),
-                                          ("down", 300, 24, 24, 16)])
+                                          ("down", 300, 24, 24, 16), ("up", 3, 12, 12, 512), ("down", 2, 12, 12, 64),
+                                          ("down", 2, 14, 12, 32), ("up", 70, 12, 12, 64)])
 def test_resampler_on_the_matrix_cores(ops, kind, B, H, W, C):
     """sei_sepmap2_bf16 (Ideal{Down,Up}sample as two small-GEMM passes on v_mfma_f32_16x16x32_bf16, bf16 mode) against
     the f32 kernel and against float64 on the matrices of models/_mats.py: activations are rounded to bf16 (x, and the
@@ -247,7 +248,8 @@ def test_resampler_on_the_matrix_cores(ops, kind, B, H, W, C):
         yb = ops.sepmap2_16(xin, mats, ho, wo, out16=True)           # sei_sepmap2_bf16_out16: the same accumulators, rounded once
         assert yb.dtype == torch.bfloat16 and torch.equal(yb, y16.bfloat16())
     assert _native.lib().sei_sepmap2_bf16_eligible(2, 6, 6, 12, 12, 2048) == 0     # small levels stay on the f32 kernels
-    assert _native.lib().sei_sepmap2_bf16_eligible(2, 12, 12, 24, 24, 512) == 0
+    assert _native.lib().sei_sepmap2_bf16_eligible(2, 12, 12, 24, 24, 512) == 1    # (round 5: input extents from 12)
+    assert _native.lib().sei_sepmap2_bf16_eligible(2, 8, 8, 16, 16, 512) == 0
     assert _native.lib().sei_sepmap2_bf16_eligible(2, 96, 96, 192, 192, 128) == 0  # the x4 network's fine levels: sei_sepmap2_big
 
 
