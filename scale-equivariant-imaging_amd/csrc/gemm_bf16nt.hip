@@ -876,6 +876,11 @@ int pq_choose_rr(const NtArgs &g) {
 // one's 26-byte-per-element epilogue with the other's main loop (tools/exp_dw_adam_pq.py: 8192 x 32768 x 864 1288 us =
 // 5.5 TB/s against 1537 us on 256 x 256 quadrant tiles, 2048 x 8192 x 3456 178 against 182 us). The quadrant kernel's Adam
 // epilogue stays reachable through sei_gemm_bf16nt_dw2_adam_ex (tile 30 / 33) and is held to the loop's results by a test.
+// (The two co-resident workgroups run in phase -- both in the main loop, then both in the epilogue. Starting every CU's
+// second workgroup late by 7 - 40 us, so that one's epilogue falls under the other's main loop, only ADDS the delay:
+// tools/exp_adam_stagger.py, 2048 x 8192 x 3456 184 -> 188 ... 210 us, 8192 x 32768 x 864 1409 -> 1412 ... 1434. The main loop
+// of a 128 x 128 tile moves 1.77 MB of operands through the CU's global -> LDS path against the epilogue's 0.43 MB: both
+// phases are bound by that same path, so there is nothing to hide one under the other.)
 bool pq_adam_auto(const NtArgs &) { return false; }
 
 extern "C" int sei_colsum_bf16(const uint16_t *X, float *out, size_t M, int N, void *stream);     // bf16_support.hip
