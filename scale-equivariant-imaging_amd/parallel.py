@@ -212,8 +212,10 @@ class FlatGradientReducer:
         current stream behind them."""
         s, e = self.bounds[k]
         lo, hi = self.own_slice(k)
+        in_place = self._in_place()
         for buf in buffers:
-            src = buf[lo:hi].clone()              # (gloo has no in-place form; a 1/world copy of the chunk)
+            # RCCL: the in-place form (send buffer = this rank's slot of the receive buffer); gloo has none: a 1/world copy
+            src = buf[lo:hi] if in_place else buf[lo:hi].clone()
             self._gather_work.append(dist.all_gather_into_tensor(buf[s:e], src, group=self.group, async_op=True))
 
     def gathered_gradient(self):
@@ -232,14 +234,32 @@ class FlatGradientReducer:
             w.wait()
         self._gather_work = []
 
+    def _in_place(self):
+        """RCCL / NCCL take the in-place forms of both halves -- the reduce-scatter's output is this rank's slot of its
+        input, the all-gather's input is this rank's slot of its output (recvbuff == sendbuff + rank * count): no share
+        buffers, no 1/world staging copies, and with one rank (secondary.dist1) no copy at all. gloo has no such form.
+        SEI_EXCHANGE_OUT_OF_PLACE=1 restores the separate share buffers."""
+        return (dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+                and os.environ.get("SEI_EXCHANGE_OUT_OF_PLACE") != "1")
+
+    def _share_buffer(self, k, chunk, world):
+        """Where chunk k's reduce-scatter delivers this rank's share: its own slot of the chunk (in place) or a buffer."""
+        n = chunk.numel() // world
+        if self._in_place():
+            r = dist.get_rank(self.group)
+            share = self._shards[k] = chunk[r * n:(r + 1) * n]
+            return share
+        share = self._shards.get(k)
+        if share is None or share.numel() != n or share.dtype != chunk.dtype or share._base is not None:
+            share = self._shards[k] = torch.empty(n, dtype=chunk.dtype, device=chunk.device)
+        return share
+
     def _exchange(self, k):
         s, e = self.bounds[k]
         chunk = self.comm[s:e]
         world = dist.get_world_size(self.group)
         if self.is_sharded(k):
-            share = self._shards.get(k)
-            if share is None or share.numel() != (e - s) // world or share.dtype != chunk.dtype:
-                share = self._shards[k] = torch.empty((e - s) // world, dtype=chunk.dtype, device=chunk.device)
+            share = self._share_buffer(k, chunk, world)
             self._work[k] = dist.reduce_scatter_tensor(share, chunk, op=dist.ReduceOp.SUM, group=self.group,
                                                        async_op=True)
             return
@@ -249,9 +269,7 @@ class FlatGradientReducer:
             warnings.warn(f"FlatGradientReducer: chunk [{s}, {e}) cannot be cut into {world} aligned shares; it is "
                           "all-reduced and every rank steps the whole of it")
         if self.mode == "rs_ag" and (e - s) % world == 0:
-            share = self._shards.get(k)
-            if share is None or share.numel() != (e - s) // world:
-                share = self._shards[k] = torch.empty((e - s) // world, dtype=chunk.dtype, device=chunk.device)
+            share = self._share_buffer(k, chunk, world)
             rs = dist.reduce_scatter_tensor(share, chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if dist.get_backend(self.group) != "nccl":
                 rs.wait()             # gloo runs async work on a thread pool: order the two halves by hand
