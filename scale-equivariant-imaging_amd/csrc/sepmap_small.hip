@@ -99,6 +99,67 @@ __global__ __launch_bounds__(SS_THREADS) void sepmap_small_kernel(const float *_
     }
 }
 
+// The same map with NO LDS and no barrier (3 x 3 and 6 x 6 inputs: the deep levels of a 48-pixel crop): a WAVE item is one
+// image x 64 channels, lane = channel; the HI x WI inputs of the lane's channel sit in registers, both passes run there,
+// the coefficients come through the scalar cache. The staged kernel above spends two workgroup barriers per 2 - 9 KB tile
+// and, with 6 output columns on 4 waves, leaves two waves idle in every second round; here waves never wait for one
+// another and 32 of them fit a CU. Same FMA order: bit-identical results. tools/exp_sepmap_small.py, us per launch, staged
+// -> this kernel (64 / 96 images): 3 -> 6 at 8192 channels 34.7 -> 19.8 / 48.3 -> 25.0 (4.8 / 5.7 TB/s), 6 -> 12 at 2048
+// 40.4 -> 27.9 / 51.0 -> 33.6, 6 -> 3 at 2048 11.5 -> 11.4 / 12.5 -> 11.0. (Extents as template arguments: with run-time
+// extents the 64 load offsets took 128 SGPRs and the kernel spilled 255 of them.)
+template <int HI, int WI>
+__global__ __launch_bounds__(SS_THREADS) void sepmap_small_wave_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                       const float *__restrict__ L1, const float *__restrict__ R1,
+                                                                       const float *__restrict__ L2, const float *__restrict__ R2,
+                                                                       SsGeom g, int items) {
+    const int Ho = g.Ho, Wo = g.Wo, C = g.C;
+    const int groups = C / SS_CH;
+    const int c = threadIdx.x & 63;
+    const int w0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int item = blockIdx.x * (SS_THREADS / 64) + w0; item < items; item += gridDim.x * (SS_THREADS / 64)) {
+        const int b = item / groups, c0 = (item - b * groups) * SS_CH;
+        const float *xb = x + (size_t)b * HI * WI * C + c0 + c;
+        float xin[HI][WI];
+#pragma unroll
+        for (int hi = 0; hi < HI; ++hi)
+#pragma unroll
+            for (int wi = 0; wi < WI; ++wi) xin[hi][wi] = xb[(size_t)(hi * WI + wi) * C];
+        for (int wo = 0; wo < Wo; ++wo) {
+            const float *r1p = R1 + wo * WI, *r2p = R2 + wo * WI;
+            float t1[HI], t2[HI];
+#pragma unroll
+            for (int hi = 0; hi < HI; ++hi) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int wi = 0; wi < WI; ++wi) {
+                    a1 = fmaf(r1p[wi], xin[hi][wi], a1);
+                    a2 = fmaf(r2p[wi], xin[hi][wi], a2);
+                }
+                t1[hi] = a1;
+                t2[hi] = a2;
+            }
+            const size_t ybase = ((size_t)b * Ho * Wo + wo) * C + c0 + c;
+            float *yb = y + ybase;
+            unsigned short *yb16 = reinterpret_cast<unsigned short *>(y) + ybase;
+            for (int ho = 0; ho < Ho; ++ho) {
+                const float *l1p = L1 + ho * HI, *l2p = L2 + ho * HI;
+                float acc = 0.f;
+#pragma unroll
+                for (int hi = 0; hi < HI; ++hi) {
+                    acc = fmaf(l1p[hi], t1[hi], acc);
+                    acc = fmaf(l2p[hi], t2[hi], acc);
+                }
+                if (g.out16) {
+                    const __bf16 h = (__bf16)acc;
+                    yb16[(size_t)ho * Wo * C] = __builtin_bit_cast(unsigned short, h);
+                } else {
+                    yb[(size_t)ho * Wo * C] = acc;
+                }
+            }
+        }
+    }
+}
+
 inline bool ss_plan(int B, int Hi, int Wi, int Ho, int Wo, int C) {
     if (B <= 0 || C <= 0 || C % SS_CH != 0) return false;
     if (Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || Hi > SS_MAX_IN || Wi > SS_MAX_IN || Ho > SS_MAX_OUT || Wo > SS_MAX_OUT)
@@ -121,6 +182,17 @@ int ss_launch(const float *x, float *y, const float *L1, const float *R1, const 
     return sei_launch_status();
 }
 
+template <int HI, int WI>
+int ss_launch_wave(const float *x, float *y, const float *L1, const float *R1, const float *L2, const float *R2,
+                   const SsGeom &g, hipStream_t s) {
+    const int items = g.B * (g.C / SS_CH);                      // wave items: four per workgroup
+    const int wgs = (items + 3) / 4;
+    const int grid = wgs < 256 * 8 ? wgs : 256 * 8;            // 29 - 62 VGPRs: eight workgroups (32 waves) per CU
+    hipLaunchKernelGGL((sepmap_small_wave_kernel<HI, WI>), dim3((unsigned)grid), dim3(SS_THREADS), 0, s, x, y, L1, R1, L2, R2, g,
+                       items);
+    return sei_launch_status();
+}
+
 }  // namespace
 
 // 1 when sei_sepmap2_small serves this shape (input extents <= 8, output extents <= 24, C % 64 == 0), else 0.
@@ -137,6 +209,9 @@ extern "C" int sei_sepmap2_small(const float *x, void *y, int out_bf16, int B, i
     if (!ss_plan(B, Hi, Wi, Ho, Wo, C)) return SEI_ERR_BAD_ARG;
     SsGeom g{B, Hi, Wi, Ho, Wo, C, out_bf16};
     hipStream_t s = (hipStream_t)stream;
+    // the two input shapes of a 48-pixel crop's deep levels: the barrier-free kernel, extents as template arguments
+    if (Hi == 3 && Wi == 3) return ss_launch_wave<3, 3>(x, reinterpret_cast<float *>(y), L1, R1, L2, R2, g, s);
+    if (Hi == 6 && Wi == 6) return ss_launch_wave<6, 6>(x, reinterpret_cast<float *>(y), L1, R1, L2, R2, g, s);
     const int e = Hi > Wi ? Hi : Wi;
     if (e <= 4) return ss_launch<4>(x, reinterpret_cast<float *>(y), L1, R1, L2, R2, g, s);
     return ss_launch<8>(x, reinterpret_cast<float *>(y), L1, R1, L2, R2, g, s);
