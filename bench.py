@@ -270,7 +270,7 @@ def _gemm_bytes(name, a):
     if name == "sei_gemm_bf16nt_colsum":                       # operands + the GELU' input in, the bf16 result out
         M, Nn, K = a[7:10]
         return 2 * K * (M + Nn) + M * Nn * (2 + (4 if a[11] else 0))
-    if name in ("sei_gemm_bf16nt", "sei_gemm_bf16nt_ex"):
+    if name in ("sei_gemm_bf16nt", "sei_gemm_bf16nt_ex", "sei_gemm_bf16nt_ws"):      # (_ws: the same leading arguments)
         M, Nn, K, epi = a[8:12]
         extra = sum(4 for ptr in (a[13], a[14]) if ptr) if epi != 6 else 0          # R1 / R2 (BIAS_ROWSCALE: M floats)
         return 2 * K * (M + Nn) + M * Nn * ((4 if a[6] else 0) + (2 if a[7] else 0) + extra + (2 if a[15] else 0)

@@ -32,7 +32,7 @@ extern "C" {
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
-#define SEI_ABI_VERSION 10
+#define SEI_ABI_VERSION 11
 int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
@@ -399,6 +399,28 @@ int sei_gemm_bf16nt_colsum(const uint16_t *A, int lda, int a_rmajor, const uint1
  * launch set away from what the oracle comparison covered. (The reference has no counterpart: its GEMMs are torch's,
  * src/models/convolutional.py:33-51.) */
 size_t sei_gemm_bf16nt_plan(int a_rmajor, int b_rmajor, int out_f32, int out_bf16, int M, int N, int K, int epilogue);
+
+/* Split-K through slabs (ABI 11). sei_gemm_bf16nt_ex and sei_gemm_bf16nt_colsum (colsum != NULL: D16 only,
+ * SEI_EPI_MUL_DGELU or SEI_EPI_NONE) with a caller-owned workspace for the K slices of the quadrant kernel: `ws` points to
+ * ws_bytes (>= 16 KiB) of device memory, 256-byte aligned, whose FIRST 16 KiB ARE ZERO before the first call (tile counters:
+ * every call leaves them zero again; the remainder needs no initialisation) and which only one stream uses at a time.
+ * Each K slice of a tile stores its accumulators into its slab (write-through), draws a ticket from the tile's counter, and
+ * the slice that draws the last one adds the other slabs to its registers and runs the whole epilogue: no zero-fill
+ * launch, no float atomics (1.3 TB/s chip-wide on MI355X against ~6 TB/s of plain stores), results that do not depend on
+ * the order in which slices finish when there are two of them, and EVERY epilogue may split (bf16 / GELU / GELU' results
+ * and riding column sums included), which the atomics form could not offer. No workgroup waits for another. ws = NULL, a
+ * workspace too small for the launch (16 KiB + tiles * slices * tile bytes) or a launch off the quadrant kernel: exactly
+ * the entry points above. splitk > 0 asks for that many slices where the schedule can split (tests, experiments).
+ * (The reference's GEMMs are torch's: src/models/convolutional.py:33-51, 96-150; this is how their K-heavy, row-poor
+ * shapes -- 288 ... 3456 rows at the two deepest U-Net levels -- fill 256 CUs.)
+ * sei_gemm_bf16nt_plan_ws: the schedule with a workspace of ws_bytes (as sei_gemm_bf16nt_plan; bit 15 of the split count
+ * set when the slices meet in slabs). */
+int sei_gemm_bf16nt_ws(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                       float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
+                       const float *R1, const float *R2, uint16_t *D2_16, float *colsum, void *ws, size_t ws_bytes,
+                       int tile, int splitk, void *stream);
+size_t sei_gemm_bf16nt_plan_ws(int a_rmajor, int b_rmajor, int out_f32, int out_bf16, int M, int N, int K, int epilogue,
+                               size_t ws_bytes);
 
 #ifdef SEI_TUNING
 /* Tools-only build (make tuning -> libsei_hip_tuning.so; not part of libsei_hip.so).

@@ -68,6 +68,7 @@ SIGNATURES = {
     "sei_cast_bf16_colsum_weighted": [_P, _P, _P, _P, _I, _I, _P],
     "sei_gemm_bf16nt": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sei_gemm_bf16nt_colsum": [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P],
+    "sei_gemm_bf16nt_ws": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P],
     "sei_fold_many": [_P, _I, _P],
     "sei_transpose_bf16_many": [_P, _I, _P],
     "sei_gemm_bf16nt_dw2": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
@@ -179,10 +180,11 @@ SIZE_QUERIES = {
     "sei_rowgemm_dgelu_bf16_eligible": [_L, _I, _I],
     "sei_rowgemm_ln_bf16_eligible": [_L, _I, _I],
     "sei_gemm_bf16nt_plan": [_I, _I, _I, _I, _I, _I, _I, _I],
+    "sei_gemm_bf16nt_plan_ws": [_I, _I, _I, _I, _I, _I, _I, _I, _Z],
     "sei_conv3x3_bwd_weight_parts_count": [_I, _I, _I, _I, _I, _I, _I],
     "sei_sepmap2_small_eligible": [_I, _I, _I, _I, _I, _I],
 }
-ABI_VERSION = 10      # SEI_ABI_VERSION of include/sei_hip.h this table was written against
+ABI_VERSION = 11      # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 
 
 class NativeLibraryError(RuntimeError):
@@ -214,13 +216,20 @@ def lib():
     return _lib
 
 
-def gemm_plan(a_rmajor, b_rmajor, out_f32, out_bf16, M, Nn, K, epilogue):
+def gemm_plan(a_rmajor, b_rmajor, out_f32, out_bf16, M, Nn, K, epilogue, ws_bytes=0):
     """(family, tile rows, tile columns, K splits) of the launch sei_gemm_bf16nt would make (sei_gemm_bf16nt_plan: nothing
-    is launched); family "nt" = gemm_bf16nt_kernel, "pq" = gemm_bf16pq_kernel. Raises on shapes the entry point refuses."""
-    code = lib().sei_gemm_bf16nt_plan(int(a_rmajor), int(b_rmajor), int(out_f32), int(out_bf16), M, Nn, K, epilogue)
+    is launched); family "nt" = gemm_bf16nt_kernel, "pq" = gemm_bf16pq_kernel. ws_bytes > 0: the launch sei_gemm_bf16nt_ws
+    would make with a split-K workspace of that size, and a fifth element says whether the K slices meet in slabs.
+    Raises on shapes the entry point refuses."""
+    if ws_bytes:
+        code = lib().sei_gemm_bf16nt_plan_ws(int(a_rmajor), int(b_rmajor), int(out_f32), int(out_bf16), M, Nn, K, epilogue,
+                                             int(ws_bytes))
+    else:
+        code = lib().sei_gemm_bf16nt_plan(int(a_rmajor), int(b_rmajor), int(out_f32), int(out_bf16), M, Nn, K, epilogue)
     if code == 0:
         raise NativeLibraryError("sei_gemm_bf16nt_plan: arguments sei_gemm_bf16nt would refuse")
-    return {1: "nt", 2: "pq"}[code >> 48], (code >> 32) & 0xFFFF, (code >> 16) & 0xFFFF, code & 0xFFFF
+    plan = {1: "nt", 2: "pq"}[code >> 48], (code >> 32) & 0xFFFF, (code >> 16) & 0xFFFF, code & 0x7FFF
+    return plan + (bool(code & 0x8000),) if ws_bytes else plan
 
 
 def stream():

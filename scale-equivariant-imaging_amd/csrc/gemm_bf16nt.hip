@@ -85,6 +85,18 @@ struct NtArgs {
     // grid per image; only interior rows are written, to row (b H + y - 1) W + x - 1 of D32 / R1 (the NHWC tensors),
     // with LeakyReLU(0.01) before the residual when unpad_act. unpad_W = 0: rows as they are.
     int unpad_H, unpad_W, unpad_act;
+    // Split-K through slabs (quadrant kernel, sei_gemm_bf16nt_ws): every K slice of a tile stores its accumulators into its
+    // slab of the caller's workspace (write-through), draws a ticket from the tile's counter, and the slice that draws the
+    // last one adds the other slabs to its registers and runs the WHOLE epilogue (any epilogue: the sum is complete) --
+    // no zero-fill launch, no float atomics (1.3 TB/s chip-wide: 29 us for a 288 x 128 tile's 147 KB per workgroup).
+    // ws_cnt: one counter per tile, zero between launches (the last arriver puts it back); ws_slab: tiles x splits slabs
+    // of BM x BN floats in accumulator order. nullptr: split launches add their tiles with float atomics as before.
+    float *ws_slab;
+    unsigned *ws_cnt;
+    // host-side only: the caller's workspace as handed over, and an explicit number of K slices (0 = the dispatcher's)
+    void *ws;
+    size_t ws_bytes;
+    int force_splitk;
 };
 
 typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
@@ -859,6 +871,47 @@ int pq_choose(const NtArgs &g, bool would_split) {
     return 0;
 }
 
+// With a split-K workspace (sei_gemm_bf16nt_ws): the float32-output launches above that split K -- and the ones the rules
+// above leave on the 128 x 128 loop because their atomics cost more than the split bought -- choose tile width AND slice
+// count together from a cost model in microseconds, fitted to tools/exp_splitk_slabs.py (batch 32 shapes, MI355X):
+//   per round of 256 workgroups: k-tiles per slice x c + o (+ e0 + e1 (S - 1) when split: slab store, ticket, slab reads),
+//   c = 0.95 / 1.5 us per k-tile of a 128- / 256-column tile fed from L2 / MALL (1.05 / 1.75 when the weight is too large
+//   to stay there and streams from HBM), o = 10 / 16, e0 + e1 (S - 1) = 5 + 3 (S - 1) / 8 + 5 (S - 1).
+// Model -> measured (us; today's launch in brackets): 2304 x 2048 x 8192: 128 columns, 2 slices 79 -> 80 (102, atomics);
+// 1152 x 2048 x 8192: 128, 4: 54 -> 54 (70 on the 128 x 128 loop); 3456 x 2048 x 8192: 256, 2: 125 -> 131 (154); 4608 x 512 x
+// 2048: 128, 3: 32 -> 30 (34); 576 x 8192 x 32768: 256, 4: 263 -> 269 (283); 864 x 8192 x 32768: 128, 4: 475 -> 455 (470).
+// Returns 10 * RF + NF and sets g.force_splitk, or 0 (no workspace, not such a launch: the rules above decide).
+int pq_choose_slabs(NtArgs &g, bool would_split) {
+    const int M = g.M, N = g.N, K = g.K;
+    if (!g.ws || !would_split || g.epilogue == SEI_EPI_ACCUM || g.force_tile != 0 || g.force_splitk != 0) return 0;
+    if (K < 2048 || K % BK != 0 || N < 512 || !pq_eligible(g)) return 0;
+    const int rf = M % 288 == 0 ? 9 : ((M % 256 == 0 || M >= 4096) ? 8 : 0);
+    if (!rf) return 0;
+    const size_t tm = sei_ceil_div(M, 32 * rf), kt = (size_t)K / BK;
+    const bool from_hbm = (double)N * (double)K * 2.0 >= 128.0 * 1048576.0;
+    double best = 1e30;
+    int best_nf = 0, best_sk = 1;
+    for (int nf = 2; nf <= 4; nf += 2) {
+        const size_t tiles = tm * sei_ceil_div(N, 64 * nf);
+        const double c = nf == 2 ? (from_hbm ? 1.05 : 0.95) : (from_hbm ? 1.75 : 1.5);
+        const double o = nf == 2 ? 10.0 : 16.0, e0 = nf == 2 ? 5.0 : 8.0, e1 = nf == 2 ? 3.0 : 5.0;
+        const size_t slab = (size_t)32 * rf * 64 * nf * 4;
+        for (size_t sk = 1; sk <= 16 && sk * 4 <= kt; ++sk) {
+            if (sk > 1 && (tiles > 4096 || 16384 + tiles * sk * slab > g.ws_bytes || sk * slab >= ((size_t)1 << 31))) break;
+            const double rounds = (double)sei_ceil_div(tiles * sk, 256);
+            const double cost = rounds * ((double)sei_ceil_div(kt, sk) * c + o + (sk > 1 ? e0 + e1 * (double)(sk - 1) : 0.0));
+            if (cost < best * 0.98) {
+                best = cost;
+                best_nf = nf;
+                best_sk = (int)sk;
+            }
+        }
+    }
+    if (!best_nf) return 0;
+    g.force_splitk = best_sk;
+    return 10 * rf + best_nf;
+}
+
 // Weight gradients (both operands reduction-major). Rounds 1-4 kept them all on the 128 x 128 loop: the quadrant schedule
 // tied at K = 3456 and lost at K = 864 -- measured while the compiler drained vmcnt in front of every transposing read
 // (sei_common.h, dma16_*). Re-measured with the inline-asm DMA (tools/exp_dw_pq.py, float32 store): 2048 x 8192 x 3456
@@ -888,20 +941,23 @@ extern "C" int sei_colsum_bf16(const uint16_t *X, float *out, size_t M, int N, v
 static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
                     float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
                     const float *R1, const float *R2, uint16_t *D2_16, int tile, int band,
-                    void *stream, unsigned long long *plan, float *colsum = nullptr);
+                    void *stream, unsigned long long *plan, float *colsum = nullptr, void *ws = nullptr,
+                    size_t ws_bytes = 0, int splitk = 0);
 
 // The column sums ride in the quadrant kernel's epilogue where the launch takes it unsplit with a bf16 result; any other
 // schedule is followed by the column-sum kernel over the result (same quantity, one more launch).
 static int nt_entry_colsum(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
-                           uint16_t *D16, int M, int N, int K, int epilogue, const float *R1, float *colsum, void *stream) {
+                           uint16_t *D16, int M, int N, int K, int epilogue, const float *R1, float *colsum, void *stream,
+                           void *ws = nullptr, size_t ws_bytes = 0, int tile = 0, int splitk = 0) {
     unsigned long long plan = 0;
-    int rc = nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, nullptr, D16, M, N, K, epilogue, nullptr, R1, nullptr, nullptr, 0, 0,
-                      stream, &plan);
+    int rc = nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, nullptr, D16, M, N, K, epilogue, nullptr, R1, nullptr, nullptr, tile, 0,
+                      stream, &plan, nullptr, ws, ws_bytes, splitk);
     if (rc != SEI_OK) return rc;
-    const bool rides = (plan >> 48) == 2 && (plan & 0xFFFF) == 1 && N % 4 == 0 &&
+    // (unsplit, or split through slabs: the last arriver's epilogue sees the complete tile)
+    const bool rides = (plan >> 48) == 2 && ((plan & 0xFFFF) == 1 || (plan & 0x8000) != 0) && N % 4 == 0 &&
                        (reinterpret_cast<uintptr_t>(colsum) & 15) == 0;
-    rc = nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, nullptr, D16, M, N, K, epilogue, nullptr, R1, nullptr, nullptr, 0, 0,
-                  stream, nullptr, rides ? colsum : nullptr);
+    rc = nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, nullptr, D16, M, N, K, epilogue, nullptr, R1, nullptr, nullptr, tile, 0,
+                  stream, nullptr, rides ? colsum : nullptr, ws, ws_bytes, splitk);
     if (rc != SEI_OK || rides) return rc;
     return sei_colsum_bf16(D16, colsum, (size_t)M, N, stream);
 }
@@ -909,8 +965,8 @@ static int nt_entry_colsum(const uint16_t *A, int lda, int a_rmajor, const uint1
 static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
                     float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
                     const float *R1, const float *R2, uint16_t *D2_16, int tile, int band,
-                    void *stream, unsigned long long *plan, float *colsum) {
-    SEI_REQUIRE(A && B && (D32 || D16) && M > 0 && N > 0 && K > 0);
+                    void *stream, unsigned long long *plan, float *colsum, void *ws, size_t ws_bytes, int splitk) {
+    SEI_REQUIRE(A && B && (D32 || D16) && M > 0 && N > 0 && K > 0 && splitk >= 0);
     SEI_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0);
     SEI_REQUIRE(lda >= (a_rmajor ? M : K) && ldb >= (b_rmajor ? N : K));
     if (a_rmajor) SEI_REQUIRE(M % 8 == 0);
@@ -928,6 +984,7 @@ static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
     if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU) SEI_REQUIRE(R1);
     if (epilogue == SEI_EPI_ACCUM) SEI_REQUIRE(D32 && !D16);
     NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.A = A; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
     g.A2 = A; g.B2 = B; g.k_seg = K;                       // one reduction segment
@@ -935,6 +992,7 @@ static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
     g.batch = 1;
     g.plan = plan;
     g.colsum = colsum;
+    g.ws = ws; g.ws_bytes = ws ? ws_bytes : 0; g.force_splitk = splitk;
     SEI_REQUIRE(tile >= 0 && band >= 0);
     if (epilogue == SEI_EPI_BIAS_SCALE_RES && tile == 0)                // the quadrant kernel has no such epilogue
         tile = (N > 128 && N <= 192) ? 6 : 1;
@@ -1015,8 +1073,10 @@ static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
         return launch_nt<2, 1, 2, 4, true, true>(g, s);
     }
     if (a_rmajor) return launch_nt<2, 1, 2, 4, true, false>(g, s);
+    // (slabs serve every epilogue: also the convolution behind the downsampler, float32 out with its bias scaled per row)
+    const int slab_code = pq_choose_slabs(g, would_split || (epilogue == SEI_EPI_BIAS_ROWSCALE && D32 && !D16));
     if (b_rmajor) {
-        switch (pq_choose(g, would_split)) {
+        switch (slab_code ? slab_code : pq_choose(g, would_split)) {
             case 94: return launch_pq<9, 4, false, true>(g, s);
             case 92: return launch_pq<9, 2, false, true>(g, s);
             case 84: return launch_pq<8, 4, false, true>(g, s);
@@ -1049,7 +1109,7 @@ static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
     // 110 vs 144 us for 192x256). Skinny outputs (the 8192-channel bottleneck: M = 288 or 576 rows against
     // N = 8192 / 32768) are weight-streaming: there 192x256 wins (M = 288: 221 vs 309 us), padding included,
     // and 96x256 never does. A 256x256 tile on this loop needs the rolled epilogue of gemm_bf16pp.h.
-    switch (pq_choose(g, would_split)) {
+    switch (slab_code ? slab_code : pq_choose(g, would_split)) {
         case 94: return launch_pq<9, 4>(g, s);
         case 92: return launch_pq<9, 2>(g, s);
         case 84: return launch_pq<8, 4>(g, s);
@@ -1091,12 +1151,45 @@ extern "C" int sei_gemm_bf16nt_colsum(const uint16_t *A, int lda, int a_rmajor, 
     return nt_entry_colsum(A, lda, a_rmajor, B, ldb, b_rmajor, D16, M, N, K, epilogue, R1, colsum, stream);
 }
 
+// sei_gemm_bf16nt / sei_gemm_bf16nt_colsum with a split-K workspace (NtArgs::ws_slab): `ws` = ws_bytes of device memory,
+// 256-byte aligned, whose first 16 KiB are ZERO before the first call and are left zero by every call (tile counters; the
+// rest needs no initialisation), used by ONE stream at a time. Launches of the quadrant kernel that split K then meet in
+// slabs instead of float atomics, and launches whose epilogue the atomics could not serve (bf16 / GELU / GELU' results,
+// riding column sums) may split too. ws = nullptr: exactly sei_gemm_bf16nt_ex / sei_gemm_bf16nt_colsum. colsum != nullptr
+// asks for sei_gemm_bf16nt_colsum's semantics (D16 only, SEI_EPI_MUL_DGELU or SEI_EPI_NONE). tile as sei_gemm_bf16nt_ex;
+// splitk > 0 asks for that many K slices where the schedule can split at all (experiments, tests), 0 = automatic.
+extern "C" int sei_gemm_bf16nt_ws(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
+                                  float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
+                                  const float *R1, const float *R2, uint16_t *D2_16, float *colsum, void *ws,
+                                  size_t ws_bytes, int tile, int splitk, void *stream) {
+    SEI_REQUIRE(tile >= 0 && splitk >= 0 && (ws == nullptr || ws_bytes >= 16384));
+    if (colsum) {
+        SEI_REQUIRE(D16 && !D32 && (epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_NONE));
+        return nt_entry_colsum(A, lda, a_rmajor, B, ldb, b_rmajor, D16, M, N, K, epilogue, R1, colsum, stream, ws, ws_bytes,
+                               tile, splitk);
+    }
+    return nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, D32, D16, M, N, K, epilogue, bias, R1, R2, D2_16, tile, 0, stream,
+                    nullptr, nullptr, ws, ws_bytes, splitk);
+}
+
 // The schedule sei_gemm_bf16nt would take for these shapes, launching nothing (host arithmetic only, no GPU needed):
 // (family << 48) | (tile rows << 32) | (tile columns << 16) | K splits, family 1 = the 128 x 128 loop's kernel
 // (gemm_bf16nt_kernel, whatever its tile), 2 = the quadrant schedule (gemm_bf16pq_kernel); 0 = arguments the entry point
 // would refuse. Operands are taken as densely packed and 16-byte aligned, which is what models/_ops.py passes.
+static size_t nt_plan(int a_rmajor, int b_rmajor, int out_f32, int out_bf16, int M, int N, int K, int epilogue,
+                      size_t ws_bytes);
 extern "C" size_t sei_gemm_bf16nt_plan(int a_rmajor, int b_rmajor, int out_f32, int out_bf16, int M, int N, int K,
                                        int epilogue) {
+    return nt_plan(a_rmajor, b_rmajor, out_f32, out_bf16, M, N, K, epilogue, 0);
+}
+// ... and the schedule sei_gemm_bf16nt_ws would take with a workspace of ws_bytes (bit 15 of the split count set: the K
+// slices meet in slabs).
+extern "C" size_t sei_gemm_bf16nt_plan_ws(int a_rmajor, int b_rmajor, int out_f32, int out_bf16, int M, int N, int K,
+                                          int epilogue, size_t ws_bytes) {
+    return nt_plan(a_rmajor, b_rmajor, out_f32, out_bf16, M, N, K, epilogue, ws_bytes);
+}
+static size_t nt_plan(int a_rmajor, int b_rmajor, int out_f32, int out_bf16, int M, int N, int K, int epilogue,
+                      size_t ws_bytes) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const uint16_t *fake16 = reinterpret_cast<const uint16_t *>(uintptr_t(1) << 20);      // never dereferenced
     float *fake32 = reinterpret_cast<float *>(uintptr_t(1) << 20);
@@ -1109,7 +1202,8 @@ extern "C" size_t sei_gemm_bf16nt_plan(int a_rmajor, int b_rmajor, int out_f32, 
                             out_f32 ? fake32 : nullptr, out_bf16 ? const_cast<uint16_t *>(fake16) : nullptr, M, N, K,
                             epilogue, with_bias ? fake32 : nullptr, with_r1 ? fake32 : nullptr,
                             epilogue == SEI_EPI_BIAS_SCALE_RES ? fake32 : nullptr,
-                            epilogue == SEI_EPI_BIAS_GELU ? const_cast<uint16_t *>(fake16) : nullptr, 0, 0, nullptr, &plan);
+                            epilogue == SEI_EPI_BIAS_GELU ? const_cast<uint16_t *>(fake16) : nullptr, 0, 0, nullptr, &plan,
+                            nullptr, ws_bytes ? fake32 : nullptr, ws_bytes, 0);
     return rc == SEI_OK ? (size_t)plan : 0;
 }
 
@@ -1121,6 +1215,7 @@ extern "C" int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, in
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
     NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
@@ -1160,6 +1255,7 @@ extern "C" int sei_gemm_bf16nt_dw2_adam_ex(const uint16_t *A1, const uint16_t *A
     SEI_REQUIRE((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
                 ((uintptr_t)param_bf16 & 7) == 0);              // the epilogue moves whole quads
     NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = param; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = SEI_EPI_NONE;
@@ -1196,6 +1292,7 @@ extern "C" int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0 && ((uintptr_t)D16 & 7) == 0);
     NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = nullptr; g.D16 = D16; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = SEI_EPI_NONE;
@@ -1217,6 +1314,7 @@ extern "C" int sei_gemm_bf16nt_dw2_taps(const uint16_t *A1, const uint16_t *A2, 
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
     NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
     g.epilogue = accumulate ? SEI_EPI_ACCUM : SEI_EPI_NONE;
@@ -1247,6 +1345,7 @@ extern "C" int sei_gemm_bf16nt_conv(const uint16_t *Ap, int cin_pad, const int *
     SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS);
     if (epilogue == SEI_EPI_BIAS) SEI_REQUIRE(bias);
     NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.batch = 1;
     g.A = Ap; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = 9 * cin_pad; g.lda = cin_pad; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = nullptr; g.R2 = nullptr; g.D2_16 = nullptr;
@@ -1271,6 +1370,7 @@ extern "C" int sei_gemm_bf16nt_conv_unpad(const uint16_t *Ap, int cin_pad, const
     NtArgs g;
     g.plan = nullptr;
     g.colsum = nullptr;
+    g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.batch = 1;
     g.A = Ap; g.B = B; g.D32 = y; g.D16 = nullptr; g.M = Bimg * (H + 2) * (W + 2); g.N = N; g.K = 9 * cin_pad;
     g.lda = cin_pad; g.ldb = ldb;

@@ -521,10 +521,69 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     if (wr == 0) bar();                               // rebalance the barrier count of the two groups
     }
 
+    // ---- split K through slabs (NtArgs::ws_slab; cdna_hip_programming.md, "in-launch split-K reduction", the ticket form
+    // with write-through stores): every slice stores its accumulators as they stand -- (i, f) fragment of thread tid at
+    // float4 index (i NF + f) NT + tid of the slice's slab: 1 KiB of whole lines per wave-instruction, sc1 --, drains its
+    // stores, and after a workgroup barrier ONE lane draws the tile's ticket (agent-scope add). The slice that draws the
+    // last ticket puts the counter back to zero, acquires once, adds the other slices' slabs to its registers (sc1 loads)
+    // and goes on as an UNSPLIT launch's workgroup would: every epilogue is available, nothing is zero-filled and no
+    // float atomic is issued. No workgroup waits for another one, so there is nothing here that dispatch order, placement
+    // or residency can stall. (All slices of a tile land on one XCD with this block order -- bid % 8 does not depend on
+    // zs --, which the protocol does not rely on.)
+    const bool slabs = g.splitk > 1 && g.ws_slab != nullptr;
+    if (slabs) {
+        constexpr unsigned SLAB_BYTES = (unsigned)G::BM * G::BN * 4u;
+        typedef unsigned pq_u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            g.ws_slab + (size_t)ord * g.splitk * (G::BM * G::BN), 0, (int)(SLAB_BYTES * (unsigned)g.splitk), 0x00020000);
+        const unsigned lane_off = (unsigned)threadIdx.x * 16u;
+        const unsigned mine = (unsigned)zs * SLAB_BYTES;
+#pragma unroll
+        for (int i = 0; i < RF; ++i)
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pq_u32x4, acc[i][f]), rs,
+                                                       mine + (unsigned)(i * NF + f) * (NT * 16u) + lane_off, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave, before the barrier in front of the ticket
+        __syncthreads();
+        volatile unsigned *mail = reinterpret_cast<volatile unsigned *>(smem);     // (the stages are free: no second LDS object)
+        if (threadIdx.x == 0)
+            mail[0] = __hip_atomic_fetch_add(g.ws_cnt + ord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned ticket = mail[0];
+        if (ticket != (unsigned)g.splitk - 1u) return;            // workgroup-uniform: the slab is this slice's whole result
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(g.ws_cnt + ord, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                          // (also: every thread has read the mail word)
+        constexpr int IB = RF % 3 == 0 ? 3 : (NF == 4 ? 2 : 4);   // fragment rows per batch: 6-12 loads of 16 B in flight per lane
+        static_assert(RF % IB == 0, "whole batches");
+#pragma unroll 1
+        for (int sl = 0; sl < g.splitk; ++sl) {
+            if (sl == zs) continue;
+            const unsigned theirs = (unsigned)sl * SLAB_BYTES + lane_off;
+#pragma unroll
+            for (int i0 = 0; i0 < RF; i0 += IB) {
+                pq_u32x4 t[IB][NF];
+#pragma unroll
+                for (int i = 0; i < IB; ++i)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+                        t[i][f] = __builtin_amdgcn_raw_buffer_load_b128(rs, theirs + (unsigned)((i0 + i) * NF + f) * (NT * 16u), 0, 16);
+#pragma unroll
+                for (int i = 0; i < IB; ++i)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) acc[i0 + i][f] += __builtin_bit_cast(f32x4, t[i][f]);
+            }
+        }
+    }
+
     // ---- epilogue through a wave-private LDS patch: 16 rows x 16 NF columns at a time ------------------------
     const int epi = g.epilogue;
     const bool lead = zs == 0;
-    const bool split = g.splitk > 1;
+    const bool split = g.splitk > 1 && !slabs;         // (float atomics; a slab launch's last arriver holds the complete sum)
     constexpr int LDW = G::EPI_LDW;
     float *patch = reinterpret_cast<float *>(smem) + wave * 16 * LDW;
     constexpr int LPR = 4 * NF;                        // lanes per patch row (one float4 each)
@@ -757,17 +816,34 @@ int launch_pq(NtArgs &g, hipStream_t s) {
     g.tiles_per_xcd = (int)sei_ceil_div(tiles, 8);
     g.splitk = 1;
     g.k_per_split = g.K;
+    g.ws_slab = nullptr;
+    g.ws_cnt = nullptr;
+    const size_t ktiles = sei_ceil_div(g.K, BK);
     const bool splittable = g.epilogue == SEI_EPI_NONE || g.epilogue == SEI_EPI_BIAS ||
                             g.epilogue == SEI_EPI_BIAS_RES || g.epilogue == SEI_EPI_ACCUM;
-    if (!ADAM && splittable && g.D32 && !g.D16 && g.K >= 8 * BK) {         // (the Adam epilogue needs the complete sum)
-        const size_t slots = 256, ktiles = sei_ceil_div(g.K, BK);
+    const bool atomics_ok = splittable && g.D32 && !g.D16;               // partial sums added into a zero-filled float output
+    // slabs (NtArgs::ws_slab): a 16-KiB block of tile counters, then tiles x splits slabs; any epilogue but ACCUM's running sum
+    // (whose atomics need no zero fill) and Adam's; a workspace too small for the launch leaves it on the atomics / unsplit
+    constexpr size_t WS_HEAD = 16384, SLAB = (size_t)G::BM * G::BN * 4;
+    auto slabs_fit = [&](size_t sk) {
+        return g.ws != nullptr && (reinterpret_cast<uintptr_t>(g.ws) & 255) == 0 && tiles <= WS_HEAD / 4 &&
+               g.ws_bytes >= WS_HEAD + tiles * sk * SLAB && sk * SLAB < ((size_t)1 << 31);
+    };
+    const bool slabs_ok = !ADAM && g.epilogue != SEI_EPI_ACCUM && slabs_fit(2);
+    if (!ADAM && (atomics_ok || slabs_ok) && g.K >= 8 * BK) {            // (the Adam epilogue needs the complete sum)
+        const size_t slots = 256;
         const size_t max_sk = ktiles / 4 < 16 ? ktiles / 4 : 16;
+        // in k-tile times: prologue + epilogue of every workgroup; split launches pay the slab store, the ticket and one
+        // slab read per further slice (slabs) or the atomics (modelled at 2: measured 30-60 k-tile times per workgroup,
+        // which is why the model kept most launches unsplit)
         const double overhead = 8.0 + (g.epilogue == SEI_EPI_ACCUM ? 0.0 : 2.0);
         double best = 1e30;
         size_t best_sk = 1;
         for (size_t sk = 1; sk <= max_sk; ++sk) {
+            if (sk > 1 && slabs_ok && !slabs_fit(sk)) break;
             const double rounds = (double)sei_ceil_div(tiles * sk, slots);
-            const double cost = rounds * ((double)sei_ceil_div(ktiles, sk) + overhead + (sk > 1 ? 2.0 : 0.0));
+            const double extra = sk == 1 ? 0.0 : (slabs_ok ? 6.0 + 3.0 * (double)(sk - 1) : 2.0);
+            const double cost = rounds * ((double)sei_ceil_div(ktiles, sk) + overhead + extra);
             if (cost < best * 0.97) {
                 best = cost;
                 best_sk = sk;
@@ -776,16 +852,27 @@ int launch_pq(NtArgs &g, hipStream_t s) {
 #ifdef SEI_TUNING
         if (g_tuning_splitk > 0) best_sk = (size_t)g_tuning_splitk < ktiles ? (size_t)g_tuning_splitk : ktiles;
 #endif
+        if (g.force_splitk > 0 && (size_t)g.force_splitk <= ktiles && (atomics_ok || slabs_fit((size_t)g.force_splitk)))
+            best_sk = (size_t)g.force_splitk;
         if (best_sk > 1) {
             g.k_per_split = (int)(sei_ceil_div(ktiles, best_sk) * BK);
             g.splitk = (int)sei_ceil_div(g.K, g.k_per_split);
+            if (slabs_ok && g.splitk > 1 && slabs_fit((size_t)g.splitk)) {
+                g.ws_cnt = reinterpret_cast<unsigned *>(g.ws);
+                g.ws_slab = reinterpret_cast<float *>(reinterpret_cast<char *>(g.ws) + WS_HEAD);
+            } else if (!atomics_ok) {
+                g.splitk = 1;
+                g.k_per_split = g.K;
+            }
         }
     }
     if (g.plan) {
-        *g.plan = (2ull << 48) | ((unsigned long long)G::BM << 32) | ((unsigned long long)G::BN << 16) | (unsigned)g.splitk;
+        // (bit 15 of the split count: the slices meet in slabs, not in float atomics)
+        *g.plan = (2ull << 48) | ((unsigned long long)G::BM << 32) | ((unsigned long long)G::BN << 16) | (unsigned)g.splitk |
+                  (g.ws_slab ? 0x8000u : 0u);
         return SEI_OK;
     }
-    if (g.splitk > 1 && g.epilogue != SEI_EPI_ACCUM) {
+    if (g.splitk > 1 && g.ws_slab == nullptr && g.epilogue != SEI_EPI_ACCUM) {
         const size_t n = (size_t)g.M * g.N;
         size_t zg = sei_ceil_div(n / 4 + 1, 256);
         if (zg > 2048) zg = 2048;

@@ -158,6 +158,23 @@ def gemm(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2
 
 _JOINT_SPLIT = None      # (B1, B2) while one backward pass serves the step's two model calls (joint_rows), else None
 
+# Split-K workspace of the quadrant GEMM (sei_gemm_bf16nt_ws, include/sei_hip.h): one per (device, stream), created on first
+# use with its 16-KiB block of tile counters zero -- every launch leaves them zero --, kept for the life of the process.
+# SEI_SPLITK_WS_MIB = 0 puts the split launches back on float atomics (sei_gemm_bf16nt / _colsum: the round-1..5 path).
+SPLITK_WS_MIB = int(os.environ.get("SEI_SPLITK_WS_MIB", "256"))
+_SPLITK_WS = {}
+
+
+def splitk_workspace(device):
+    """(pointer, bytes) of this stream's split-K workspace, or (None, 0) when switched off."""
+    if SPLITK_WS_MIB <= 0:
+        return None, 0
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = _SPLITK_WS[key] = torch.zeros(SPLITK_WS_MIB << 20, dtype=torch.uint8, device=device)
+    return ws.data_ptr(), ws.numel()
+
 
 def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=None, R2=None, D2_16=None,
               lda=None, ldb=None, a_rmajor=False, b_rmajor=False, tile=0, band=0, flops=None, _whole=False, colsum=None):
@@ -203,15 +220,22 @@ def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=Non
     args = (A16.data_ptr(), lda, int(a_rmajor), B16.data_ptr(), ldb, int(b_rmajor), N.ptr(out32), N.ptr(out16), M, Nn,
             K, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2_16))
     fl = 2.0 * M * Nn * K if flops is None else float(flops)
+    ws, ws_bytes = (None, 0) if (tile or band or a_rmajor) else splitk_workspace(A16.device)
     if colsum is not None:
         if out32 is not None or out16 is None or epi not in (EPI_NONE, EPI_MUL_DGELU) or tile or band or bias is not None \
                 or R2 is not None or D2_16 is not None:
             raise ValueError("gemm_nt16(colsum=): a bf16 result with EPI_NONE / EPI_MUL_DGELU on the automatic dispatch")
+        if ws is not None:
+            _gemm_call(fl, "sei_gemm_bf16nt_ws", *args, colsum.data_ptr(), ws, ws_bytes, 0, 0)
+            return
         _gemm_call(fl, "sei_gemm_bf16nt_colsum", A16.data_ptr(), lda, int(a_rmajor), B16.data_ptr(), ldb, int(b_rmajor),
                    out16.data_ptr(), M, Nn, K, epi, N.ptr(R1), colsum.data_ptr())
         return
     if tile or band:
         _gemm_call(fl, "sei_gemm_bf16nt_ex", *args, int(tile), int(band))
+    elif ws is not None:
+        # (K slices of the quadrant kernel meet in slabs of the workspace: no zero fill, no float atomics)
+        _gemm_call(fl, "sei_gemm_bf16nt_ws", *args, None, ws, ws_bytes, 0, 0)
     else:
         _gemm_call(fl, "sei_gemm_bf16nt", *args)
 

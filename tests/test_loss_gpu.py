@@ -239,6 +239,11 @@ def _launch_plans(records):
             fam, bm, bn, sk = _native.gemm_plan(a[2], a[5], False, True, M, Nn, K, epi)
             plans.setdefault((fam, bm, bn), set()).add((M, Nn, K, sk))
             continue
+        if entry == "sei_gemm_bf16nt_ws":                   # (split-K workspace: slices meet in slabs where they split)
+            M, Nn, K, epi = a[8:12]
+            fam, bm, bn, sk, _ = _native.gemm_plan(a[2], a[5], bool(a[6]), bool(a[7]), M, Nn, K, epi, ws_bytes=a[18])
+            plans.setdefault((fam, bm, bn), set()).add((M, Nn, K, sk))
+            continue
         if entry != "sei_gemm_bf16nt":
             continue
         M, Nn, K, epi = a[8:12]

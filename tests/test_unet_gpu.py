@@ -1058,6 +1058,69 @@ def test_gemm_with_the_result_s_column_sums_in_the_epilogue(ops, M, N, K, brm):
     assert relerr(plain, plain16.double().sum(0)) < 2e-6
 
 
+@pytest.mark.parametrize("M,Nn,K,brm,kind,tile", [(1152, 2048, 8192, 0, "res", 32), (576, 2048, 4096, 1, "none", 31),
+                                                  (288, 4096, 2048, 0, "gelu", 32), (576, 1024, 2048, 1, "dgelu", 31),
+                                                  (512, 640, 1024, 0, "res", 33), (300, 520, 1032, 1, "none", 30),
+                                                  (864, 2048, 8192, 1, "none", 0)])
+def test_split_k_through_slabs(ops, M, Nn, K, brm, kind, tile):
+    """sei_gemm_bf16nt_ws (ABI 11): the quadrant kernel's K slices meet in slabs of a caller-owned workspace -- stored
+    write-through, one ticket per slice, the last arriver adds the others and runs the WHOLE epilogue -- against the unsplit
+    launch of the same tile: equal to float32 rounding of the regrouped sum for every epilogue (bias + residual, plain,
+    bias + GELU with two results, GELU' with a bf16 result and riding column sums), both weight orientations, 288- and
+    256-row tiles of both widths, ragged edges, 2 ... 8 slices. Two slices are bit-reproducible (a + b = b + a whichever
+    arrives last). The tile counters are zero again after every launch, so launches repeat on the same workspace; the
+    slab region is filled with NaNs and READ (the XCDs' L2s then hold stale lines of it) before the launches. tile = 0: the
+    automatic choice (cost model of pq_choose_slabs) with and without the workspace."""
+    import _native as N
+    gen = torch.Generator().manual_seed(M + Nn + K)
+    A = torch.randn((M, K), generator=gen).bfloat16().cuda()
+    B = (torch.randn((K, Nn) if brm else (Nn, K), generator=gen) / K ** 0.5).bfloat16().cuda()
+    bias, R1 = torch.randn(Nn, generator=gen).cuda(), torch.randn((M, Nn), generator=gen).cuda()
+    ws_bytes = 64 << 20
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device="cuda")
+    ws[16384:].view(torch.float32).fill_(float("nan"))
+    assert bool(torch.isnan(ws[16384:].view(torch.float32).sum()))            # (a pass of plain loads over every slab line)
+    epi = {"res": ops.EPI_BIAS_RES, "none": ops.EPI_NONE, "gelu": ops.EPI_BIAS_GELU, "dgelu": ops.EPI_MUL_DGELU}[kind]
+
+    def run(workspace, splitk):
+        d32 = torch.full((M, Nn), 7.0, device="cuda") if kind != "dgelu" else None
+        d16 = torch.full((M, Nn), 7.0, device="cuda", dtype=torch.bfloat16) if kind == "dgelu" else None
+        d2 = torch.full((M, Nn), 7.0, device="cuda", dtype=torch.bfloat16) if kind == "gelu" else None
+        cs = torch.ones(Nn, device="cuda") if kind == "dgelu" else None
+        N.call("sei_gemm_bf16nt_ws", A.data_ptr(), K, 0, B.data_ptr(), Nn if brm else K, brm, N.ptr(d32), N.ptr(d16), M, Nn, K,
+               epi, bias.data_ptr() if kind in ("res", "gelu") else None, R1.data_ptr() if kind in ("res", "dgelu") else None,
+               None, N.ptr(d2), N.ptr(cs), None if workspace is None else workspace.data_ptr(),
+               0 if workspace is None else ws_bytes, tile, splitk)
+        torch.cuda.synchronize()
+        return tuple(t for t in (d32, d16, d2, cs) if t is not None)
+
+    def counters():
+        return int(ws[:16384].view(torch.int32).abs().sum())
+
+    base = run(None, 1 if tile else 0)
+    if tile == 0:
+        fam, bm, bn, sk, slabs = N.gemm_plan(0, brm, True, False, M, Nn, K, epi, ws_bytes=ws_bytes)
+        assert (fam, bm, bn, slabs) == ("pq", 288, 128, True) and sk > 1, (fam, bm, bn, sk, slabs)
+        got = run(ws, 0)
+        assert relerr(got[0], base[0]) < 3e-6 and counters() == 0
+        return
+    tried = 0
+    for sk in (2, 3, 4, 8):
+        if K // 64 < 4 * sk:
+            continue
+        tried += 1
+        got, again = run(ws, sk), run(ws, sk)
+        assert counters() == 0, "tile counters are zero between launches"
+        for g_, a_, b_ in zip(got, again, base):
+            # (bf16 results: single values move by one ulp where the regrouped float32 sum rounds the other way, and the
+            # column sums of those values with them)
+            tol = 2e-2 if g_.dtype == torch.bfloat16 else (5e-3 if g_.dim() == 1 else 3e-6)
+            assert relerr(g_, b_) < tol and relerr(a_, b_) < tol, (sk, g_.dtype, g_.dim())
+            if sk == 2 and g_.dim() == 2:
+                assert torch.equal(g_, a_), "two slices: the sum does not depend on which one arrives last"
+    assert tried >= 2
+
+
 @pytest.mark.parametrize("M,Nn,K1,K2", [(2048, 6144, 640, 1032), (512, 768, 96, 200), (2048, 8192, 1152, 2304)])
 def test_adam_epilogue_of_the_quadrant_schedule(M, Nn, K1, K2):
     """sei_gemm_bf16nt_dw2_adam_ex: the quadrant kernel's Adam epilogue (tiles 30 / 33: 256 x 256 / 256 x 128) against the
