@@ -301,6 +301,104 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_vec_kernel(
     }
 }
 
+// wide rows in ONE pass (C = 1024 NV, NV <= 8; round 5): a workgroup takes whole rows -- a thread owns NV float4 of the row,
+// 1 KiB apart, so x and gy are read ONCE (the two-pass form below reads both twice: 565 MB per 113-MB tensor where this one
+// moves 340 MB + the partials) --, folds the row's two sums over its four waves through LDS, writes gx, and keeps the
+// parameter-gradient partials of ITS rows in registers: part[workgroup][2 C] for sei_fold_many / ln_bwd_fold_kernel.
+// The next row's loads are issued before the current row's sums are exchanged.
+template <int NV>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_row_kernel(
+    const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gy, const float *__restrict__ res,
+    float *__restrict__ gx, float *__restrict__ part, size_t rows) {
+    constexpr int C = 1024 * NV;
+    __shared__ float red[2][2][LN_THREADS / 64];               // [row parity][sum][wave]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float invC = 1.0f / (float)C;
+    float4 gam[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        gam[e] = *reinterpret_cast<const float4 *>(gamma + 4 * (threadIdx.x + e * LN_THREADS));
+        dg[e] = db[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 xv[NV], gv[NV], xn[NV], gn[NV];
+    size_t row = blockIdx.x;
+    if (row < rows) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const size_t o = row * C + 4 * (threadIdx.x + e * LN_THREADS);
+            xn[e] = *reinterpret_cast<const float4 *>(x + o);
+            gn[e] = *reinterpret_cast<const float4 *>(gy + o);
+        }
+    }
+    int parity = 0;
+    for (; row < rows; row += gridDim.x, parity ^= 1) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            xv[e] = xn[e];
+            gv[e] = gn[e];
+        }
+        const size_t next = row + gridDim.x;
+        if (next < rows) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                const size_t o = next * C + 4 * (threadIdx.x + e * LN_THREADS);
+                xn[e] = *reinterpret_cast<const float4 *>(x + o);
+                gn[e] = *reinterpret_cast<const float4 *>(gy + o);
+            }
+        }
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+#define SEI_LN_ROW_LANE(f)                               \
+    xv[e].f = (xv[e].f - mu) * rs;                       \
+    dg[e].f = fmaf(gv[e].f, xv[e].f, dg[e].f);           \
+    db[e].f += gv[e].f;                                  \
+    gv[e].f *= gam[e].f;                                 \
+    s1 += gv[e].f;                                       \
+    s2 = fmaf(gv[e].f, xv[e].f, s2);
+            SEI_LN_ROW_LANE(x) SEI_LN_ROW_LANE(y) SEI_LN_ROW_LANE(z) SEI_LN_ROW_LANE(w)
+#undef SEI_LN_ROW_LANE
+        }
+        s1 = sei_wave_sum(s1);
+        s2 = sei_wave_sum(s2);
+        if (lane == 0) {
+            red[parity][0][wave] = s1;
+            red[parity][1][wave] = s2;
+        }
+        __syncthreads();                                         // (the other parity's words are free: two barriers back)
+        s1 = s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_THREADS / 64; ++k) {
+            s1 += red[parity][0][k];
+            s2 += red[parity][1][k];
+        }
+        s1 *= invC;
+        s2 *= invC;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const size_t o = row * C + 4 * (threadIdx.x + e * LN_THREADS);
+            float4 o4;
+            o4.x = rs * (gv[e].x - s1 - xv[e].x * s2);
+            o4.y = rs * (gv[e].y - s1 - xv[e].y * s2);
+            o4.z = rs * (gv[e].z - s1 - xv[e].z * s2);
+            o4.w = rs * (gv[e].w - s1 - xv[e].w * s2);
+            if (res) {
+                const float4 r4 = *reinterpret_cast<const float4 *>(res + o);
+                o4.x += r4.x; o4.y += r4.y; o4.z += r4.z; o4.w += r4.w;
+            }
+            *reinterpret_cast<float4 *>(gx + o) = o4;
+        }
+    }
+    float *out = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+        *reinterpret_cast<float4 *>(out + 4 * (threadIdx.x + e * LN_THREADS)) = dg[e];
+        *reinterpret_cast<float4 *>(out + C + 4 * (threadIdx.x + e * LN_THREADS)) = db[e];
+    }
+}
+
 // wide rows, pass 1: stats[row] = (mean_c(gy*gamma), mean_c(gy*gamma*xhat)); one workgroup per row.
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_rowstats_kernel(
     const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean,
@@ -381,25 +479,114 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_cols_kernel(
 // sei_fold_many: the folds of MANY reducing kernels in one launch (the LayerNorm / depthwise weight gradients of a whole
 // backward pass: 34 + 18 launches of ~5 us per U-Net step, ~146 per SwinIR step). A job is one destination with up to
 // three partial-sum arrays (the model calls of the step that share the parameter), folded one after the other into the
-// running value exactly as the separate launches did: same slices, same order, bit-identical. A workgroup owns 16
+// running value exactly as the separate launches did: same slices, same order, bit-identical. A workgroup owns 64
 // consecutive entries of one job and finds it by walking the job table in the kernel arguments.
 struct FoldManyArgs {
     SeiFoldJob job[SEI_FOLD_MAX_JOBS];
     int njobs;
 };
-__global__ __launch_bounds__(256) void fold_many_kernel(FoldManyArgs g) {
-    __shared__ float red[16][16];
+// (round 5: 16 slices x 64 lanes per workgroup, a lane owning FOUR consecutive entries where the job's rows are float4-able
+// (ncol % 4 == 0, 16-byte aligned partial rows: every job of the U-Net step) and one entry otherwise. With 16 entries per
+// 256-thread workgroup every wave-instruction touched four partial rows for 64 bytes each -- half of every line it fetched
+// -- and the launch spent its time starting ~400 k waves of three loads each: 144 MB per U-Net step at 1.4 TB/s. Slices,
+// strides and the order of every addition are unchanged: results are bit-identical to the 16-entry form.)
+constexpr int FOLD_LANES = 64, FOLD_SLICES = 16, FOLD_NQ = 4;
+__device__ __forceinline__ bool fold_vec4(const SeiFoldJob &J) {
+    bool ok = (J.ncol & 3) == 0;
+    for (int sg = 0; sg < J.nseg; ++sg) ok = ok && (reinterpret_cast<uintptr_t>(J.part[sg]) & 15) == 0;
+    return ok;
+}
+__device__ __forceinline__ float *fold_dst(const SeiFoldJob &J, int e) {
+    if (J.kind == SEI_FOLD_DWCONV7) {                            // e = t C + c -> gw[c][t], t < 49; bias gradient behind
+        const int t = e / J.split, c = e - t * J.split;
+        return t < 49 ? J.a + (size_t)c * 49 + t : (J.b ? J.b + c : nullptr);
+    }                                                            // a | b | c, `split` entries each (c may be absent)
+    return e < J.split ? J.a + e : e < 2 * J.split ? J.b + (e - J.split) : (J.c ? J.c + (e - 2 * J.split) : nullptr);
+}
+__global__ __launch_bounds__(FOLD_SLICES * FOLD_LANES) void fold_many_kernel(FoldManyArgs g) {
+    __shared__ __attribute__((aligned(16))) float red[FOLD_SLICES][4 * FOLD_LANES * FOLD_NQ];
     int j = 0, first = 0;
+    bool vec = false;
     for (; j < g.njobs; ++j) {                                  // (uniform: scalar loads from the argument block)
-        const int wgs = (g.job[j].ncol + 15) >> 4;
+        vec = fold_vec4(g.job[j]);
+        const int per = vec ? 4 * FOLD_LANES * FOLD_NQ : FOLD_LANES;
+        const int wgs = (g.job[j].ncol + per - 1) / per;
         if ((int)blockIdx.x < first + wgs) break;
         first += wgs;
     }
     if (j >= g.njobs) return;
     const SeiFoldJob &J = g.job[j];
-    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int e = ((int)blockIdx.x - first) * 16 + el;
+    const int el = threadIdx.x % FOLD_LANES, slice = threadIdx.x / FOLD_LANES;
     const int ncol = J.ncol;
+    if (vec) {
+        // FOLD_NQ strips of 256 entries per workgroup, every strip's loads issued before the first sum: with one 16-byte
+        // load per lane in flight (a dozen partial rows per depthwise job) two resident workgroups kept 32 KB per CU in
+        // the air and the launch ran at 1.4 TB/s whatever the access shape
+        const int e0 = ((int)blockIdx.x - first) * (4 * FOLD_LANES * FOLD_NQ) + 4 * el;     // strip q: e0 + 256 q
+        float4 total = make_float4(0.f, 0.f, 0.f, 0.f);      // running value of the strip this wave finishes (slice < FOLD_NQ)
+        auto add = [](float4 &a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+        for (int sg = 0; sg < J.nseg; ++sg) {
+            const float *part = J.part[sg];
+            const int groups = J.groups[sg];
+            float4 s0[FOLD_NQ], s1[FOLD_NQ], s2[FOLD_NQ], s3[FOLD_NQ];
+#pragma unroll
+            for (int q = 0; q < FOLD_NQ; ++q) s0[q] = s1[q] = s2[q] = s3[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int p = slice;
+            for (; p + 48 < groups; p += 64) {
+#pragma unroll
+                for (int q = 0; q < FOLD_NQ; ++q) {
+                    const int e = e0 + 4 * FOLD_LANES * q;
+                    if (e < ncol) {
+                        add(s0[q], *reinterpret_cast<const float4 *>(part + (size_t)p * ncol + e));
+                        add(s1[q], *reinterpret_cast<const float4 *>(part + (size_t)(p + 16) * ncol + e));
+                        add(s2[q], *reinterpret_cast<const float4 *>(part + (size_t)(p + 32) * ncol + e));
+                        add(s3[q], *reinterpret_cast<const float4 *>(part + (size_t)(p + 48) * ncol + e));
+                    }
+                }
+            }
+            for (; p < groups; p += 16) {
+#pragma unroll
+                for (int q = 0; q < FOLD_NQ; ++q) {
+                    const int e = e0 + 4 * FOLD_LANES * q;
+                    if (e < ncol) add(s0[q], *reinterpret_cast<const float4 *>(part + (size_t)p * ncol + e));
+                }
+            }
+            __syncthreads();                                     // (the last segment's read of red)
+#pragma unroll
+            for (int q = 0; q < FOLD_NQ; ++q) {
+                float4 r;
+                r.x = (s0[q].x + s1[q].x) + (s2[q].x + s3[q].x); r.y = (s0[q].y + s1[q].y) + (s2[q].y + s3[q].y);
+                r.z = (s0[q].z + s1[q].z) + (s2[q].z + s3[q].z); r.w = (s0[q].w + s1[q].w) + (s2[q].w + s3[q].w);
+                *reinterpret_cast<float4 *>(&red[slice][4 * FOLD_LANES * q + 4 * el]) = r;
+            }
+            __syncthreads();
+            // the 16 slices' sums of strip q are folded by wave q (FOLD_NQ <= 16), in slice order
+            if (slice < FOLD_NQ) {
+                const int e = e0 + 4 * FOLD_LANES * slice;
+                if (e < ncol) {
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int k = 0; k < FOLD_SLICES; ++k)
+                        add(sum, *reinterpret_cast<const float4 *>(&red[k][4 * FOLD_LANES * slice + 4 * el]));
+                    // the running value takes the segments one by one, as the separate launches added them
+                    float *d0 = fold_dst(J, e), *d1 = fold_dst(J, e + 1), *d2 = fold_dst(J, e + 2), *d3 = fold_dst(J, e + 3);
+                    float4 &t = total;
+                    if (sg == 0) {
+                        t.x = d0 ? *d0 : 0.f; t.y = d1 ? *d1 : 0.f; t.z = d2 ? *d2 : 0.f; t.w = d3 ? *d3 : 0.f;
+                    }
+                    add(t, sum);
+                    if (sg == J.nseg - 1) {
+                        if (d0) *d0 = t.x;
+                        if (d1) *d1 = t.y;
+                        if (d2) *d2 = t.z;
+                        if (d3) *d3 = t.w;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const int e = ((int)blockIdx.x - first) * FOLD_LANES + el;
     float total = 0.f;
     for (int sg = 0; sg < J.nseg; ++sg) {
         const float *part = J.part[sg];
@@ -421,15 +608,8 @@ __global__ __launch_bounds__(256) void fold_many_kernel(FoldManyArgs g) {
         if (slice == 0 && e < ncol) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s += red[k][el];
-            // the running value takes the segments one by one, as the separate launches added them
-            float *dst;
-            if (J.kind == SEI_FOLD_DWCONV7) {                    // e = t C + c -> gw[c][t], t < 49; bias gradient behind
-                const int t = e / J.split, c = e - t * J.split;
-                dst = t < 49 ? J.a + (size_t)c * 49 + t : (J.b ? J.b + c : nullptr);
-            } else {                                             // a | b | c, `split` entries each (c may be absent)
-                dst = e < J.split ? J.a + e : e < 2 * J.split ? J.b + (e - J.split) : (J.c ? J.c + (e - 2 * J.split) : nullptr);
-            }
+            for (int k = 0; k < FOLD_SLICES; ++k) s += red[k][el];
+            float *dst = fold_dst(J, e);
             if (dst) {
                 if (sg == 0) total = *dst;
                 total += s;
@@ -1489,7 +1669,7 @@ extern "C" int sei_ln_fwd(const float *x, const float *gamma, const float *beta,
 namespace {
 // launch plan of sei_ln_bwd; workspace = [stats: 2*rows floats (wide only)] [partials: nparts * 2C floats]
 struct LnBwdPlan {
-    int kind;                 // 0 legacy (atomics, no workspace), 1 narrow vectorised, 2 wide two-pass
+    int kind;                 // 0 legacy (atomics, no workspace), 1 narrow vectorised, 2 wide two-pass, 3 wide one-pass
     int G, NV;
     unsigned grid, col_blocks, chunks;
     int rows_per_chunk;
@@ -1508,6 +1688,14 @@ inline LnBwdPlan ln_bwd_plan(size_t rows, int C) {
         size_t cap = ((size_t)1 << 20) / (2 * (size_t)C);     // <= 1M partial floats
         if (cap > 512) cap = 512;                             // two workgroups per CU stream at full rate; fewer partials to fold
         p.grid = (unsigned)(sweeps < cap ? sweeps : cap);
+        p.nparts = p.grid;
+        return p;
+    }
+    if (C % 1024 == 0 && C <= 8192 && rows >= 64) {            // whole rows per workgroup, x and gy read once
+        p.kind = 3;
+        p.NV = C / 1024;
+        const size_t cap = C >= 8192 ? 256 : 512;               // partial rows: 2 C floats each (<= 17 MB)
+        p.grid = (unsigned)(rows < cap ? rows : cap);
         p.nparts = p.grid;
         return p;
     }
@@ -1578,6 +1766,22 @@ extern "C" int sei_ln_bwd_res(const float *x, const float *gamma, const float *m
                 default: return SEI_ERR_BAD_ARG;
             }
 #undef SEI_LN_VEC
+        } else if (p.kind == 3) {
+#define SEI_LN_ROW(NN)                                                                                        \
+    hipLaunchKernelGGL((ln_bwd_row_kernel<NN>), dim3(p.grid), dim3(LN_THREADS), 0, s, x, gamma, mean, rstd, gy, \
+                       res, gx, part, rows);                                                                  \
+    break;
+            switch (p.NV) {
+                case 1: SEI_LN_ROW(1)
+                case 2: SEI_LN_ROW(2)
+                case 3: SEI_LN_ROW(3)
+                case 4: SEI_LN_ROW(4)
+                case 5: SEI_LN_ROW(5)
+                case 6: SEI_LN_ROW(6)
+                case 7: SEI_LN_ROW(7)
+                default: SEI_LN_ROW(8)
+            }
+#undef SEI_LN_ROW
         } else {
             float2 *stats = reinterpret_cast<float2 *>(work);
             hipLaunchKernelGGL(ln_bwd_rowstats_kernel, dim3((unsigned)rows), dim3(LN_THREADS), 0, s, x, gamma, mean,
@@ -1953,10 +2157,12 @@ extern "C" int sei_fold_many(const SeiFoldJob *jobs, int njobs, void *stream) {
         for (int sg = 0; sg < J.nseg; ++sg) SEI_REQUIRE(J.part[sg] && J.groups[sg] > 0);
         for (int k = 0; k < j; ++k) SEI_REQUIRE(jobs[k].a != J.a);      // one job per destination: no two workgroups add to one address
         g.job[j] = J;
-        wgs += sei_ceil_div((size_t)J.ncol, 16);
+        bool vec = (J.ncol & 3) == 0;                           // as fold_vec4 in the kernel
+        for (int sg = 0; sg < J.nseg; ++sg) vec = vec && (reinterpret_cast<uintptr_t>(J.part[sg]) & 15) == 0;
+        wgs += sei_ceil_div((size_t)J.ncol, vec ? 4 * FOLD_LANES * FOLD_NQ : FOLD_LANES);
     }
     g.njobs = njobs;
     SEI_REQUIRE(wgs < ((size_t)1 << 31));
-    hipLaunchKernelGGL(fold_many_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(fold_many_kernel, dim3((unsigned)wgs), dim3(FOLD_SLICES * FOLD_LANES), 0, (hipStream_t)stream, g);
     return sei_launch_status();
 }

@@ -158,18 +158,21 @@ def gemm(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2
 
 _JOINT_SPLIT = None      # (B1, B2) while one backward pass serves the step's two model calls (joint_rows), else None
 
-# Split-K workspace of the quadrant GEMM (sei_gemm_bf16nt_ws, include/sei_hip.h): one per (device, stream), created on first
-# use with its 16-KiB block of tile counters zero -- every launch leaves them zero --, kept for the life of the process.
+# Split-K workspace of the quadrant GEMM (sei_gemm_bf16nt_ws, include/sei_hip.h): one per device, created on first use
+# with its 16-KiB block of tile counters zero -- every launch leaves them zero --, kept for the life of the process. ONE
+# per device, not per stream: the warm-up steps run on one side stream and the capture on another, and a workspace first
+# touched inside the capture would put its 256-MiB zero fill into the graph (replayed every step). The forward / data-gradient
+# GEMMs that use it are a chain on whichever single stream runs the step (leaf launches -- weight gradients -- never do).
 # SEI_SPLITK_WS_MIB = 0 puts the split launches back on float atomics (sei_gemm_bf16nt / _colsum: the round-1..5 path).
 SPLITK_WS_MIB = int(os.environ.get("SEI_SPLITK_WS_MIB", "256"))
 _SPLITK_WS = {}
 
 
 def splitk_workspace(device):
-    """(pointer, bytes) of this stream's split-K workspace, or (None, 0) when switched off."""
+    """(pointer, bytes) of this device's split-K workspace, or (None, 0) when switched off."""
     if SPLITK_WS_MIB <= 0:
         return None, 0
-    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    key = torch.device(device).index
     ws = _SPLITK_WS.get(key)
     if ws is None:
         ws = _SPLITK_WS[key] = torch.zeros(SPLITK_WS_MIB << 20, dtype=torch.uint8, device=device)

@@ -114,7 +114,7 @@ def test_gemm_splitk_weight_gradient_shape(ops):
 # ------------------------------------------------------------------ LayerNorm, dwconv, conv3x3, colsum, adam
 @pytest.mark.parametrize("rows,C", [(500, 32), (77, 128), (300, 512), (40, 2048), (9, 8192), (64, 3), (10, 12), (5, 700),
                                     (4099, 8), (1000, 16), (333, 64), (2500, 256), (700, 1024), (130, 4096), (50, 520),
-                                    (20000, 32)])
+                                    (20000, 32), (600, 2048), (300, 8192), (1000, 3072)])
 def test_layernorm_fwd_bwd(ops, rows, C):
     gen = torch.Generator().manual_seed(rows + C)
     x = torch.randn((rows, C), generator=gen) * 2 + 0.5
