@@ -171,14 +171,25 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_group_kernel(const float *__r
     }
 }
 
+// four normalised values of one quad: 8 bytes of bf16 or 16 bytes of float32 (sei_ln_fwd's fast path, round 5)
+__device__ __forceinline__ void ln_store4(unsigned short *p, float a, float b, float c, float d) {
+    uint2 w;
+    w.x = (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
+    w.y = (unsigned)f2bf(c) | ((unsigned)f2bf(d) << 16);
+    *reinterpret_cast<uint2 *>(p) = w;
+}
+__device__ __forceinline__ void ln_store4(float *p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
+}
+
 // Narrow rows with 16-byte lanes (C = 4 * L * NV, L a power of two <= 64, NV <= 2, i.e. C <= 512): L lanes own a row,
 // NV float4 each; 256 / L rows per sweep. One 16-byte load and one 8-byte store per quad instead of four 4-byte
 // loads and four 2-byte stores -- the scalar kernel above ran the 18.9-MB level-0 / level-1 tensors at 1.6 TB/s.
-template <int L, int NV>
+template <int L, int NV, typename OT = unsigned short>
 __global__ __launch_bounds__(256) void ln_fwd_bf16_quad_kernel(const float *__restrict__ x,
                                                                const float *__restrict__ gamma,
                                                                const float *__restrict__ beta,
-                                                               unsigned short *__restrict__ y,
+                                                               OT *__restrict__ y,
                                                                float *__restrict__ mean, float *__restrict__ rstd,
                                                                size_t rows, float eps) {
     constexpr int C = 4 * L * NV, RPB = 256 / L;
@@ -208,12 +219,9 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_quad_kernel(const float *__re
         const float rs = 1.0f / sqrtf(group_sum<L>(q) * invC + eps);
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
-            uint2 w;
-            w.x = (unsigned)f2bf(fmaf((v[e].x - mu) * rs, gam[e].x, bet[e].x)) |
-                  ((unsigned)f2bf(fmaf((v[e].y - mu) * rs, gam[e].y, bet[e].y)) << 16);
-            w.y = (unsigned)f2bf(fmaf((v[e].z - mu) * rs, gam[e].z, bet[e].z)) |
-                  ((unsigned)f2bf(fmaf((v[e].w - mu) * rs, gam[e].w, bet[e].w)) << 16);
-            *reinterpret_cast<uint2 *>(y + row * C + 4 * (lg + e * L)) = w;
+            ln_store4(y + row * C + 4 * (lg + e * L), fmaf((v[e].x - mu) * rs, gam[e].x, bet[e].x),
+                      fmaf((v[e].y - mu) * rs, gam[e].y, bet[e].y), fmaf((v[e].z - mu) * rs, gam[e].z, bet[e].z),
+                      fmaf((v[e].w - mu) * rs, gam[e].w, bet[e].w));
         }
         if (lg == 0) {
             mean[row] = mu;
@@ -273,11 +281,11 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_wide_kernel(const float *__re
 // Wide rows with 16-byte lanes: RW waves (1, 2 or 4) own a row, each lane up to 8 float4 (C <= 2048 * RW,
 // C % 4 == 0); row data lives in registers (one HBM read), statistics by wave shuffles (+ one LDS exchange
 // when RW > 1). 4 / RW rows per workgroup.
-template <int RW>
+template <int RW, typename OT = unsigned short>
 __global__ __launch_bounds__(256) void ln_fwd_bf16_vec_kernel(const float *__restrict__ x,
                                                               const float *__restrict__ gamma,
                                                               const float *__restrict__ beta,
-                                                              unsigned short *__restrict__ y,
+                                                              OT *__restrict__ y,
                                                               float *__restrict__ mean, float *__restrict__ rstd,
                                                               size_t rows, int C, float eps) {
     __shared__ float part[2][4];
@@ -328,18 +336,14 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_vec_kernel(const float *__res
         }
         const float rs = 1.0f / sqrtf(qq * invC + eps);
         if (live) {
-            uint2 *yr = reinterpret_cast<uint2 *>(y + row * C);
+            OT *yr = y + row * C;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int q = lane + 64 * wr + e * STRIDE;
                 if (q < nq) {
                     const float4 gm = reinterpret_cast<const float4 *>(gamma)[q], bt = reinterpret_cast<const float4 *>(beta)[q];
-                    uint2 o;
-                    o.x = (unsigned)f2bf(fmaf((v[e].x - mu) * rs, gm.x, bt.x)) |
-                          ((unsigned)f2bf(fmaf((v[e].y - mu) * rs, gm.y, bt.y)) << 16);
-                    o.y = (unsigned)f2bf(fmaf((v[e].z - mu) * rs, gm.z, bt.z)) |
-                          ((unsigned)f2bf(fmaf((v[e].w - mu) * rs, gm.w, bt.w)) << 16);
-                    yr[q] = o;
+                    ln_store4(yr + 4 * (size_t)q, fmaf((v[e].x - mu) * rs, gm.x, bt.x), fmaf((v[e].y - mu) * rs, gm.y, bt.y),
+                              fmaf((v[e].z - mu) * rs, gm.z, bt.z), fmaf((v[e].w - mu) * rs, gm.w, bt.w));
                 }
             }
             if (lane == 0 && wr == 0) {
@@ -490,6 +494,12 @@ extern "C" int sei_weight_shadow_bf16(const float *w, uint16_t *w16, uint16_t *w
     return sei_launch_status();
 }
 
+// Grid cap of the cast + column-sum kernel. Every workgroup ends in one float atomic per column, and those are what the launch
+// waits for: tools/exp_cast.py, the step's ten casts with 512 / 1024 / 2048 workgroups: 145 / 232 / 346 us (and eight rows in
+// flight per lane on 1024: 191 against 134 in the step).
+#ifndef SEI_CAST_WGS
+#define SEI_CAST_WGS 512
+#endif
 static int cast_colsum_launch(const float *x, uint16_t *x16, float *colsum, const float *row_weight, int R, int C,
                               void *stream) {
     const int quads = C / 4;
@@ -497,7 +507,7 @@ static int cast_colsum_launch(const float *x, uint16_t *x16, float *colsum, cons
     while (tpr < quads && tpr < 256) tpr <<= 1;
     const unsigned col_blocks = (unsigned)sei_ceil_div(quads, tpr);
     size_t rpb = (size_t)(256 / tpr) * 4;
-    while (sei_ceil_div((size_t)R, rpb) * col_blocks > 512 && rpb < (size_t)R) rpb *= 2;
+    while (sei_ceil_div((size_t)R, rpb) * col_blocks > (size_t)SEI_CAST_WGS && rpb < (size_t)R) rpb *= 2;
     hipLaunchKernelGGL(cast_colsum_kernel, dim3((unsigned)sei_ceil_div((size_t)R, rpb), col_blocks), dim3(256), 0,
                        (hipStream_t)stream, x, x16, colsum, (size_t)R, C, tpr, rpb, row_weight);
     return sei_launch_status();
@@ -527,6 +537,49 @@ extern "C" int sei_cast_transpose_bf16(const void *x, int x_is_bf16, uint16_t *x
         hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)x,
                            x16, xt16, R, C, ldt, colsum);
     return sei_launch_status();
+}
+
+// sei_ln_fwd's 16-byte-lane path (unet_kernels.hip calls it first): the kernels above with a float32 result. Returns -1 for
+// shapes they do not take (the scalar-lane kernels of unet_kernels.hip then run). The Downsample LayerNorms of the U-Net
+// (147456 x 32 ... 2304 x 2048 per step) ran at 1.6-2.1 TB/s on 4-byte lanes.
+__attribute__((visibility("hidden"))) int sei_ln_fwd_f32_lanes16(const float *x, const float *gamma, const float *beta, float *y,
+                                                                 float *mean, float *rstd, size_t rows, int C, float eps,
+                                                                 hipStream_t s) {
+    // (C < 32: the scalar lanes stay -- rows of 2-8 channels are ill-conditioned in float32 and the tiny goldens were taken
+    // with that summation order)
+    if (C % 4 != 0 || C < 32 || C > 8192 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) |
+                                    reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(y)) & 15) != 0)
+        return -1;
+    if (C > 512) {
+        const int rw = C <= 2048 ? 1 : (C <= 4096 ? 2 : 4);
+        size_t grid = sei_ceil_div(rows, (size_t)(4 / rw));
+        if (grid > 8192) grid = 8192;
+        if (rw == 1) hipLaunchKernelGGL((ln_fwd_bf16_vec_kernel<1, float>), dim3((unsigned)grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps);
+        else if (rw == 2) hipLaunchKernelGGL((ln_fwd_bf16_vec_kernel<2, float>), dim3((unsigned)grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps);
+        else hipLaunchKernelGGL((ln_fwd_bf16_vec_kernel<4, float>), dim3((unsigned)grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, eps);
+        return sei_launch_status();
+    }
+    if (((C / 4) & (C / 4 - 1)) != 0) return -1;
+    const int q = C / 4, nv = q > 64 ? q / 64 : 1, lanes = q / nv;
+    size_t grid = sei_ceil_div(rows, (size_t)(256 / lanes));
+    if (grid > 2048) grid = 2048;
+#define SEI_LN_QUAD32(LL, NN)                                                                                          \
+    hipLaunchKernelGGL((ln_fwd_bf16_quad_kernel<LL, NN, float>), dim3((unsigned)grid), dim3(256), 0, s, x, gamma, beta, y, \
+                       mean, rstd, rows, eps);                                                                          \
+    return sei_launch_status();
+    switch (lanes * 100 + nv) {
+        case 101: { SEI_LN_QUAD32(1, 1) }
+        case 201: { SEI_LN_QUAD32(2, 1) }
+        case 401: { SEI_LN_QUAD32(4, 1) }
+        case 801: { SEI_LN_QUAD32(8, 1) }
+        case 1601: { SEI_LN_QUAD32(16, 1) }
+        case 3201: { SEI_LN_QUAD32(32, 1) }
+        case 6401: { SEI_LN_QUAD32(64, 1) }
+        case 6402: { SEI_LN_QUAD32(64, 2) }
+        default: break;
+    }
+#undef SEI_LN_QUAD32
+    return -1;
 }
 
 extern "C" int sei_ln_fwd_bf16(const float *x, const float *gamma, const float *beta, uint16_t *y, float *mean,

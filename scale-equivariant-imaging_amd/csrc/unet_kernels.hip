@@ -1645,11 +1645,19 @@ inline int ln_group(int C) {
 }
 }  // namespace
 
+__attribute__((visibility("hidden"))) int sei_ln_fwd_f32_lanes16(const float *x, const float *gamma, const float *beta, float *y,
+                                                                 float *mean, float *rstd, size_t rows, int C, float eps,
+                                                                 hipStream_t s);                  // bf16_support.hip
+
 extern "C" int sei_ln_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
                           float *rstd, size_t rows, int C, float eps, void *stream) {
     SEI_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0 && C > 0);
     if (C > LN_WIDE_EPT * LN_THREADS) return SEI_ERR_TOO_LARGE;
     hipStream_t s = (hipStream_t)stream;
+    {   // 16-byte lanes where the shape allows (C = 4 * 2^k up to 512, any multiple of 4 above)
+        const int rc = sei_ln_fwd_f32_lanes16(x, gamma, beta, y, mean, rstd, rows, C, eps, s);
+        if (rc >= 0) return rc;
+    }
     if (C > 64 * LN_EPL) {
         hipLaunchKernelGGL(ln_fwd_wide_kernel, dim3(capped_grid(rows, 1, 8192)), dim3(LN_THREADS), 0, s, x, gamma,
                            beta, y, mean, rstd, rows, C, eps);
