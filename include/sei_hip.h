@@ -410,7 +410,8 @@ size_t sei_gemm_bf16nt_plan(int a_rmajor, int b_rmajor, int out_f32, int out_bf1
  * the order in which slices finish when there are two of them, and EVERY epilogue may split (bf16 / GELU / GELU' results
  * and riding column sums included), which the atomics form could not offer. No workgroup waits for another. ws = NULL, a
  * workspace too small for the launch (16 KiB + tiles * slices * tile bytes) or a launch off the quadrant kernel: exactly
- * the entry points above. splitk > 0 asks for that many slices where the schedule can split (tests, experiments).
+ * the entry points above. tile / band: as sei_gemm_bf16nt_ex (0 = automatic). splitk > 0 asks for that many slices where
+ * the schedule can split (tests, experiments).
  * (The reference's GEMMs are torch's: src/models/convolutional.py:33-51, 96-150; this is how their K-heavy, row-poor
  * shapes -- 288 ... 3456 rows at the two deepest U-Net levels -- fill 256 CUs.)
  * sei_gemm_bf16nt_plan_ws: the schedule with a workspace of ws_bytes (as sei_gemm_bf16nt_plan; bit 15 of the split count
@@ -418,7 +419,7 @@ size_t sei_gemm_bf16nt_plan(int a_rmajor, int b_rmajor, int out_f32, int out_bf1
 int sei_gemm_bf16nt_ws(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
                        float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
                        const float *R1, const float *R2, uint16_t *D2_16, float *colsum, void *ws, size_t ws_bytes,
-                       int tile, int splitk, void *stream);
+                       int tile, int band, int splitk, void *stream);
 size_t sei_gemm_bf16nt_plan_ws(int a_rmajor, int b_rmajor, int out_f32, int out_bf16, int M, int N, int K, int epilogue,
                                size_t ws_bytes);
 

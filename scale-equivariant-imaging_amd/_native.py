@@ -68,7 +68,7 @@ SIGNATURES = {
     "sei_cast_bf16_colsum_weighted": [_P, _P, _P, _P, _I, _I, _P],
     "sei_gemm_bf16nt": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sei_gemm_bf16nt_colsum": [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P],
-    "sei_gemm_bf16nt_ws": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P],
+    "sei_gemm_bf16nt_ws": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P],
     "sei_fold_many": [_P, _I, _P],
     "sei_transpose_bf16_many": [_P, _I, _P],
     "sei_gemm_bf16nt_dw2": [_P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],

@@ -948,15 +948,15 @@ static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
 // schedule is followed by the column-sum kernel over the result (same quantity, one more launch).
 static int nt_entry_colsum(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
                            uint16_t *D16, int M, int N, int K, int epilogue, const float *R1, float *colsum, void *stream,
-                           void *ws = nullptr, size_t ws_bytes = 0, int tile = 0, int splitk = 0) {
+                           void *ws = nullptr, size_t ws_bytes = 0, int tile = 0, int splitk = 0, int band = 0) {
     unsigned long long plan = 0;
-    int rc = nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, nullptr, D16, M, N, K, epilogue, nullptr, R1, nullptr, nullptr, tile, 0,
+    int rc = nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, nullptr, D16, M, N, K, epilogue, nullptr, R1, nullptr, nullptr, tile, band,
                       stream, &plan, nullptr, ws, ws_bytes, splitk);
     if (rc != SEI_OK) return rc;
     // (unsplit, or split through slabs: the last arriver's epilogue sees the complete tile)
     const bool rides = (plan >> 48) == 2 && ((plan & 0xFFFF) == 1 || (plan & 0x8000) != 0) && N % 4 == 0 &&
                        (reinterpret_cast<uintptr_t>(colsum) & 15) == 0;
-    rc = nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, nullptr, D16, M, N, K, epilogue, nullptr, R1, nullptr, nullptr, tile, 0,
+    rc = nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, nullptr, D16, M, N, K, epilogue, nullptr, R1, nullptr, nullptr, tile, band,
                   stream, nullptr, rides ? colsum : nullptr, ws, ws_bytes, splitk);
     if (rc != SEI_OK || rides) return rc;
     return sei_colsum_bf16(D16, colsum, (size_t)M, N, stream);
@@ -1156,19 +1156,19 @@ extern "C" int sei_gemm_bf16nt_colsum(const uint16_t *A, int lda, int a_rmajor, 
 // rest needs no initialisation), used by ONE stream at a time. Launches of the quadrant kernel that split K then meet in
 // slabs instead of float atomics, and launches whose epilogue the atomics could not serve (bf16 / GELU / GELU' results,
 // riding column sums) may split too. ws = nullptr: exactly sei_gemm_bf16nt_ex / sei_gemm_bf16nt_colsum. colsum != nullptr
-// asks for sei_gemm_bf16nt_colsum's semantics (D16 only, SEI_EPI_MUL_DGELU or SEI_EPI_NONE). tile as sei_gemm_bf16nt_ex;
+// asks for sei_gemm_bf16nt_colsum's semantics (D16 only, SEI_EPI_MUL_DGELU or SEI_EPI_NONE). tile / band as sei_gemm_bf16nt_ex;
 // splitk > 0 asks for that many K slices where the schedule can split at all (experiments, tests), 0 = automatic.
 extern "C" int sei_gemm_bf16nt_ws(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
                                   float *D32, uint16_t *D16, int M, int N, int K, int epilogue, const float *bias,
                                   const float *R1, const float *R2, uint16_t *D2_16, float *colsum, void *ws,
-                                  size_t ws_bytes, int tile, int splitk, void *stream) {
-    SEI_REQUIRE(tile >= 0 && splitk >= 0 && (ws == nullptr || ws_bytes >= 16384));
+                                  size_t ws_bytes, int tile, int band, int splitk, void *stream) {
+    SEI_REQUIRE(tile >= 0 && band >= 0 && splitk >= 0 && (ws == nullptr || ws_bytes >= 16384));
     if (colsum) {
         SEI_REQUIRE(D16 && !D32 && (epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_NONE));
         return nt_entry_colsum(A, lda, a_rmajor, B, ldb, b_rmajor, D16, M, N, K, epilogue, R1, colsum, stream, ws, ws_bytes,
-                               tile, splitk);
+                               tile, splitk, band);
     }
-    return nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, D32, D16, M, N, K, epilogue, bias, R1, R2, D2_16, tile, 0, stream,
+    return nt_entry(A, lda, a_rmajor, B, ldb, b_rmajor, D32, D16, M, N, K, epilogue, bias, R1, R2, D2_16, tile, band, stream,
                     nullptr, nullptr, ws, ws_bytes, splitk);
 }
 

@@ -811,6 +811,10 @@ int launch_pq(NtArgs &g, hipStream_t s) {
     const size_t tiles = (size_t)g.tiles_m * g.tiles_n;
     SEI_REQUIRE(tiles < ((size_t)1 << 27));
     int band = g.force_band > 0 ? g.force_band : 6;       // ~sqrt(32 tiles in flight per XCD)
+    // (narrow outputs -- up to 16 tile columns -- take one band: with 6 the last band of an 8-column output is 2 columns wide;
+    // tools/exp_band.py: 3456 x 2048 x 8192 132 -> 121 us, 2304 x 2048 x 8192 85.7 -> 83.2. Wide outputs keep 6: 576 x 8192 x
+    // 32768 reads 266 us with 6, 290 with 16, 356 with 1 -- all row tiles of a tile column on one XCD is the WORST order)
+    if (g.force_band <= 0 && g.tiles_n <= 16) band = g.tiles_n;
     if (band > g.tiles_n) band = g.tiles_n;
     g.band = band;
     g.tiles_per_xcd = (int)sei_ceil_div(tiles, 8);

@@ -229,7 +229,7 @@ def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=Non
                 or R2 is not None or D2_16 is not None:
             raise ValueError("gemm_nt16(colsum=): a bf16 result with EPI_NONE / EPI_MUL_DGELU on the automatic dispatch")
         if ws is not None:
-            _gemm_call(fl, "sei_gemm_bf16nt_ws", *args, colsum.data_ptr(), ws, ws_bytes, 0, 0)
+            _gemm_call(fl, "sei_gemm_bf16nt_ws", *args, colsum.data_ptr(), ws, ws_bytes, 0, 0, 0)
             return
         _gemm_call(fl, "sei_gemm_bf16nt_colsum", A16.data_ptr(), lda, int(a_rmajor), B16.data_ptr(), ldb, int(b_rmajor),
                    out16.data_ptr(), M, Nn, K, epi, N.ptr(R1), colsum.data_ptr())
@@ -238,7 +238,7 @@ def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=Non
         _gemm_call(fl, "sei_gemm_bf16nt_ex", *args, int(tile), int(band))
     elif ws is not None:
         # (K slices of the quadrant kernel meet in slabs of the workspace: no zero fill, no float atomics)
-        _gemm_call(fl, "sei_gemm_bf16nt_ws", *args, None, ws, ws_bytes, 0, 0)
+        _gemm_call(fl, "sei_gemm_bf16nt_ws", *args, None, ws, ws_bytes, 0, 0, 0)
     else:
         _gemm_call(fl, "sei_gemm_bf16nt", *args)
 

@@ -1090,7 +1090,7 @@ def test_split_k_through_slabs(ops, M, Nn, K, brm, kind, tile):
         N.call("sei_gemm_bf16nt_ws", A.data_ptr(), K, 0, B.data_ptr(), Nn if brm else K, brm, N.ptr(d32), N.ptr(d16), M, Nn, K,
                epi, bias.data_ptr() if kind in ("res", "gelu") else None, R1.data_ptr() if kind in ("res", "dgelu") else None,
                None, N.ptr(d2), N.ptr(cs), None if workspace is None else workspace.data_ptr(),
-               0 if workspace is None else ws_bytes, tile, splitk)
+               0 if workspace is None else ws_bytes, tile, 0, splitk)
         torch.cuda.synchronize()
         return tuple(t for t in (d32, d16, d2, cs) if t is not None)
 

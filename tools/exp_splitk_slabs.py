@@ -75,10 +75,10 @@ def main():
             pdf = torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
             want = ref * (cdf + x * pdf)
 
-        def call(ws_t, tile, sk):
+        def call(ws_t, tile, sk, band=0):
             N.call("sei_gemm_bf16nt_ws", A.data_ptr(), K, 0, B.data_ptr(), Nn if brm else K, brm, N.ptr(D32), N.ptr(D16), M, Nn, K,
                    epi, bias.data_ptr() if kind in ("res", "gelu") else None, R1.data_ptr() if kind in ("res", "dgelu") else None,
-                   None, N.ptr(D2), N.ptr(cs), None if ws_t is None else ws_t.data_ptr(), 0 if ws_t is None else ws_bytes, tile, sk)
+                   None, N.ptr(D2), N.ptr(cs), None if ws_t is None else ws_t.data_ptr(), 0 if ws_t is None else ws_bytes, tile, band, sk)
 
         def err():
             got = (D32 if D32 is not None else D16).double()
