@@ -269,7 +269,7 @@ int sei_ln_bwd_res(const float *x, const float *gamma, const float *mean, const 
  * Destinations of different jobs must differ (checked). The partial sums must stay untouched until this launch. */
 #define SEI_FOLD_SPLIT 0
 #define SEI_FOLD_DWCONV7 1
-#define SEI_FOLD_MAX_JOBS 40
+#define SEI_FOLD_MAX_JOBS 48   /* (48 x 80 bytes of job table + the count: under the 4-KiB kernel-argument block) */
 typedef struct SeiFoldJob {
     float *a, *b, *c;
     int ncol, split, kind, nseg;
@@ -329,6 +329,14 @@ int sei_cast_transpose_bf16(const void *x, int x_is_bf16, uint16_t *x16, uint16_
  * is this weighted sum of the output gradient's rows, taken while that gradient is cast for the GEMMs. C % 4 == 0. */
 int sei_cast_bf16_colsum_weighted(const float *x, uint16_t *x16, const float *row_weight, float *colsum, int R, int C,
                                   void *stream);
+/* The same cast with its (weighted when row_weight != NULL) column sums left as PARTIAL sums, one row of C floats per row
+ * block: part[g][c], g < sei_cast_bf16_colsum_parts_count(R, C) (0: shape not taken, C % 4 != 0). The bias gradients of a
+ * backward pass (src/models/convolutional.py:33-51, 96-150: every 1x1 convolution's bias) then join the pass's other
+ * partial sums in ONE sei_fold_many launch (SEI_FOLD_SPLIT, ncol = split = C) instead of ending every cast in one float
+ * atomic per column and workgroup -- which is what sized the atomics form's grid (512 workgroups; 2048 here). ABI 11. */
+size_t sei_cast_bf16_colsum_parts_count(int R, int C);
+int sei_cast_bf16_colsum_parts(const float *x, uint16_t *x16, const float *row_weight, float *part, int R, int C,
+                               void *stream);
 
 /* Several bf16 transposes in ONE launch: job k copies src (R, C) bf16 to dst (C, R). The fused pointwise MLP's backward
  * (sei_mlp_fused_bwd) reads both 1x1 weights of a ConvBlock transposed (src/models/convolutional.py:33-51: conv2 / conv3);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "sei_colsum_bf16": [_P, _P, _Z, _I, _P],
     "sei_cast_transpose_bf16": [_P, _I, _P, _P, _I, _I, _I, _P, _P],
     "sei_cast_bf16_colsum_weighted": [_P, _P, _P, _P, _I, _I, _P],
+    "sei_cast_bf16_colsum_parts": [_P, _P, _P, _P, _I, _I, _P],
     "sei_gemm_bf16nt": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sei_gemm_bf16nt_colsum": [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P],
     "sei_gemm_bf16nt_ws": [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _I, _P],
@@ -146,7 +147,7 @@ class FoldJob(_c.Structure):
                 ("part", _P * 3), ("groups", _I * 3), ("reserved", _I)]
 
 
-FOLD_SPLIT, FOLD_DWCONV7, FOLD_MAX_JOBS = 0, 1, 40
+FOLD_SPLIT, FOLD_DWCONV7, FOLD_MAX_JOBS = 0, 1, 48
 
 
 class TransposeJob(_c.Structure):
@@ -183,6 +184,7 @@ SIZE_QUERIES = {
     "sei_gemm_bf16nt_plan_ws": [_I, _I, _I, _I, _I, _I, _I, _I, _Z],
     "sei_conv3x3_bwd_weight_parts_count": [_I, _I, _I, _I, _I, _I, _I],
     "sei_sepmap2_small_eligible": [_I, _I, _I, _I, _I, _I],
+    "sei_cast_bf16_colsum_parts_count": [_I, _I],
 }
 ABI_VERSION = 11      # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 

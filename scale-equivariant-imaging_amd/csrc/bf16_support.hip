@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const T *__restrict
 __global__ __launch_bounds__(256) void cast_colsum_kernel(const float *__restrict__ x,
                                                           unsigned short *__restrict__ x16,
                                                           float *__restrict__ colsum, size_t R, int C, int tpr,
-                                                          size_t rows_per_block, const float *__restrict__ row_weight) {
+                                                          size_t rows_per_block, const float *__restrict__ row_weight,
+                                                          float *__restrict__ part) {
     __shared__ float red[256 * 4];
     const int rsubs = 256 / tpr;
     const int cl = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void cast_colsum_kernel(const float *__restric
         }
         for (; r < r1; r += rsubs) emit(r, *reinterpret_cast<const float4 *>(col + r * C));
     }
-    if (!colsum) return;                                        // uniform over the workgroup
+    if (!colsum && !part) return;                               // uniform over the workgroup
     const int width = tpr * 4;
     red[rsub * width + cl * 4 + 0] = s.x;
     red[rsub * width + cl * 4 + 1] = s.y;
@@ -116,7 +117,10 @@ __global__ __launch_bounds__(256) void cast_colsum_kernel(const float *__restric
         if (c0 + e >= C) break;
         float t = 0.f;
         for (int q = 0; q < rsubs; ++q) t += red[q * width + e];
-        atomicAdd(colsum + c0 + e, t);
+        // part: this row block's sums as one row of [row blocks][C] partial sums (sei_cast_bf16_colsum_parts: folded later by
+        // sei_fold_many, no atomics here -- they are what bounds the atomics form's grid, tools/exp_cast.py)
+        if (part) part[(size_t)blockIdx.x * C + c0 + e] = t;
+        else atomicAdd(colsum + c0 + e, t);
     }
 }
 
@@ -500,17 +504,46 @@ extern "C" int sei_weight_shadow_bf16(const float *w, uint16_t *w16, uint16_t *w
 #ifndef SEI_CAST_WGS
 #define SEI_CAST_WGS 512
 #endif
-static int cast_colsum_launch(const float *x, uint16_t *x16, float *colsum, const float *row_weight, int R, int C,
-                              void *stream) {
+#ifndef SEI_CAST_PARTS_WGS
+#define SEI_CAST_PARTS_WGS 2048
+#endif
+// rows per workgroup for a grid of at most `cap` workgroups
+static size_t cast_rows_per_block(int R, int C, size_t cap, int *tpr_out, unsigned *col_blocks_out) {
     const int quads = C / 4;
     int tpr = 1;
     while (tpr < quads && tpr < 256) tpr <<= 1;
     const unsigned col_blocks = (unsigned)sei_ceil_div(quads, tpr);
     size_t rpb = (size_t)(256 / tpr) * 4;
-    while (sei_ceil_div((size_t)R, rpb) * col_blocks > (size_t)SEI_CAST_WGS && rpb < (size_t)R) rpb *= 2;
+    while (sei_ceil_div((size_t)R, rpb) * col_blocks > cap && rpb < (size_t)R) rpb *= 2;
+    *tpr_out = tpr;
+    *col_blocks_out = col_blocks;
+    return rpb;
+}
+static int cast_colsum_launch(const float *x, uint16_t *x16, float *colsum, const float *row_weight, int R, int C,
+                              void *stream, float *part = nullptr) {
+    int tpr;
+    unsigned col_blocks;
+    const size_t rpb = cast_rows_per_block(R, C, part ? (size_t)SEI_CAST_PARTS_WGS : (size_t)SEI_CAST_WGS, &tpr, &col_blocks);
     hipLaunchKernelGGL(cast_colsum_kernel, dim3((unsigned)sei_ceil_div((size_t)R, rpb), col_blocks), dim3(256), 0,
-                       (hipStream_t)stream, x, x16, colsum, (size_t)R, C, tpr, rpb, row_weight);
+                       (hipStream_t)stream, x, x16, colsum, (size_t)R, C, tpr, rpb, row_weight, part);
     return sei_launch_status();
+}
+
+// The cast with its column sums left as PARTIAL sums: part[g][c] = sum over row block g of (row_weight[r]) x[r][c], g <
+// sei_cast_bf16_colsum_parts_count(R, C) -- for sei_fold_many (kind SEI_FOLD_SPLIT, ncol = split = C) at the end of the
+// backward pass, with the pass's other partial sums. No atomics, so the grid is sized for bandwidth (2048 workgroups).
+extern "C" size_t sei_cast_bf16_colsum_parts_count(int R, int C) {
+    if (R <= 0 || C <= 0 || C % 4 != 0) return 0;
+    int tpr;
+    unsigned col_blocks;
+    const size_t rpb = cast_rows_per_block(R, C, (size_t)SEI_CAST_PARTS_WGS, &tpr, &col_blocks);
+    return sei_ceil_div((size_t)R, rpb);
+}
+extern "C" int sei_cast_bf16_colsum_parts(const float *x, uint16_t *x16, const float *row_weight, float *part, int R, int C,
+                                          void *stream) {
+    SEI_REQUIRE(x && x16 && part && R > 0 && C > 0 && C % 4 == 0);
+    SEI_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(x16) & 7) == 0);
+    return cast_colsum_launch(x, x16, nullptr, row_weight, R, C, stream, part);
 }
 
 // x (R, C) float32 -> x16 bf16 copy, and colsum[c] += sum_r row_weight[r] x[r][c] from the same pass (un-rounded input).

@@ -485,6 +485,7 @@ struct FoldManyArgs {
     SeiFoldJob job[SEI_FOLD_MAX_JOBS];
     int njobs;
 };
+static_assert(sizeof(FoldManyArgs) <= 4096, "the job table travels in the kernel-argument block");
 // (round 5: 16 slices x 64 lanes per workgroup, a lane owning FOUR consecutive entries where the job's rows are float4-able
 // (ncol % 4 == 0, 16-byte aligned partial rows: every job of the U-Net step) and one entry otherwise. With 16 entries per
 // 256-thread workgroup every wave-instruction touched four partial rows for 64 bytes each -- half of every line it fetched

@@ -727,11 +727,27 @@ def gemm_mixed(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=No
     return out
 
 
+CAST_COLSUM_PARTS = os.environ.get("SEI_CAST_COLSUM_ATOMICS") != "1"      # (A/B: the round-1..5 atomics form)
+
+
 def cast16(x2d, colsum_into_=None, row_weight=None):
     """f32 (R, C) -> bf16 copy; colsum_into_: accumulate the column sums (a bias gradient) in the same pass, each row
     times row_weight[r] when given (the downsampler's convolution: DownsampleFn16)."""
     R, C = x2d.shape
     x16 = _alloc((R, C), torch.bfloat16, x2d.device)
+    if colsum_into_ is not None and CAST_COLSUM_PARTS and C % 4 == 0:
+        # the column sums leave as per-row-block partial sums and join the pass's deferred folds (no atomics: the grid is
+        # sized for bandwidth); outside a backward pass, or switched off, the atomics form below
+        parts = N.lib().sei_cast_bf16_colsum_parts_count(R, C)
+        ms = _state_for(colsum_into_.data_ptr())["milestone"]
+        # (a bias gradient between the two early-released weight gradients must be final when their event fires: such a
+        # destination -- none in the U-Net, whose only bias there comes from a GEMM epilogue -- keeps the atomics)
+        early = ms is not None and min(ms[0]) <= colsum_into_.data_ptr() <= max(ms[0])
+        if parts > 0 and not early:
+            work = torch.empty(parts * C, dtype=torch.float32, device=x2d.device)
+            if defer_fold(colsum_into_, None, None, C, C, N.FOLD_SPLIT, work, 0, parts):
+                N.call("sei_cast_bf16_colsum_parts", x2d.data_ptr(), x16.data_ptr(), N.ptr(row_weight), work.data_ptr(), R, C)
+                return x16
     if row_weight is not None and colsum_into_ is not None and C % 4 == 0:
         N.call("sei_cast_bf16_colsum_weighted", x2d.data_ptr(), x16.data_ptr(), row_weight.data_ptr(), colsum_into_.data_ptr(),
                R, C)
