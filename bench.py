@@ -320,7 +320,7 @@ _STREAM_FAMILIES = [
      ("sei_blur_", "sei_scale_resample_", "sei_scale_params", "sei_axpy", "sei_sure_terms", "sei_sure_loss", "sei_mse_terms", "sei_mse_loss",
       "sei_resample_")),
 ]
-PMC_TRAFFIC_FILE = "r05_b_unet_pmc_gemm.json"      # the committed PMC pass `roofline.traffic` is read from
+PMC_TRAFFIC_FILE = "r05_g_unet_pmc_gemm.json"      # the committed PMC pass `roofline.traffic` is read from
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
