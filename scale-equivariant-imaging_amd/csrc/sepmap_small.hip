@@ -162,9 +162,15 @@ __global__ __launch_bounds__(SS_THREADS) void sepmap_small_wave_kernel(const flo
 
 inline bool ss_plan(int B, int Hi, int Wi, int Ho, int Wo, int C) {
     if (B <= 0 || C <= 0 || C % SS_CH != 0) return false;
-    if (Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || Hi > SS_MAX_IN || Wi > SS_MAX_IN || Ho > SS_MAX_OUT || Wo > SS_MAX_OUT)
+    // 12 x 12 inputs REDUCED to at most 6 x 6 (the transposed 6 -> 12 upsampler of the backward pass, 2048 channels): the
+    // barrier-free wave kernel with the 144 inputs in registers -- 36 outputs per lane, unlike the 12 -> 24 case above
+    // (tools/exp_sepmap_reduce12.py, us, this kernel / the matrix-core kernel: 96 x 2048 channels 40 / 78, 96 x 512 15.7 / 22.6,
+    // 64 x 512 14.2 / 16.0, 32 x 512 15.3 / 9.8 -- from 512 wave items on)
+    const bool reduce12 = Hi == 12 && Wi == 12 && Ho <= 6 && Wo <= 6 && (size_t)B * (C / SS_CH) >= 512;
+    if (Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || ((Hi > SS_MAX_IN || Wi > SS_MAX_IN) && !reduce12) || Ho > SS_MAX_OUT ||
+        Wo > SS_MAX_OUT)
         return false;
-    if (Hi * Wi > SS_MAX_PIX) return false;
+    if (Hi * Wi > SS_MAX_PIX && !reduce12) return false;
     return (size_t)B * (C / SS_CH) < ((size_t)1 << 31) && (size_t)B * Ho * Wo * C < ((size_t)1 << 40);
 }
 
@@ -212,6 +218,7 @@ extern "C" int sei_sepmap2_small(const float *x, void *y, int out_bf16, int B, i
     // the two input shapes of a 48-pixel crop's deep levels: the barrier-free kernel, extents as template arguments
     if (Hi == 3 && Wi == 3) return ss_launch_wave<3, 3>(x, reinterpret_cast<float *>(y), L1, R1, L2, R2, g, s);
     if (Hi == 6 && Wi == 6) return ss_launch_wave<6, 6>(x, reinterpret_cast<float *>(y), L1, R1, L2, R2, g, s);
+    if (Hi == 12 && Wi == 12) return ss_launch_wave<12, 12>(x, reinterpret_cast<float *>(y), L1, R1, L2, R2, g, s);
     const int e = Hi > Wi ? Hi : Wi;
     if (e <= 4) return ss_launch<4>(x, reinterpret_cast<float *>(y), L1, R1, L2, R2, g, s);
     return ss_launch<8>(x, reinterpret_cast<float *>(y), L1, R1, L2, R2, g, s);

@@ -255,7 +255,7 @@ def test_resampler_on_the_matrix_cores(ops, kind, B, H, W, C):
 
 @pytest.mark.parametrize("kind,B,H,W,C", [("down", 64, 6, 6, 2048), ("up", 2, 3, 3, 8192), ("up", 5, 6, 6, 2048),
                                           ("down", 2, 8, 6, 64), ("up", 1, 2, 2, 128), ("down", 3, 8, 4, 192),
-                                          ("down", 700, 4, 4, 64), ("up", 3, 8, 8, 128)])
+                                          ("down", 700, 4, 4, 64), ("up", 3, 8, 8, 128), ("down", 40, 12, 12, 1024)])
 def test_resampler_of_the_deep_levels_in_one_pass(ops, kind, B, H, W, C):
     """sei_sepmap2_small (Ideal{Down,Up}sample at input extents <= 8: the 6- and 3-pixel images of a 48-pixel crop,
     reference src/models/convolutional.py:54-92,113-133) against float64 on the matrices of models/_mats.py and against the
@@ -289,7 +289,9 @@ def test_resampler_of_the_deep_levels_in_one_pass(ops, kind, B, H, W, C):
     assert ran >= 1
     assert _native.lib().sei_sepmap2_small_eligible(2, 24, 24, 12, 12, 128) == 0     # sei_sepmap2_bf16's extents
     assert _native.lib().sei_sepmap2_small_eligible(2, 6, 6, 3, 3, 32) == 0          # C % 64
-    assert _native.lib().sei_sepmap2_small_eligible(2, 12, 12, 6, 6, 512) == 0       # 12 x 12 inputs: the two-launch kernels win
+    assert _native.lib().sei_sepmap2_small_eligible(2, 12, 12, 6, 6, 512) == 0       # 12 x 12 inputs, few items: the others win
+    assert _native.lib().sei_sepmap2_small_eligible(96, 12, 12, 6, 6, 2048) == 1     # ... reduced to 6 x 6 on >= 512 wave items
+    assert _native.lib().sei_sepmap2_small_eligible(96, 12, 12, 24, 24, 512) == 0    # 12 -> 24 stays on the matrix cores
 
 
 @pytest.mark.parametrize("B,H,W,C", DW_SHAPES[:6])
