@@ -111,12 +111,16 @@ template <int HI, int WI>
 __global__ __launch_bounds__(SS_THREADS) void sepmap_small_wave_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                        const float *__restrict__ L1, const float *__restrict__ R1,
                                                                        const float *__restrict__ L2, const float *__restrict__ R2,
-                                                                       SsGeom g, int items) {
+                                                                       SsGeom g, int items, int parts) {
     const int Ho = g.Ho, Wo = g.Wo, C = g.C;
     const int groups = C / SS_CH;
     const int c = threadIdx.x & 63;
     const int w0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int item = blockIdx.x * (SS_THREADS / 64) + w0; item < items; item += gridDim.x * (SS_THREADS / 64)) {
+    // parts > 1: an item's output columns are dealt to `parts` waves (each reads the item's inputs: L1 / L2 hits) -- with few
+    // items (32 images x 2048 channels = 1024) one wave per SIMD walked a whole item on its own: load, 2592 FMAs, 144 stores
+    const int cols = Wo / parts;
+    for (int wi_ = blockIdx.x * (SS_THREADS / 64) + w0; wi_ < items * parts; wi_ += gridDim.x * (SS_THREADS / 64)) {
+        const int item = wi_ / parts, part = wi_ - item * parts;
         const int b = item / groups, c0 = (item - b * groups) * SS_CH;
         const float *xb = x + (size_t)b * HI * WI * C + c0 + c;
         float xin[HI][WI];
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(SS_THREADS) void sepmap_small_wave_kernel(const flo
         for (int hi = 0; hi < HI; ++hi)
 #pragma unroll
             for (int wi = 0; wi < WI; ++wi) xin[hi][wi] = xb[(size_t)(hi * WI + wi) * C];
-        for (int wo = 0; wo < Wo; ++wo) {
+        for (int wo = part * cols; wo < (part + 1) * cols; ++wo) {
             const float *r1p = R1 + wo * WI, *r2p = R2 + wo * WI;
             float t1[HI], t2[HI];
 #pragma unroll
@@ -192,10 +196,14 @@ template <int HI, int WI>
 int ss_launch_wave(const float *x, float *y, const float *L1, const float *R1, const float *L2, const float *R2,
                    const SsGeom &g, hipStream_t s) {
     const int items = g.B * (g.C / SS_CH);                      // wave items: four per workgroup
-    const int wgs = (items + 3) / 4;
+    // output columns of an item over 2, 3, 4 or 6 waves while that keeps the launch under ~8 waves per SIMD
+    int parts = 1;
+    for (int cand : {2, 3, 4, 6})
+        if (g.Wo % cand == 0 && (size_t)items * cand <= 8192) parts = cand;
+    const int wgs = (items * parts + 3) / 4;
     const int grid = wgs < 256 * 8 ? wgs : 256 * 8;            // 29 - 62 VGPRs: eight workgroups (32 waves) per CU
     hipLaunchKernelGGL((sepmap_small_wave_kernel<HI, WI>), dim3((unsigned)grid), dim3(SS_THREADS), 0, s, x, y, L1, R1, L2, R2, g,
-                       items);
+                       items, parts);
     return sei_launch_status();
 }
 
