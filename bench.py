@@ -201,7 +201,7 @@ def _stream_bytes(name, a):
         return 6 * a[4] * a[5]
     if name == "sei_transpose_bf16_many":                  # every matrix in and out once (bf16)
         return sum(4 * a[0][k].R * a[0][k].C for k in range(a[1]))
-    if name == "sei_cast_bf16_colsum_weighted":
+    if name in ("sei_cast_bf16_colsum_weighted", "sei_cast_bf16_colsum_parts"):      # (x, x16, row_weight, colsum | part, R, C)
         return 6 * a[4] * a[5]
     if name == "sei_cast_bf16":
         return 6 * a[2]

@@ -908,6 +908,18 @@ int pq_choose_slabs(NtArgs &g, bool would_split) {
         }
     }
     if (!best_nf) return 0;
+    // One row tile against a weight that streams from HBM (288 x 8192 x 32768, the B-row bottleneck convolution): the model's
+    // per-k-tile constants do not hold once all 256 CUs pull on the weight (tools/exp_l4_slices.py, us: 128 columns x 3 / 4
+    // slices 202 / 213, 256 columns x 6 / 7 / 8 slices 193 / 190 / 203) -- 256-column tiles on ~224 workgroups
+    if (from_hbm && tm == 1 && N >= 4096) {
+        const size_t tiles4 = sei_ceil_div(N, 256), slab4 = (size_t)32 * rf * 256 * 4;
+        size_t sk = 224 / tiles4;
+        if (sk * 4 > kt) sk = kt / 4;
+        if (sk >= 2 && 16384 + tiles4 * sk * slab4 <= g.ws_bytes) {
+            best_nf = 4;
+            best_sk = (int)sk;
+        }
+    }
     g.force_splitk = best_sk;
     return 10 * rf + best_nf;
 }

@@ -323,8 +323,8 @@ def test_timed_configuration_vs_oracle(B, oracle_dtype):
         if B == 32:
             assert ("pq", 288, 256) in plans and ("pq", 288, 128) in plans, sorted(plans)
             assert any(sk > 1 for key in plans if key[0] == "pq" for *_, sk in plans[key]), "split-K quadrant launches"
-            assert {(576, 32768, 8192, 1), (576, 8192, 32768, 4)} <= plans[("pq", 288, 256)]
-            assert {(288, 32768, 8192, 1), (288, 8192, 32768, 4)} <= plans[("pq", 288, 128)]
+            assert {(576, 32768, 8192, 1), (576, 8192, 32768, 4), (288, 8192, 32768, 7)} <= plans[("pq", 288, 256)]
+            assert {(288, 32768, 8192, 1), (2304, 2048, 8192, 2), (1152, 2048, 8192, 4)} <= plans[("pq", 288, 128)]
         else:
             assert any(M in (72, 144) and Nn == 32768 for M, Nn, _, _ in plans[("nt", 128, 128)]), sorted(plans)
         print("launch plans:", {k: len(v) for k, v in sorted(plans.items())})
