@@ -1123,6 +1123,49 @@ def test_split_k_through_slabs(ops, M, Nn, K, brm, kind, tile):
     assert tried >= 2
 
 
+def test_split_k_slabs_under_uneven_load(ops):
+    """The slab hand-off under the conditions in which a missing release / acquire shows (cdna_hip_programming.md, Guideline
+    16, Pitfall 3): 150 launches of two-slice and four-slice GEMMs while a second stream keeps HBM and the L2s busy with large
+    copies, so that slices of a tile finish far apart and on busy caches. Two slices must reproduce the first launch's bits
+    every time; four slices stay within float32 rounding of it; the counters are zero at the end."""
+    import _native as N
+    gen = torch.Generator().manual_seed(11)
+    M, Nn, K = 1152, 2048, 4096
+    A = torch.randn((M, K), generator=gen).bfloat16().cuda()
+    B = (torch.randn((Nn, K), generator=gen) / K ** 0.5).bfloat16().cuda()
+    bias, R1 = torch.randn(Nn, generator=gen).cuda(), torch.randn((M, Nn), generator=gen).cuda()
+    ws_bytes = 64 << 20
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device="cuda")
+    out = torch.empty((M, Nn), device="cuda")
+    big_a, big_b = torch.randn(64 << 20, device="cuda"), torch.empty(64 << 20, device="cuda")
+    side = torch.cuda.Stream()
+
+    def run(sk):
+        N.call("sei_gemm_bf16nt_ws", A.data_ptr(), K, 0, B.data_ptr(), K, 0, out.data_ptr(), None, M, Nn, K, ops.EPI_BIAS_RES,
+               bias.data_ptr(), R1.data_ptr(), None, None, None, ws.data_ptr(), ws_bytes, 32, 0, sk)
+
+    run(2)
+    torch.cuda.synchronize()
+    first = out.clone()
+    run(1)
+    unsplit = out.clone()
+    assert relerr(first, unsplit) < 3e-6
+    bad2 = torch.zeros((), device="cuda")
+    worst4 = torch.zeros((), device="cuda")
+    for it in range(150):
+        with torch.cuda.stream(side):
+            big_b.copy_(big_a)                               # 512 MB of traffic beside every launch
+        run(2)
+        bad2 += (out != first).any()
+        run(4)
+        worst4 = torch.maximum(worst4, (out - first).abs().max())
+    side.synchronize()
+    torch.cuda.synchronize()
+    assert float(bad2) == 0.0, "a two-slice launch changed bits under load"
+    assert float(worst4) < 3e-6 * float(first.abs().max())
+    assert int(ws[:16384].view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize("M,Nn,K1,K2", [(2048, 6144, 640, 1032), (512, 768, 96, 200), (2048, 8192, 1152, 2304)])
 def test_adam_epilogue_of_the_quadrant_schedule(M, Nn, K1, K2):
     """sei_gemm_bf16nt_dw2_adam_ex: the quadrant kernel's Adam epilogue (tiles 30 / 33: 256 x 256 / 256 x 128) against the
