@@ -960,7 +960,8 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_c32_to_small_kernel(
             win[ky][0] = load(i + ky - 1, j0 - 1);
             win[ky][1] = load(i + ky - 1, j0);
         }
-        float outv[C3L_RUN];                              // lane co < CS keeps channel co of the run
+        // this lane's (input channel's) share of every output of the run first: part[jl * CS + co]
+        float part[C3L_RUN * CS];
 #pragma unroll
         for (int jb = 0; jb < C3L_RUN + 2; jb += 3) {
 #pragma unroll
@@ -971,7 +972,6 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_c32_to_small_kernel(
 #pragma unroll
                         for (int ky = 0; ky < 3; ++ky) win[ky][(s3 + 2) % 3] = load(i + ky - 1, j0 + jl + 1);
                     }
-                    float mine = 0.f;
 #pragma unroll
                     for (int co = 0; co < CS; ++co) {
                         float a = 0.f;
@@ -979,22 +979,44 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_c32_to_small_kernel(
                         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                             for (int kx = 0; kx < 3; ++kx) a = fmaf(wr[co][ky * 3 + kx], win[ky][(s3 + kx) % 3], a);
-                        a = half_wave_sum(a);
-                        if (ci == co) mine = a;
+                        part[jl * CS + co] = a;
                     }
-                    outv[jl] = mine;
                 }
             }
         }
-        if (ci < CS) {
-            const float bv = bias ? bias[ci] : 0.f;
+        // ... then ONE transposing butterfly over the 32 lanes for all C3L_RUN * CS sums (round 5): at offset 16, 8, 4, 2 a
+        // lane keeps one half of its values and hands the other half to its partner, so the value count halves with the
+        // lane distance -- 8 CS + 4 CS + 2 CS + CS exchanges and a last plain stage of CS instead of 5 per sum (240 -> 48 at
+        // CS = 3; a PMC pass had 30 of the 45 VALU and all 15 LDS instructions per pixel step in the per-sum butterflies).
+        // Every sum is added in the same tree as before: bit-identical. Afterwards lanes 2 jl and 2 jl + 1 both hold the CS
+        // outputs of pixel jl.
+#define SEI_C3_STAGE(OFF, NV)                                                                   \
+        {                                                                                       \
+            const bool up = (ci & (OFF)) != 0;                                                  \
+            _Pragma("unroll") for (int k = 0; k < (NV) / 2; ++k) {                              \
+                const float send = up ? part[k] : part[k + (NV) / 2];                           \
+                const float keep = up ? part[k + (NV) / 2] : part[k];                           \
+                part[k] = keep + __shfl_xor(send, (OFF), 64);                                   \
+            }                                                                                   \
+        }
+        SEI_C3_STAGE(16, C3L_RUN * CS)
+        SEI_C3_STAGE(8, C3L_RUN * CS / 2)
+        SEI_C3_STAGE(4, C3L_RUN * CS / 4)
+        SEI_C3_STAGE(2, C3L_RUN * CS / 8)
+#undef SEI_C3_STAGE
 #pragma unroll
-            for (int jl = 0; jl < C3L_RUN; ++jl)
-                if (jl < jn) {
-                    const size_t o = img_index(nchw_out, b, ci, i, j0 + jl, CS, H, W);
-                    const float v = outv[jl] + bv;
+        for (int co = 0; co < CS; ++co) part[co] += __shfl_xor(part[co], 1, 64);
+        {
+            const int jl = ci >> 1;                       // this lane pair's pixel of the run
+            if (jl < jn) {
+#pragma unroll
+                for (int co = 0; co < CS; ++co) {
+                    if ((co & 1) != (ci & 1)) continue;   // the pair's two lanes share the CS stores
+                    const size_t o = img_index(nchw_out, b, co, i, j0 + jl, CS, H, W);
+                    const float v = part[co] + (bias ? bias[co] : 0.f);
                     y[o] = res ? v + res[o] : v;
                 }
+            }
         }
     }
 }
