@@ -828,6 +828,10 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_small_to_c32_kernel(
     for (size_t p = ((size_t)blockIdx.x * C3_THREADS + threadIdx.x) >> 2; p < npix; p += ((size_t)gridDim.x * C3_THREADS) >> 2) {
         const int j = (int)(p % W), i = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
         float4 a0 = b0, a1 = b1;
+        // (round 5: ONE 64-bit pixel address, then 32-bit tap / channel offsets -- img_index() per tap and channel was three
+        // 64-bit multiplies each: a PMC pass counted 697 VALU instructions per wave around its 216 FMAs)
+        const float *px = x + (nchw_in ? ((size_t)b * CS * H + i) * W + j : (((size_t)b * H + i) * W + j) * CS);
+        const int pstr = nchw_in ? 1 : CS, cstr = nchw_in ? H * W : 1;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int ii = i + ky - 1;
@@ -836,9 +840,10 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_small_to_c32_kernel(
             for (int kx = 0; kx < 3; ++kx) {
                 const int jj = j + kx - 1;
                 if (jj < 0 || jj >= W) continue;
+                const float *tp = px + ((ky - 1) * W + (kx - 1)) * pstr;
 #pragma unroll
                 for (int ci = 0; ci < CS; ++ci) {
-                    const float v = x[img_index(nchw_in, b, ci, ii, jj, CS, H, W)];
+                    const float v = tp[ci * cstr];
                     const float4 w0 = *reinterpret_cast<const float4 *>(sw + (ci * 9 + ky * 3 + kx) * 32 + 8 * q);
                     const float4 w1 = *reinterpret_cast<const float4 *>(sw + (ci * 9 + ky * 3 + kx) * 32 + 8 * q + 4);
                     a0.x = fmaf(w0.x, v, a0.x); a0.y = fmaf(w0.y, v, a0.y); a0.z = fmaf(w0.z, v, a0.z); a0.w = fmaf(w0.w, v, a0.w);
