@@ -238,9 +238,15 @@ class FlatGradientReducer:
         """RCCL / NCCL take the in-place forms of both halves -- the reduce-scatter's output is this rank's slot of its
         input, the all-gather's input is this rank's slot of its output (recvbuff == sendbuff + rank * count): no share
         buffers, no 1/world staging copies, and with one rank (secondary.dist1) no copy at all. gloo has no such form.
-        SEI_EXCHANGE_OUT_OF_PLACE=1 restores the separate share buffers."""
+
+        OPT-IN (SEI_EXCHANGE_IN_PLACE=1): RCCL has run this code at world size 1 only, where in-place does nothing; the
+        default is the out-of-place form (separate share buffers, a 1/world staging copy per gather) that the gloo
+        world-2 tests execute. tests/test_ddp_gpu.py::test_in_place_exchange_matches_out_of_place_rccl compares the two
+        on a box with >= 2 GPUs. In place, `comm` OUTSIDE own_slice(k) is UNDEFINED after reduce_async in mode "sharded":
+        it still holds this rank's unreduced local gradients next to the reduced share, and shard(k) aliases the bucket
+        -- read the whole reduced bucket through gathered_gradient() only."""
         return (dist.is_initialized() and dist.get_backend(self.group) == "nccl"
-                and os.environ.get("SEI_EXCHANGE_OUT_OF_PLACE") != "1")
+                and os.environ.get("SEI_EXCHANGE_IN_PLACE") == "1")
 
     def _share_buffer(self, k, chunk, world):
         """Where chunk k's reduce-scatter delivers this rank's share: its own slot of the chunk (in place) or a buffer."""

@@ -34,7 +34,8 @@ def main():
 
     import parallel                                     # before any GPU call: spawns nothing, reads the env
     rank, local, world = parallel.init_from_env()
-    torch.cuda.set_device(0)                            # the ranks of the rehearsal share the one GPU (gloo exchange)
+    # the ranks of the rehearsal share the one GPU (gloo exchange); over RCCL (no SEI_DIST_BACKEND) each takes its own
+    torch.cuda.set_device(local if world > 1 and torch.distributed.get_backend() == "nccl" else 0)
     import bench
     import physics
     import models

@@ -13,8 +13,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "ddp_worker.py")
 
 
-def _run(out, world, extra):
-    env = dict(os.environ, SEI_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(out, world, extra, backend="gloo", more_env=None):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SEI_DIST_BACKEND", None)
+    if backend == "gloo":
+        env["SEI_DIST_BACKEND"] = "gloo"
+    env.update(more_env or {})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     if world == 1:
@@ -64,3 +68,24 @@ def test_two_ranks_on_one_gpu_match_the_single_process_run(tmp_path, extra, tol)
         assert abs((l2 + sigma2 / 4) - (l1 + sigma2 / 8)) < max(tol, 1e-4) * abs(l1), (two[0]["losses"], one[0]["losses"])
     assert relerr(two[0]["params"], one[0]["params"]) < 2e-3               # Adam's first steps are sign-like
     assert np.isfinite(two[0]["losses"]).all()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL refuses two ranks on one device: needs >= 2 GPUs")
+@pytest.mark.parametrize("extra", [
+    ["--dtype", "f32", "--graph", "0", "--mode", "rs_ag"],                         # sharded optimizer step
+    ["--dtype", "f32", "--graph", "0", "--mode", "rs_ag", "--shard", "0"],         # reduce-scatter + all-gather of gradients
+    ["--dtype", "bf16", "--graph", "1", "--mode", "rs_ag", "--comm", "bf16", "--direct-min", "60000"]])
+def test_in_place_exchange_matches_out_of_place_rccl(tmp_path, extra):
+    """Two RCCL ranks on two GPUs: the in-place forms of reduce-scatter / all-gather (SEI_EXCHANGE_IN_PLACE=1: the share is
+    this rank's slot of the chunk) against the default separate share buffers -- bit-identical gathered gradient,
+    parameters, moments and losses (the same reductions in the same order; only where the result lands differs).
+    parallel.FlatGradientReducer._in_place stays opt-in until this has passed on hardware."""
+    runs = {}
+    for name, env in (("out_of_place", {}), ("in_place", {"SEI_EXCHANGE_IN_PLACE": "1"})):
+        runs[name] = _run(str(tmp_path / name), 2, extra, backend="nccl", more_env=env)
+    for r in range(2):
+        a, b = runs["out_of_place"][r], runs["in_place"][r]
+        assert a["losses"] == b["losses"]
+        for key in ("grads_step0", "params", "exp_avg"):
+            assert torch.equal(a[key], b[key]), (r, key)
+    assert torch.equal(runs["in_place"][0]["params"], runs["in_place"][1]["params"])

@@ -123,6 +123,60 @@ def test_proposed_loss_vs_golden(golden, tag):
         assert relerr(p.grad, g[f"grad.{k}"]) < 5e-4, (k, relerr(p.grad, g[f"grad.{k}"]))
 
 
+# ------------------------------------------------------------------ the reference's in-tree R2R / EI loss, golden G13
+@pytest.mark.parametrize("tag", ["deblur", "sr2"])
+def test_r2r_and_ei_glue_vs_reference_golden(golden, tag):
+    """G13 = src/losses/r2r.py run by the reference's own code on its own U-Net, physics and ScalingTransform
+    (tools/gen_golden.py gen_r2r). (i) losses.r2r.R2REILoss on the HIP path: loss terms and every weight gradient;
+    (ii) the hot path's losses.ei.EILoss (restated from deepinv) against the same EI term: the reference's ei_loss
+    is EILoss with x_net = model(y + 0.5 sigma n1) and measurement noise 1.5 sigma."""
+    import physics
+    import transforms
+    from losses.ei import EILoss, mse
+    from losses.r2r import R2REILoss
+    from models.convolutional import ConvolutionalModel
+    g = golden(f"g13_r2r_{tag}")
+    up = 1 if tag == "deblur" else 2
+    m = ConvolutionalModel(in_channels=3, upsampling_rate=up, residual=True, inner_residual=True,
+                           num_conv_blocks=1, hidden_channels=8, inout_convs=True, scales=3)
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("sd.")})
+    m = m.cuda()
+    net = lambda v, *ignored: m(v)
+    sigma = 5 / 255
+    if tag == "deblur":
+        op = physics.BlurV2(kernel=physics.get_kernel("Gaussian_R2")[None, None])
+    else:
+        op = physics.Downsampling(rate=2, antialias=True)
+    y, n0, n1, n2 = (dev(g[k]) for k in ("y", "n0", "n1", "n2"))
+    # the float64 run's draws, rounded to float32 (rates are exact; centres move by 1e-8)
+    params = (dev(g["f64.rate"].astype(np.float32)), dev(g["f64.center"].astype(np.float32)).view(-1, 1, 1, 2))
+    scaling = transforms.ScalingTransform(kind="padded", antialias=False)
+    T = lambda v: scaling(v, params=params)
+    for through in (False, True):
+        p = "f64." + ("grad_through_T." if through else "")
+        lf = R2REILoss(transform=T, sigma=sigma, no_grad=not through, metric=None)
+        l_r2r = lf.r2r_loss(y=y, physics=op, model=net, _unit_noise=n0)
+        l_ei = lf.ei_loss(y=y, physics=op, model=net, _n1=n1, _n2=n2)
+        assert rel(l_r2r, g[p + "loss_r2r"]) < 1e-4 and rel(l_ei, g[p + "loss_ei"]) < 1e-4
+        m.zero_grad_flat()
+        total = lf(y=y, physics=op, model=net, _noise=(n0, n1, n2))
+        assert rel(total, g[p + "loss"]) < 1e-4
+        total.backward()
+        for k, q in m.named_parameters():
+            if p + f"grad.{k}" in g.files:
+                assert relerr(q.grad, g[p + f"grad.{k}"]) < 5e-4, (k, relerr(q.grad, g[p + f"grad.{k}"]))
+            else:
+                assert rel(q.grad.norm(), g[p + f"gradnorm.{k}"]) < 5e-4, (p, k)
+    # (ii) the hot path's EI glue
+    with torch.no_grad():
+        x1 = m((y + 0.5 * sigma * n1).contiguous())
+    assert relerr(x1, g["f64.x1"]) < 2e-5
+    op.noise_model = physics.GaussianNoise(sigma=1.5 * sigma)
+    ei = EILoss(transform=scaling, metric=mse(), weight=1.0, no_grad=True)
+    val = ei(x_net=x1, physics=op, model=net, transform_params=params, noise=n2)
+    assert rel(val, g["f64.loss_ei"]) < 1e-4
+
+
 def test_fused_and_literal_pass_orders_agree():
     import physics
     import models

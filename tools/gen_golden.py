@@ -9,7 +9,7 @@ arithmetic is exercised by the goldens below except `adjoint_function`, which is
 `torch.autograd.functional.vjp` (flagged "vjp" in the fixture names).
 
 What is written is DATA ONLY: seeded inputs and the outputs the reference produced for them
-(SURVEY.md section 8c, G1..G11). The reference cannot travel to the GPU box; these files can.
+(G12 noise2inverse; G13 the in-tree R2R / EI loss). The reference cannot travel to the GPU box; these files can.
 
     python tools/gen_golden.py            # writes tests/golden/*.npz + manifest json
 """
@@ -138,6 +138,113 @@ def gen_noise2inverse():
     up = n2i.ImageSlices(num_splits=4, task="sr", physics_filter=None, degradation_inverse_fn=lambda v: 2.0 * v)
     arrs["sr.slice1"] = _np(up(y)[1])
     _save("g12_noise2inverse", **arrs)
+
+
+def gen_r2r():
+    """G13: src/losses/r2r.py (in-tree; imported by path).  `R2RLoss` (:7-23) and `R2REILoss` (:26-57), whose
+    `ei_loss` is the reference authors' own near-copy of deepinv's EILoss ("slightly modified for consistent input
+    noise"): it pins, by the reference's code, T under no_grad, y2 = A(x2), the noise placement and the metric.
+    The file's only third-party symbol is `deepinv.loss.metric.mse` (:4): a one-class shell (mean squared error over
+    all elements, flagged "mse shell") stands in for it.  Everything else is the reference: the h8s3 U-Net
+    (models/convolutional.py), BlurV2 / Downsampling (physics), ScalingTransform("padded", antialias=False)
+    (transforms.py, unmodified: its rand draws come from manual_seed(5)).  The backbone is called as
+    `model(y, physics)`; src/models/__init__.py:148-149 (`Model.forward(x, *args)`, not importable: deepinv at the
+    top) drops the extras, and so does the wrapper here.  torch.randn_like is patched to hand out the three saved
+    normal draws in call order (pert, epsilon1, epsilon2)."""
+    os.makedirs(OUT, exist_ok=True)
+    _install_deepinv_shell()
+    loss_mod = types.ModuleType("deepinv.loss")
+    metric_mod = types.ModuleType("deepinv.loss.metric")
+
+    class mse(torch.nn.Module):                      # "mse shell"
+        def forward(self, x, y):
+            return torch.nn.functional.mse_loss(x, y)
+
+    metric_mod.mse = mse
+    loss_mod.metric = metric_mod
+    sys.modules["deepinv"].loss = loss_mod
+    sys.modules["deepinv.loss"] = loss_mod
+    sys.modules["deepinv.loss.metric"] = metric_mod
+    if REF_SRC not in sys.path:
+        sys.path.insert(0, REF_SRC)
+    physics = importlib.import_module("physics")
+    transforms = importlib.import_module("transforms")
+    conv = _load_by_path("ref_convolutional", os.path.join(REF_SRC, "models", "convolutional.py"))
+    r2r = _load_by_path("ref_r2r", os.path.join(REF_SRC, "losses", "r2r.py"))
+    torch.set_num_threads(8)
+    sigma = 5 / 255
+    print("G13 r2r / ei_loss")
+    for tag, rate in [("deblur", 1), ("sr2", 2)]:
+        torch.manual_seed(0)
+        m32 = conv.ConvolutionalModel(in_channels=3, upsampling_rate=rate, residual=True, inner_residual=True,
+                                      num_conv_blocks=1, hidden_channels=8, inout_convs=True, scales=3)
+        with torch.no_grad():
+            for n, p in m32.named_parameters():
+                if ".ln." in n:
+                    p.add_(0.05 * torch.randn_like(p))
+        if rate == 1:
+            phys_op = physics.BlurV2(kernel=physics.BlurKernel("Gaussian_R2").to_tensor("cpu"))
+            S = 48
+        else:
+            phys_op = physics.Downsampling(rate=rate, antialias=True)
+            S = 24
+        B = 2
+        y32 = _rand((B, 3, S, S), 130)
+        n0, n1, n2 = (_randn((B, 3, S, S), 131 + i) for i in range(3))
+        arrs = {"y": _np(y32), "n0": _np(n0), "n1": _np(n1), "n2": _np(n2)}
+        for k2, v in m32.state_dict().items():
+            arrs[f"sd.{k2}"] = _np(v)
+        import copy
+        for dt, dn in [(torch.float64, "f64"), (torch.float32, "f32")]:
+            m = copy.deepcopy(m32).to(dt)
+            y = y32.to(dt)
+            net = lambda v, *ignored, m=m: m(v)
+            for no_grad in (True, False):
+                ng = "" if no_grad else "grad_through_T."
+                seen = {}
+                T = transforms.ScalingTransform(kind="padded", antialias=False)
+
+                class Recorder(torch.nn.Module):        # passes x through the reference transform, keeps in/out
+                    def forward(self, x):
+                        out = T(x)
+                        seen["x1"], seen["x2"] = x.detach().clone(), out.detach().clone()
+                        return out
+
+                lf = r2r.R2REILoss(transform=Recorder(), sigma=sigma, no_grad=no_grad, metric=None)
+                draws = iter([n0.to(dt), n1.to(dt), n2.to(dt)])
+                saved = torch.randn_like
+                torch.randn_like = lambda t, **kw: next(draws).clone()
+                try:
+                    torch.manual_seed(5)                   # ScalingTransform's rand(B), rand(B, 2)
+                    l_r2r = lf.r2r_loss(y=y, physics=phys_op, model=net)
+                    l_ei = lf.ei_loss(y=y, physics=phys_op, model=net)
+                finally:
+                    torch.randn_like = saved
+                total = l_r2r + l_ei
+                # the forward() of the class is the same sum: check it on the same draws
+                draws = iter([n0.to(dt), n1.to(dt), n2.to(dt)])
+                torch.randn_like = lambda t, **kw: next(draws).clone()
+                try:
+                    torch.manual_seed(5)
+                    assert torch.equal(lf(y=y, physics=phys_op, model=net), total)
+                finally:
+                    torch.randn_like = saved
+                torch.manual_seed(5)
+                r, c = transforms.sample_downsampling_parameters(B, "cpu", dt, [0.75, 0.5])
+                m.zero_grad()
+                total.backward()
+                p = f"{dn}.{ng}"
+                arrs[p + "rate"], arrs[p + "center"] = _np(r), _np(c.view(-1, 2))
+                arrs[p + "loss_r2r"], arrs[p + "loss_ei"], arrs[p + "loss"] = _np(l_r2r), _np(l_ei), _np(total)
+                if no_grad:
+                    arrs[p + "x1"], arrs[p + "x2"] = _np(seen["x1"]), _np(seen["x2"])
+                # full gradients for the float64 default (no_grad) run; per-tensor norms for the other three
+                for k2, q in m.named_parameters():
+                    if dn == "f64" and no_grad:
+                        arrs[p + f"grad.{k2}"] = _np(q.grad).astype(np.float32)
+                    else:
+                        arrs[p + f"gradnorm.{k2}"] = _np(q.grad.norm())
+        _save(f"g13_r2r_{tag}", **arrs)
 
 
 def main():
@@ -507,6 +614,9 @@ def main():
 if __name__ == "__main__":
     if sys.argv[1:] == ["--only", "g12"]:
         gen_noise2inverse()
+    elif sys.argv[1:] == ["--only", "g13"]:
+        gen_r2r()
     else:
         main()
         gen_noise2inverse()
+        gen_r2r()
