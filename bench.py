@@ -37,7 +37,8 @@ sys.path.insert(0, os.path.join(ROOT, "scale-equivariant-imaging_amd"))
 sys.path.insert(1, ROOT)
 
 # MI355X_MICROARCH.md, dense spec peaks: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
+# (bf16x3: three bf16 MFMA products per algorithmic product -- priced against a third of the bf16 peak)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3.0}
 CROP, NOISE, KERNEL = 48, 5, "Gaussian_R2"
 
 
@@ -789,8 +790,9 @@ def main():
     ap.add_argument("--full256", action="store_true",
                     help="secondary series of SURVEY 8d: --no-Loss__crop_training_pairs, the network sees the whole "
                          "256x256 pair (28x the pixels of the default 48-crop); use a small --batch")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
-                    help="arithmetic type of the 1x1-conv GEMMs (f32 = parity mode, bf16 = throughput mode)")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="bf16",
+                    help="arithmetic type of the 1x1-conv GEMMs (f32 = parity mode, bf16 = throughput mode, bf16x3 = split-bf16 "
+                         "parity mode: three bf16 MFMA products per float32 product)")
     opt = ap.parse_args()
 
     import parallel
@@ -859,6 +861,10 @@ def main():
         short_run("f32", {}, "f32", 5, 20,
                   "BASELINE configs[1] with exact-f32 MFMA GEMMs (v_mfma_f32_32x32x2_f32): the reference's own arithmetic, "
                   "the mode every 1e-4 parity claim is made in; same launch path (hipGraph replay, flat-bucket Adam)")
+        short_run("bf16x3", {}, "bf16x3", 3, 10,
+                  "BASELINE configs[1] with every float32 GEMM evaluated as three bf16 MFMA products of bf16 head / remainder "
+                  "operands (csrc/bf16x3.hip): 16 mantissa bits per operand, held to the float32 mode's 1e-4 bars "
+                  "(tests/test_loss_gpu.py::test_default_unet_step_vs_oracle[bf16x3]); same launch path as the f32 series")
         # SURVEY 8(d)'s other two series of configs[1]: the reference's default batch, and the un-cropped pairs
         short_run("b8", {"batch": 8}, "bf16", 2, 5,
                   "BASELINE configs[1] at the reference's default batch 8 (demo/train.py:53)")

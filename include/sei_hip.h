@@ -32,7 +32,7 @@ extern "C" {
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
-#define SEI_ABI_VERSION 11
+#define SEI_ABI_VERSION 12
 int sei_abi_version(void);
 /* Fills name[0..n) with the gfx target the code objects were built for ("gfx950"). */
 int sei_build_target(char *name, int n);
@@ -318,6 +318,14 @@ int sei_weight_shadow_bf16(const float *w, uint16_t *w16, uint16_t *wt16, int R,
 int sei_ln_fwd_bf16(const float *x, const float *gamma, const float *beta, uint16_t *y, float *mean,
                     float *rstd, size_t rows, int C, float eps, void *stream);
 int sei_colsum_bf16(const uint16_t *X, float *out, size_t M, int N, void *stream);
+/* Split-bf16 GEMM mode (--compute_dtype bf16x3: models/_ops.py gemm_x3; reference src/models/convolutional.py:33-51, float32
+ * 1x1 convolutions). planes: 2 n bf16 -- planes[i] = bf16(x[i]) (head), planes[n + i] = bf16(x[i] - head) (remainder);
+ * n % 4 == 0. A product a b is then evaluated as a_lo b_hi + a_hi b_lo + a_hi b_hi by three sei_gemm_bf16nt launches that
+ * accumulate in float32; the two epilogues that are not additive run as the element-wise passes below (exact erf forms,
+ * as SEI_EPI_BIAS_GELU / SEI_EPI_MUL_DGELU of sei_gemm_f32 apply them). */
+int sei_split_bf16x2(const float *x, uint16_t *planes, size_t n, void *stream);
+int sei_gelu_f32(const float *x, float *y, size_t n, void *stream);            /* y = gelu(x) */
+int sei_mul_dgelu_f32(float *d, const float *h, size_t n, void *stream);      /* d *= gelu'(h) */
 /* x (R,C) float32 or bf16 -> x16 (R,C) bf16 copy (optional, float32 input only) and xt16 (C,ldt) bf16
  * transpose (optional) whose columns R..ldt-1 are zero: a K-padded operand for sei_gemm_bf16nt.
  * colsum (optional): colsum[c] += sum_r x[r][c] in float32 -- the bias gradient, from the same pass. */

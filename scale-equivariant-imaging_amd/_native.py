@@ -64,6 +64,9 @@ SIGNATURES = {
     "sei_weight_shadow_bf16": [_P, _P, _P, _I, _I, _P],
     "sei_ln_fwd_bf16": [_P, _P, _P, _P, _P, _P, _Z, _I, _F, _P],
     "sei_colsum_bf16": [_P, _P, _Z, _I, _P],
+    "sei_split_bf16x2": [_P, _P, _Z, _P],
+    "sei_gelu_f32": [_P, _P, _Z, _P],
+    "sei_mul_dgelu_f32": [_P, _P, _Z, _P],
     "sei_cast_transpose_bf16": [_P, _I, _P, _P, _I, _I, _I, _P, _P],
     "sei_cast_bf16_colsum_weighted": [_P, _P, _P, _P, _I, _I, _P],
     "sei_cast_bf16_colsum_parts": [_P, _P, _P, _P, _I, _I, _P],
@@ -186,7 +189,7 @@ SIZE_QUERIES = {
     "sei_sepmap2_small_eligible": [_I, _I, _I, _I, _I, _I],
     "sei_cast_bf16_colsum_parts_count": [_I, _I],
 }
-ABI_VERSION = 11      # SEI_ABI_VERSION of include/sei_hip.h this table was written against
+ABI_VERSION = 12      # SEI_ABI_VERSION of include/sei_hip.h this table was written against
 
 
 class NativeLibraryError(RuntimeError):

@@ -531,6 +531,9 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
     // or residency can stall. (All slices of a tile land on one XCD with this block order -- bid % 8 does not depend on
     // zs --, which the protocol does not rely on.)
     const bool slabs = g.splitk > 1 && g.ws_slab != nullptr;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "the slab ticket protocol's cache hints (aux = 16: sc1) are written for the gfx942 / gfx950 memory model"
+#endif
     if (slabs) {
         constexpr unsigned SLAB_BYTES = (unsigned)G::BM * G::BN * 4u;
         typedef unsigned pq_u32x4 __attribute__((ext_vector_type(4)));
@@ -548,7 +551,10 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
         __syncthreads();
         volatile unsigned *mail = reinterpret_cast<volatile unsigned *>(smem);     // (the stages are free: no second LDS object)
         if (threadIdx.x == 0)
-            mail[0] = __hip_atomic_fetch_add(g.ws_cnt + ord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ACQ_REL at agent scope: the release half orders this workgroup's (drained, barrier-joined) slab stores
+            // before the ticket, the acquire half orders the last arriver's slab loads after it -- the memory model says so
+            // by itself; the sc1 hints on the stores / loads and the explicit drain stay for speed, not for correctness
+            mail[0] = __hip_atomic_fetch_add(g.ws_cnt + ord, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned ticket = mail[0];
         if (ticket != (unsigned)g.splitk - 1u) return;            // workgroup-uniform: the slab is this slice's whole result

@@ -157,14 +157,13 @@ __global__ __launch_bounds__(SMM_THREADS) void sepmap_mfma_kernel(const float *_
     // 16 lane offsets that never change (VGPRs, set once), the row offset in an SGPR. As 48 separately computed 64-bit
     // addresses the three rows in flight took 96 address registers (239 VGPRs, spills once the prefetch below was added),
     // and the address temporaries aliased load destinations still in flight (an s_waitcnt vmcnt in front of the address
-    // arithmetic). Columns j >= Wi are CLAMPED to the row's last pixel rather than masked: they meet the zero padding of
-    // R's rows, and a finite value times zero is what a masked zero gives (a NaN in that pixel reaches every output of
-    // the row through the dense R anyway).
+    // arithmetic). Columns j >= Wi get an offset beyond the resource's num_records (an image is < 2^31 bytes, smm_plan):
+    // the buffer load returns 0 for them, as a masked load would -- no Inf * 0 = NaN against the zero padding of R's rows.
     unsigned offs[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int j = (e >> 3) * 32 + lg * 8 + (e & 7);
-        offs[e] = (unsigned)(((j < g.Wi ? j : g.Wi - 1) * g.C + lc) * 4);
+        offs[e] = j < g.Wi ? (unsigned)((j * g.C + lc) * 4) : 0x7ffffff0u;
     }
     const unsigned row_bytes = (unsigned)g.Wi * g.C * 4, slice_bytes = (unsigned)g.Hi * row_bytes;
     typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -186,7 +185,8 @@ __global__ __launch_bounds__(SMM_THREADS) void sepmap_mfma_kernel(const float *_
         float *base = const_cast<float *>(x) + (size_t)b * g.Hi * g.Wi * g.C + c0;
         return __builtin_amdgcn_make_buffer_rsrc(base, 0, slice_bytes - (unsigned)c0 * 4, 0x00020000);
     };
-    // Three rows in flight per wave (rows wave, wave + 8, wave + 16 of the item): loaded for the FIRST item here, for every
+    // Two rows in flight per wave (rows wave, wave + SMM_WAVES of the item; row + 2 SMM_WAVES follows as a buffer comes free):
+    // loaded for the FIRST item here, for every
     // later one right before the previous item's pass H -- that pass only reads LDS and stores y, so the next image's
     // loads run under it (with 24-row images: all of them).
     float va[16], vb[16];

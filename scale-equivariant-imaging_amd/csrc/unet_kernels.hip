@@ -1908,7 +1908,7 @@ extern "C" int sei_conv3x3_fwd(const float *x, const float *w, const float *bias
 
 namespace {
 inline bool c3_mfma_ok(size_t npix, int Cin, int Cout, int nchw_x, int nchw_gy) {
-    const bool small_out = Cin == 32 && Cout <= 3 && !nchw_x, small_in = Cout == 32 && Cin <= 3 && !nchw_gy;
+    const bool small_out = Cin == 32 && Cout >= 1 && Cout <= 3 && !nchw_x, small_in = Cout == 32 && Cin >= 1 && Cin <= 3 && !nchw_gy;
     return (small_out || small_in) && npix < ((size_t)1 << 40);
 }
 inline unsigned c3_mfma_grid(size_t npix, size_t workgroups, size_t &ppw) {
@@ -1940,7 +1940,7 @@ extern "C" size_t sei_conv3x3_bwd_weight_parts_count(int B, int H, int W, int Ci
 }
 extern "C" int sei_conv3x3_bwd_weight_parts(const float *x, const float *gy, float *part, int B, int H, int W, int Cin,
                                             int Cout, int nchw_x, int nchw_gy, void *stream) {
-    SEI_REQUIRE(x && gy && part && B > 0 && H > 0 && W > 0);
+    SEI_REQUIRE(x && gy && part && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
     const size_t npix = (size_t)B * H * W;
     SEI_REQUIRE(c3_mfma_ok(npix, Cin, Cout, nchw_x, nchw_gy));
     size_t ppw;

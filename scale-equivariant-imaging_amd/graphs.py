@@ -95,9 +95,13 @@ class GraphedLossStep:
 
         from models import _ops
         _ops.weight_grad_views(reset=True, owner=backbone)           # record this model's weight-gradient views only
-        side = torch.cuda.Stream(device=device)
+        _ops.reset_splitk_counters(device)
+        # warm-up AND capture on this one stream: the split-K workspace of the GEMMs belongs to a (device, stream), and a
+        # stream that first meets it while capturing gets none (models/_ops.py splitk_workspace)
+        side = self._capture_stream = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
+            self._splitk_ws = _ops.own_splitk_workspace(device)      # this graph's own, alive as long as the graph is
             for _ in range(warmup):                  # settle caches / allocator outside capture
                 fwd_bwd()
         torch.cuda.current_stream(device).wait_stream(side)
@@ -153,7 +157,7 @@ class GraphedLossStep:
         self.graph = torch.cuda.CUDAGraph(keep_graph=True) if count_nodes else torch.cuda.CUDAGraph()
         self.node_counts = None
         try:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=side):
                 self.static_loss = fwd_bwd()
             if self.direct_views and _ops.direct_bf16_launches(backbone) != {v.data_ptr() for v in self.direct_views}:
                 raise RuntimeError("bf16 gradients into the exchange buffer: not every registered weight was written "
@@ -171,6 +175,7 @@ class GraphedLossStep:
                 reducer.set_direct_ranges([])
             raise
         finally:
+            _ops.release_splitk_workspace(device, side, self._splitk_ws)
             _ops.set_weight_grad_milestone(None, None, owner=backbone)
             _ops.set_fused_adam(None, None, owner=backbone)
             _ops.set_direct_bf16_grads(None, owner=backbone)

@@ -77,7 +77,8 @@ class recording:
 # thin launch helpers (pointers + sizes only; shapes are checked here, on the host)
 # ---------------------------------------------------------------------------------------------
 _GEMM_PROFILE = None     # bench.py: list of (flops, entry point, ctypes args) recorded while enabled
-_GEMM_ENTRY = {"f32": "sei_gemm_f32_ex", "bf16": "sei_gemm_bf16_ex"}
+# "bf16x3": the float32 layer functions with every GEMM evaluated as three bf16 MFMA products (gemm_x3 below)
+_GEMM_ENTRY = {"f32": "sei_gemm_f32_ex", "bf16": "sei_gemm_bf16_ex", "bf16x3": None}
 _COMPUTE_DTYPE = "f32"
 
 
@@ -85,8 +86,10 @@ _DTYPE_SCOPE = []            # innermost compute_dtype_scope (a model call or a 
 
 
 def set_compute_dtype(name):
-    """The PROCESS DEFAULT of the arithmetic type of the 1x1-convolution GEMMs: "f32" (exact-f32 MFMA; the parity mode)
-    or "bf16" (bf16 MFMA with f32 accumulation; operands stay f32 in HBM). Everything else is f32 either way. A backbone
+    """The PROCESS DEFAULT of the arithmetic type of the 1x1-convolution GEMMs: "f32" (exact-f32 MFMA; the parity mode),
+    "bf16" (bf16 MFMA with f32 accumulation; GEMM-only activations stored in bf16) or "bf16x3" (float32 storage and layer
+    functions as "f32"; each GEMM as three bf16 MFMA products of bf16 head / remainder operands, f32 accumulation: 16
+    mantissa bits per operand, the second parity mode). Everything else is f32 either way. A backbone
     may carry its own (`backbone.compute_dtype = "f32" | "bf16"`, None = the default): its forward pass and the backward
     functions it recorded run under it (`compute_dtype_scope`), so two models of different modes can live in one process."""
     global _COMPUTE_DTYPE
@@ -151,32 +154,91 @@ def _gemm_call(flops, entry, *args):
 def gemm(A, Bm, M, Nn, K, ta, tb, epi, out=None, bias=None, R1=None, R2=None, D2=None, allow_splitk=True):
     if out is None:
         out = torch.empty((M, Nn), dtype=torch.float32, device=A.device)
-    _gemm_call(2.0 * M * Nn * K, _GEMM_ENTRY[get_compute_dtype()], A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K,
+    if get_compute_dtype() == "bf16x3" and _x3_ok(A, Bm, M, Nn, K, ta, tb, epi):
+        return gemm_x3(A, Bm, M, Nn, K, ta, tb, epi, out, bias, R1, R2, D2)
+    _gemm_call(2.0 * M * Nn * K, _GEMM_ENTRY[get_compute_dtype()] or "sei_gemm_f32_ex", A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, Nn, K,
                ta, tb, epi, N.ptr(bias), N.ptr(R1), N.ptr(R2), N.ptr(D2), 1, 0, 0, 0, int(allow_splitk))
     return out
 
 
 _JOINT_SPLIT = None      # (B1, B2) while one backward pass serves the step's two model calls (joint_rows), else None
 
-# Split-K workspace of the quadrant GEMM (sei_gemm_bf16nt_ws, include/sei_hip.h): one per device, created on first use
-# with its 16-KiB block of tile counters zero -- every launch leaves them zero --, kept for the life of the process. ONE
-# per device, not per stream: the warm-up steps run on one side stream and the capture on another, and a workspace first
-# touched inside the capture would put its 256-MiB zero fill into the graph (replayed every step). The forward / data-gradient
-# GEMMs that use it are a chain on whichever single stream runs the step (leaf launches -- weight gradients -- never do).
-# SEI_SPLITK_WS_MIB = 0 puts the split launches back on float atomics (sei_gemm_bf16nt / _colsum: the round-1..5 path).
+# Split-K workspace of the quadrant GEMM (sei_gemm_bf16nt_ws, include/sei_hip.h): tile counters in its first 16 KiB (zero
+# between launches: every launch leaves them zero) + the slabs the K slices meet in. The ticket protocol indexes counters
+# and slabs by tile ordinal alone, so two launches in flight at once must never share one: a workspace belongs to ONE
+# (device, stream) -- launches on a stream are a chain. Eager launches find theirs in a small registry (created on the
+# stream's first eager use; the least recently used one is dropped when a device has SPLITK_WS_STREAMS of them). A stream
+# that is CAPTURING and has none gets none (its 256-MiB zero fill would be replayed with the graph): those launches take
+# the float-atomics path (sei_gemm_bf16nt / _colsum). graphs.GraphedLossStep therefore warms up and captures on one side
+# stream with a workspace OF ITS OWN (`own_splitk_workspace` ... `release_splitk_workspace`: registered for that stream
+# while the step is being built, kept alive by the graph's owner afterwards): its replays -- serialised by the graph
+# itself -- never share it with anybody, whatever stream they are launched from, and torch handing the same pooled stream
+# to somebody else later cannot alias it. SEI_SPLITK_WS_MIB = 0 switches the workspace off everywhere (round-1..5 path).
 SPLITK_WS_MIB = int(os.environ.get("SEI_SPLITK_WS_MIB", "256"))
-_SPLITK_WS = {}
+SPLITK_WS_STREAMS = 4
+SPLITK_COUNTER_BYTES = 16 << 10
+_SPLITK_WS = {}              # (device index, stream handle) -> uint8 tensor; insertion order = least recently used first
+
+
+def _splitk_key(device):
+    dev = torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    return dev, torch.cuda.current_stream(dev).cuda_stream
 
 
 def splitk_workspace(device):
-    """(pointer, bytes) of this device's split-K workspace, or (None, 0) when switched off."""
+    """(pointer, bytes) of the split-K workspace of (`device`, its current stream), or (None, 0): switched off, or the
+    stream is capturing without one."""
     if SPLITK_WS_MIB <= 0:
         return None, 0
-    key = torch.device(device).index
-    ws = _SPLITK_WS.get(key)
+    key = _splitk_key(device)
+    ws = _SPLITK_WS.pop(key, None)
     if ws is None:
-        ws = _SPLITK_WS[key] = torch.zeros(SPLITK_WS_MIB << 20, dtype=torch.uint8, device=device)
+        if torch.cuda.is_current_stream_capturing():
+            return None, 0
+        mine = [k for k in _SPLITK_WS if k[0] == key[0]]
+        if len(mine) >= SPLITK_WS_STREAMS:
+            del _SPLITK_WS[mine[0]]              # (freed in stream order by the caching allocator: its launches are queued)
+        ws = torch.zeros(SPLITK_WS_MIB << 20, dtype=torch.uint8, device=f"cuda:{key[0]}")
+    _SPLITK_WS[key] = ws                         # most recently used last
     return ws.data_ptr(), ws.numel()
+
+
+def own_splitk_workspace(device):
+    """A NEW workspace registered for (`device`, its current stream), returned to the caller, who keeps it alive for as
+    long as launches recorded on this stream may run (a captured graph) and calls release_splitk_workspace when it has
+    finished recording. None when switched off."""
+    if SPLITK_WS_MIB <= 0:
+        return None
+    key = _splitk_key(device)
+    ws = _SPLITK_WS[key] = torch.zeros(SPLITK_WS_MIB << 20, dtype=torch.uint8, device=f"cuda:{key[0]}")
+    return ws
+
+
+def release_splitk_workspace(device, stream, ws):
+    """Take `ws` (from own_splitk_workspace on `stream`) out of the registry: later eager launches on that stream handle
+    get a workspace of their own."""
+    dev = torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    key = (dev, stream.cuda_stream)
+    if ws is not None and _SPLITK_WS.get(key) is ws:
+        del _SPLITK_WS[key]
+
+
+def reset_splitk_counters(device):
+    """Zero the tile counters of every workspace of `device`, each on the stream that owns it (a launch that never
+    finished -- a fault survived by the process -- would leave tickets behind, and no slice would ever draw the last one).
+    Not under capture. graphs.GraphedLossStep calls it before its warm-up."""
+    dev = torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    for (d, handle), ws in _SPLITK_WS.items():
+        if d == dev:
+            with torch.cuda.stream(torch.cuda.ExternalStream(handle, device=f"cuda:{dev}") if handle else
+                                   torch.cuda.default_stream(dev)):
+                ws[:SPLITK_COUNTER_BYTES].zero_()
 
 
 def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=None, R2=None, D2_16=None,
@@ -241,6 +303,67 @@ def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=Non
         _gemm_call(fl, "sei_gemm_bf16nt_ws", *args, None, ws, ws_bytes, 0, 0, 0)
     else:
         _gemm_call(fl, "sei_gemm_bf16nt", *args)
+
+
+# ---------------------------------------------------------------------------------------------
+# --compute_dtype bf16x3: a float32 GEMM as three bf16 MFMA products (csrc/bf16x3.hip has the arithmetic and the error
+# bound). Operands are split once into bf16 head / remainder PLANES ((2, rows, cols): either plane is a dense operand of
+# sei_gemm_bf16nt in whatever orientation the float32 GEMM read the tensor), weights once per optimizer step. The three
+# launches accumulate into the float32 result, small terms first; additive epilogues (bias, residuals, the running
+# gradient) ride on the first launch, GELU / GELU' follow as element-wise passes.
+# ---------------------------------------------------------------------------------------------
+def _x3_ok(A, Bm, M, Nn, K, ta, tb, epi):
+    """Shapes sei_gemm_bf16nt takes (K % 8, 16-byte rows of the reduction-major operands); anything else -- the 3-channel
+    ends of the network never come here -- stays on the float32 GEMM."""
+    if not (A.is_cuda and A.dtype == torch.float32 and Bm.dtype == torch.float32 and K % 8 == 0 and Nn % 4 == 0):
+        return False
+    if (ta and M % 8) or (not tb and Nn % 8) or A.numel() % 4 or Bm.numel() % 4 or not A.is_contiguous() \
+            or not Bm.is_contiguous():
+        return False
+    return epi in (EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_ACCUM, EPI_BIAS_ROWSCALE)
+
+
+def split_x2(t):
+    """(2, *t.shape) bf16: head and remainder planes of a float32 tensor. A parameter's planes are cached until its
+    values change (this model's optimizer kernel / load_state_dict: `_generation`, torch's version counter) -- and rebuilt
+    once inside a capture, so that every replay splits the weights of ITS step."""
+    def fresh():
+        planes = torch.empty((2,) + tuple(t.shape), dtype=torch.bfloat16, device=t.device)
+        N.call("sei_split_bf16x2", t.data_ptr(), planes.data_ptr(), t.numel())
+        return planes
+    if not isinstance(t, torch.nn.Parameter):
+        return fresh()
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (_generation(getattr(t, "_sei_plain_state", None)), t._version, t.data_ptr(), capturing)
+    hit = getattr(t, "_sei_split", None)
+    if hit is None or hit[0] != key:
+        hit = (key, fresh())
+        t._sei_split = hit
+    return hit[1]
+
+
+def gemm_x3(A, Bm, M, Nn, K, ta, tb, epi, out, bias=None, R1=None, R2=None, D2=None):
+    """gemm()'s contract (float32 operands as stored: A (M, K) or (K, M) when ta, Bm (N, K) when tb else (K, N))."""
+    a2, b2 = split_x2(A).view(2, -1), split_x2(Bm).view(2, -1)
+    (a_hi, a_lo), (b_hi, b_lo) = a2, b2
+    arm, brm = bool(ta), not tb
+    third = 2.0 * M * Nn * K / 3.0                    # (algorithmic FLOPs are booked once over the three launches)
+    first = {EPI_BIAS_GELU: EPI_BIAS, EPI_MUL_DGELU: EPI_NONE}.get(epi, epi)
+    if arm and brm and epi == EPI_ACCUM and (2 * K) % 8 == 0:
+        # a weight gradient: the two products with the head of A share one two-segment launch
+        _gemm_call(2.0 * third, "sei_gemm_bf16nt_dw2", a_hi.data_ptr(), a_hi.data_ptr(), M, b_lo.data_ptr(), b_hi.data_ptr(),
+                   Nn, out.data_ptr(), M, Nn, K, K, 1)
+        gemm_nt16(a_lo, b_hi, M, Nn, K, EPI_ACCUM, out32=out, a_rmajor=True, b_rmajor=True, flops=third)
+        return out
+    gemm_nt16(a_lo, b_hi, M, Nn, K, first, out32=out, bias=bias, R1=R1 if first != EPI_NONE else None,
+              R2=R2 if first == EPI_BIAS_RES else None, a_rmajor=arm, b_rmajor=brm, flops=third)
+    gemm_nt16(a_hi, b_lo, M, Nn, K, EPI_ACCUM, out32=out, a_rmajor=arm, b_rmajor=brm, flops=third)
+    gemm_nt16(a_hi, b_hi, M, Nn, K, EPI_ACCUM, out32=out, a_rmajor=arm, b_rmajor=brm, flops=third)
+    if epi == EPI_BIAS_GELU:
+        N.call("sei_gelu_f32", out.data_ptr(), D2.data_ptr(), out.numel())
+    elif epi == EPI_MUL_DGELU:
+        N.call("sei_mul_dgelu_f32", out.data_ptr(), R1.data_ptr(), out.numel())
+    return out
 
 
 def layer_norm(x2d, gamma, beta):

@@ -49,7 +49,7 @@ def build_parser():
     flag("--GroundTruthDataset__split", type=str, default="val")
     flag("--SyntheticDataset__deterministic_measurements", action=BooleanOptionalAction, default=True)
     flag("--memoize_gt", action=BooleanOptionalAction, default=False)
-    flag("--compute_dtype", choices=["f32", "bf16"], default="f32")          # build-side addition
+    flag("--compute_dtype", choices=["f32", "bf16", "bf16x3"], default="f32")          # build-side addition
     return parser
 
 

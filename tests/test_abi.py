@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     handle = ctypes.CDLL(_native.LIB_PATH)       # loads on a GPU-less host: no HIP call at load time
     missing = [name for name in declared() if not hasattr(handle, name)]
     assert not missing, f"declared in sei_hip.h but not exported: {missing}"
-    assert handle.sei_abi_version() == _native.ABI_VERSION == 11
+    assert handle.sei_abi_version() == _native.ABI_VERSION == 12
     buf = ctypes.create_string_buffer(16)
     assert handle.sei_build_target(buf, 16) == 0 and buf.value == b"gfx950"
 

@@ -237,10 +237,32 @@ def test_loss_surface_and_methods():
 
 
 # ------------------------------------------------------------------ full-size network: config[1] parity
-def test_default_unet_step_vs_oracle():
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_default_unet_step_vs_oracle(mode):
     """The benchmarked network (hidden 32, 5 scales, 645 M parameters) at the training crop size:
     restored images within 1e-4 relative and 0.01 dB PSNR of the float32 CPU path; loss and gradient
-    norms within 1e-4 (SURVEY 8d 'parity check in the same run')."""
+    norms within 1e-4 (SURVEY 8d 'parity check in the same run'). mode: the exact-f32 MFMA GEMMs, and the split-bf16
+    mode (three bf16 MFMA products per float32 product, models/_ops.py gemm_x3) held to the SAME bars."""
+    from models import _ops
+    prev = _ops.set_compute_dtype(mode)
+    try:
+        _default_unet_step_vs_oracle(B=2)
+    finally:
+        _ops.set_compute_dtype(prev)
+
+
+def test_split_bf16_step_vs_oracle_at_a_batch_whose_weight_gradients_split_too():
+    """bf16x3 at batch 8 (72 bottleneck rows: every GEMM of the step, weight gradients included, runs as three bf16
+    products -- at batch 2 the 18-row reductions of the deepest weight gradients stay on the float32 GEMM), same bars."""
+    from models import _ops
+    prev = _ops.set_compute_dtype("bf16x3")
+    try:
+        _default_unet_step_vs_oracle(B=8)
+    finally:
+        _ops.set_compute_dtype(prev)
+
+
+def _default_unet_step_vs_oracle(B):
     import bench
     import metrics
     import models
@@ -253,11 +275,11 @@ def test_default_unet_step_vs_oracle():
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.get_weights().items()}   # CPU, f32
     model.to("cuda")
     gen = torch.Generator().manual_seed(11)
-    B = 2
     xgt = torch.rand((B, 3, 48, 48), generator=gen)
     b_int = torch.randn((B, 3, 36, 36), generator=gen)
     noise = torch.randn((B, 3, 48, 48), generator=gen)
-    rate, center = torch.tensor([0.75, 0.5]), torch.tensor([[0.3, -0.2], [-0.5, 0.6]])
+    rate = torch.tensor([0.75, 0.5]).repeat(B // 2)
+    center = torch.tensor([[0.3, -0.2], [-0.5, 0.6]]).repeat(B // 2, 1)
     k = tp.blur_kernel("Gaussian_R2")
     A = lambda v: tp.blur_fft(v, k)
     y = A(xgt) + 5 / 255 * torch.randn((B, 3, 48, 48), generator=gen)
@@ -938,6 +960,30 @@ def test_graphed_step_matches_eager():
     before = torch.cuda.get_rng_state()
     graphed.graph.replay()
     assert torch.equal(before, torch.cuda.get_rng_state())
+
+
+def test_every_captured_step_owns_its_split_k_workspace():
+    """The slab workspace of the split-K GEMMs holds per-tile counters: two launches in flight at once must not share one
+    (ADVICE r5). A GraphedLossStep records its launches against a workspace of its own, which it keeps alive and which
+    leaves the per-stream registry once the graph is built."""
+    import bench
+    import physics
+    import models
+    from graphs import GraphedLossStep
+    from losses import get_loss
+    from models import _ops
+    from optim import FlatAdam
+    steps = []
+    for _ in range(2):
+        args = bench.reference_args("cuda", 8, 3)
+        torch.manual_seed(0)
+        p = physics.get_physics(args, "cuda")
+        model = models.get_model(args, p, "cuda").to("cuda")
+        steps.append(GraphedLossStep(get_loss(args, p), model, FlatAdam(model, lr=1e-4), (4, 3, 48, 48)))
+    a, b = steps[0]._splitk_ws, steps[1]._splitk_ws
+    assert a is not None and b is not None and a.data_ptr() != b.data_ptr()
+    assert all(ws is not a and ws is not b for ws in _ops._SPLITK_WS.values())
+    assert sum(1 for k in _ops._SPLITK_WS if k[0] == 0) <= _ops.SPLITK_WS_STREAMS
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])

@@ -670,23 +670,109 @@ def test_weight_gradient_reduction_major(ops, M, Np, Kp):
     assert relerr(acc, ref) < 5e-6
 
 
-def test_splitk_gemm_inside_hipgraph(ops):
-    """A split-K GEMM (zero-fill + atomics) replayed from a captured graph must not accumulate stale sums."""
+@pytest.mark.parametrize("M,N,K", [(2304, 512, 128), (576, 2048, 512), (288, 512, 2048), (72, 8192, 2048), (4608, 128, 512)])
+def test_split_bf16_gemm_against_float64(ops, M, N, K):
+    """models/_ops.py gemm_x3 (--compute_dtype bf16x3): every orientation and epilogue the float32 layer functions use,
+    against float64 -- a float32-class result (relative error of a few 1e-6 of the largest entry; one bf16 product alone is
+    ~3e-3) from three bf16 MFMA launches; and the head / remainder planes themselves."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn((M, K), generator=gen)
+    planes = ops.split_x2(x.cuda())
+    hi, lo = planes[0].float().cpu(), planes[1].float().cpu()
+    assert torch.equal(hi, x.bfloat16().float()) and torch.equal(lo, (x - hi).bfloat16().float())
+    assert float((x - hi - lo).abs().max() / x.abs().max()) < 2.0 ** -16
+    prev = ops.set_compute_dtype("bf16x3")
+    try:
+        w = 0.05 * torch.randn((N, K), generator=gen)
+        bias, res = torch.randn((N,), generator=gen), torch.randn((M, N), generator=gen)
+        xd, wd, bd, rd = x.cuda(), w.cuda(), bias.cuda(), res.cuda()
+        ref = x.double() @ w.double().T
+        scale = float(ref.abs().max())
+        tol = 4e-6
+        # forward orientation: A (M, K), B (N, K); bias + GELU with the second output
+        h4 = torch.empty((M, N), device="cuda")
+        h3 = ops.gemm(xd, wd, M, N, K, 0, 1, ops.EPI_BIAS_GELU, bias=bd, D2=h4)
+        want = ref + bias.double()
+        assert float((h3.cpu().double() - want).abs().max()) < tol * scale
+        assert float((h4.cpu().double() - torch.nn.functional.gelu(want)).abs().max()) < tol * scale
+        out = ops.gemm(xd, wd, M, N, K, 0, 1, ops.EPI_BIAS_RES, bias=bd, R1=rd, R2=rd)
+        assert float((out.cpu().double() - (want + 2 * res.double())).abs().max()) < tol * scale
+        s = torch.rand((M,), generator=gen)
+        out = ops.gemm(xd, wd, M, N, K, 0, 1, ops.EPI_BIAS_ROWSCALE, bias=bd, R1=s.cuda())
+        assert float((out.cpu().double() - (ref + s.double()[:, None] * bias.double())).abs().max()) < tol * scale
+        # data gradient: B (K', N') read reduction-major; plain and with GELU'
+        g = torch.randn((M, N), generator=gen)
+        gd = g.cuda()
+        gref = g.double() @ w.double()
+        gx = ops.gemm(gd, wd, M, K, N, 0, 0, ops.EPI_NONE)
+        assert float((gx.cpu().double() - gref).abs().max()) < tol * float(gref.abs().max())
+        pre = torch.randn((M, K), generator=gen)
+        gx = ops.gemm(gd, wd, M, K, N, 0, 0, ops.EPI_MUL_DGELU, R1=pre.cuda())
+        p64 = pre.double().requires_grad_(True)
+        (dg,) = torch.autograd.grad(torch.nn.functional.gelu(p64).sum(), p64)
+        assert float((gx.cpu().double() - gref * dg).abs().max()) < tol * float(gref.abs().max())
+        # weight gradient: both operands reduction-major, accumulated into a running gradient
+        base = torch.randn((N, K), generator=gen)
+        acc = base.clone().cuda()
+        ops.gemm(gd, xd, N, K, M, 1, 0, ops.EPI_ACCUM, out=acc)
+        wref = g.double().T @ x.double()
+        assert float((acc.cpu().double() - (wref + base.double())).abs().max()) < tol * float(wref.abs().max())
+    finally:
+        ops.set_compute_dtype(prev)
+
+
+@pytest.mark.parametrize("same_stream", [False, True])
+def test_splitk_gemm_inside_hipgraph(ops, same_stream):
+    """A split-K GEMM replayed from a captured graph must not accumulate stale sums. same_stream: warm-up and capture on
+    one side stream, so the launch meets its (device, stream) slab workspace (what graphs.GraphedLossStep does); otherwise
+    the capturing stream has no workspace yet and the launch takes the zero-fill + float-atomics path."""
     gen = torch.Generator().manual_seed(5)
     M, N, K = 2304, 128, 512                      # 18 tiles, long K: the split-K path
     A = torch.randn((M, K), generator=gen).bfloat16().cuda()
     Bm = torch.randn((N, K), generator=gen).bfloat16().cuda()
     ref = A.double().cpu() @ Bm.double().cpu().T
     out = torch.full((M, N), 7.0, device="cuda")
-    ops.gemm_nt16(A, Bm, M, N, K, ops.EPI_NONE, out32=out)          # warm up outside capture
+    side = torch.cuda.Stream()
+    ops._SPLITK_WS.pop((0, side.cuda_stream), None)       # (torch hands out pooled streams: forget an earlier user's)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side if same_stream else torch.cuda.current_stream()):
+        ops.gemm_nt16(A, Bm, M, N, K, ops.EPI_NONE, out32=out)          # warm up outside capture
     torch.cuda.synchronize()
+    assert ((0, side.cuda_stream) in ops._SPLITK_WS) == same_stream
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, stream=side):
+        assert (ops.splitk_workspace("cuda:0")[0] is not None) == same_stream
         ops.gemm_nt16(A, Bm, M, N, K, ops.EPI_NONE, out32=out)
     for _ in range(3):
         graph.replay()
         torch.cuda.synchronize()
         assert relerr(out, ref) < 3e-6
+
+
+def test_splitk_workspaces_belong_to_one_stream_each(ops):
+    """Two split-K launches in flight on two streams use two workspaces (the ticket protocol indexes counters and slabs
+    by tile ordinal alone); both results are right, and reset_splitk_counters leaves every counter block zero."""
+    gen = torch.Generator().manual_seed(6)
+    M, N, K = 2304, 128, 2048
+    A = torch.randn((M, K), generator=gen).bfloat16().cuda()
+    B1, B2 = (torch.randn((N, K), generator=gen).bfloat16().cuda() for _ in range(2))
+    outs = [torch.empty((M, N), device="cuda") for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for _ in range(20):
+        for st, Bm, out in zip(streams, (B1, B2), outs):
+            with torch.cuda.stream(st):
+                ops.gemm_nt16(A, Bm, M, N, K, ops.EPI_NONE, out32=out)
+    torch.cuda.synchronize()
+    mine = [(0, st.cuda_stream) for st in streams]
+    assert all(k in ops._SPLITK_WS for k in mine) and ops._SPLITK_WS[mine[0]] is not ops._SPLITK_WS[mine[1]]
+    assert sum(1 for k in ops._SPLITK_WS if k[0] == 0) <= ops.SPLITK_WS_STREAMS      # least recently used ones are dropped
+    for Bm, out in zip((B1, B2), outs):
+        assert relerr(out, A.double().cpu() @ Bm.double().cpu().T) < 3e-6
+    ops.reset_splitk_counters("cuda:0")
+    torch.cuda.synchronize()
+    for key in mine:
+        assert int(ops._SPLITK_WS[key][:ops.SPLITK_COUNTER_BYTES].max()) == 0
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (576, 512, 128), (288, 2048, 512), (136, 264, 72), (2304, 128, 512),

@@ -79,8 +79,9 @@ def build_parser():
     flag("--fused_optimizer", default=True, **onoff)
     flag("--fix_batched_crop", default=False, **onoff)
     flag("--max_steps", type=int, default=None, help="stop each epoch after this many steps (smoke runs)")
-    flag("--compute_dtype", choices=["f32", "bf16"], default="f32",
-         help="1x1-conv GEMM arithmetic: f32 (reference precision) or bf16 MFMA with f32 accumulation")
+    flag("--compute_dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
+         help="1x1-conv GEMM arithmetic: f32 (reference precision), bf16 MFMA with f32 accumulation, or bf16x3 (three bf16 "
+              "MFMA products of head / remainder operands per float32 GEMM: 16 mantissa bits, held to the f32 parity bars)")
     flag("--hip_graph", default=True, **onoff)
     flag("--fuse_optimizer_step", default=True, **onoff,
          help="one GPU, bf16, hipGraph replay: weights of at least 2^24 elements (the U-Net's two deepest levels) take their "
