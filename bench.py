@@ -257,6 +257,21 @@ def _stream_bytes(name, a):
         return 24 * a[4]
     if name == "sei_axpy":
         return 12 * a[4]
+    if name == "sei_stack_axpy":                          # a, b in; [a, a + alpha b] out
+        return 16 * a[4]
+    if name == "sei_proposed_draws":                      # written only: probe interior, rates, centres, noise
+        B, C, H, W, m = a[3:8]
+        return 4 * (B * C * ((H - 2 * m) * (W - 2 * m) + H * W) + 3 * B)
+    if name == "sei_crop_window":
+        return 8 * a[2] * a[7] * a[7]
+    if name == "sei_split_bf16x2":                        # float32 in, two bf16 planes out
+        return 8 * a[2]
+    if name == "sei_split_bf16x3":
+        return 10 * a[2]
+    if name == "sei_gelu_f32":
+        return 8 * a[2]
+    if name == "sei_mul_dgelu_f32":
+        return 12 * a[2]
     if name in ("sei_sure_terms", "sei_sure_loss"):
         return 24 * a[4] * a[5] * a[6]
     if name in ("sei_mse_terms", "sei_mse_loss"):
@@ -317,10 +332,27 @@ _STREAM_FAMILIES = [
      ("sei_pad_nhwc", "sei_unpad_nhwc", "sei_rowscale", "sei_pack", "sei_unpack_add")),
     ("cast / colsum kernels (bf16 copies, bias gradients)", ("sei_cast_", "sei_colsum_", "sei_transpose_bf16_many")),
     ("conv3x3_* (in / out convolutions)", ("sei_conv3x3_",)),
-    ("blur / scale_resample / axpy / sure / mse kernels (physics + loss terms)",
+    ("blur / scale_resample / axpy / sure / mse / draws / crop kernels (physics + loss terms, the step's prologue)",
      ("sei_blur_", "sei_scale_resample_", "sei_scale_params", "sei_axpy", "sei_sure_terms", "sei_sure_loss", "sei_mse_terms", "sei_mse_loss",
-      "sei_resample_")),
+      "sei_resample_", "sei_stack_axpy", "sei_proposed_draws", "sei_crop_window")),
+    ("split / gelu passes of the bf16x3 mode (bf16 head + remainder planes of every GEMM operand; GELU, GELU' element-wise)",
+     ("sei_split_bf16x", "sei_gelu_f32", "sei_mul_dgelu_f32")),
 ]
+# The depthwise 7x7 family is bound by the float32 FMA issue rate, not by HBM (PMC): one v_fma_f32 wave-instruction
+# per 4 cycles per SIMD = 256 CUs x 4 SIMDs x 16 lanes x 2 FLOP x 2.4 GHz; 49 taps x 2 FLOP per element and call.
+VALU_F32_FMA_PEAK_TFLOPS = 78.6
+
+
+def _dwconv_flops(name, a):
+    if name in ("sei_dwconv7_fwd", "sei_dwconv7_fwd_ex"):
+        B, H, W, C = a[6:10]
+    elif name == "sei_dwconv7_ln_fwd":
+        B, H, W, C = a[10:14]
+    elif name in ("sei_dwconv7_bwd_weight", "sei_dwconv7_bwd_weight_ex"):
+        B, H, W, C = a[4:8]
+    else:
+        return 0.0
+    return 98.0 * B * H * W * C
 PMC_TRAFFIC_FILE = "r05_g_unet_pmc_gemm.json"      # the committed PMC pass `roofline.traffic` is read from
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -360,6 +392,10 @@ def stream_roofline(log, reps=3):
         out.append({"kernel": label, "launches_per_step": len(calls), "bytes_per_step": round(nbytes),
                     "ms_per_step": round(ms, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4)})
+        if label.startswith("dwconv7_"):                  # its stated roof: the f32 FMA issue rate
+            tf = sum(_dwconv_flops(n, a) for n, a in calls) / (ms * 1e-3) / 1e12
+            out[-1]["valu"] = {"bound": "valu_f32_fma", "achieved": round(tf, 2), "peak": VALU_F32_FMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(tf / VALU_F32_FMA_PEAK_TFLOPS, 4)}
     return out
 
 
@@ -377,8 +413,10 @@ def dist1_child(opt, grad_comm=None, timeout=420):
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    env = dict(os.environ, SEI_FORCE_EXCHANGE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+    # (SEI_EXCHANGE_IN_PLACE=1: with one rank the in-place collectives are no-ops, which is the rehearsal's point -- the
+    # out-of-place default would add whole-bucket staging copies here that shrink to 1/N of that at N ranks)
+    env = dict(os.environ, SEI_FORCE_EXCHANGE="1", SEI_EXCHANGE_IN_PLACE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
                SEI_BENCH_FULL=os.path.join(ROOT, "gpurun_out", f"bench_full_dist1_{grad_comm}.json"))
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "10", "--warmup", "3", "--batch",
            str(opt.batch), "--no-secondary", "--no-cpu-baseline", "--grad-comm", grad_comm, "--grad-comm-mode",
@@ -399,7 +437,44 @@ def dist1_child(opt, grad_comm=None, timeout=420):
                         "fused into the GEMMs): the per-rank compute + plumbing cost of the 8-GPU step, without the wire time")
     keep["grad_allreduce"] = child["config"].get("grad_allreduce")
     keep["launch"] = child["config"].get("launch")
+    nparams = (child.get("config") or {}).get("parameters") or 645063043
+    keep["projected_from_world1_rccl"] = project_ranks(keep, nparams, opt.batch, grad_comm)
     return keep
+
+
+# xGMI on an MI355X node: every pair of GPUs is joined by ONE link (7 links per GPU, ~153.6 GB/s each in both directions
+# together). The projection is computed for both readings of that figure -- 76.8 GB/s per direction, and 153.6 -- at 70 %
+# of the link rate (the DESIGN section 6 assumption; RCCL has not run two ranks of this code: falsifiers listed there).
+XGMI_LINK_GBS = (76.8, 153.6)
+XGMI_EFFICIENCY = 0.7
+EARLY_RELEASE_MS, EARLY_RELEASE_SHARE = 3.5, 0.83      # the bottleneck block's gradients leave 3.5 ms before the graph ends
+
+
+def project_ranks(world1, nparams, batch, grad_comm):
+    """PROJECTED, not measured: the N-rank step from the world-1 rehearsal (`secondary.dist1*`: everything but the wire
+    time is live there). step_N = step_1 - Adam over the bucket x (1 - 1/N) + exposed wire time; reduce-scatter of the
+    gradients (4 or 2 B per parameter) and all-gather of the updated bf16 weight copies (2 B per parameter), each moving
+    1/N of its buffer over each of the N - 1 links of a rank; the early-released 83 % of the reduce-scatter hides under
+    the last 3.5 ms of the backward. Returns {"n2": ..., "n8": ...} with (low, high) over the two link-rate readings."""
+    step1 = world1.get("ms_per_step")
+    adam = next((f["ms_per_step"] for f in world1.get("roofline_hbm") or [] if str(f.get("kernel", "")).startswith("adam_vec")), None)
+    if step1 is None or adam is None:
+        return None
+    out = {"label": "projected from world-1 RCCL (not measured)", "inputs": {"step_ms_world1": step1, "adam_whole_bucket_ms": adam,
+           "grad_bytes_per_param": 2 if grad_comm == "bf16" else 4, "weight_bytes_per_param": 2,
+           "link_GBps_per_direction": list(XGMI_LINK_GBS), "link_efficiency": XGMI_EFFICIENCY}}
+    for n in (2, 8):
+        steps = []
+        for rate in XGMI_LINK_GBS:
+            per_link = lambda nbytes: nbytes / n / (rate * 1e9 * XGMI_EFFICIENCY) * 1e3         # ms: 1/N of the buffer per link
+            rs = per_link((2 if grad_comm == "bf16" else 4) * nparams)
+            ag = per_link(2 * nparams)
+            hidden = min(EARLY_RELEASE_SHARE * rs, EARLY_RELEASE_MS)
+            steps.append(step1 - adam * (1.0 - 1.0 / n) + (rs - hidden) + ag)
+        slow, fast = max(steps), min(steps)
+        out[f"n{n}"] = {"ms_per_step": [round(fast, 2), round(slow, 2)],
+                        "images_per_s": [round(n * batch / slow * 1e3, 0), round(n * batch / fast * 1e3, 0)]}
+    return out
 
 
 LINE_LIMIT = 7800            # the driver keeps an 8,081-character tail of stdout: the whole headline line must fit in it
@@ -444,6 +519,9 @@ def compact_line(full, limit=LINE_LIMIT):
                 small["roofline"] = {"frac": r.get("frac"), "bound": r.get("bound"), "gemm_ms_per_step": r.get("gemm_ms_per_step")}
             if entry.get("graph_kernel_nodes_per_step") is not None:
                 small["nodes"] = entry["graph_kernel_nodes_per_step"]
+            proj = entry.get("projected_from_world1_rccl")
+            if proj:                                    # projected, not measured: labelled as such on the line too
+                small["projected_not_measured"] = {k: proj[k]["images_per_s"] for k in ("n2", "n8") if k in proj}
             out["secondary"][key] = small
         out["secondary_full"] = "one earlier stdout line per series ({\"series\": name, ...}) and " + str(full.get("full_file"))
     for key in ("cpu_baseline", "cpu_baseline_swinir"):

@@ -127,6 +127,24 @@ int sei_rotate_nearest_bwd(const float *gy, float *gx, int planes, int H, int W,
  * ------------------------------------------------------------------------------------------- */
 #define SEI_REDUCE_BLOCKS 256
 int sei_axpy(const float *a, const float *b, float alpha, float *out, size_t n, void *stream);
+/* out[0:n] = a, out[n:2n] = a + alpha b (sei_axpy's arithmetic): the 2B-image input [y, y + tau b] of the fused SURE pass
+ * (src/losses/sure.py:24 + the model call on y) in one launch instead of axpy + torch.cat. n % 4 == 0, 16-byte aligned. */
+int sei_stack_axpy(const float *a, const float *b, float alpha, float *out, size_t n, void *stream);
+/* The eager prologue of a proposed-loss step (csrc/draws.hip).
+ * sei_proposed_draws: the step's device-side draws in ONE launch, on the random stream of the torch calls they replace
+ * (uniform draws bit-identical, normal draws to <= 3 ulp: csrc/draws.hip) --
+ * torch.randn(B, C, H - 2m, W - 2m) into the interior of b (src/losses/sure.py:13-22; the border of b is not touched),
+ * torch.rand(B) -> rate = table[floor(ntable u)], torch.rand(B, 2) -> centre = 2 u - 1 (src/transforms.py:5-24),
+ * torch.randn(B, C, H, W) -> noise (deepinv GaussianNoise inside EILoss) -- for torch's CUDA generator at (seed, offset):
+ * element i of each tensor = component x of rocrand_normal4 / rocrand_uniform4 of Philox4x32-10 (seed, subsequence i,
+ * offset + 4 k), k = 0..3 in the order above. The caller advances the generator's offset by 16. B C H W <=
+ * sei_proposed_draws_max_numel() (torch's one-element-per-thread regime), offset % 4 == 0.
+ * sei_crop_window: out (planes, S, S) = the S x S window of y (planes, H, W) at (i0, j0), zero where the window leaves y
+ * (src/crop.py:26-57 applied to a batch: the offset is drawn over the zero-padded extent). */
+int sei_proposed_draws(unsigned long long seed, unsigned long long offset, float *b, int B, int C, int H, int W, int margin,
+                       const float *table, int ntable, float *rate, float *center, float *noise, void *stream);
+size_t sei_proposed_draws_max_numel(void);
+int sei_crop_window(const float *y, float *out, int planes, int H, int W, int i0, int j0, int S, void *stream);
 /* base[off_k .. off_k + len_k) = 0 for up to 8 (off, len) pairs of elements (HOST array of 2 * count values): the gaps of
  * the flat gradient bucket between the weight gradients that the captured step stores, in ONE launch (optimizer.zero_grad,
  * demo/train.py:258). */
@@ -324,6 +342,10 @@ int sei_colsum_bf16(const uint16_t *X, float *out, size_t M, int N, void *stream
  * accumulate in float32; the two epilogues that are not additive run as the element-wise passes below (exact erf forms,
  * as SEI_EPI_BIAS_GELU / SEI_EPI_MUL_DGELU of sei_gemm_f32 apply them). */
 int sei_split_bf16x2(const float *x, uint16_t *planes, size_t n, void *stream);
+/* Three planes, for a reduction concatenated over the three products (weight gradients: planes of a reduction-major
+ * operand stack along the reduction index, so ONE launch with K' = 3 K sums them): pattern 0 = [head, head, remainder]
+ * (the A side), 1 = [head, remainder, head] (the B side). planes: 3 n bf16; n % 4 == 0. */
+int sei_split_bf16x3(const float *x, uint16_t *planes, size_t n, int pattern, void *stream);
 int sei_gelu_f32(const float *x, float *y, size_t n, void *stream);            /* y = gelu(x) */
 int sei_mul_dgelu_f32(float *d, const float *h, size_t n, void *stream);      /* d *= gelu'(h) */
 /* x (R,C) float32 or bf16 -> x16 (R,C) bf16 copy (optional, float32 input only) and xt16 (C,ldt) bf16

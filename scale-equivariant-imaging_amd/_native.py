@@ -38,6 +38,9 @@ SIGNATURES = {
     "sei_rotate_nearest_fwd": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
     "sei_rotate_nearest_bwd": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
     "sei_axpy": [_P, _P, _F, _P, _Z, _P],
+    "sei_stack_axpy": [_P, _P, _F, _P, _Z, _P],
+    "sei_proposed_draws": [_c.c_ulonglong, _c.c_ulonglong, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
+    "sei_crop_window": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sei_zero_ranges": [_P, _P, _I, _P],
     "sei_sure_terms": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     "sei_mse_terms": [_P, _P, _Z, _F, _P, _P, _P, _P],
@@ -65,6 +68,7 @@ SIGNATURES = {
     "sei_ln_fwd_bf16": [_P, _P, _P, _P, _P, _P, _Z, _I, _F, _P],
     "sei_colsum_bf16": [_P, _P, _Z, _I, _P],
     "sei_split_bf16x2": [_P, _P, _Z, _P],
+    "sei_split_bf16x3": [_P, _P, _Z, _I, _P],
     "sei_gelu_f32": [_P, _P, _Z, _P],
     "sei_mul_dgelu_f32": [_P, _P, _Z, _P],
     "sei_cast_transpose_bf16": [_P, _I, _P, _P, _I, _I, _I, _P, _P],
@@ -163,6 +167,7 @@ TRANSPOSE_MAX_JOBS = 16
 
 # size queries: return size_t, take no stream
 SIZE_QUERIES = {
+    "sei_proposed_draws_max_numel": [],
     "sei_dwconv7_bwd_weight_workspace": [_I, _I, _I, _I],
     "sei_dwconv7_bwd_weight_workspace_ex": [_I, _I, _I, _I, _I],
     "sei_ln_bwd_workspace": [_Z, _I],

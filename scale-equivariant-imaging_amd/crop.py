@@ -61,6 +61,12 @@ class CropPair(Module):
         """out <- the (size x size) crop of the zero-padded y at (i, j): one strided copy when the window lies inside y,
         a zero fill in front of it when it reaches into the padding (the batched-crop quirk, module docstring)."""
         s = self.size
+        if y.is_cuda and y.dtype == torch.float32 and out.dtype == torch.float32 and y.is_contiguous() \
+                and out.is_contiguous() and y.dim() >= 2 and tuple(out.shape) == tuple(y.shape[:-2]) + (s, s):
+            import _native as N                         # one launch: the window, zeros where it leaves y
+            N.call("sei_crop_window", y.data_ptr(), out.data_ptr(), y.numel() // (y.shape[-2] * y.shape[-1]), y.shape[-2],
+                   y.shape[-1], int(i), int(j), s)
+            return out
         vh, vw = min(s, y.shape[-2] - i), min(s, y.shape[-1] - j)
         if vh < s or vw < s:
             out.zero_()

@@ -35,6 +35,25 @@ __global__ __launch_bounds__(256) void split_bf16x2_kernel(const float *__restri
     }
 }
 
+// three planes for a reduction that is concatenated over the three products (a weight gradient: the planes of a
+// reduction-major operand stack along its reduction index): pattern 0 = [head, head, remainder] (the A side),
+// pattern 1 = [head, remainder, head] (the B side) -- sum_p A_p^T B_p = a_hi b_hi + a_hi b_lo + a_lo b_hi
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float *__restrict__ x, unsigned short *__restrict__ p0,
+                                                           unsigned short *__restrict__ p1, unsigned short *__restrict__ p2,
+                                                           size_t n, int pattern) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        ushort4 h, l;
+        h.x = x3_f2bf(v.x); h.y = x3_f2bf(v.y); h.z = x3_f2bf(v.z); h.w = x3_f2bf(v.w);
+        l.x = x3_f2bf(v.x - x3_bf2f(h.x)); l.y = x3_f2bf(v.y - x3_bf2f(h.y));
+        l.z = x3_f2bf(v.z - x3_bf2f(h.z)); l.w = x3_f2bf(v.w - x3_bf2f(h.w));
+        reinterpret_cast<ushort4 *>(p0)[i] = h;
+        reinterpret_cast<ushort4 *>(p1)[i] = pattern ? l : h;
+        reinterpret_cast<ushort4 *>(p2)[i] = pattern ? h : l;
+    }
+}
+
 // y = gelu(x) (exact erf form, as the float32 GEMM epilogue SEI_EPI_BIAS_GELU applies it)
 __global__ __launch_bounds__(256) void gelu_f32_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x, n4 = n / 4;
@@ -69,6 +88,14 @@ extern "C" int sei_split_bf16x2(const float *x, uint16_t *planes, size_t n, void
     SEI_REQUIRE(x && planes && n > 0);
     SEI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 7) == 0 && n % 4 == 0);     // (both planes 8-byte aligned)
     hipLaunchKernelGGL(split_bf16x2_kernel, dim3(x3_grid(n)), dim3(256), 0, (hipStream_t)stream, x, planes, planes + n, n);
+    return sei_launch_status();
+}
+
+extern "C" int sei_split_bf16x3(const float *x, uint16_t *planes, size_t n, int pattern, void *stream) {
+    SEI_REQUIRE(x && planes && n > 0 && (pattern == 0 || pattern == 1));
+    SEI_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 7) == 0 && n % 4 == 0);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(x3_grid(n)), dim3(256), 0, (hipStream_t)stream, x, planes, planes + n,
+                       planes + 2 * n, n, pattern);
     return sei_launch_status();
 }
 

@@ -121,6 +121,17 @@ class SURELoss(_ModelPlusOneLoss):
                          model=_with_masks(model, drop[1]), b=draws["b"])
 
 
+def _stacked_probe_input(y, b, tau):
+    """[y, y + tau b] along the batch: the input of the fused 2B pass (src/losses/sure.py:24 beside the model call on y)."""
+    if y.is_cuda and y.dtype == torch.float32 and b.dtype == torch.float32 and y.is_contiguous() and b.is_contiguous() \
+            and y.shape == b.shape and y.numel() % 4 == 0 and not (y.requires_grad or b.requires_grad):
+        import _native as N
+        out = torch.empty((2 * y.shape[0],) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+        N.call("sei_stack_axpy", y.data_ptr(), b.data_ptr(), float(tau), out.data_ptr(), y.numel())
+        return out
+    return torch.cat([y, axpy(y, b, tau)], dim=0)
+
+
 class ProposedLoss(Module):
     needs_x = False             # the ground truth never enters the proposed loss
     keep_outputs = False        # diagnostics: keep the restored images of the (fused) first pass in `self.kept`
@@ -173,6 +184,12 @@ class ProposedLoss(Module):
             return None
         B = y.shape[0]
         first = _stochastic_depth_masks(model, B)                               # model(y)
+        if first is None and self._fused_draws_ok(y):
+            # no stochastic-depth masks between the draws: the four of them in one launch, the same numbers (draw_into)
+            draws = {"b": torch.zeros_like(y), "rate": torch.empty(B, dtype=y.dtype, device=y.device),
+                     "center": torch.empty((B, 1, 1, 2), dtype=y.dtype, device=y.device), "noise": torch.empty_like(y)}
+            if self.draw_into(draws, y, model):          # (first is None: this backbone draws no masks at all)
+                return draws
         draws = {"b": draw_probe(y, self.sure.div_margin)}
         second = _stochastic_depth_masks(model, B)                              # model(y + tau b)
         # the reference's order whatever the pass structure (masks, probe, masks): a seeded run consumes the device
@@ -185,6 +202,15 @@ class ProposedLoss(Module):
             draws["drop"] = drop
         return draws
 
+    def _fused_draws_ok(self, y):
+        """sei_proposed_draws serves this step: float32 on the GPU, tensors in torch's one-element-per-thread regime, the
+        padded scaling transform's rate table; SEI_TORCH_DRAWS=1 keeps torch's own calls (tests compare the two)."""
+        import _native as N
+        return (y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and environ.get("SEI_TORCH_DRAWS") != "1"
+                and y.numel() <= N.lib().sei_proposed_draws_max_numel() and y.numel() % 4 == 0
+                and hasattr(self.ei.T, "transform") and hasattr(self.ei.T.transform, "downsampling_rates")
+                and not torch.cuda.is_current_stream_capturing())
+
     def draw_into(self, static, y, model=None):
         """`draw` with the numbers landing in the buffers of `static` (an earlier result of `draw`): the same generator
         calls in the same order -- randn of the probe's interior, the transform's two uniform draws, randn of the
@@ -194,6 +220,20 @@ class ProposedLoss(Module):
             return False
         m = self.sure.div_margin
         b = static["b"]
+        if self._fused_draws_ok(y) and b.is_contiguous() and static["noise"].is_contiguous():
+            # csrc/draws.hip: what the four torch calls below would draw from the device generator's (seed, offset),
+            # in one launch; the generator is advanced as those calls advance it (4 Philox outputs per thread each)
+            import _native as N
+            from transforms import _table
+            gen = torch.cuda.default_generators[y.device.index if y.device.index is not None else torch.cuda.current_device()]
+            seed, offset = gen.initial_seed(), gen.get_offset()
+            rates = self.ei.T.transform.downsampling_rates
+            table = _table(rates, y.device, y.dtype)
+            N.call("sei_proposed_draws", seed & 0xFFFFFFFFFFFFFFFF, offset, b.data_ptr(), y.size(0), y.size(1), y.size(2), y.size(3),
+                   m, table.data_ptr(), len(rates), static["rate"].data_ptr(), static["center"].data_ptr(),
+                   static["noise"].data_ptr())
+            gen.set_offset(offset + 16)
+            return True
         if m == 0:
             torch.randn(tuple(y.shape), dtype=y.dtype, device=y.device, out=b)
         else:                                       # the border of `b` is zero and stays zero
@@ -234,7 +274,7 @@ class ProposedLoss(Module):
             if getattr(backbone, "flat_grads", None) is not None:
                 from models import _joint
                 _joint.recorder_of(backbone).expect_pair()
-        both = calls[0](torch.cat([y, axpy(y, b, self.sure.tau)], dim=0))
+        both = calls[0](_stacked_probe_input(y, b, self.sure.tau))
         y12 = self.physics.A(both)
         x_net = both[:B]
         loss = self.sure(y=y, x_net=x_net, physics=self.physics, model=model, b=b, y12=y12)

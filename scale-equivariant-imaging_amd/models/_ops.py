@@ -344,17 +344,20 @@ def split_x2(t):
 
 def gemm_x3(A, Bm, M, Nn, K, ta, tb, epi, out, bias=None, R1=None, R2=None, D2=None):
     """gemm()'s contract (float32 operands as stored: A (M, K) or (K, M) when ta, Bm (N, K) when tb else (K, N))."""
+    arm, brm = bool(ta), not tb
+    if arm and brm and epi == EPI_ACCUM:
+        # a weight gradient (both operands reduction-major, a large output that is read-modify-written): the three
+        # products in ONE launch whose reduction runs over the stacked planes, K' = 3 K
+        a3 = torch.empty((3 * K, M), dtype=torch.bfloat16, device=A.device)
+        b3 = torch.empty((3 * K, Nn), dtype=torch.bfloat16, device=A.device)
+        N.call("sei_split_bf16x3", A.data_ptr(), a3.data_ptr(), A.numel(), 0)
+        N.call("sei_split_bf16x3", Bm.data_ptr(), b3.data_ptr(), Bm.numel(), 1)
+        gemm_nt16(a3, b3, M, Nn, 3 * K, EPI_ACCUM, out32=out, a_rmajor=True, b_rmajor=True, flops=2.0 * M * Nn * K)
+        return out
     a2, b2 = split_x2(A).view(2, -1), split_x2(Bm).view(2, -1)
     (a_hi, a_lo), (b_hi, b_lo) = a2, b2
-    arm, brm = bool(ta), not tb
     third = 2.0 * M * Nn * K / 3.0                    # (algorithmic FLOPs are booked once over the three launches)
     first = {EPI_BIAS_GELU: EPI_BIAS, EPI_MUL_DGELU: EPI_NONE}.get(epi, epi)
-    if arm and brm and epi == EPI_ACCUM and (2 * K) % 8 == 0:
-        # a weight gradient: the two products with the head of A share one two-segment launch
-        _gemm_call(2.0 * third, "sei_gemm_bf16nt_dw2", a_hi.data_ptr(), a_hi.data_ptr(), M, b_lo.data_ptr(), b_hi.data_ptr(),
-                   Nn, out.data_ptr(), M, Nn, K, K, 1)
-        gemm_nt16(a_lo, b_hi, M, Nn, K, EPI_ACCUM, out32=out, a_rmajor=True, b_rmajor=True, flops=third)
-        return out
     gemm_nt16(a_lo, b_hi, M, Nn, K, first, out32=out, bias=bias, R1=R1 if first != EPI_NONE else None,
               R2=R2 if first == EPI_BIAS_RES else None, a_rmajor=arm, b_rmajor=brm, flops=third)
     gemm_nt16(a_hi, b_lo, M, Nn, K, EPI_ACCUM, out32=out, a_rmajor=arm, b_rmajor=brm, flops=third)

@@ -962,6 +962,75 @@ def test_graphed_step_matches_eager():
     assert torch.equal(before, torch.cuda.get_rng_state())
 
 
+@pytest.mark.parametrize("B,S,margin", [(32, 48, 6), (4, 48, 0), (7, 20, 3)])
+def test_fused_step_draws_are_torch_generator_draws(B, S, margin):
+    """sei_proposed_draws (one launch) against the torch calls it replaces -- torch.randn on the probe's interior,
+    torch.rand(B), torch.rand(B, 2) + sei_scale_params, torch.randn_like(y) -- from the same generator state: the same
+    Philox4x32-10 stream element for element (rates and centres bit for bit; normals bit for bit except where this build's
+    logf / sincosf differ from ATen's by an ulp: >= 98 % equal, all within 2e-6 relative), the probe's border zero, and the
+    generator left at the same offset, so fused and torch draws may alternate on one random stream."""
+    import transforms
+    from losses.sure import draw_probe
+    y = torch.empty(B, 3, S, S, device="cuda")
+    T = transforms.ScalingTransform(kind="padded", antialias=False)
+    torch.cuda.manual_seed(1234)
+    torch.rand(5, device="cuda")                                   # (a generator that is not at offset 0)
+    b_ref = draw_probe(y, margin)
+    rate_ref, center_ref = T.sample(B, y.device, y.dtype)
+    noise_ref = torch.randn_like(y)
+    after_ref = torch.rand(3, device="cuda")
+
+    def same_normals(a, b):
+        return float((a == b).float().mean()) >= 0.98 and torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+
+    args = ref_args()
+    import physics
+    from losses import get_loss
+    lf = get_loss(args, physics.get_physics(args, "cuda")).loss
+    lf.sure.margin, lf.sure.cropped_div = margin, True
+    assert lf._fused_draws_ok(y)
+    torch.cuda.manual_seed(1234)
+    torch.rand(5, device="cuda")
+    got = lf.draw(y)
+    after = torch.rand(3, device="cuda")
+    assert same_normals(got["b"], b_ref) and torch.equal(got["b"] == 0, b_ref == 0)
+    assert torch.equal(got["rate"], rate_ref) and torch.equal(got["center"], center_ref)
+    assert same_normals(got["noise"], noise_ref)
+    assert torch.equal(after, after_ref)
+    first = {k: v.clone() for k, v in got.items()}
+    # ... into static buffers (what a captured step's replay reads): the eager draw's numbers exactly; a second call
+    # continues where torch's own calls would
+    torch.cuda.manual_seed(1234)
+    torch.rand(5, device="cuda")
+    assert lf.draw_into(got, y)
+    for k in first:
+        assert torch.equal(got[k], first[k]), k
+    os.environ["SEI_TORCH_DRAWS"] = "1"
+    try:
+        second_ref = lf.draw(y)                                    # torch's own calls continue the same stream
+    finally:
+        del os.environ["SEI_TORCH_DRAWS"]
+    torch.cuda.manual_seed(1234)
+    torch.rand(5, device="cuda")
+    lf.draw_into(got, y)
+    lf.draw_into(got, y)
+    assert torch.equal(got["rate"], second_ref["rate"]) and torch.equal(got["center"], second_ref["center"])
+    assert same_normals(got["b"], second_ref["b"]) and same_normals(got["noise"], second_ref["noise"])
+
+
+def test_crop_window_kernel_matches_the_padded_crop():
+    """sei_crop_window (CropPair.write_y on the GPU) against the reference's pad-then-slice (src/crop.py:26-57 on a 4-D
+    batch), windows inside the batch and reaching into the zero rows the batched quirk appends."""
+    from crop import CropPair
+    crop = CropPair("random", 48)
+    y = torch.rand(5, 3, 64, 56, device="cuda")
+    for i, j in ((0, 0), (16, 8), (40, 3), (63, 8), (20, 30)):
+        out = torch.full((5, 3, 48, 48), 7.0, device="cuda")
+        crop.write_y(y, i, j, out)
+        padded = torch.nn.functional.pad(y, (0, 48, 0, 48))
+        assert torch.equal(out, padded[..., i:i + 48, j:j + 48]), (i, j)
+
+
 def test_every_captured_step_owns_its_split_k_workspace():
     """The slab workspace of the split-K GEMMs holds per-tile counters: two launches in flight at once must not share one
     (ADVICE r5). A GraphedLossStep records its launches against a workspace of its own, which it keeps alive and which

@@ -688,7 +688,7 @@ def test_split_bf16_gemm_against_float64(ops, M, N, K):
         xd, wd, bd, rd = x.cuda(), w.cuda(), bias.cuda(), res.cuda()
         ref = x.double() @ w.double().T
         scale = float(ref.abs().max())
-        tol = 4e-6
+        tol = 1.2e-5                  # (operands carry 2^-18 each, the dropped a_lo b_lo another 2^-18; measured up to 6e-6)
         # forward orientation: A (M, K), B (N, K); bias + GELU with the second output
         h4 = torch.empty((M, N), device="cuda")
         h3 = ops.gemm(xd, wd, M, N, K, 0, 1, ops.EPI_BIAS_GELU, bias=bd, D2=h4)
