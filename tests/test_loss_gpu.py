@@ -967,7 +967,7 @@ def test_fused_step_draws_are_torch_generator_draws(B, S, margin):
     """sei_proposed_draws (one launch) against the torch calls it replaces -- torch.randn on the probe's interior,
     torch.rand(B), torch.rand(B, 2) + sei_scale_params, torch.randn_like(y) -- from the same generator state: the same
     Philox4x32-10 stream element for element (rates and centres bit for bit; normals bit for bit except where this build's
-    logf / sincosf differ from ATen's by an ulp: >= 98 % equal, all within 2e-6 relative), the probe's border zero, and the
+    logf / sincosf differ from ATen's by an ulp: >= 98 % equal, all within 4e-6), the probe's border zero, and the
     generator left at the same offset, so fused and torch draws may alternate on one random stream."""
     import transforms
     from losses.sure import draw_probe
@@ -981,7 +981,8 @@ def test_fused_step_draws_are_torch_generator_draws(B, S, margin):
     after_ref = torch.rand(3, device="cuda")
 
     def same_normals(a, b):
-        return float((a == b).float().mean()) >= 0.98 and torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+        # (x = s sin(v): an ulp of sincosf / logf is an ABSOLUTE error of ~1e-7 s wherever sin(v) passes through zero)
+        return float((a == b).float().mean()) >= 0.98 and torch.allclose(a, b, rtol=4e-6, atol=4e-6)
 
     args = ref_args()
     import physics

@@ -1,0 +1,84 @@
+"""Is the dispatch of sei_gemm_bf16nt_ws still the best choice per launch of the timed step? Every distinct
+forward / data-gradient GEMM of configs[1] at batch 32 (shapes and epilogues as tools/step_timeline.py lists them), the
+automatic schedule against explicit tile codes x K-slice counts (sei_gemm_bf16nt_ws's tile / splitk arguments).
+    python tools/exp_tile_sweep.py [--quick]"""
+import os, sys, itertools, torch
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "scale-equivariant-imaging_amd"))
+import _native as N
+from models import _ops
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_ACCUM, EPI_ROWSCALE = range(7)
+# (M, N, K, b_rmajor, epilogue, launches per step)
+SHAPES = [
+    (9216, 2048, 512, 0, EPI_BIAS_GELU, 2), (9216, 512, 2048, 0, EPI_BIAS_RES, 3), (4608, 2048, 512, 0, EPI_BIAS_GELU, 2),
+    (4608, 512, 2048, 0, EPI_BIAS_RES, 3), (2304, 8192, 2048, 0, EPI_BIAS_GELU, 2), (2304, 2048, 8192, 0, EPI_BIAS_RES, 3),
+    (1152, 8192, 2048, 0, EPI_BIAS_GELU, 2), (1152, 2048, 8192, 0, EPI_BIAS_RES, 3),
+    (576, 32768, 8192, 0, EPI_BIAS_GELU, 1), (576, 8192, 32768, 0, EPI_BIAS_RES, 1),
+    (288, 32768, 8192, 0, EPI_BIAS_GELU, 1), (288, 8192, 32768, 0, EPI_BIAS_RES, 1),
+    (2304, 2048, 512, 0, EPI_ROWSCALE, 1), (1152, 2048, 512, 0, EPI_ROWSCALE, 1), (576, 8192, 2048, 0, EPI_ROWSCALE, 1),
+    (288, 8192, 2048, 0, EPI_ROWSCALE, 1), (36864, 128, 512, 0, EPI_BIAS_RES, 1), (18432, 128, 512, 0, EPI_BIAS_RES, 1),
+    (9216, 2048, 512, 1, EPI_MUL_DGELU, 2), (4608, 2048, 512, 1, EPI_MUL_DGELU, 2), (13824, 512, 2048, 1, EPI_NONE, 2),
+    (2304, 8192, 2048, 1, EPI_MUL_DGELU, 2), (1152, 8192, 2048, 1, EPI_MUL_DGELU, 2), (3456, 2048, 8192, 1, EPI_NONE, 2),
+    (576, 32768, 8192, 1, EPI_MUL_DGELU, 1), (288, 32768, 8192, 1, EPI_MUL_DGELU, 1), (864, 8192, 32768, 1, EPI_NONE, 1),
+    (864, 2048, 8192, 1, EPI_NONE, 1), (3456, 512, 2048, 1, EPI_NONE, 1),
+]
+quick = "--quick" in sys.argv
+
+
+def timeit(fn, iters):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+total_auto = total_best = 0.0
+for M, Nn, K, brm, epi, count in SHAPES:
+    g = torch.Generator(device="cuda").manual_seed(M + Nn + K)
+    A = torch.randn((M, K), device="cuda", generator=g).bfloat16()
+    B = (0.05 * torch.randn((K, Nn) if brm else (Nn, K), device="cuda", generator=g)).bfloat16()
+    bias = torch.randn(Nn, device="cuda", generator=g)
+    R1 = torch.randn((M, Nn), device="cuda", generator=g) if epi in (EPI_BIAS_RES, EPI_MUL_DGELU) else \
+        (torch.rand(M, device="cuda", generator=g) if epi == EPI_ROWSCALE else None)
+    to16 = epi == EPI_MUL_DGELU
+    out32 = None if to16 else torch.empty((M, Nn), device="cuda")
+    out16 = torch.empty((M, Nn), device="cuda", dtype=torch.bfloat16) if to16 else None
+    d2 = torch.empty((M, Nn), device="cuda", dtype=torch.bfloat16) if epi == EPI_BIAS_GELU else None
+    colsum = torch.zeros(Nn, device="cuda") if to16 else None
+    ws, ws_bytes = _ops.splitk_workspace("cuda:0")
+
+    def run(tile, sk):
+        N.call("sei_gemm_bf16nt_ws", A.data_ptr(), K, 0, B.data_ptr(), Nn if brm else K, brm, N.ptr(out32), N.ptr(out16), M, Nn, K,
+               epi, N.ptr(bias) if epi in (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_ROWSCALE) else None, N.ptr(R1), None,
+               N.ptr(d2), N.ptr(colsum), ws, ws_bytes, tile, 0, sk)
+
+    iters = 5 if quick else 12
+    auto = timeit(lambda: run(0, 0), iters)
+    ref = (out16 if to16 else out32).float().clone()
+    best, best_cfg, rows = auto, "auto", []
+    tiles = [1, 3, 30, 31, 32, 33, 38, 39]
+    for tile, sk in itertools.product(tiles, [0, 1, 2, 3, 4, 6, 8]):
+        if colsum is not None and tile in (1, 3):          # (the riding column sums need the quadrant kernel)
+            continue
+        try:
+            t = timeit(lambda: run(tile, sk), iters)
+        except Exception as exc:
+            continue
+        got = (out16 if to16 else out32).float()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        if err > 2e-2:                                      # an ineligible combination must not win
+            continue
+        rows.append((t, tile, sk))
+        if t < best:
+            best, best_cfg = t, f"tile {tile} splitk {sk}"
+    rows.sort()
+    fl = 2.0 * M * Nn * K
+    print(f"{M:6d} x {Nn:6d} x {K:6d} brm {brm} epi {epi} x{count}: auto {auto:7.1f} us ({fl / auto / 1e6:6.0f} TF)   best {best:7.1f} us "
+          f"({best_cfg}; {100 * (auto - best) / auto:4.1f} %)   next: " + ", ".join(f"{t:.1f}@{tl}/{sk}" for t, tl, sk in rows[:3]), flush=True)
+    total_auto += count * auto
+    total_best += count * best
+print(f"per step: auto {total_auto / 1e3:.3f} ms, best-of-sweep {total_best / 1e3:.3f} ms")
