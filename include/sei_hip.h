@@ -31,6 +31,24 @@ extern "C" {
 #define SEI_ERR_BAD_ARG 10001      /* NULL pointer, non-positive size, unsupported size */
 #define SEI_ERR_TOO_LARGE 10002    /* a tile would not fit in LDS / a tap count above the limit */
 
+/* ---------------------------------------------------------------------------------------------
+ * STABLE SURFACE -- what a maintainer binding the reference's own modules needs (INTEGRATION.md section B shows the
+ * ctypes stub for each at its reference call site); names, argument meaning and error behaviour are kept across ABI
+ * versions:
+ *   sei_abi_version, sei_build_target
+ *   physics      sei_blur_sep_circ, sei_blur_dense_circ, sei_resample_sepband
+ *   EI transform sei_scale_resample_fwd, sei_scale_resample_bwd
+ *   loss terms   sei_axpy, sei_sure_terms, sei_mse_terms
+ *   U-Net (f32)  sei_conv3x3_fwd, sei_conv3x3_bwd_weight, sei_dwconv7_fwd, sei_dwconv7_bwd_weight (+ _workspace),
+ *                sei_ln_fwd, sei_ln_bwd (+ sei_ln_bwd_workspace), sei_gemm_f32, sei_colsum_f32, sei_sepmap2
+ *   U-Net (bf16) sei_cast_bf16, sei_ln_fwd_bf16, sei_gemm_bf16nt
+ *   optimizer    sei_adam_fused
+ * INTERNAL -- everything else in this header: fused, schedule-specific (_ex, _ws, _dw2*, _plan, _eligible, _parts,
+ * _count ...), SwinIR and measurement entry points that this build's own host layer (models/_ops.py, graphs.py, optim.py,
+ * bench.py) calls. They are exported and documented here because that host layer sits above the C ABI, but they follow the
+ * kernels: they may change with SEI_ABI_VERSION.
+ * --------------------------------------------------------------------------------------------- */
+
 /* ABI version of this header; sei_abi_version() returns the value the library was built with. */
 #define SEI_ABI_VERSION 12
 int sei_abi_version(void);
@@ -145,6 +163,13 @@ int sei_proposed_draws(unsigned long long seed, unsigned long long offset, float
                        const float *table, int ntable, float *rate, float *center, float *noise, void *stream);
 size_t sei_proposed_draws_max_numel(void);
 int sei_crop_window(const float *y, float *out, int planes, int H, int W, int i0, int j0, int S, void *stream);
+/* Glue of the step that torch ops used to provide (one launch each, so that a captured step holds no ATen kernel):
+ * sei_concat2_f32: out = [a | b] (na, nb % 4 == 0; nb = 0: a plain copy) -- the joint backward's 3B-row gradient, a model
+ * input into its arena buffer; sei_scale_dev_f32: out = x * (*scalar), the scalar on the device -- a loss term's stored
+ * gradient times the incoming gradient of its value; sei_add_scalars: *out = *a + *b -- the sum of two loss terms. */
+int sei_concat2_f32(const float *a, size_t na, const float *b, size_t nb, float *out, void *stream);
+int sei_scale_dev_f32(const float *x, const float *scalar, float *out, size_t n, void *stream);
+int sei_add_scalars(const float *a, const float *b, float *out, void *stream);
 /* base[off_k .. off_k + len_k) = 0 for up to 8 (off, len) pairs of elements (HOST array of 2 * count values): the gaps of
  * the flat gradient bucket between the weight gradients that the captured step stores, in ONE launch (optimizer.zero_grad,
  * demo/train.py:258). */

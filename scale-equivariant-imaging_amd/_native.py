@@ -41,6 +41,9 @@ SIGNATURES = {
     "sei_stack_axpy": [_P, _P, _F, _P, _Z, _P],
     "sei_proposed_draws": [_c.c_ulonglong, _c.c_ulonglong, _P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     "sei_crop_window": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "sei_concat2_f32": [_P, _Z, _P, _Z, _P, _P],
+    "sei_scale_dev_f32": [_P, _P, _P, _Z, _P],
+    "sei_add_scalars": [_P, _P, _P, _P],
     "sei_zero_ranges": [_P, _P, _I, _P],
     "sei_sure_terms": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P],
     "sei_mse_terms": [_P, _P, _Z, _F, _P, _P, _P, _P],
@@ -289,6 +292,31 @@ def call(name, *args):
         else:
             what = f"hipError_t {rc}"
         raise NativeLibraryError(f"{name} failed: {what}")
+
+
+def scale_by(x, scalar):
+    """x * scalar for a 0-dim device `scalar` (the incoming gradient of a loss value): one own launch where it applies."""
+    if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0 and isinstance(scalar, torch.Tensor) \
+            and scalar.is_cuda and scalar.dtype == torch.float32 and scalar.numel() == 1:
+        out = torch.empty_like(x)
+        call("sei_scale_dev_f32", x.data_ptr(), scalar.data_ptr(), out.data_ptr(), x.numel())
+        return out
+    return x * scalar
+
+
+def copy_into(dst, a, b=None):
+    """dst <- a (b None) or the concatenation [a | b] along the leading dimension, as one own launch where it applies."""
+    ok = all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 4 == 0)
+             for t in (dst, a, b))
+    if ok and dst.numel() == a.numel() + (0 if b is None else b.numel()):
+        call("sei_concat2_f32", a.data_ptr(), a.numel(), ptr(b), 0 if b is None else b.numel(), dst.data_ptr())
+        return dst
+    if b is None:
+        dst.copy_(a.reshape(dst.shape))
+    else:
+        dst[:a.shape[0]].copy_(a)
+        dst[a.shape[0]:].copy_(b)
+    return dst
 
 
 def graph_kernel_nodes(graph):

@@ -100,7 +100,54 @@ __global__ __launch_bounds__(256) void stack_axpy_kernel(const float *__restrict
     }
 }
 
+// out = [a (na floats) | b (nb floats)]: the joint backward's 3B-row gradient from the two model calls' gradients, a model
+// input into its arena buffer (nb = 0) -- one launch where autograd-side torch code issued one memcpy node per piece
+__global__ __launch_bounds__(256) void concat2_kernel(const float *__restrict__ a, size_t na, const float *__restrict__ b,
+                                                      size_t nb, float *__restrict__ out) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n4 = (na + nb) / 4, a4 = na / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<float4 *>(out)[i] = i < a4 ? reinterpret_cast<const float4 *>(a)[i]
+                                                    : reinterpret_cast<const float4 *>(b)[i - a4];
+}
+
+// out = x * (*s): a stored gradient times the scalar gradient of the loss value (the backward of the loss-term functions)
+__global__ __launch_bounds__(256) void scale_dev_kernel(const float *__restrict__ x, const float *__restrict__ s,
+                                                        float *__restrict__ out, size_t n) {
+    const float k = *s;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4 *>(x)[i];
+        v.x *= k; v.y *= k; v.z *= k; v.w *= k;
+        reinterpret_cast<float4 *>(out)[i] = v;
+    }
+}
+
+__global__ void add_scalars_kernel(const float *a, const float *b, float *out) { *out = *a + *b; }
+
 }  // namespace
+
+extern "C" int sei_concat2_f32(const float *a, size_t na, const float *b, size_t nb, float *out, void *stream) {
+    SEI_REQUIRE(a && out && na > 0 && na % 4 == 0 && nb % 4 == 0 && (nb == 0 || b));
+    SEI_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0);
+    size_t grid = sei_ceil_div((na + nb) / 4, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(concat2_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, out);
+    return sei_launch_status();
+}
+
+extern "C" int sei_scale_dev_f32(const float *x, const float *scalar, float *out, size_t n, void *stream) {
+    SEI_REQUIRE(x && scalar && out && n > 0 && n % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0);
+    size_t grid = sei_ceil_div(n / 4, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(scale_dev_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, scalar, out, n);
+    return sei_launch_status();
+}
+
+extern "C" int sei_add_scalars(const float *a, const float *b, float *out, void *stream) {
+    SEI_REQUIRE(a && b && out);
+    hipLaunchKernelGGL(add_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, b, out);
+    return sei_launch_status();
+}
 
 extern "C" int sei_proposed_draws(unsigned long long seed, unsigned long long offset, float *b, int B, int C, int H, int W,
                                   int margin, const float *table, int ntable, float *rate, float *center, float *noise,

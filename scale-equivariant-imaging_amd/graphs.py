@@ -87,10 +87,15 @@ class GraphedLossStep:
 
         self.store_weight_grads = False
 
+        unit = torch.ones((), dtype=torch.float32, device=device)     # the root gradient (autograd would fill one per step)
+
         def fwd_bwd():
             self.backbone.zero_grad_flat(store_weight_grads=self.store_weight_grads)
             value = self.inner(x=self.static_x, y=self.static_y, model=self.model, draws=self.static_draws)
-            value.backward()
+            if value.dim() == 0 and value.dtype == torch.float32:
+                value.backward(unit)
+            else:
+                value.backward()
             return value.detach()
 
         from models import _ops

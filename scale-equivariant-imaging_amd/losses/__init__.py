@@ -121,6 +121,28 @@ class SURELoss(_ModelPlusOneLoss):
                          model=_with_masks(model, drop[1]), b=draws["b"])
 
 
+class _SumLossTerms(torch.autograd.Function):
+    """a + b for two 0-dim loss terms on the GPU as one own launch (the backward hands the incoming gradient to both)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        import _native as N
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        N.call("sei_add_scalars", a.data_ptr(), b.data_ptr(), out.data_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        return go, go
+
+
+def _sum_terms(a, b):
+    if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.is_cuda and b.is_cuda and a.dim() == 0 and b.dim() == 0 \
+            and a.dtype == torch.float32 and b.dtype == torch.float32:
+        return _SumLossTerms.apply(a, b)
+    return a + b
+
+
 def _stacked_probe_input(y, b, tau):
     """[y, y + tau b] along the batch: the input of the fused 2B pass (src/losses/sure.py:24 beside the model call on y)."""
     if y.is_cuda and y.dtype == torch.float32 and b.dtype == torch.float32 and y.is_contiguous() and b.is_contiguous() \
@@ -280,7 +302,7 @@ class ProposedLoss(Module):
         loss = self.sure(y=y, x_net=x_net, physics=self.physics, model=model, b=b, y12=y12)
         if self.keep_outputs:
             self.kept = {"x_net": x_net.detach()}
-        return loss + self.ei(x=x, x_net=x_net, y=y, physics=self.physics, model=calls[-1], **ei_kw)
+        return _sum_terms(loss, self.ei(x=x, x_net=x_net, y=y, physics=self.physics, model=calls[-1], **ei_kw))
 
 
 class Loss(Module):

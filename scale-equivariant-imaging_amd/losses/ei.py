@@ -30,7 +30,7 @@ class _MseTerms(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go):
         (ga,) = ctx.saved_tensors
-        g = ga * go
+        g = N.scale_by(ga, go)
         return g, (-g if ctx.needs_input_grad[1] else None), None
 
 

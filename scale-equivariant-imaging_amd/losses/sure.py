@@ -50,9 +50,9 @@ class _SureTerms(torch.autograd.Function):
     def backward(ctx, go):
         if ctx.joint:
             (g,) = ctx.saved_tensors
-            return (None, g * go) + (None,) * 7
+            return (None, N.scale_by(g, go)) + (None,) * 7
         g1, g2 = ctx.saved_tensors
-        return (None, g1 * go, g2 * go) + (None,) * 6
+        return (None, N.scale_by(g1, go), N.scale_by(g2, go)) + (None,) * 6
 
 
 def draw_probe(y, margin):

@@ -233,9 +233,9 @@ def _walk(rec, backbone, which):
             _walk(rec, backbone, (which[1],))
             return
         g1, g2 = rec.parked[0], rec.parked[1]
-        go = torch.empty((g1.shape[0] + g2.shape[0],) + tuple(g1.shape[1:]), dtype=g1.dtype, device=g1.device)
-        go[:g1.shape[0]].copy_(g1)
-        go[g1.shape[0]:].copy_(g2)
+        import _native as N
+        go = N.copy_into(torch.empty((g1.shape[0] + g2.shape[0],) + tuple(g1.shape[1:]), dtype=g1.dtype, device=g1.device),
+                         g1.contiguous(), g2.contiguous())
         fns = [fn for fn, _ in tapes[0]]
     else:
         ctxs = [c for _, c in tapes[0]]

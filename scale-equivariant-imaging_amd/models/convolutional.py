@@ -236,8 +236,7 @@ class ConvolutionalModel(FlatParameterBucket, Module):
                 and _ops.get_compute_dtype() == "bf16" and rec.wants(y):
             rec.begin(y)
             with _ops.recording(rec):
-                y_in = _ops._alloc(tuple(y.shape), y.dtype, y.device)
-                y_in.copy_(y)
+                y_in = N.copy_into(_ops._alloc(tuple(y.shape), y.dtype, y.device), y)
                 x_hat = self.seq[-1](y_in, x_is_nchw=True)
             call, pair = rec.current, rec.pair
             if not rec.end():

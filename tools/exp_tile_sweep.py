@@ -75,6 +75,12 @@ for M, Nn, K, brm, epi, count in SHAPES:
         rows.append((t, tile, sk))
         if t < best:
             best, best_cfg = t, f"tile {tile} splitk {sk}"
+    auto = min(auto, timeit(lambda: run(0, 0), iters))     # (again after the sweep: the first timing of a shape runs cold)
+    if best_cfg != "auto":                                  # ... and the winner once more, back to back with it
+        tile_b, sk_b = (int(v) for v in best_cfg.replace("tile ", "").replace("splitk ", "").split())
+        best = min(best, timeit(lambda: run(tile_b, sk_b), iters))
+        if best >= auto:
+            best, best_cfg = auto, "auto"
     rows.sort()
     fl = 2.0 * M * Nn * K
     print(f"{M:6d} x {Nn:6d} x {K:6d} brm {brm} epi {epi} x{count}: auto {auto:7.1f} us ({fl / auto / 1e6:6.0f} TF)   best {best:7.1f} us "
