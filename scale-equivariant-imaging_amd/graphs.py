@@ -87,7 +87,9 @@ class GraphedLossStep:
 
         self.store_weight_grads = False
 
-        unit = torch.ones((), dtype=torch.float32, device=device)     # the root gradient (autograd would fill one per step)
+        # the root gradient (autograd would fill a fresh one per step); allocated OUTSIDE the graph's pool, so it must live
+        # as long as the graph whose kernels read it
+        unit = self._unit_grad = torch.ones((), dtype=torch.float32, device=device)
 
         def fwd_bwd():
             self.backbone.zero_grad_flat(store_weight_grads=self.store_weight_grads)
