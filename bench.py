@@ -353,7 +353,7 @@ def _dwconv_flops(name, a):
     else:
         return 0.0
     return 98.0 * B * H * W * C
-PMC_TRAFFIC_FILE = "r05_g_unet_pmc_gemm.json"      # the committed PMC pass `roofline.traffic` is read from
+PMC_TRAFFIC_FILE = "r06_f_unet_pmc_gemm.json"      # the committed PMC pass `roofline.traffic` is read from
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
