@@ -153,8 +153,11 @@ inline DwTiling dw_tiling(int B, int H, int W) {
     return t;
 }
 
+#ifndef SEI_DW_WGRAD_OCC
+#define SEI_DW_WGRAD_OCC 3          // workgroups per CU the weight-gradient instantiation is compiled for (A/B builds: 2)
+#endif
 template <bool WEIGHT_GRAD>
-__global__ __launch_bounds__(DW_THREADS, 3) void dwconv7_tiled_kernel(
+__global__ __launch_bounds__(DW_THREADS, WEIGHT_GRAD ? SEI_DW_WGRAD_OCC : 3) void dwconv7_tiled_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
     const float *__restrict__ res, float res_scale, float *__restrict__ y, const float *__restrict__ gy,
     float *__restrict__ part, int H, int W, int C, int flip, int th, int tw, int tiles_i, int tiles_j,

@@ -668,7 +668,9 @@ def test_other_methods_vs_oracle(method):
     (["--method", "proposed", "--ProposedLoss__transforms", "Shifts"], False),
     (["--method", "proposed", "--ProposedLoss__transforms", "Rotations+Shifts"], False),
     (["--method", "proposed", "--ScalingTransform__kind", "normal"], False),
-    (["--method", "proposed", "--ScalingTransform__antialias", "--batch_size", "1"], False)])
+    (["--method", "proposed", "--ScalingTransform__antialias", "--batch_size", "1"], False),
+    # the split-bf16 parity mode through the driver (hidden 32: its GEMM shapes take gemm_x3; captured like the f32 mode)
+    (["--method", "proposed", "--compute_dtype", "bf16x3", "--ConvolutionalModel__hidden_channels", "32"], True)])
 def test_train_script_methods_and_transforms(tmp_path, flags, graphed):
     """train.py with default --hip_graph for every supported method / transform: steps that draw on the host or
     sync with it (Shifts, the normal kind, the antialiased variant) must fall back to the eager step instead of
