@@ -289,8 +289,6 @@ def _gemm_bytes(name, a):
     if name in ("sei_gemm_bf16nt", "sei_gemm_bf16nt_ex", "sei_gemm_bf16nt_ws"):      # (_ws: the same leading arguments)
         M, Nn, K, epi = a[8:12]
         extra = sum(4 for ptr in (a[13], a[14]) if ptr) if epi != 6 else 0          # R1 / R2 (BIAS_ROWSCALE: M floats)
-        if epi == 8:                                                                 # MUL_DGELU16: the pre-activation is bf16
-            extra = 2
         return 2 * K * (M + Nn) + M * Nn * ((4 if a[6] else 0) + (2 if a[7] else 0) + extra + (2 if a[15] else 0)
                                             + (4 if epi == 5 else 0))
     if name in ("sei_gemm_bf16_ex", "sei_gemm_f32_ex"):

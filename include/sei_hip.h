@@ -331,9 +331,6 @@ int sei_fold_many(const SeiFoldJob *jobs, int njobs, void *stream);
 #define SEI_EPI_BIAS_ROWSCALE 6   /* D = acc + bias[n]*R1[m]                                  */
 #define SEI_EPI_BIAS_SCALE_RES 7  /* D = R2 + R1[m]*(acc + bias[n])  (stochastic depth: one factor per row; not in the
                                      quadrant-schedule kernel: sei_gemm_bf16nt takes a 128-row tile for it) */
-#define SEI_EPI_MUL_DGELU16 8     /* sei_gemm_bf16nt* only: SEI_EPI_MUL_DGELU with R1 stored as bf16 (uint16_t *, same
-                                     (M, N) layout) -- the bf16 mode keeps the pre-activation h3 = conv2(h2) + b2 in bf16:
-                                     SEI_EPI_BIAS_GELU with D32 = NULL, D16 = h3 writes it, this epilogue reads it */
 int sei_gemm_f32(const float *A, const float *B, float *D, int M, int N, int K, int transA,
                  int transB, int epilogue, const float *bias, const float *R1, const float *R2,
                  float *D2, void *stream);

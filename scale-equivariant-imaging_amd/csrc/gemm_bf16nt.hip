@@ -97,17 +97,7 @@ struct NtArgs {
     void *ws;
     size_t ws_bytes;
     int force_splitk;
-    // SEI_EPI_MUL_DGELU16: R1 points to bf16 values (the entry point sets this and epilogue = SEI_EPI_MUL_DGELU)
-    int r1_bf16;
 };
-
-__device__ __forceinline__ float nt_bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
-// four consecutive values of an epilogue operand that is float32, or bf16 when `is16` (uniform)
-__device__ __forceinline__ float4 nt_load_r4(const float *p, size_t off, bool is16) {
-    if (!is16) return *reinterpret_cast<const float4 *>(p + off);
-    const ushort4 h = *reinterpret_cast<const ushort4 *>(reinterpret_cast<const unsigned short *>(p) + off);
-    return make_float4(nt_bf2f(h.x), nt_bf2f(h.y), nt_bf2f(h.z), nt_bf2f(h.w));
-}
 
 typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 nt_load4(const float *p) {
@@ -301,8 +291,7 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
             const int row = row_base + (r & 3) + 8 * (r >> 2);
             const bool ok = col < N && row < M;
             const size_t o = (size_t)row * N + col;
-            a1[i][j][r] = (ok && aux1p) ? ((g.r1_bf16 && epi == SEI_EPI_MUL_DGELU)
-                                               ? nt_bf2f(reinterpret_cast<const unsigned short *>(aux1p)[o]) : aux1p[o]) : 0.f;
+            a1[i][j][r] = (ok && aux1p) ? aux1p[o] : 0.f;
             a2[i][j][r] = (ok && aux2p) ? aux2p[o] : 0.f;
         }
     };
@@ -631,7 +620,7 @@ __global__ __launch_bounds__(NT, (NSTAGE == 1 ? 3 : 1)) void gemm_bf16nt_kernel(
                         v[u].x += b.x; v[u].y += b.y; v[u].z += b.z; v[u].w += b.w;
                     }
                     if (epi == SEI_EPI_BIAS_RES || epi == SEI_EPI_MUL_DGELU)
-                        r1[u] = nt_load_r4(g.R1, off[u], g.r1_bf16 && epi == SEI_EPI_MUL_DGELU);
+                        r1[u] = *reinterpret_cast<const float4 *>(g.R1 + off[u]);
                     else if (epi == SEI_EPI_ACCUM) r1[u] = *reinterpret_cast<const float4 *>(D32p + off[u]);
                     if (epi == SEI_EPI_BIAS_SCALE_RES || (epi == SEI_EPI_BIAS_RES && g.R2))
                         r2[u] = *reinterpret_cast<const float4 *>(g.R2 + off[u]);
@@ -995,8 +984,6 @@ static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
     if (a_rmajor) SEI_REQUIRE(M % 8 == 0);
     if (b_rmajor) SEI_REQUIRE(N % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0);
-    const int r1_bf16 = epilogue == SEI_EPI_MUL_DGELU16;        // (R1 is then a uint16_t array behind the float pointer)
-    if (r1_bf16) epilogue = SEI_EPI_MUL_DGELU;
     SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU ||
                 epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_ACCUM ||
                 epilogue == SEI_EPI_BIAS_ROWSCALE || epilogue == SEI_EPI_BIAS_SCALE_RES);
@@ -1008,7 +995,7 @@ static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
     if (epilogue == SEI_EPI_BIAS_GELU) SEI_REQUIRE(D2_16);
     if (epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU) SEI_REQUIRE(R1);
     if (epilogue == SEI_EPI_ACCUM) SEI_REQUIRE(D32 && !D16);
-    NtArgs g; g.r1_bf16 = 0; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.A = A; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb;
     g.epilogue = epilogue; g.bias = bias; g.R1 = R1; g.R2 = R2; g.D2_16 = D2_16;
@@ -1018,7 +1005,6 @@ static int nt_entry(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B,
     g.plan = plan;
     g.colsum = colsum;
     g.ws = ws; g.ws_bytes = ws ? ws_bytes : 0; g.force_splitk = splitk;
-    g.r1_bf16 = r1_bf16;
     SEI_REQUIRE(tile >= 0 && band >= 0);
     if (epilogue == SEI_EPI_BIAS_SCALE_RES && tile == 0)                // the quadrant kernel has no such epilogue
         tile = (N > 128 && N <= 192) ? 6 : 1;
@@ -1173,7 +1159,7 @@ extern "C" int sei_gemm_bf16nt(const uint16_t *A, int lda, int a_rmajor, const u
 extern "C" int sei_gemm_bf16nt_colsum(const uint16_t *A, int lda, int a_rmajor, const uint16_t *B, int ldb, int b_rmajor,
                                       uint16_t *D16, int M, int N, int K, int epilogue, const float *R1, float *colsum,
                                       void *stream) {
-    SEI_REQUIRE(D16 && colsum && (epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_MUL_DGELU16 || epilogue == SEI_EPI_NONE));
+    SEI_REQUIRE(D16 && colsum && (epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_NONE));
     return nt_entry_colsum(A, lda, a_rmajor, B, ldb, b_rmajor, D16, M, N, K, epilogue, R1, colsum, stream);
 }
 
@@ -1190,7 +1176,7 @@ extern "C" int sei_gemm_bf16nt_ws(const uint16_t *A, int lda, int a_rmajor, cons
                                   size_t ws_bytes, int tile, int band, int splitk, void *stream) {
     SEI_REQUIRE(tile >= 0 && band >= 0 && splitk >= 0 && (ws == nullptr || ws_bytes >= 16384));
     if (colsum) {
-        SEI_REQUIRE(D16 && !D32 && (epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_MUL_DGELU16 || epilogue == SEI_EPI_NONE));
+        SEI_REQUIRE(D16 && !D32 && (epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_NONE));
         return nt_entry_colsum(A, lda, a_rmajor, B, ldb, b_rmajor, D16, M, N, K, epilogue, R1, colsum, stream, ws, ws_bytes,
                                tile, splitk, band);
     }
@@ -1221,7 +1207,7 @@ static size_t nt_plan(int a_rmajor, int b_rmajor, int out_f32, int out_bf16, int
     float *fake32 = reinterpret_cast<float *>(uintptr_t(1) << 20);
     const bool with_bias = epilogue == SEI_EPI_BIAS || epilogue == SEI_EPI_BIAS_GELU || epilogue == SEI_EPI_BIAS_RES ||
                            epilogue == SEI_EPI_BIAS_ROWSCALE || epilogue == SEI_EPI_BIAS_SCALE_RES;
-    const bool with_r1 = epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU || epilogue == SEI_EPI_MUL_DGELU16 ||
+    const bool with_r1 = epilogue == SEI_EPI_BIAS_RES || epilogue == SEI_EPI_MUL_DGELU ||
                          epilogue == SEI_EPI_BIAS_ROWSCALE || epilogue == SEI_EPI_BIAS_SCALE_RES;
     unsigned long long plan = 0;
     const int rc = nt_entry(fake16, a_rmajor ? M : K, a_rmajor, fake16, b_rmajor ? N : K, b_rmajor,
@@ -1240,7 +1226,7 @@ extern "C" int sei_gemm_bf16nt_dw2_ex(const uint16_t *A1, const uint16_t *A2, in
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
-    NtArgs g; g.r1_bf16 = 0; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
@@ -1280,7 +1266,7 @@ extern "C" int sei_gemm_bf16nt_dw2_adam_ex(const uint16_t *A1, const uint16_t *A
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
     SEI_REQUIRE((((uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0 &&
                 ((uintptr_t)param_bf16 & 7) == 0);              // the epilogue moves whole quads
-    NtArgs g; g.r1_bf16 = 0; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = param; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
@@ -1317,7 +1303,7 @@ extern "C" int sei_gemm_bf16nt_dw2_bf16out(const uint16_t *A1, const uint16_t *A
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0 && ((uintptr_t)D16 & 7) == 0);
-    NtArgs g; g.r1_bf16 = 0; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = nullptr; g.D16 = D16; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
@@ -1339,7 +1325,7 @@ extern "C" int sei_gemm_bf16nt_dw2_taps(const uint16_t *A1, const uint16_t *A2, 
     SEI_REQUIRE(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N);
     SEI_REQUIRE((K1 + K2) % 8 == 0);
     SEI_REQUIRE((((uintptr_t)A1 | (uintptr_t)A2 | (uintptr_t)B1 | (uintptr_t)B2) & 15) == 0);
-    NtArgs g; g.r1_bf16 = 0; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.A = A1; g.B = B1; g.A2 = A2; g.B2 = B2; g.k_seg = K1;
     g.D32 = D32; g.D16 = nullptr; g.M = M; g.N = N; g.K = K1 + K2; g.lda = lda; g.ldb = ldb;
@@ -1370,7 +1356,7 @@ extern "C" int sei_gemm_bf16nt_conv(const uint16_t *Ap, int cin_pad, const int *
     SEI_REQUIRE(ldb >= 9 * cin_pad && ldb % 8 == 0 && (((uintptr_t)Ap | (uintptr_t)B) & 15) == 0);
     SEI_REQUIRE(epilogue == SEI_EPI_NONE || epilogue == SEI_EPI_BIAS);
     if (epilogue == SEI_EPI_BIAS) SEI_REQUIRE(bias);
-    NtArgs g; g.r1_bf16 = 0; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
+    NtArgs g; g.plan = nullptr; g.colsum = nullptr; g.unpad_H = 0; g.unpad_W = 0; g.unpad_act = 0;
     g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;
     g.batch = 1;
     g.A = Ap; g.B = B; g.D32 = D32; g.D16 = D16; g.M = M; g.N = N; g.K = 9 * cin_pad; g.lda = cin_pad; g.ldb = ldb;
@@ -1394,7 +1380,6 @@ extern "C" int sei_gemm_bf16nt_conv_unpad(const uint16_t *Ap, int cin_pad, const
     SEI_REQUIRE((((uintptr_t)y | (uintptr_t)res) & 15) == 0 && (act == 0 || act == 1));
     SEI_REQUIRE((size_t)Bimg * (H + 2) * (W + 2) < ((size_t)1 << 31));
     NtArgs g;
-    g.r1_bf16 = 0;
     g.plan = nullptr;
     g.colsum = nullptr;
     g.ws_slab = nullptr; g.ws_cnt = nullptr; g.ws = nullptr; g.ws_bytes = 0; g.force_splitk = 0;

@@ -713,17 +713,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16pq_kernel(NtArgs g) {
             v[p] = *reinterpret_cast<const f32x4 *>(patch + (p * RPP + prow) * LDW + pc4);
             a1[p] = a2[p] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (aux1 && g.r1_bf16 && epi == SEI_EPI_MUL_DGELU) {      // (uniform) the pre-activation was stored as bf16
-#pragma unroll
-            for (int p = 0; p < NF; ++p) {
-                const int row = row_base + p * RPP;
-                const bool ok = col_ok && row < M;
-                const ushort4 h = *reinterpret_cast<const ushort4 *>(reinterpret_cast<const unsigned short *>(aux1) +
-                                                                     (ok ? (size_t)row * N + col : 0));
-                const f32x4 x = f32x4{nt_bf2f(h.x), nt_bf2f(h.y), nt_bf2f(h.z), nt_bf2f(h.w)};
-                a1[p] = ok ? x : a1[p];
-            }
-        } else if (aux1) {
+        if (aux1) {
 #pragma unroll
             for (int p = 0; p < NF; ++p) {
                 const int row = row_base + p * RPP;

@@ -14,7 +14,6 @@ import _native as N
 from . import _mats
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_ACCUM, EPI_BIAS_ROWSCALE = range(7)
-EPI_MUL_DGELU16 = 8          # sei_gemm_bf16nt*: MUL_DGELU whose R1 (the stored pre-activation) is bf16
 LN_EPS = 1e-6
 
 
@@ -288,9 +287,9 @@ def gemm_nt16(A16, B16, M, Nn, K, epi, out32=None, out16=None, bias=None, R1=Non
     fl = 2.0 * M * Nn * K if flops is None else float(flops)
     ws, ws_bytes = (None, 0) if (tile or band or a_rmajor) else splitk_workspace(A16.device)
     if colsum is not None:
-        if out32 is not None or out16 is None or epi not in (EPI_NONE, EPI_MUL_DGELU, EPI_MUL_DGELU16) or tile or band or bias is not None \
+        if out32 is not None or out16 is None or epi not in (EPI_NONE, EPI_MUL_DGELU) or tile or band or bias is not None \
                 or R2 is not None or D2_16 is not None:
-            raise ValueError("gemm_nt16(colsum=): a bf16 result with EPI_NONE / EPI_MUL_DGELU[16] on the automatic dispatch")
+            raise ValueError("gemm_nt16(colsum=): a bf16 result with EPI_NONE / EPI_MUL_DGELU on the automatic dispatch")
         if ws is not None:
             _gemm_call(fl, "sei_gemm_bf16nt_ws", *args, colsum.data_ptr(), ws, ws_bytes, 0, 0, 0)
             return
@@ -1447,9 +1446,6 @@ def _transposed16(w16):
     return wt
 
 
-H3_F32 = os.environ.get("SEI_H3_F32") == "1"
-
-
 class ConvBlockFn16(torch.autograd.Function):
     """ConvBlockFn with bf16 storage of h2 / h4 / gh3 and the direct-to-LDS GEMMs (C % 64 == 0). At the shallow
     levels (C in FUSED_MLP_CHANNELS) conv2 -> GELU -> conv3 + residual is ONE launch whose 4C-wide hidden activation
@@ -1477,15 +1473,9 @@ class ConvBlockFn16(torch.autograd.Function):
             ctx.params = (w1, b1, gamma, beta, w2, b2, w3, b3)
             ctx.twice = twice
             return out.view(B, H, W, C)
-        # the pre-activation h3 is only ever read by gelu'(h3) in the backward's epilogue: stored as bf16 (the mode's rule
-        # for activations that feed nothing but GEMM launches: 4 instead of 6 bytes per element leave this epilogue, 2 instead
-        # of 4 enter the data gradient's; SEI_H3_F32=1 keeps float32 for A/B runs)
-        h3 = _alloc((M, 4 * C), torch.float32 if H3_F32 else torch.bfloat16, x.device)
+        h3 = _alloc((M, 4 * C), torch.float32, x.device)
         h4 = _alloc((M, 4 * C), torch.bfloat16, x.device)
-        if H3_F32:
-            gemm_nt16(h2, w2_16, M, 4 * C, C, EPI_BIAS_GELU, out32=h3, bias=b2, D2_16=h4)
-        else:
-            gemm_nt16(h2, w2_16, M, 4 * C, C, EPI_BIAS_GELU, out16=h3, bias=b2, D2_16=h4)
+        gemm_nt16(h2, w2_16, M, 4 * C, C, EPI_BIAS_GELU, out32=h3, bias=b2, D2_16=h4)
         out = _alloc((M, C), torch.float32, x.device)
         gemm_nt16(h4, w3_16, M, C, 4 * C, EPI_BIAS_RES, out32=out, bias=b3, R1=x, R2=x if twice else None)
         ctx.save_for_backward(x, h1, mean, rstd, h2, h3, h4)
@@ -1508,8 +1498,7 @@ class ConvBlockFn16(torch.autograd.Function):
         go16 = cast16(go2, colsum_into_=grad_of(b3))
         gh3 = torch.empty((M, 4 * C), dtype=torch.bfloat16, device=x.device)
         # (go W3) gelu'(h3), with conv2's bias gradient = its column sums riding in the epilogue (no pass over gh3)
-        gemm_nt16(go16, shadow(w3), M, 4 * C, C, EPI_MUL_DGELU16 if h3.dtype == torch.bfloat16 else EPI_MUL_DGELU, out16=gh3,
-                  R1=h3, b_rmajor=True, colsum=grad_of(b2))
+        gemm_nt16(go16, shadow(w3), M, 4 * C, C, EPI_MUL_DGELU, out16=gh3, R1=h3, b_rmajor=True, colsum=grad_of(b2))
         weight_grad16(go16, h4, grad_of(w3).view(C, 4 * C))
         gh2 = torch.empty((M, C), dtype=torch.float32, device=x.device)
         gemm_nt16(gh3, shadow(w2), M, C, 4 * C, EPI_NONE, out32=gh2, b_rmajor=True)

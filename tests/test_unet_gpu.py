@@ -670,41 +670,6 @@ def test_weight_gradient_reduction_major(ops, M, Np, Kp):
     assert relerr(acc, ref) < 5e-6
 
 
-@pytest.mark.parametrize("M,N,K,brm", [(2304, 2048, 512, False), (576, 8192, 2048, True), (1152, 512, 128, True), (136, 264, 72, False),
-                                         (9216, 2048, 512, True)])
-def test_bf16_pre_activation_epilogues(ops, M, N, K, brm):
-    """The bf16 mode stores the pre-activation h3 as bf16: SEI_EPI_BIAS_GELU with a bf16 result writes exactly the rounding
-    of the float32 result (and the same gelu output), and SEI_EPI_MUL_DGELU16 (R1 read as bf16) gives bit for bit what
-    SEI_EPI_MUL_DGELU gives on the same values held in float32 -- on the quadrant kernel, the row-patch epilogue of the
-    128 x 128 loop and its element-wise epilogue (ragged shape), with and without the riding column sums."""
-    gen = torch.Generator().manual_seed(M + N)
-    A = torch.randn((M, K), generator=gen).bfloat16().cuda()
-    B = (0.05 * torch.randn((K, N) if brm else (N, K), generator=gen)).bfloat16().cuda()
-    bias = torch.randn((N,), generator=gen).cuda()
-    if not brm:
-        h3_32, h4_a = torch.empty((M, N), device="cuda"), torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
-        h3_16, h4_b = torch.empty((M, N), device="cuda", dtype=torch.bfloat16), torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_GELU, out32=h3_32, bias=bias, D2_16=h4_a)
-        ops.gemm_nt16(A, B, M, N, K, ops.EPI_BIAS_GELU, out16=h3_16, bias=bias, D2_16=h4_b)
-        assert torch.equal(h3_16, h3_32.bfloat16()) and torch.equal(h4_a, h4_b)
-    pre = torch.randn((M, N), generator=gen).bfloat16().cuda()
-    pre32 = pre.float()
-    for with_colsum in ((False, True) if N % 4 == 0 else (False,)):
-        outs = []
-        for epi, r1 in ((ops.EPI_MUL_DGELU, pre32), (ops.EPI_MUL_DGELU16, pre)):
-            out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
-            cs = torch.zeros(N, device="cuda") if with_colsum else None
-            ops.gemm_nt16(A, B, M, N, K, epi, out16=out, R1=r1, b_rmajor=brm, colsum=cs)
-            outs.append((out, cs))
-        assert torch.equal(outs[0][0], outs[1][0])
-        if with_colsum:
-            assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-4)      # (float atomics: arrival order)
-    out32 = [torch.empty((M, N), device="cuda") for _ in range(2)]
-    ops.gemm_nt16(A, B, M, N, K, ops.EPI_MUL_DGELU, out32=out32[0], R1=pre32, b_rmajor=brm)
-    ops.gemm_nt16(A, B, M, N, K, ops.EPI_MUL_DGELU16, out32=out32[1], R1=pre, b_rmajor=brm)
-    assert torch.equal(out32[0], out32[1])
-
-
 @pytest.mark.parametrize("M,N,K", [(2304, 512, 128), (576, 2048, 512), (288, 512, 2048), (72, 8192, 2048), (4608, 128, 512)])
 def test_split_bf16_gemm_against_float64(ops, M, N, K):
     """models/_ops.py gemm_x3 (--compute_dtype bf16x3): every orientation and epilogue the float32 layer functions use,
