@@ -71,6 +71,20 @@ def test_argument_errors_are_reported_not_launched():
     assert L.sei_blur_sep_circ(None, None, None, None, 13, 13, 1, 8, 8, 0, None) == 10001
     assert L.sei_axpy(None, None, 1.0, None, 4, None) == 10001
     assert L.sei_scale_resample_fwd(None, None, None, None, 1, 3, 8, 8, 8, 8, None) == 10001
+    # ABI 12: the step prologue, the glue kernels and the split-bf16 passes refuse bad arguments on the host too
+    assert L.sei_proposed_draws(1, 0, None, 2, 3, 48, 48, 6, None, 2, None, None, None, None) == 10001
+    assert L.sei_proposed_draws(1, 2, 8, 2, 3, 48, 48, 6, 8, 2, 8, 8, 8, None) == 10001          # offset % 4 != 0
+    assert L.sei_proposed_draws(1, 0, 8, 2, 3, 12, 12, 6, 8, 2, 8, 8, 8, None) == 10001         # margin swallows the image
+    assert L.sei_proposed_draws(1, 0, 8, 4096, 3, 48, 48, 6, 8, 2, 8, 8, 8, None) == 10001      # beyond one element per thread
+    assert L.sei_proposed_draws_max_numel() == 256 * 2048
+    assert L.sei_crop_window(None, None, 6, 64, 64, 0, 0, 48, None) == 10001
+    assert L.sei_stack_axpy(None, None, 0.01, None, 16, None) == 10001
+    assert L.sei_concat2_f32(None, 16, None, 0, None, None) == 10001
+    assert L.sei_scale_dev_f32(None, None, None, 16, None) == 10001
+    assert L.sei_add_scalars(None, None, None, None) == 10001
+    assert L.sei_split_bf16x2(None, None, 16, None) == 10001 and L.sei_split_bf16x2(16, 16, 6, None) == 10001   # n % 4
+    assert L.sei_split_bf16x3(16, 16, 16, 2, None) == 10001                                     # pattern is 0 or 1
+    assert L.sei_gelu_f32(None, None, 16, None) == 10001 and L.sei_mul_dgelu_f32(None, None, 16, None) == 10001
 
 
 def test_product_refuses_cpu_tensors():
