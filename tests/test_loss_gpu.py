@@ -262,12 +262,14 @@ def test_split_bf16_step_vs_oracle_at_a_batch_whose_weight_gradients_split_too()
         _ops.set_compute_dtype(prev)
 
 
-def _default_unet_step_vs_oracle(B):
+def _default_unet_step_vs_oracle(B, modes=None):
+    """modes: run the HIP path once per arithmetic mode against ONE evaluation of the CPU oracle (None: the mode in effect)."""
     import bench
     import metrics
     import models
     import physics
     from losses.sure import embed_probe
+    from models import _ops
     args = bench.reference_args("cuda")
     p = physics.get_physics(args, "cuda")
     torch.manual_seed(0)
@@ -288,21 +290,34 @@ def _default_unet_step_vs_oracle(B):
                                 b=b_int, n=noise)
     ref.backward()
     yd = y.cuda()
-    loss, got = _proposed_manual(model, p, yd, embed_probe(yd, b_int.cuda(), 6), noise.cuda(), rate.cuda(),
-                                 center.cuda(), 6)
-    assert relerr(got["x_net"], aux["x_net"]) < 1e-4
-    for i in range(B):
-        d = abs(float(metrics.psnr_fn(got["x_net"][i].cpu(), xgt[i])) - float(tp.psnr_y(aux["x_net"][i].detach(), xgt[i])))
-        assert d < 0.01
-    assert rel(loss, ref) < 1e-4
-    model.get_backbone().zero_grad_flat()
-    loss.backward()
-    params = dict(model.get_backbone().named_parameters())
-    worst = 0.0
-    for kname, v in sd.items():
-        gn, rn = float(params[kname].grad.double().norm()), float(v.grad.double().norm())
-        worst = max(worst, abs(gn - rn) / rn)
-    assert worst < 1e-4, worst
+    for mode in (modes or [None]):
+        prev = _ops.set_compute_dtype(mode) if mode is not None else None
+        try:
+            loss, got = _proposed_manual(model, p, yd, embed_probe(yd, b_int.cuda(), 6), noise.cuda(), rate.cuda(),
+                                         center.cuda(), 6)
+            assert relerr(got["x_net"], aux["x_net"]) < 1e-4, mode
+            for i in range(B):
+                d = abs(float(metrics.psnr_fn(got["x_net"][i].cpu(), xgt[i])) - float(tp.psnr_y(aux["x_net"][i].detach(), xgt[i])))
+                assert d < 0.01, mode
+            assert rel(loss, ref) < 1e-4, mode
+            model.get_backbone().zero_grad_flat()
+            loss.backward()
+            params = dict(model.get_backbone().named_parameters())
+            worst = 0.0
+            for kname, v in sd.items():
+                gn, rn = float(params[kname].grad.double().norm()), float(v.grad.double().norm())
+                worst = max(worst, abs(gn - rn) / rn)
+            assert worst < 1e-4, (mode, worst)
+        finally:
+            if mode is not None:
+                _ops.set_compute_dtype(prev)
+
+
+def test_parity_modes_at_the_timed_batch_vs_oracle():
+    """The two parity modes END TO END at the batch bench.py times (B = 32: 576 + 288 bottleneck rows, where the f32 GEMM's
+    96 x 128 tiles and the quadrant tiles of the bf16x3 launches exist), against one evaluation of the
+    float32 CPU oracle: restored images 1e-4 / 0.01 dB, loss 1e-4, every parameter-gradient norm 1e-4."""
+    _default_unet_step_vs_oracle(B=32, modes=["f32", "bf16x3"])
 
 
 def _launch_plans(records):
