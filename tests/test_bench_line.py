@@ -94,3 +94,21 @@ def test_emit_prints_series_first_and_the_headline_last(tmp_path, capsys, monkey
     _check(lines[-1], full)
     with open(tmp_path / "full.json") as f:
         assert json.load(f)["secondary"]["sr4"]["roofline_hbm"]
+
+
+def test_recorded_round6_run_keeps_the_valu_roofline_and_the_projection():
+    """Round 6's line (profiles/r06_h_bench_default_full.json: ten secondary series, the depthwise family's VALU roofline,
+    the N = 2 / N = 8 projection of the world-1 rehearsal): under 8 kB with those objects on it, the projection labelled
+    as not measured."""
+    with open(os.path.join(ROOT, "profiles", "r06_h_bench_default_full.json")) as f:
+        full = json.load(f)
+    out = _check(bench.compact_line(full), full)
+    dw = next(fam for fam in out["roofline_hbm"] if fam["kernel"].startswith("dwconv7_"))
+    assert dw["valu"]["bound"] == "valu_f32_fma" and 0 < dw["valu"]["frac"] < 1 and dw["valu"]["peak"] == bench.VALU_F32_FMA_PEAK_TFLOPS
+    assert set(out["secondary"]) >= {"f32", "bf16x3", "b8", "full256", "sr4", "swinir_sr2", "device_cache", "dist1", "dist1_bf16"}
+    for key in ("dist1", "dist1_bf16"):
+        proj = out["secondary"][key]["projected_not_measured"]
+        assert set(proj) == {"n2", "n8"} and all(lo <= hi for lo, hi in proj.values())
+        assert proj["n8"][0] > 3500                                  # BASELINE.json's 8-GPU target, on the pessimistic link reading
+        want = bench.project_ranks(full["secondary"][key], 645063043, 32, "bf16" if key.endswith("bf16") else "f32")
+        assert proj["n2"] == want["n2"]["images_per_s"] and "not measured" in want["label"]
