@@ -9,20 +9,8 @@ import _native as N
 from models import _ops
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_MUL_DGELU, EPI_ACCUM, EPI_ROWSCALE = range(7)
-# (M, N, K, b_rmajor, epilogue, launches per step)
-SHAPES = [
-    (9216, 2048, 512, 0, EPI_BIAS_GELU, 2), (9216, 512, 2048, 0, EPI_BIAS_RES, 3), (4608, 2048, 512, 0, EPI_BIAS_GELU, 2),
-    (4608, 512, 2048, 0, EPI_BIAS_RES, 3), (2304, 8192, 2048, 0, EPI_BIAS_GELU, 2), (2304, 2048, 8192, 0, EPI_BIAS_RES, 3),
-    (1152, 8192, 2048, 0, EPI_BIAS_GELU, 2), (1152, 2048, 8192, 0, EPI_BIAS_RES, 3),
-    (576, 32768, 8192, 0, EPI_BIAS_GELU, 1), (576, 8192, 32768, 0, EPI_BIAS_RES, 1),
-    (288, 32768, 8192, 0, EPI_BIAS_GELU, 1), (288, 8192, 32768, 0, EPI_BIAS_RES, 1),
-    (2304, 2048, 512, 0, EPI_ROWSCALE, 1), (1152, 2048, 512, 0, EPI_ROWSCALE, 1), (576, 8192, 2048, 0, EPI_ROWSCALE, 1),
-    (288, 8192, 2048, 0, EPI_ROWSCALE, 1), (36864, 128, 512, 0, EPI_BIAS_RES, 1), (18432, 128, 512, 0, EPI_BIAS_RES, 1),
-    (9216, 2048, 512, 1, EPI_MUL_DGELU, 2), (4608, 2048, 512, 1, EPI_MUL_DGELU, 2), (13824, 512, 2048, 1, EPI_NONE, 2),
-    (2304, 8192, 2048, 1, EPI_MUL_DGELU, 2), (1152, 8192, 2048, 1, EPI_MUL_DGELU, 2), (3456, 2048, 8192, 1, EPI_NONE, 2),
-    (576, 32768, 8192, 1, EPI_MUL_DGELU, 1), (288, 32768, 8192, 1, EPI_MUL_DGELU, 1), (864, 8192, 32768, 1, EPI_NONE, 1),
-    (864, 2048, 8192, 1, EPI_NONE, 1), (3456, 512, 2048, 1, EPI_NONE, 1),
-]
+sys.path.insert(1, os.path.join(ROOT, "tools"))
+from exp_tile_sweep_shapes import SHAPES
 quick = "--quick" in sys.argv
 
 
