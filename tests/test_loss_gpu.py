@@ -1036,6 +1036,35 @@ def test_fused_step_draws_are_torch_generator_draws(B, S, margin):
     assert same_normals(got["b"], second_ref["b"]) and same_normals(got["noise"], second_ref["noise"])
 
 
+def test_crop_pair_on_the_gpu_vs_reference_golden(golden):
+    """G14 (src/crop.py run by its own code): the product's crop.CropPair -- forward, and draw_offsets + write_y (the
+    sei_crop_window launch a captured step uses) -- on the GPU, same CPU seeds: the same elements in the same places."""
+    from crop import CropPair
+    g = golden("g14_crop")
+    for tag in ("deblur", "deblur_small", "sr2", "sr4", "item3d", "deblur48"):
+        xs, ys = tuple(int(v) for v in g[f"{tag}.xshape"]), tuple(int(v) for v in g[f"{tag}.yshape"])
+        size, ratio = (int(v) for v in g[f"{tag}.cfg"])
+        x = (1 + torch.arange(int(np.prod(xs)), dtype=torch.float32)).view(xs).cuda()
+        y = (1 + torch.arange(int(np.prod(ys)), dtype=torch.float32)).view(ys).cuda()
+        crop = CropPair("random", size)
+        k = 0
+        while f"{tag}.seed{k}.xc" in g.files:
+            torch.manual_seed(k)
+            xc, yc = crop(x, y, xy_size_ratio=ratio)
+            assert np.array_equal(xc.cpu().numpy().astype(np.int32), g[f"{tag}.seed{k}.xc"]), (tag, k)
+            assert np.array_equal(yc.cpu().numpy().astype(np.int32), g[f"{tag}.seed{k}.yc"]), (tag, k)
+            if len(ys) == 4:                                   # the captured step's path: offsets, then one launch
+                torch.manual_seed(k)
+                i, j, _, _ = crop.draw_offsets(y.shape)
+                out = torch.full(tuple(ys[:2]) + (size, size), -1.0, device="cuda")
+                crop.write_y(y, i, j, out)
+                assert np.array_equal(out.cpu().numpy().astype(np.int32), g[f"{tag}.seed{k}.yc"]), (tag, k)
+            k += 1
+        xc, yc = CropPair("center", size)(x, y, xy_size_ratio=ratio)
+        assert np.array_equal(xc.cpu().numpy().astype(np.int32), g[f"{tag}.center.xc"])
+        assert np.array_equal(yc.cpu().numpy().astype(np.int32), g[f"{tag}.center.yc"])
+
+
 def test_crop_window_kernel_matches_the_padded_crop():
     """sei_crop_window (CropPair.write_y on the GPU) against the reference's pad-then-slice (src/crop.py:26-57 on a 4-D
     batch), windows inside the batch and reaching into the zero rows the batched quirk appends."""

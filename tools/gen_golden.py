@@ -9,7 +9,7 @@ arithmetic is exercised by the goldens below except `adjoint_function`, which is
 `torch.autograd.functional.vjp` (flagged "vjp" in the fixture names).
 
 What is written is DATA ONLY: seeded inputs and the outputs the reference produced for them
-(G12 noise2inverse; G13 the in-tree R2R / EI loss). The reference cannot travel to the GPU box; these files can.
+(G12 noise2inverse; G13 the in-tree R2R / EI loss; G14 CropPair on batches). The reference cannot travel to the GPU box; these files can.
 
     python tools/gen_golden.py            # writes tests/golden/*.npz + manifest json
 """
@@ -245,6 +245,51 @@ def gen_r2r():
                     else:
                         arrs[p + f"gradnorm.{k2}"] = _np(q.grad.norm())
         _save(f"g13_r2r_{tag}", **arrs)
+
+
+def gen_crop():
+    """G14: src/crop.py (imported by path) -- CropPair / MinSizePadding on BATCHES, i.e. the batched-crop quirk (SURVEY a8:
+    MinSizePadding reads x.shape[1], x.shape[2] as height and width, which on a 4-D batch are C and H). Its only third-party
+    symbols are torchvision.transforms.functional.pad and .crop: a two-function shell stands in (flagged "TF shell": pad =
+    constant F.pad in torchvision's [left, top, right, bottom] order, crop = the in-bounds slice -- every crop the reference
+    makes here is in bounds). The two CPU randint draws come from manual_seed(k), k = 0..5."""
+    os.makedirs(OUT, exist_ok=True)
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tf = types.ModuleType("torchvision.transforms.functional")
+
+    def pad(img, padding, fill=0, padding_mode="constant"):          # "TF shell"
+        assert padding_mode == "constant" and len(padding) == 4
+        left, top, right, bottom = padding
+        return torch.nn.functional.pad(img, (left, right, top, bottom), value=fill)
+
+    def crop(img, top, left, height, width):                         # "TF shell"
+        assert top >= 0 and left >= 0 and top + height <= img.shape[-2] and left + width <= img.shape[-1]
+        return img[..., top:top + height, left:left + width]
+
+    tf.pad, tf.crop = pad, crop
+    tvt.functional = tf
+    tv.transforms = tvt
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tf})
+    ref_crop = _load_by_path("ref_crop", os.path.join(REF_SRC, "crop.py"))
+    print("G14 crop")
+    arrs = {}
+    # (values = 1 + the element's flat index: a crop then shows which element went where, zeros are padding; small crop
+    # sizes keep the fixture small -- the quirk scales with them: size - 3 zero rows are appended to a 3-channel batch)
+    for tag, xs, ys, size, ratio in [("deblur", (2, 3, 20, 17), (2, 3, 20, 17), 12, 1), ("deblur_small", (2, 3, 10, 14), (2, 3, 10, 14), 12, 1),
+                                     ("sr2", (2, 3, 24, 24), (2, 3, 12, 12), 12, 2), ("sr4", (1, 3, 64, 64), (1, 3, 16, 16), 16, 4),
+                                     ("item3d", (3, 30, 26), (3, 15, 13), 12, 2), ("deblur48", (1, 3, 64, 56), (1, 3, 64, 56), 48, 1)]:
+        x = (1 + torch.arange(int(np.prod(xs)), dtype=torch.float32)).view(xs)
+        y = (1 + torch.arange(int(np.prod(ys)), dtype=torch.float32)).view(ys)
+        arrs[f"{tag}.xshape"], arrs[f"{tag}.yshape"] = np.array(xs), np.array(ys)
+        arrs[f"{tag}.cfg"] = np.array([size, ratio])
+        for k in range(6 if size < 48 else 2):
+            torch.manual_seed(k)
+            xc, yc = ref_crop.CropPair("random", size)(x, y, xy_size_ratio=ratio)
+            arrs[f"{tag}.seed{k}.xc"], arrs[f"{tag}.seed{k}.yc"] = _np(xc).astype(np.int32), _np(yc).astype(np.int32)
+        xc, yc = ref_crop.CropPair("center", size)(x, y, xy_size_ratio=ratio)
+        arrs[f"{tag}.center.xc"], arrs[f"{tag}.center.yc"] = _np(xc).astype(np.int32), _np(yc).astype(np.int32)
+    _save("g14_crop", **arrs)
 
 
 def main():
@@ -616,7 +661,10 @@ if __name__ == "__main__":
         gen_noise2inverse()
     elif sys.argv[1:] == ["--only", "g13"]:
         gen_r2r()
+    elif sys.argv[1:] == ["--only", "g14"]:
+        gen_crop()
     else:
         main()
         gen_noise2inverse()
         gen_r2r()
+        gen_crop()
