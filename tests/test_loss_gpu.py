@@ -177,6 +177,45 @@ def test_r2r_and_ei_glue_vs_reference_golden(golden, tag):
     assert rel(val, g["f64.loss_ei"]) < 1e-4
 
 
+# ------------------------------------------------------------------ the reference's own loss layer end to end, golden G15
+@pytest.mark.parametrize("tag", ["deblur", "sr2"])
+def test_loss_layer_vs_reference_classes_golden(golden, tag):
+    """G15 = the reference's get_physics / get_loss / Loss.forward / ProposedLoss run by their own code on a seeded CPU
+    generator (tools/gen_golden.py gen_loss_glue). The product's get_loss built from the same flags picks the same margin
+    and crop ratio, and its loss layer on the GPU -- crop at the offsets that seed drew, the draws that seed handed out
+    injected -- gives the reference's float32 loss value and gradient norms."""
+    import bench
+    import physics as physics_pkg
+    from crop import CropPair
+    from losses import get_loss
+    from losses.sure import embed_probe
+    from models.convolutional import ConvolutionalModel
+    g = golden(f"g15_loss_glue_{tag}")
+    up = 1 if tag == "deblur" else 2
+    args = bench.reference_args("cuda", hidden=8, scales=3, task="deblurring" if tag == "deblur" else "sr", sr_factor=None if tag == "deblur" else 2)
+    p = physics_pkg.get_physics(args, "cuda")
+    lf = get_loss(args, p)
+    margin = int(g["sure_margin"])
+    assert lf.loss.sure.margin == margin and lf.loss.sure.div_margin == margin and lf.xy_size_ratio == int(g["xy_size_ratio"])
+    m = ConvolutionalModel(in_channels=3, upsampling_rate=up, residual=True, inner_residual=True, num_conv_blocks=1,
+                           hidden_channels=8, inout_convs=True, scales=3)
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("sd.")})
+    m = m.cuda()
+    y = dev(g["y"])
+    for seed in (0, 1):
+        pre = f"f32.seed{seed}."
+        i, j = (int(v) for v in g[pre + "ij"])
+        yc = CropPair("random", 48).write_y(y, i, j, torch.empty(y.shape[0], 3, 48, 48, device="cuda"))
+        draws = {"b": embed_probe(yc, dev(g[pre + "b"]), margin), "rate": dev(g[pre + "rate"]),
+                 "center": dev(g[pre + "center"]).view(-1, 1, 1, 2), "noise": dev(g[pre + "n"])}
+        m.zero_grad_flat()
+        val = lf.loss(x=None, y=yc, model=m, draws=draws)
+        assert rel(val, g[pre + "loss"]) < 1e-4, (seed, float(val), float(g[pre + "loss"]))
+        val.backward()
+        for k, q in m.named_parameters():
+            assert rel(q.grad.norm(), g[pre + f"gradnorm.{k}"]) < 1e-3, (seed, k)
+
+
 def test_fused_and_literal_pass_orders_agree():
     import physics
     import models

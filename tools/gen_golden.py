@@ -9,7 +9,7 @@ arithmetic is exercised by the goldens below except `adjoint_function`, which is
 `torch.autograd.functional.vjp` (flagged "vjp" in the fixture names).
 
 What is written is DATA ONLY: seeded inputs and the outputs the reference produced for them
-(G12 noise2inverse; G13 the in-tree R2R / EI loss; G14 CropPair on batches). The reference cannot travel to the GPU box; these files can.
+(G12 noise2inverse; G13 the in-tree R2R / EI loss; G14 CropPair on batches; G15 the loss layer end to end). The reference cannot travel to the GPU box; these files can.
 
     python tools/gen_golden.py            # writes tests/golden/*.npz + manifest json
 """
@@ -290,6 +290,144 @@ def gen_crop():
         xc, yc = ref_crop.CropPair("center", size)(x, y, xy_size_ratio=ratio)
         arrs[f"{tag}.center.xc"], arrs[f"{tag}.center.yc"] = _np(xc).astype(np.int32), _np(yc).astype(np.int32)
     _save("g14_crop", **arrs)
+
+
+def gen_loss_glue():
+    """G15: the reference's OWN loss layer end to end -- src/losses/__init__.py (get_loss :210-266 with demo/train.py's
+    default flags :35-61, Loss.forward :203-207, ProposedLoss :67-142) around src/crop.py, src/losses/sure.py,
+    src/transforms.py, src/physics (get_physics) and the h8s3 U-Net of src/models/convolutional.py, on the CPU generator
+    (manual_seed(k): the crop's two randint draws, SURE's randn, the transform's rand(B) / rand(B, 2), the measurement
+    noise's randn_like, in the order the reference's code consumes them).
+    Shells (deepinv / torchvision are absent), all flagged: `deepinv.loss.EILoss` and `SupLoss` as their documented
+    v0.2.0 forward [recollection; the EI arithmetic itself is pinned by G13, the reference's in-tree near-copy],
+    `deepinv.loss.metric.mse`, `deepinv.physics.GaussianNoise` (x + sigma randn_like(x)), `LinearPhysics.__call__`
+    (noise_model(A(x))), placeholders for `deepinv.transform.Rotate` / `Shift` (not exercised), torchvision's TF.pad /
+    TF.crop (G14's shell). What is pinned is the reference's glue: the margin rule of get_loss, crop-then-method,
+    the loss list and its keyword protocol, the summation, and the ORDER in which the generator is consumed."""
+    import argparse
+    os.makedirs(OUT, exist_ok=True)
+    _install_deepinv_shell()
+    dinv = sys.modules["deepinv"]
+    loss_mod, metric_mod, tr_mod = (types.ModuleType(n) for n in ("deepinv.loss", "deepinv.loss.metric", "deepinv.transform"))
+
+    class mse(torch.nn.Module):                      # "mse shell"
+        def forward(self, x, y):
+            return torch.nn.functional.mse_loss(x, y)
+
+    class SupLoss(torch.nn.Module):                  # "SupLoss shell"
+        def __init__(self, metric=None):
+            super().__init__()
+            self.metric = metric if metric is not None else torch.nn.MSELoss()
+
+        def forward(self, x_net, x, **kwargs):
+            return self.metric(x_net, x)
+
+    class EILoss(torch.nn.Module):                   # "EILoss shell" (deepinv v0.2.0's forward, [recollection]; see G13)
+        def __init__(self, transform, metric=None, apply_noise=True, weight=1.0, no_grad=False):
+            super().__init__()
+            self.T, self.metric, self.noise, self.weight, self.no_grad = transform, metric, apply_noise, weight, no_grad
+
+        def forward(self, x_net, physics, model, **kwargs):
+            if self.no_grad:
+                with torch.no_grad():
+                    x2 = self.T(x_net)
+            else:
+                x2 = self.T(x_net)
+            y = physics(x2) if self.noise else physics.A(x2)
+            x3 = model(y, physics)
+            return self.weight * self.metric(x3, x2)
+
+    class _Unused(torch.nn.Module):
+        def forward(self, x):
+            raise RuntimeError("placeholder: not exercised by G15")
+
+    metric_mod.mse = mse
+    loss_mod.metric, loss_mod.SupLoss, loss_mod.EILoss = metric_mod, SupLoss, EILoss
+    tr_mod.Rotate, tr_mod.Shift = _Unused, _Unused
+    dinv.loss, dinv.transform = loss_mod, tr_mod
+    sys.modules.update({"deepinv.loss": loss_mod, "deepinv.loss.metric": metric_mod, "deepinv.transform": tr_mod})
+    tv, tvt, tf = (types.ModuleType(n) for n in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional"))
+
+    def pad(img, padding, fill=0, padding_mode="constant"):          # "TF shell" (as G14)
+        left, top, right, bottom = padding
+        return torch.nn.functional.pad(img, (left, right, top, bottom), value=fill)
+
+    def crop(img, top, left, height, width):
+        assert top >= 0 and left >= 0 and top + height <= img.shape[-2] and left + width <= img.shape[-1]
+        return img[..., top:top + height, left:left + width]
+
+    tf.pad, tf.crop = pad, crop
+    tvt.functional, tv.transforms = tf, tvt
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tf})
+    if REF_SRC not in sys.path:
+        sys.path.insert(0, REF_SRC)
+    physics = importlib.import_module("physics")
+    losses = importlib.import_module("losses")
+    transforms = importlib.import_module("transforms")
+    conv = _load_by_path("ref_convolutional", os.path.join(REF_SRC, "models", "convolutional.py"))
+    torch.set_num_threads(8)
+    print("G15 loss glue")
+    for tag, task, rate in [("deblur", "deblurring", None), ("sr2", "sr", 2)]:
+        # src/settings.py's and demo/train.py's defaults for the flags get_physics / get_loss read
+        args = argparse.Namespace(task=task, kernel="Gaussian_R2" if task == "deblurring" else None, sr_factor=rate, noise_level=5,
+                                  physics_v2=True, physics_true_adjoint=False, method="proposed", partial_sure=True,
+                                  sure_margin=None, partial_sure_sr=False, sure_cropped_div=True, sure_averaged_cst=None,
+                                  Loss__crop_training_pairs=True, Loss__crop_size=48, ProposedLoss__stop_gradient=True,
+                                  ProposedLoss__sure_alternative=None, ProposedLoss__alpha_tradeoff=1.0,
+                                  ProposedLoss__transforms="Scaling_Transforms", ScalingTransform__kind="padded",
+                                  ScalingTransform__antialias=False)
+        phys = physics.get_physics(args, "cpu")
+        lf = losses.get_loss(args, phys)
+        inner = lf.loss
+        assert type(inner).__name__ == "ProposedLoss" and [type(f).__name__ for f in inner.loss_fns] == ["SureGaussianLoss", "EILoss"]
+        torch.manual_seed(0)
+        m32 = conv.ConvolutionalModel(in_channels=3, upsampling_rate=rate or 1, residual=True, inner_residual=True,
+                                      num_conv_blocks=1, hidden_channels=8, inout_convs=True, scales=3)
+        with torch.no_grad():
+            for n, p in m32.named_parameters():
+                if ".ln." in n:
+                    p.add_(0.05 * torch.randn_like(p))
+        r = rate or 1
+        B, S = 2, 48
+        x32 = _rand((B, 3, 64 * r, 64 * r), 150)
+        y32 = _rand((B, 3, 64, 64), 151)
+        arrs = {"x": _np(x32), "y": _np(y32), "sure_margin": np.array(inner.loss_fns[0].margin),
+                "cropped_div": np.array(int(inner.loss_fns[0].cropped_div)), "xy_size_ratio": np.array(lf.xy_size_ratio)}
+        for k2, v in m32.state_dict().items():
+            arrs[f"sd.{k2}"] = _np(v)
+        import copy
+        for dt, dn in [(torch.float64, "f64"), (torch.float32, "f32")]:
+            m = copy.deepcopy(m32).to(dt)
+
+            class Net(torch.nn.Module):                  # src/models/__init__.py:148-149: Model.forward(x, *args) drops the extras
+                def forward(self, v, *ignored):
+                    return m(v)
+
+            for seed in (0, 1):
+                torch.manual_seed(seed)
+                val = lf(x=x32.to(dt), y=y32.to(dt), model=Net())
+                m.zero_grad()
+                val.backward()
+                p = f"{dn}.seed{seed}."
+                arrs[p + "loss"] = _np(val)
+                for k2, q in m.named_parameters():
+                    if dn == "f64" and seed == 0:
+                        arrs[p + f"grad.{k2}"] = _np(q.grad).astype(np.float32)
+                    else:
+                        arrs[p + f"gradnorm.{k2}"] = _np(q.grad.norm())
+                # the numbers that seed hands out, in the reference's order (for a path that must have them injected)
+                torch.manual_seed(seed)
+                hy = y32.shape[-2] + max(0, S - 3)                    # MinSizePadding on a batch: size - C rows appended
+                wy = y32.shape[-1] + max(0, S - y32.shape[-2])
+                i = torch.randint(0, hy - S + 1, size=(1,)).item()
+                j = torch.randint(0, wy - S + 1, size=(1,)).item()
+                mg = int(inner.loss_fns[0].margin)
+                b = torch.randn(B, 3, S - 2 * mg, S - 2 * mg, dtype=dt) if mg else torch.randn(B, 3, S, S, dtype=dt)
+                rr, cc = transforms.sample_downsampling_parameters(B, "cpu", dt, [0.75, 0.5])
+                nn_ = torch.randn(B, 3, S, S, dtype=dt)
+                arrs[p + "ij"] = np.array([i, j])
+                arrs[p + "b"], arrs[p + "rate"], arrs[p + "center"], arrs[p + "n"] = _np(b), _np(rr), _np(cc.view(-1, 2)), _np(nn_)
+        _save(f"g15_loss_glue_{tag}", **arrs)
 
 
 def main():
@@ -663,8 +801,11 @@ if __name__ == "__main__":
         gen_r2r()
     elif sys.argv[1:] == ["--only", "g14"]:
         gen_crop()
+    elif sys.argv[1:] == ["--only", "g15"]:
+        gen_loss_glue()
     else:
         main()
         gen_noise2inverse()
         gen_r2r()
         gen_crop()
+        gen_loss_glue()
