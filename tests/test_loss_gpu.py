@@ -215,6 +215,27 @@ def test_loss_layer_vs_reference_classes_golden(golden, tag):
         val.backward()
         for k, q in m.named_parameters():
             assert rel(q.grad.norm(), g[pre + f"gradnorm.{k}"]) < 1e-3, (seed, k)
+        # the other methods through the reference's own classes: supervised needs no device draw at all -- the product's
+        # Loss.forward from the same CPU seed (its CropPair draws the reference's two offsets) must give the reference's value
+        import argparse
+        a2 = argparse.Namespace(**vars(args))
+        a2.method = "supervised"
+        sup = get_loss(a2, p)
+        m.zero_grad_flat()
+        torch.manual_seed(seed)
+        v3 = sup(x=dev(g["x"]), y=y, model=net)
+        assert rel(v3, g[pre + "supervised.loss"]) < 1e-4, (seed, "supervised")
+        v3.backward()
+        got = torch.stack([q.grad.norm() for q in m.parameters()])
+        assert relerr(got, g[pre + "supervised.gradnorm"]) < 1e-3
+        a2.method = "sure"
+        sure = get_loss(a2, p)
+        m.zero_grad_flat()
+        v2 = sure.loss(x=None, y=yc, model=net, draws={"b": draws["b"]})
+        assert rel(v2, g[pre + "sure.loss"]) < 1e-4, (seed, "sure")
+        v2.backward()
+        got = torch.stack([q.grad.norm() for q in m.parameters()])
+        assert relerr(got, g[pre + "sure.gradnorm"]) < 1e-3
 
 
 def test_fused_and_literal_pass_orders_agree():

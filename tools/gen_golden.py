@@ -380,6 +380,12 @@ def gen_loss_glue():
         lf = losses.get_loss(args, phys)
         inner = lf.loss
         assert type(inner).__name__ == "ProposedLoss" and [type(f).__name__ for f in inner.loss_fns] == ["SureGaussianLoss", "EILoss"]
+        # the other methods behind the same surface, through the reference's own SURELoss / SupervisedLoss
+        others = {}
+        for method in ("sure", "supervised"):
+            a2 = argparse.Namespace(**vars(args))
+            a2.method = method
+            others[method] = losses.get_loss(a2, phys)
         torch.manual_seed(0)
         m32 = conv.ConvolutionalModel(in_channels=3, upsampling_rate=rate or 1, residual=True, inner_residual=True,
                                       num_conv_blocks=1, hidden_channels=8, inout_convs=True, scales=3)
@@ -415,6 +421,13 @@ def gen_loss_glue():
                         arrs[p + f"grad.{k2}"] = _np(q.grad).astype(np.float32)
                     else:
                         arrs[p + f"gradnorm.{k2}"] = _np(q.grad.norm())
+                for method, lf2 in others.items():     # (sure: crop, then its randn; supervised: crop only)
+                    torch.manual_seed(seed)
+                    v2 = lf2(x=x32.to(dt), y=y32.to(dt), model=Net())
+                    m.zero_grad()
+                    v2.backward()
+                    arrs[p + f"{method}.loss"] = _np(v2)
+                    arrs[p + f"{method}.gradnorm"] = _np(torch.stack([q.grad.norm() for q in m.parameters()]))
                 # the numbers that seed hands out, in the reference's order (for a path that must have them injected)
                 torch.manual_seed(seed)
                 hy = y32.shape[-2] + max(0, S - 3)                    # MinSizePadding on a batch: size - C rows appended
