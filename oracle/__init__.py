@@ -14,9 +14,12 @@ Two layers, both pinned against golden vectors captured from the reference itsel
   convolution, explicit antialias weights, explicit bicubic/reflection sampler, DFT-matrix form of
   the FFT resamplers). These are the formulas the HIP kernels implement.
 
-Parity pin status: PINNED for every in-tree reference function (goldens G1..G9, G11 are reference
-outputs). UNPINNED for the deepinv-owned glue (EILoss, GaussianNoise), which is
-restated from its documented behaviour only -- see DESIGN.md.
+Parity pin status: PINNED for every in-tree reference function (goldens G1..G9, G11..G15 are reference
+outputs: G13 = the reference's in-tree R2R / EI loss, which pins the EI arithmetic that `ei_loss` restates from deepinv;
+G14 = CropPair on batches; G15 = the reference's own get_loss / Loss.forward / ProposedLoss / SURELoss / SupervisedLoss
+end to end on a seeded generator, with deepinv's EILoss / GaussianNoise as flagged shells). UNPINNED, restated from
+documented behaviour only: deepinv's own source for EILoss / GaussianNoise (not in the reference tree), SwinIR
+(`swinir_path.py`), the PSNR-Y metric (kornia / torchmetrics) -- see DESIGN.md section 2.
 """
 
 
